@@ -1,0 +1,250 @@
+// BLS12-381 scalar field Fr (= Bandersnatch base field) for gfx950, 8 x 32-bit limbs.
+//
+// In-memory form is the reference's: Montgomery (R = 2^256), little-endian, 32 bytes per element
+// (ark-ff 0.4.2 `Fp<MontBackend<FrConfig,4>>` = BigInt([u64;4]); /root/reference/src/utils.rs:32-37
+// spells out COEFF_D in exactly this form).  A 4xu64 LE element is bit-identical to 8xu32 LE, so
+// device buffers are imported/exported without conversion.
+//
+// CDNA4 has no 64-bit integer multiplier; the natural machine word is v_mad_u64_u32
+// (32x32+64 -> 64).  p = 1 (mod 2^32) gives -p^-1 = 0xffffffff, so the Montgomery quotient digit
+// is just the negated low limb (no multiply), and p[1] = 0xffffffff turns one more product per
+// reduction step into shifts/subtracts.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GM_HD __host__ __device__ __forceinline__
+#else
+#define GM_HD inline
+#endif
+
+namespace gm {
+
+struct Fr {
+    uint32_t l[8];
+};
+
+// modulus p, little-endian 32-bit limbs
+#define GM_P0 0x00000001u
+#define GM_P1 0xffffffffu
+#define GM_P2 0xfffe5bfeu
+#define GM_P3 0x53bda402u
+#define GM_P4 0x09a1d805u
+#define GM_P5 0x3339d808u
+#define GM_P6 0x299d7d48u
+#define GM_P7 0x73eda753u
+
+GM_HD uint32_t fr_p(int i) {
+    switch (i) {
+        case 0: return GM_P0; case 1: return GM_P1; case 2: return GM_P2; case 3: return GM_P3;
+        case 4: return GM_P4; case 5: return GM_P5; case 6: return GM_P6; default: return GM_P7;
+    }
+}
+
+GM_HD Fr fr_zero() {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = 0;
+    return r;
+}
+
+// R mod p  (Montgomery form of 1)
+GM_HD Fr fr_one() {
+    Fr r;
+    r.l[0] = 0xfffffffeu; r.l[1] = 0x00000001u; r.l[2] = 0x00034802u; r.l[3] = 0x5884b7fau;
+    r.l[4] = 0xecbc4ff5u; r.l[5] = 0x998c4fefu; r.l[6] = 0xacc5056fu; r.l[7] = 0x1824b159u;
+    return r;
+}
+
+// Montgomery form of the Bandersnatch coefficient d  (KAT: /root/reference/src/utils.rs:35)
+GM_HD Fr fr_coeff_d() {
+    Fr r;
+    r.l[0] = 0x47a2c730u; r.l[1] = 0xa8dced1bu; r.l[2] = 0xad3cccc7u; r.l[3] = 0x381c065au;
+    r.l[4] = 0x188351f8u; r.l[5] = 0x53ff52e1u; r.l[6] = 0x990fe940u; r.l[7] = 0x362e8d63u;
+    return r;
+}
+
+GM_HD bool fr_is_zero(const Fr& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.l[i];
+    return o == 0;
+}
+
+GM_HD bool fr_eq(const Fr& a, const Fr& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.l[i] ^ b.l[i];
+    return o == 0;
+}
+
+// r = a - p if a >= p else a      (a < 2p)
+GM_HD Fr fr_reduce_once(const Fr& a) {
+    Fr t;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t d = (uint64_t)a.l[i] - fr_p(i) - borrow;
+        t.l[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = borrow ? a.l[i] : t.l[i];
+    return r;
+}
+
+GM_HD Fr fr_add(const Fr& a, const Fr& b) {
+    Fr s;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.l[i] + b.l[i];
+        s.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    // a, b < p < 2^255  =>  no carry out of limb 7
+    return fr_reduce_once(s);
+}
+
+GM_HD Fr fr_dbl(const Fr& a) { return fr_add(a, a); }
+
+GM_HD Fr fr_sub(const Fr& a, const Fr& b) {
+    Fr d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)a.l[i] - b.l[i] - borrow;
+        d.l[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    uint32_t mask = borrow ? 0xffffffffu : 0u;
+    uint64_t c = 0;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)d.l[i] + (fr_p(i) & mask);
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+GM_HD Fr fr_neg(const Fr& a) {
+    if (fr_is_zero(a)) return a;
+    Fr r;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)fr_p(i) - a.l[i] - borrow;
+        r.l[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    return r;
+}
+
+// Montgomery product a*b*R^-1 mod p.  CIOS over 32-bit limbs; quotient digit m = -t0.
+GM_HD Fr fr_mul(const Fr& a, const Fr& b) {
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t bi = b.l[i];
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (uint64_t)a.l[j] * bi + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[8] = (uint32_t)c;
+        // p < 2^255 and a,b < p keep the running value below 2p*2^32: no 10th limb is needed.
+        const uint32_t m = 0u - t[0];
+        // t0 + m*p0 = t0 + m = 0 or 2^32
+        uint64_t k = (t[0] != 0) ? 1 : 0;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            k += (uint64_t)m * fr_p(j) + t[j];
+            t[j - 1] = (uint32_t)k;
+            k >>= 32;
+        }
+        k += t[8];
+        t[7] = (uint32_t)k;
+        t[8] = (uint32_t)(k >> 32);
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    // result < 2p and < 2^256 (t[8] == 0 since 2p < 2^256)
+    return fr_reduce_once(r);
+}
+
+GM_HD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
+
+// x * R  (into Montgomery form): multiply by R^2
+GM_HD Fr fr_r2() {
+    Fr r;
+    r.l[0] = 0xf3f29c6du; r.l[1] = 0xc999e990u; r.l[2] = 0x87925c23u; r.l[3] = 0x2b6cedcbu;
+    r.l[4] = 0x7254398fu; r.l[5] = 0x05d31496u; r.l[6] = 0x9f59ff11u; r.l[7] = 0x0748d9d9u;
+    return r;
+}
+
+GM_HD Fr fr_to_mont(const Fr& a) { return fr_mul(a, fr_r2()); }
+
+GM_HD Fr fr_from_mont(const Fr& a) {
+    Fr one = fr_zero();
+    one.l[0] = 1;
+    return fr_mul(a, one);
+}
+
+GM_HD Fr fr_from_u64(uint64_t v) {
+    Fr a = fr_zero();
+    a.l[0] = (uint32_t)v;
+    a.l[1] = (uint32_t)(v >> 32);
+    return fr_to_mont(a);
+}
+
+// a^(p-2)
+GM_HD Fr fr_inv(const Fr& a) {
+    // p - 2, little-endian 32-bit limbs
+    const uint32_t e[8] = {0xffffffffu, 0xfffffffeu, GM_P2, GM_P3, GM_P4, GM_P5, GM_P6, GM_P7};
+    Fr acc = fr_one();
+    for (int i = 7; i >= 0; i--) {
+        for (int bit = 31; bit >= 0; bit--) {
+            acc = fr_sqr(acc);
+            if ((e[i] >> bit) & 1) acc = fr_mul(acc, a);
+        }
+    }
+    return acc;
+}
+
+// -5x  (/root/reference/src/utils.rs:40-43: two doublings, one add, one negation)
+GM_HD Fr fr_mul_by_a(const Fr& x) {
+    Fr t = fr_dbl(fr_dbl(x));
+    return fr_neg(fr_add(t, x));
+}
+
+GM_HD Fr fr_mul_by_d(const Fr& x) { return fr_mul(x, fr_coeff_d()); }
+
+// ---------------------------------------------------------------- memory (32-byte AoS elements)
+#if defined(__HIPCC__)
+__device__ __forceinline__ Fr fr_load(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    Fr r;
+    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w;
+    r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+    return r;
+}
+
+__device__ __forceinline__ void fr_store(Fr* p, const Fr& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+#endif
+
+}  // namespace gm

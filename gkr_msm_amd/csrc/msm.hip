@@ -1,0 +1,579 @@
+// Pippenger MSM over Bandersnatch for gfx950: digits -> stable bucket scatter -> bucket sums by the
+// reference's pairwise tree -> bucket reduction ("triangle") -> window points.
+//
+// What is restated (see include/gkrmsm.h for the seam list):
+//   digits / bucket scatter   /root/reference/src/cleanup/protocols/pushforward/pushforward.rs:351-361, 401-429
+//   bucket sums               /root/reference/src/cleanup/protocols/gkrs/bintree_add.rs:137-239 (+ vecvec.rs:542-654)
+//   bucket reduction          /root/reference/src/cleanup/protocols/gkrs/triangle_add.rs:101-158,
+//                             /root/reference/src/cleanup/protocols/pippenger_ending.rs:46-58
+//   recombination             /root/reference/src/cleanup/protocols/pippenger.rs:586-602
+//
+// MI355X mapping.  The bucket image is a ragged matrix: row (y << d | digit) holds the points whose
+// window-y digit is `digit`, in x order, padded to even length with the identity (pushforward.rs:380-381,
+// vecvec.rs:181-186).  The reference adds elements (2i, 2i+1) of every row, level by level, x_logsize
+// times; projective coordinates of the bucket sums depend on exactly that association, so it is kept.
+// Rows are stored back to back (offsets always even), which makes every level a flat, perfectly
+// load-balanced map over output cells regardless of how skewed the bucket populations are; a thread
+// finds its row by binary search in the offsets table.  Each level is one launch; the three layer
+// functions l1/l2/l3 are fused in registers (the per-layer outputs are only materialised by the
+// witness builder in witness.hip, which the sumcheck needs; the MSM does not).
+#include "algfn.cuh"
+#include "common.hpp"
+
+namespace gm {
+
+static constexpr uint32_t PAD_IDX = 0xffffffffu;
+static constexpr int CHUNK = 1024;  // x-range handled by one wave in the scatter passes
+
+struct Point3 {
+    Fr x, y, z;
+};
+
+__device__ __forceinline__ Point3 pt_identity() {
+    Point3 p;
+    p.x = fr_zero();
+    p.y = fr_one();
+    p.z = fr_one();
+    return p;
+}
+
+// (x1,y1) + (x2,y2) through affine l1 -> l2 -> l3 (bintree level 0)
+__device__ __forceinline__ Point3 aff_add(const Fr& x1, const Fr& y1, const Fr& x2, const Fr& y2) {
+    Fr in[4] = {x1, y1, x2, y2};
+    Fr a[3], b[3], c[3];
+    aff_l1(in, a);
+    aff_l2(a, b);
+    aff_l3(b, c);
+    Point3 r;
+    r.x = c[0]; r.y = c[1]; r.z = c[2];
+    return r;
+}
+
+// projective l1 -> l2 -> l3 (bintree levels >= 1, triangle)
+__device__ __forceinline__ Point3 proj_add(const Point3& p, const Point3& q) {
+    Fr in[6] = {p.x, p.y, p.z, q.x, q.y, q.z};
+    Fr a[4], b[4], c[3];
+    proj_l1(in, a);
+    proj_l2(a, b);
+    proj_l3(b, c);
+    Point3 r;
+    r.x = c[0]; r.y = c[1]; r.z = c[2];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// digits[(y - y0) * N + x] = d-bit window y of scalar x      (pushforward.rs:351-361)
+__global__ void k_digits(const uint32_t* __restrict__ scalars, uint16_t* __restrict__ digits, uint64_t N,
+                         uint32_t d_log, uint32_t y0, uint32_t nwin) {
+    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= N) return;
+    uint32_t s[9];
+    const uint4* q = reinterpret_cast<const uint4*>(scalars + x * 8);
+    uint4 lo = q[0], hi = q[1];
+    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w;
+    s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w;
+    s[8] = 0;
+    const uint32_t mask = (1u << d_log) - 1;
+    for (uint32_t w = 0; w < nwin; w++) {
+        uint32_t bit = (y0 + w) * d_log;
+        uint32_t v = 0;
+        if (bit < 256) {
+            uint32_t li = bit >> 5, sh = bit & 31;
+            uint64_t two = (uint64_t)s[li] | ((uint64_t)s[li + 1] << 32);
+            v = (uint32_t)(two >> sh) & mask;
+        }
+        digits[(uint64_t)w * N + x] = (uint16_t)v;
+    }
+}
+
+// per (window, chunk) histogram of digits; one wave per chunk
+__global__ void k_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict__ hist, uint64_t N,
+                       uint32_t nd, uint32_t nchunks, uint32_t chunk, uint64_t ntasks) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t waves = blockDim.x >> 6;
+    uint32_t* cnt = lds + wave * nd;
+    const uint64_t task = (uint64_t)blockIdx.x * waves + wave;  // = w * nchunks + c
+    if (task >= ntasks) return;  // whole wave; only wave-level barriers below
+    for (uint32_t i = lane; i < nd; i += 64) cnt[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t w = task / nchunks, c = task % nchunks;
+    const uint16_t* row = digits + w * N;
+    for (uint32_t i = lane; i < chunk; i += 64) {
+        const uint64_t x = c * chunk + i;
+        if (x < N) atomicAdd(&cnt[row[x]], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* out = hist + task * nd;
+    for (uint32_t i = lane; i < nd; i += 64) out[i] = cnt[i];
+}
+
+// exclusive scan over chunks for every (window, digit); totals -> row_len
+__global__ void k_scan_chunks(uint32_t* __restrict__ hist, uint32_t* __restrict__ row_len, uint32_t nd,
+                              uint32_t nchunks, uint32_t nrows) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;  // r = w * nd + digit
+    if (r >= nrows) return;
+    uint32_t w = r / nd, dg = r % nd;
+    uint32_t* p = hist + (uint64_t)w * nchunks * nd + dg;
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        uint32_t v = p[(uint64_t)c * nd];
+        p[(uint64_t)c * nd] = acc;
+        acc += v;
+    }
+    row_len[r] = acc;
+}
+
+// off[r] = sum_{r' < r} f(len[r']),  f = pad-to-even (image) ; single block
+__global__ void k_offsets_from_len(const uint32_t* __restrict__ len, uint32_t* __restrict__ off,
+                                   uint32_t nrows) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nrows; base += blockDim.x) {
+        uint32_t r = base + threadIdx.x;
+        uint32_t v = 0;
+        if (r < nrows) { uint32_t l = len[r]; v = l + (l & 1u); }
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t s = 1; s < blockDim.x; s <<= 1) {
+            uint32_t t = (threadIdx.x >= s) ? part[threadIdx.x - s] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (r < nrows) off[r] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry += part[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[nrows] = carry;
+}
+
+// off_out[r] from off_in: len_out = pad2(len_in / 2)    (vecvec.rs:579-594: split by LSB, re-pad)
+__global__ void k_offsets_next(const uint32_t* __restrict__ off_in, uint32_t* __restrict__ off_out,
+                               uint32_t nrows) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nrows; base += blockDim.x) {
+        uint32_t r = base + threadIdx.x;
+        uint32_t v = 0;
+        if (r < nrows) { uint32_t h = (off_in[r + 1] - off_in[r]) >> 1; v = h + (h & 1u); }
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t s = 1; s < blockDim.x; s <<= 1) {
+            uint32_t t = (threadIdx.x >= s) ? part[threadIdx.x - s] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (r < nrows) off_out[r] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry += part[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off_out[nrows] = carry;
+}
+
+// Stable rank of every x inside its bucket row: counter[w][x] = #{x' < x : digit[w][x'] == digit[w][x]}
+// (pushforward.rs:411-426), and the scatter of x into the row (cells[off[row] + counter] = x).
+// One wave walks one chunk in x order; equal-digit lanes are found with d_log ballots.
+__global__ void k_rank_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ chunk_base,
+                               const uint32_t* __restrict__ off, uint32_t* __restrict__ counter,
+                               uint32_t* __restrict__ cells, uint64_t N, uint32_t d_log, uint32_t nchunks,
+                               uint32_t chunk, uint64_t ntasks) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t nd = 1u << d_log;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t waves = blockDim.x >> 6;
+    uint32_t* cnt = lds + wave * nd;
+    const uint64_t task = (uint64_t)blockIdx.x * waves + wave;
+    if (task >= ntasks) return;  // whole wave exits together; no block-level barrier below
+    const uint64_t w = task / nchunks, c = task % nchunks;
+    const uint32_t* base = chunk_base + task * nd;
+    for (uint32_t i = lane; i < nd; i += 64) cnt[i] = base[i];
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (uint32_t i = 0; i < chunk; i += 64) {
+        const uint64_t x = c * chunk + i + lane;
+        const bool valid = x < N;
+        const uint32_t dg = valid ? digits[w * N + x] : 0u;
+        uint64_t peers = __ballot(valid);
+        for (uint32_t b = 0; b < d_log; b++) {
+            uint64_t m = __ballot((dg >> b) & 1u);
+            peers &= ((dg >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = __popcll(peers & lane_lt);
+        const uint32_t pos = cnt[dg] + before;
+        __builtin_amdgcn_wave_barrier();
+        // the highest peer lane publishes the new count
+        if (valid && (peers >> lane) == 1ull) cnt[dg] = pos + 1;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            counter[w * N + x] = pos;
+            const uint32_t row = (uint32_t)w * nd + dg;
+            cells[(uint64_t)off[row] + pos] = (uint32_t)x;
+        }
+    }
+}
+
+// identity padding of odd rows (vecvec.rs:181-186)
+__global__ void k_pad_cells(const uint32_t* __restrict__ row_len, const uint32_t* __restrict__ off,
+                            uint32_t* __restrict__ cells, uint32_t nrows) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    uint32_t l = row_len[r];
+    if (l & 1u) cells[(uint64_t)off[r] + l] = PAD_IDX;
+}
+
+__device__ __forceinline__ uint32_t find_row(const uint32_t* __restrict__ off, uint32_t nrows, uint32_t j) {
+    // largest r with off[r] <= j  (j < off[nrows])
+    uint32_t lo = 0, hi = nrows;  // invariant: off[lo] <= j < off[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// bintree level 0: gather affine points by index, add pairs (2p, 2p+1) of every row
+__global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* __restrict__ cells,
+                             const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
+                             uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= off_out[nrows]) return;
+    const uint32_t r = find_row(off_out, nrows, j);
+    const uint32_t p = j - off_out[r];
+    const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
+    Point3 res;
+    if (p < half) {
+        const uint32_t i0 = cells[(uint64_t)in0 + 2 * p], i1 = cells[(uint64_t)in0 + 2 * p + 1];
+        Fr x1 = fr_load(points_xy + 2ull * i0), y1 = fr_load(points_xy + 2ull * i0 + 1);
+        Fr x2, y2;
+        if (i1 != PAD_IDX) {
+            x2 = fr_load(points_xy + 2ull * i1);
+            y2 = fr_load(points_xy + 2ull * i1 + 1);
+        } else {
+            x2 = fr_zero();
+            y2 = fr_one();
+        }
+        res = aff_add(x1, y1, x2, y2);
+    } else {
+        res = pt_identity();  // f(row_pad): l3(l2(l1(0,1,0,1))) = (0,1,1)
+    }
+    fr_store(ox + j, res.x);
+    fr_store(oy + j, res.y);
+    fr_store(oz + j, res.z);
+}
+
+// bintree level >= 1
+__global__ void k_add_level(const Fr* __restrict__ ix, const Fr* __restrict__ iy, const Fr* __restrict__ iz,
+                            const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
+                            uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= off_out[nrows]) return;
+    const uint32_t r = find_row(off_out, nrows, j);
+    const uint32_t p = j - off_out[r];
+    const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
+    Point3 res;
+    if (p < half) {
+        const uint64_t a = (uint64_t)in0 + 2 * p;
+        Point3 P, Q;
+        P.x = fr_load(ix + a); P.y = fr_load(iy + a); P.z = fr_load(iz + a);
+        Q.x = fr_load(ix + a + 1); Q.y = fr_load(iy + a + 1); Q.z = fr_load(iz + a + 1);
+        res = proj_add(P, Q);
+    } else {
+        res = pt_identity();
+    }
+    fr_store(ox + j, res.x);
+    fr_store(oy + j, res.y);
+    fr_store(oz + j, res.z);
+}
+
+// last bintree level: every row has 0 or 2 cells; output is dense over rows
+// (vecvec_map_split_to_dense, vecvec.rs:608-654: an empty row contributes the row pad)
+template <bool LEVEL0>
+__global__ void k_add_last(const Fr* __restrict__ points_xy, const uint32_t* __restrict__ cells,
+                           const Fr* __restrict__ ix, const Fr* __restrict__ iy, const Fr* __restrict__ iz,
+                           const uint32_t* __restrict__ off_in, uint32_t nrows, Fr* __restrict__ ox,
+                           Fr* __restrict__ oy, Fr* __restrict__ oz) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t in0 = off_in[r], len = off_in[r + 1] - in0;
+    Point3 res;
+    if (LEVEL0) {
+        Fr x1 = fr_zero(), y1 = fr_one(), x2 = fr_zero(), y2 = fr_one();
+        if (len) {
+            uint32_t i0 = cells[in0], i1 = cells[in0 + 1];
+            x1 = fr_load(points_xy + 2ull * i0); y1 = fr_load(points_xy + 2ull * i0 + 1);
+            if (i1 != PAD_IDX) { x2 = fr_load(points_xy + 2ull * i1); y2 = fr_load(points_xy + 2ull * i1 + 1); }
+        }
+        res = aff_add(x1, y1, x2, y2);
+    } else {
+        Point3 P = pt_identity(), Q = pt_identity();
+        if (len) {
+            P.x = fr_load(ix + in0); P.y = fr_load(iy + in0); P.z = fr_load(iz + in0);
+            Q.x = fr_load(ix + in0 + 1); Q.y = fr_load(iy + in0 + 1); Q.z = fr_load(iz + in0 + 1);
+        }
+        res = proj_add(P, Q);
+    }
+    fr_store(ox + r, res.x);
+    fr_store(oy + r, res.y);
+    fr_store(oz + r, res.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bucket reduction, one workgroup per window.  Restates pippenger_ending.rs:46-58 (two splits at the
+// top two digit bits) + triangle_add.rs:101-158 (layers 0..d-2) + `last_step` (triangle_add.rs:88-99).
+// Window w owns nd = 2^d bucket sums; all intermediate points live in LDS.
+//
+// Layer l works on arrays of length n_l = nd >> (2 + l) holding points  a,b,c,d  and  l  carried pairs:
+//   L1..L3:  P0 = a + c, P1 = b + d, P2 = c + d, S_k = (pair_k.0 + pair_k.1)        (l + 3 adds / index)
+//   split at the next digit bit (HI(y_logsize), bundle 3): every output point is cut in lower / upper half,
+//   so the next layer sees  a'=P0.lo b'=P0.hi c'=P1.lo d'=P1.hi  and pairs (P2.lo,P2.hi),(S_0.lo,S_0.hi),...
+// The last layer is not split; its l + 3 = d + 1 points (arrays of length 1) are the window points.
+template <bool USE_LDS>
+__global__ void k_triangle(const Fr* __restrict__ bx, const Fr* __restrict__ by, const Fr* __restrict__ bz,
+                           uint32_t d_log, uint32_t nwin, Fr* __restrict__ out_cols /* 3*(d+1) cols x nwin */,
+                           Point3* __restrict__ scratch /* 2*nd points per window when !USE_LDS */) {
+    extern __shared__ unsigned char smem[];
+    const uint32_t nd = 1u << d_log;
+    const uint32_t w = blockIdx.x;
+    // nd points, layout described below (d_log = 9, 10 do not fit the default 64 KiB of LDS: global scratch)
+    Point3* cur = USE_LDS ? reinterpret_cast<Point3*>(smem) : scratch + (uint64_t)w * 2 * nd;
+    Point3* nxt = cur + nd;
+    // load: cur[q * n0 + i], q in {a,b,c,d} = (top bit, next bit) = 00,01,10,11; i = low d-2 bits
+    for (uint32_t t = threadIdx.x; t < nd; t += blockDim.x) {
+        Point3 p;
+        p.x = fr_load(bx + (uint64_t)w * nd + t);
+        p.y = fr_load(by + (uint64_t)w * nd + t);
+        p.z = fr_load(bz + (uint64_t)w * nd + t);
+        cur[t] = p;  // digit t = q * n0 + i already (q = top two bits)
+    }
+    __syncthreads();
+    const uint32_t num_layers = d_log - 2;
+    uint32_t n = nd >> 2;  // array length at this layer
+    for (uint32_t l = 0; l <= num_layers; l++) {
+        // inputs: 4 + 2l arrays of length n, array k at cur[k * n + i]
+        const uint32_t nadds = l + 3;
+        for (uint32_t t = threadIdx.x; t < nadds * n; t += blockDim.x) {
+            const uint32_t k = t / n, i = t % n;
+            uint32_t ia, ib;
+            if (k == 0) { ia = 0; ib = 2; }            // a + c
+            else if (k == 1) { ia = 1; ib = 3; }       // b + d
+            else if (k == 2) { ia = 2; ib = 3; }       // c + d
+            else { ia = 4 + 2 * (k - 3); ib = ia + 1; }  // carried pair
+            Point3 r = proj_add(cur[ia * n + i], cur[ib * n + i]);
+            if (l < num_layers) {
+                // split on the top bit of i: halves of length n/2; output point k -> arrays 2k (lo), 2k+1 (hi)
+                const uint32_t h = n >> 1;
+                const uint32_t hi = i / h, ii = i % h;
+                nxt[(2 * k + hi) * h + ii] = r;
+            } else {
+                nxt[k] = r;  // n == 1
+            }
+        }
+        __syncthreads();
+        Point3* tmp = cur; cur = nxt; nxt = tmp;
+        n >>= 1;
+    }
+    // cur[k], k = 0..d : window points; column order X0,Y0,Z0,X1,...
+    for (uint32_t k = threadIdx.x; k <= d_log; k += blockDim.x) {
+        fr_store(out_cols + (uint64_t)(3 * k + 0) * nwin + w, cur[k].x);
+        fr_store(out_cols + (uint64_t)(3 * k + 1) * nwin + w, cur[k].y);
+        fr_store(out_cols + (uint64_t)(3 * k + 2) * nwin + w, cur[k].z);
+    }
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+struct gm_msm_plan {
+    uint32_t x_log, d_log, y_size, y0, y1, nwin, nd, nrows, nchunks, chunk;
+    uint64_t N;
+    uint16_t* digits = nullptr;
+    uint32_t* counter = nullptr;
+    uint32_t* hist = nullptr;
+    uint32_t* row_len = nullptr;
+    uint32_t* off[2] = {nullptr, nullptr};
+    uint32_t* cells = nullptr;
+    Fr* lvl[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    Fr* bsum[3] = {nullptr, nullptr, nullptr};
+    Fr* win_pts = nullptr;
+    Fr* tri_scratch = nullptr;
+    uint64_t cap0, cap1;  // cell capacity of level buffers
+    size_t bytes = 0;
+};
+
+template <typename T>
+static int32_t plan_alloc(gm_msm_plan* p, T** ptr, uint64_t count) {
+    size_t b = (size_t)count * sizeof(T);
+    if (b == 0) b = 16;
+    GM_HIP(hipMalloc((void**)ptr, b));
+    p->bytes += b;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_size, uint32_t y_begin,
+                                      uint32_t y_end, gm_msm_plan** out) {
+    GM_REQUIRE(out != nullptr, "null out");
+    GM_REQUIRE(x_logsize >= 1 && x_logsize <= 26, "x_logsize %u out of range [1,26]", x_logsize);
+    GM_REQUIRE(d_logsize >= 2 && d_logsize <= 10, "d_logsize %u out of range [2,10] (examples/pippenger.rs:24)",
+               d_logsize);
+    GM_REQUIRE(y_size >= 1 && (uint64_t)y_size * d_logsize <= 256,
+               "y_size*d_logsize = %u > 256 (pushforward.rs:358 would index past the scalar bits)",
+               y_size * d_logsize);
+    GM_REQUIRE(y_begin < y_end && y_end <= y_size, "bad window range [%u,%u) of %u", y_begin, y_end, y_size);
+    gm_msm_plan* p = new gm_msm_plan();
+    p->x_log = x_logsize; p->d_log = d_logsize; p->y_size = y_size; p->y0 = y_begin; p->y1 = y_end;
+    p->nwin = y_end - y_begin; p->nd = 1u << d_logsize; p->nrows = p->nwin << d_logsize;
+    p->N = 1ull << x_logsize;
+    p->chunk = CHUNK;
+    p->nchunks = (uint32_t)((p->N + p->chunk - 1) / p->chunk);
+    const uint64_t cells_in = (uint64_t)p->nwin * p->N + p->nrows;  // + one pad per row at most
+    GM_REQUIRE(cells_in < 0xfffffff0ull, "too many cells for 32-bit offsets");
+    p->cap0 = cells_in / 2 + p->nrows + 2;
+    p->cap1 = p->cap0 / 2 + p->nrows + 2;
+    int32_t rc = GM_OK;
+#define ALLOC(ptr, n) if ((rc = plan_alloc(p, &(ptr), (n))) != GM_OK) { gm_msm_plan_destroy(p); return rc; }
+    ALLOC(p->digits, (uint64_t)p->nwin * p->N);
+    ALLOC(p->counter, (uint64_t)p->nwin * p->N);
+    ALLOC(p->hist, (uint64_t)p->nwin * p->nchunks * p->nd);
+    ALLOC(p->row_len, p->nrows);
+    ALLOC(p->off[0], p->nrows + 1);
+    ALLOC(p->off[1], p->nrows + 1);
+    ALLOC(p->cells, cells_in + 2);
+    for (int c = 0; c < 3; c++) {
+        ALLOC(p->lvl[0][c], p->cap0);
+        ALLOC(p->lvl[1][c], p->cap1);
+        ALLOC(p->bsum[c], p->nrows);
+    }
+    ALLOC(p->win_pts, (uint64_t)3 * (d_logsize + 1) * p->nwin);
+    if (2ull * p->nd * sizeof(Point3) > 48 * 1024) ALLOC(p->tri_scratch, (uint64_t)p->nwin * 2 * p->nd * 3);
+#undef ALLOC
+    *out = p;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_msm_plan_destroy(gm_msm_plan* p) {
+    if (!p) return GM_OK;
+    hipFree(p->digits); hipFree(p->counter); hipFree(p->hist); hipFree(p->row_len);
+    hipFree(p->off[0]); hipFree(p->off[1]); hipFree(p->cells);
+    for (int c = 0; c < 3; c++) { hipFree(p->lvl[0][c]); hipFree(p->lvl[1][c]); hipFree(p->bsum[c]); }
+    hipFree(p->win_pts);
+    hipFree(p->tri_scratch);
+    delete p;
+    return GM_OK;
+}
+
+extern "C" size_t gm_msm_plan_workspace_bytes(const gm_msm_plan* p) { return p ? p->bytes : 0; }
+
+extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const uint64_t* d_scalars, void* stream) {
+    GM_REQUIRE(p && d_points_xy && d_scalars, "null argument");
+    hipStream_t s = as_stream(stream);
+    const uint64_t N = p->N;
+    const uint32_t nrows = p->nrows, nd = p->nd;
+    const Fr* pts = reinterpret_cast<const Fr*>(d_points_xy);
+
+    // 1. digits
+    hipLaunchKernelGGL(k_digits, dim3(ceil_div(N, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const uint32_t*>(d_scalars), p->digits, N, p->d_log, p->y0, p->nwin);
+    GM_LAUNCH_CHECK();
+    // 2. histogram per (window, chunk), scan over chunks, row offsets
+    const uint64_t ntasks = (uint64_t)p->nwin * p->nchunks;
+    const uint32_t waves = 4;
+    hipLaunchKernelGGL(k_hist, dim3(ceil_div(ntasks, waves)), dim3(64 * waves), waves * nd * sizeof(uint32_t), s,
+                       p->digits, p->hist, N, nd, p->nchunks, p->chunk, ntasks);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_chunks, dim3(ceil_div(nrows, 256)), dim3(256), 0, s, p->hist, p->row_len, nd,
+                       p->nchunks, nrows);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_offsets_from_len, dim3(1), dim3(1024), 0, s, p->row_len, p->off[0], nrows);
+    GM_LAUNCH_CHECK();
+    // 3. stable scatter
+    hipLaunchKernelGGL(k_rank_scatter, dim3(ceil_div(ntasks, waves)), dim3(64 * waves),
+                       waves * nd * sizeof(uint32_t), s, p->digits, p->hist, p->off[0], p->counter, p->cells, N,
+                       p->d_log, p->nchunks, p->chunk, ntasks);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pad_cells, dim3(ceil_div(nrows, 256)), dim3(256), 0, s, p->row_len, p->off[0], p->cells,
+                       nrows);
+    GM_LAUNCH_CHECK();
+    // 4. bucket sums: x_log levels of pairwise adds
+    uint64_t cap_out = p->cap0;
+    int cur_off = 0;
+    if (p->x_log == 1) {
+        hipLaunchKernelGGL((k_add_last<true>), dim3(ceil_div(nrows, 128)), dim3(128), 0, s, pts, p->cells,
+                           (const Fr*)nullptr, (const Fr*)nullptr, (const Fr*)nullptr, p->off[0], nrows, p->bsum[0],
+                           p->bsum[1], p->bsum[2]);
+        GM_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(k_offsets_next, dim3(1), dim3(1024), 0, s, p->off[0], p->off[1], nrows);
+        GM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_add_level0, dim3(ceil_div(cap_out, 128)), dim3(128), 0, s, pts, p->cells, p->off[0],
+                           p->off[1], nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2]);
+        GM_LAUNCH_CHECK();
+        cur_off = 1;
+        int cur_lvl = 0;
+        uint64_t cells_cur = cap_out;
+        for (uint32_t level = 1; level + 1 < p->x_log; level++) {
+            const uint64_t cells_next = cells_cur / 2 + nrows + 2;
+            hipLaunchKernelGGL(k_offsets_next, dim3(1), dim3(1024), 0, s, p->off[cur_off], p->off[cur_off ^ 1], nrows);
+            GM_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_add_level, dim3(ceil_div(cells_next, 128)), dim3(128), 0, s, p->lvl[cur_lvl][0],
+                               p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[cur_off], p->off[cur_off ^ 1], nrows,
+                               p->lvl[cur_lvl ^ 1][0], p->lvl[cur_lvl ^ 1][1], p->lvl[cur_lvl ^ 1][2]);
+            GM_LAUNCH_CHECK();
+            cur_off ^= 1;
+            cur_lvl ^= 1;
+            cells_cur = cells_next;
+        }
+        hipLaunchKernelGGL((k_add_last<false>), dim3(ceil_div(nrows, 128)), dim3(128), 0, s, (const Fr*)nullptr,
+                           (const uint32_t*)nullptr, p->lvl[cur_lvl][0], p->lvl[cur_lvl][1], p->lvl[cur_lvl][2],
+                           p->off[cur_off], nrows, p->bsum[0], p->bsum[1], p->bsum[2]);
+        GM_LAUNCH_CHECK();
+    }
+    // 5. bucket reduction per window
+    const size_t lds = 2 * (size_t)nd * sizeof(Point3);
+    const dim3 tb(nd < 256 ? (nd < 64 ? 64 : nd) : 256);
+    if (lds <= 48 * 1024) {
+        hipLaunchKernelGGL((k_triangle<true>), dim3(p->nwin), tb, lds, s, p->bsum[0], p->bsum[1], p->bsum[2],
+                           p->d_log, p->nwin, p->win_pts, (Point3*)nullptr);
+    } else {
+        hipLaunchKernelGGL((k_triangle<false>), dim3(p->nwin), tb, 0, s, p->bsum[0], p->bsum[1], p->bsum[2],
+                           p->d_log, p->nwin, p->win_pts, reinterpret_cast<Point3*>(p->tri_scratch));
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_msm_bucket_sums(const gm_msm_plan* p, const uint64_t** d_x, const uint64_t** d_y,
+                                      const uint64_t** d_z, uint64_t* n_rows_local) {
+    GM_REQUIRE(p, "null plan");
+    if (d_x) *d_x = reinterpret_cast<const uint64_t*>(p->bsum[0]);
+    if (d_y) *d_y = reinterpret_cast<const uint64_t*>(p->bsum[1]);
+    if (d_z) *d_z = reinterpret_cast<const uint64_t*>(p->bsum[2]);
+    if (n_rows_local) *n_rows_local = p->nrows;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_msm_window_points(const gm_msm_plan* p, const uint64_t** d_cols, uint64_t* n_cols,
+                                        uint64_t* col_len) {
+    GM_REQUIRE(p, "null plan");
+    if (d_cols) *d_cols = reinterpret_cast<const uint64_t*>(p->win_pts);
+    if (n_cols) *n_cols = 3ull * (p->d_log + 1);
+    if (col_len) *col_len = p->nwin;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_msm_digits(const gm_msm_plan* p, const uint16_t** d_digits, const uint32_t** d_counter,
+                                 const uint32_t** d_row_len) {
+    GM_REQUIRE(p, "null plan");
+    if (d_digits) *d_digits = p->digits;
+    if (d_counter) *d_counter = p->counter;
+    if (d_row_len) *d_row_len = p->row_len;
+    return GM_OK;
+}

@@ -1,0 +1,92 @@
+"""ctypes binding of libgkrmsm_hip.so (the C ABI in include/gkrmsm.h).
+
+This is harness plumbing for tests and bench.py -- the product is the shared library.  There is no
+fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgkrmsm_hip.so")
+
+
+class GmError(RuntimeError):
+    pass
+
+
+class GmFn(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("prim", C.c_int32 * 4), ("count", C.c_int32 * 4)]
+
+
+FN_AFF_L1, FN_AFF_L2, FN_AFF_L3, FN_PROJ_L1, FN_PROJ_L2, FN_PROJ_L3 = 1, 2, 3, 4, 5, 6
+FN_TRI_L1, FN_ID, FN_BITCHECK, FN_PT_BIT_CHOICE = 7, 8, 9, 10
+
+
+def make_fn(*segs):
+    """make_fn((prim, count), ...)  ->  GmFn  (Stacked / Repeated composition, left to right)"""
+    f = GmFn()
+    f.nseg = len(segs)
+    for i, (p, c) in enumerate(segs):
+        f.prim[i] = p
+        f.count[i] = c
+    return f
+
+
+_lib = None
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16)
+vp = C.c_void_p
+
+_SIGS = {
+    "gm_last_error": (C.c_char_p, []),
+    "gm_version": (C.c_char_p, []),
+    "gm_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "gm_set_device": (C.c_int32, [C.c_int32]),
+    "gm_stream_sync": (C.c_int32, [vp]),
+    "gm_malloc": (C.c_int32, [C.POINTER(vp), C.c_size_t]),
+    "gm_free": (C.c_int32, [vp]),
+    "gm_memcpy_h2d": (C.c_int32, [vp, vp, C.c_size_t, vp]),
+    "gm_memcpy_d2h": (C.c_int32, [vp, vp, C.c_size_t, vp]),
+    "gm_fn_shape": (C.c_int32, [C.POINTER(GmFn), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gm_fr_batch": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64, vp]),
+    "gm_fr_host": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64]),
+    "gm_fn_host": (C.c_int32, [C.POINTER(GmFn), vp, vp, C.c_uint64]),
+    "gm_msm_plan_create": (C.c_int32, [C.c_uint32] * 5 + [C.POINTER(vp)]),
+    "gm_msm_plan_destroy": (C.c_int32, [vp]),
+    "gm_msm_plan_workspace_bytes": (C.c_size_t, [vp]),
+    "gm_msm_run": (C.c_int32, [vp, vp, vp, vp]),
+    "gm_msm_bucket_sums": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]),
+    "gm_msm_window_points": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gm_msm_digits": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "gm_msm_combine_host": (C.c_int32, [vp, C.c_uint32, C.c_uint32, vp]),
+    "gm_msm_te": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
+    "gm_bs_scalars_into_bigint": (C.c_int32, [vp, vp, C.c_uint64, vp]),
+    "gm_gen_points": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load the shared library (once).  Raises GmError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GmError("libgkrmsm_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(expected at %s)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise GmError("gkrmsm error %d: %s" % (rc, lib().gm_last_error().decode()))

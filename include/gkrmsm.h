@@ -1,0 +1,137 @@
+/* gkrmsm.h -- C ABI of libgkrmsm_hip.so: the MI355X (gfx950) drop-in for the Pippenger-MSM +
+ * GKR-sumcheck hot path of morgana-proofs/GKR-MSM.
+ *
+ * The reference is a pure-Rust crate with no FFI of its own; every entry point below names the Rust
+ * seam (file:line under /root/reference) that a `extern "C"` shim would route here (INTEGRATION.md
+ * shows the shim).  Conventions:
+ *   - every function returns 0 on success, non-zero GM_ERR_* otherwise; gm_last_error() gives text
+ *     (the reference convention is panic!/assert!, the Rust shim turns non-zero into panic!);
+ *   - field elements are BLS12-381 Fr in the reference's in-memory form: Montgomery (R = 2^256),
+ *     4 x u64 little-endian limbs, 32 bytes, i.e. `&[Fr]` passes as `*const u64` unchanged;
+ *   - Bandersnatch points are twisted-Edwards `Affine{x,y}` = 64 bytes (x then y);
+ *   - pointers named d_* are DEVICE pointers (hipMalloc / torch data_ptr), h_* are host pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); no call synchronises the
+ *     device unless it returns data into an h_* buffer;
+ *   - no hipMalloc/hipFree happens inside *_run / round / bind calls (workspaces live in handles).
+ */
+#ifndef GKRMSM_H
+#define GKRMSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_OK 0
+#define GM_ERR_INVALID 1   /* bad argument (mirrors an assert! in the reference) */
+#define GM_ERR_HIP 2       /* HIP runtime failure */
+#define GM_ERR_NO_DEVICE 3 /* no gfx950 device visible */
+#define GM_ERR_STATE 4     /* call order violated (e.g. bind before unipoly: vecvec_eq.rs:305-307) */
+
+/* ---------------------------------------------------------------- runtime */
+const char* gm_last_error(void);
+const char* gm_version(void);
+int32_t gm_device_count(int32_t* out_count);
+int32_t gm_set_device(int32_t device);
+int32_t gm_stream_sync(void* stream);
+/* plain device memory helpers for non-torch callers (the Rust shim) */
+int32_t gm_malloc(void** out_d_ptr, size_t bytes);
+int32_t gm_free(void* d_ptr);
+int32_t gm_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int32_t gm_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+
+/* ---------------------------------------------------------------- AlgFn descriptors
+ * Replaces the Rust generics `Fun: AlgFn<F>` (src/cleanup/utils/algfn.rs:21-34).  A function is a
+ * left-to-right stack of up to 4 segments (primitive id, repeat count):
+ *   StackedAlgFn::new(f1, RepeatedAlgFn::new(f2, n))  ==  nseg=2, prim={f1,f2}, count={1,n}
+ * Primitive ids: twisted_edwards_ops.rs:150-156 plus algfn.rs Id/BitCheck and gen-1 pt_bit_choice. */
+#define GM_FN_AFF_L1 1   /* affine_twisted_edwards_add_l1   (deg 2, 4 -> 3)  */
+#define GM_FN_AFF_L2 2   /* affine_twisted_edwards_add_l2   (deg 2, 3 -> 3)  */
+#define GM_FN_AFF_L3 3   /* affine_twisted_edwards_add_l3   (deg 2, 3 -> 3)  */
+#define GM_FN_PROJ_L1 4  /* twisted_edwards_add_l1          (deg 2, 6 -> 4)  */
+#define GM_FN_PROJ_L2 5  /* twisted_edwards_add_l2          (deg 2, 4 -> 4)  */
+#define GM_FN_PROJ_L3 6  /* twisted_edwards_add_l3          (deg 2, 4 -> 3)  */
+#define GM_FN_TRI_L1 7   /* triangle_twisted_edwards_add_l1 (deg 2, 12 -> 12) */
+#define GM_FN_ID 8       /* IdAlgFn::new(1); use count=n for IdAlgFn::new(n) */
+#define GM_FN_BITCHECK 9 /* BitCheckFn */
+#define GM_FN_PT_BIT_CHOICE 10 /* gkr_msm_simple.rs:82-84 */
+#define GM_FN_MAX_SEG 4
+
+typedef struct gm_fn {
+    int32_t nseg;
+    int32_t prim[GM_FN_MAX_SEG];
+    int32_t count[GM_FN_MAX_SEG];
+} gm_fn;
+
+int32_t gm_fn_shape(const gm_fn* f, int32_t* n_ins, int32_t* n_outs, int32_t* deg);
+
+/* ---------------------------------------------------------------- field batch ops (a1)
+ * Elementwise Fr arithmetic over device arrays; replaces ark-ff operator calls inside the
+ * reference's rayon loops (src/utils.rs:22-49).  op: 0 add, 1 sub, 2 mul, 3 neg(a), 4 inverse(a),
+ * 5 to-Montgomery(a), 6 from-Montgomery(a), 7 mul_by_a(a) = -5a, 8 mul_by_d(a). */
+int32_t gm_fr_batch(int32_t op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n,
+                    void* stream);
+/* same ops on host memory, scalar code (host glue; used by the CPU-side tests) */
+int32_t gm_fr_host(int32_t op, const uint64_t* h_a, const uint64_t* h_b, uint64_t* h_out, uint64_t n);
+/* exec an AlgFn on host rows: h_in = n rows x n_ins elements, h_out = n rows x n_outs elements */
+int32_t gm_fn_host(const gm_fn* f, const uint64_t* h_in, uint64_t* h_out, uint64_t n);
+
+/* ---------------------------------------------------------------- Pippenger MSM (a11, a12, a14)
+ * The reference's bucketed MSM over Bandersnatch:
+ *   digits + bucket scatter      PushForwardState::new      pushforward/pushforward.rs:351-361, 401-429
+ *   bucket sums (pairwise tree)  bintree_add witness        gkrs/bintree_add.rs:137-239
+ *   bucket reduction             triangle_add witness       gkrs/triangle_add.rs:101-158, pippenger_ending.rs:47-58
+ *   final recombination          verify_pippenger           pippenger.rs:586-602
+ * and, as a whole, the `VariableBaseMsmNonaffine::msm_bigint_nonaff(bases, bigints) -> G` call shape
+ * (msm_nonaffine.rs:41-50) for G = Bandersnatch.
+ *
+ * A plan owns all workspaces for one shape; windows [y_begin, y_end) of the y_size windows are
+ * processed by this plan (multi-GPU: one plan per rank, windows partitioned, no data-path exchange
+ * until the (d+1)-points-per-window outputs are gathered). */
+typedef struct gm_msm_plan gm_msm_plan;
+
+int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_size, uint32_t y_begin,
+                           uint32_t y_end, gm_msm_plan** out);
+int32_t gm_msm_plan_destroy(gm_msm_plan* plan);
+size_t gm_msm_plan_workspace_bytes(const gm_msm_plan* plan);
+
+/* scalars: canonical bigints (what `into_bigint()` yields, msm_nonaffine.rs:21-23), 4 x u64 LE each.
+ * Runs digits -> bucketize -> bucket sums -> bucket reduction; asynchronous on `stream`. */
+int32_t gm_msm_run(gm_msm_plan* plan, const uint64_t* d_points_xy, const uint64_t* d_scalars, void* stream);
+
+/* Results of the last run (device pointers owned by the plan, valid until the next run/destroy):
+ *   bucket sums: 3 dense columns X,Y,Z of n_rows_local = (y_end-y_begin) << d_logsize elements each,
+ *                row (y - y_begin) << d | digit  == bintree `last_step` output restricted to our windows;
+ *   window points: 3*(d_logsize+1) columns of (y_end-y_begin) elements, column order
+ *                [X0,Y0,Z0, X1,Y1,Z1, ...] == triangle `last_step` output (pippenger.rs:531-534);
+ *   digits (u16) / counter (u32): [(y - y_begin) * N + x]                (pushforward.rs:351-361, 423);
+ *   row_len (u32): bucket populations, n_rows_local entries. */
+int32_t gm_msm_bucket_sums(const gm_msm_plan* plan, const uint64_t** d_x, const uint64_t** d_y,
+                           const uint64_t** d_z, uint64_t* n_rows_local);
+int32_t gm_msm_window_points(const gm_msm_plan* plan, const uint64_t** d_cols, uint64_t* n_cols,
+                             uint64_t* col_len);
+int32_t gm_msm_digits(const gm_msm_plan* plan, const uint16_t** d_digits, const uint32_t** d_counter,
+                      const uint32_t** d_row_len);
+
+/* Final recombination acc = sum_w 2^(d*w) sum_{i>=1} 2^(i-1) P[i][w] on the host from the window points
+ * of ALL windows (h_cols: 3*(d+1) columns x n_windows, Montgomery); writes affine (x,y), 8 x u64. */
+int32_t gm_msm_combine_host(const uint64_t* h_cols, uint32_t d_logsize, uint32_t n_windows,
+                            uint64_t* h_out_xy);
+
+/* One-shot convenience: plan over all windows + run + D2H + combine; synchronises `stream`. */
+int32_t gm_msm_te(const uint64_t* d_points_xy, const uint64_t* d_scalars, uint32_t x_logsize,
+                  uint32_t d_logsize, uint32_t nbits, uint64_t* h_out_xy, void* stream);
+
+/* Bandersnatch ScalarField (Montgomery, as stored by ark `Fr` of ark-ed-on-bls12-381-bandersnatch)
+ * -> canonical bigint: the `into_bigint()` of pushforward.rs:352 / msm_nonaffine.rs:21-23. */
+int32_t gm_bs_scalars_into_bigint(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream);
+
+/* Synthetic inputs (bench / tests): n points k_i*G of the prime-order subgroup, affine Montgomery. */
+int32_t gm_gen_points(uint64_t* d_points_xy, uint64_t n, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKRMSM_H */
