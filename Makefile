@@ -1,0 +1,26 @@
+# Builds the product library (HIP, gfx950 only) and the test oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+SRC := $(wildcard gkr_msm_amd/csrc/*.hip)
+OBJ := $(patsubst gkr_msm_amd/csrc/%.hip,build/%.o,$(SRC))
+HDR := $(wildcard gkr_msm_amd/csrc/*.cuh) $(wildcard gkr_msm_amd/csrc/*.hpp) include/gkrmsm.h
+LIB := gkr_msm_amd/libgkrmsm_hip.so
+
+all: $(LIB) oracle
+
+$(LIB): $(OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+
+build/%.o: gkr_msm_amd/csrc/%.hip $(HDR)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -s -C oracle clean
+
+.PHONY: all oracle clean

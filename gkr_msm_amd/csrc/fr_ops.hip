@@ -166,6 +166,11 @@ extern "C" int32_t gm_memcpy_d2h(void* h, const void* d, size_t bytes, void* str
     return GM_OK;
 }
 
+extern "C" int32_t gm_memcpy_d2d(void* d, const void* sPtr, size_t bytes, void* stream) {
+    GM_HIP(hipMemcpyAsync(d, sPtr, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return GM_OK;
+}
+
 extern "C" int32_t gm_fn_shape(const gm_fn* f, int32_t* n_ins, int32_t* n_outs, int32_t* deg) {
     GM_REQUIRE(f && f->nseg >= 1 && f->nseg <= GM_FN_MAX_SEG, "bad gm_fn");
     GmFn g;

@@ -392,6 +392,7 @@ __global__ void k_triangle(const Fr* __restrict__ bx, const Fr* __restrict__ by,
 
 using namespace gm;
 
+#define GM_MSM_NSTAGE 7
 struct gm_msm_plan {
     uint32_t x_log, d_log, y_size, y0, y1, nwin, nd, nrows, nchunks, chunk;
     uint64_t N;
@@ -407,6 +408,10 @@ struct gm_msm_plan {
     Fr* tri_scratch = nullptr;
     uint64_t cap0, cap1;  // cell capacity of level buffers
     size_t bytes = 0;
+    // stage timing (bench only): events bracket the stages of gm_msm_run on the launch stream
+    int prof_mode = 0;  // 0 off, 1 dominant kernel only (level-0 add), 2 all stages
+    hipEvent_t ev[GM_MSM_NSTAGE + 1] = {};
+    bool ev_rec[GM_MSM_NSTAGE + 1] = {};
 };
 
 template <typename T>
@@ -461,12 +466,35 @@ extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, ui
 
 extern "C" int32_t gm_msm_plan_destroy(gm_msm_plan* p) {
     if (!p) return GM_OK;
-    hipFree(p->digits); hipFree(p->counter); hipFree(p->hist); hipFree(p->row_len);
-    hipFree(p->off[0]); hipFree(p->off[1]); hipFree(p->cells);
-    for (int c = 0; c < 3; c++) { hipFree(p->lvl[0][c]); hipFree(p->lvl[1][c]); hipFree(p->bsum[c]); }
-    hipFree(p->win_pts);
-    hipFree(p->tri_scratch);
+    (void)hipFree(p->digits); (void)hipFree(p->counter); (void)hipFree(p->hist); (void)hipFree(p->row_len);
+    (void)hipFree(p->off[0]); (void)hipFree(p->off[1]); (void)hipFree(p->cells);
+    for (int c = 0; c < 3; c++) { (void)hipFree(p->lvl[0][c]); (void)hipFree(p->lvl[1][c]); (void)hipFree(p->bsum[c]); }
+    (void)hipFree(p->win_pts);
+    (void)hipFree(p->tri_scratch);
+    for (int i = 0; i <= GM_MSM_NSTAGE; i++) if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
     delete p;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_msm_profile(gm_msm_plan* p, int32_t mode) {
+    GM_REQUIRE(p && mode >= 0 && mode <= 2, "bad argument");
+    if (mode && !p->ev[0])
+        for (int i = 0; i <= GM_MSM_NSTAGE; i++) GM_HIP(hipEventCreate(&p->ev[i]));
+    p->prof_mode = mode;
+    return GM_OK;
+}
+
+// ms per stage of the LAST run: 0 digits, 1 histogram, 2 chunk scan + offsets, 3 scatter, 4 level-0 add,
+// 5 levels >= 1, 6 triangle; -1 where not recorded.  Synchronises on the recorded events.
+extern "C" int32_t gm_msm_profile_read(gm_msm_plan* p, float* h_ms, int32_t n) {
+    GM_REQUIRE(p && h_ms && n >= GM_MSM_NSTAGE, "bad argument");
+    for (int i = 0; i < GM_MSM_NSTAGE; i++) {
+        h_ms[i] = -1.f;
+        if (p->ev_rec[i] && p->ev_rec[i + 1]) {
+            GM_HIP(hipEventSynchronize(p->ev[i + 1]));
+            GM_HIP(hipEventElapsedTime(&h_ms[i], p->ev[i], p->ev[i + 1]));
+        }
+    }
     return GM_OK;
 }
 
@@ -478,22 +506,34 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     const uint64_t N = p->N;
     const uint32_t nrows = p->nrows, nd = p->nd;
     const Fr* pts = reinterpret_cast<const Fr*>(d_points_xy);
+    for (int i = 0; i <= GM_MSM_NSTAGE; i++) p->ev_rec[i] = false;
+#define STAGE_MARK(i)                                                                                   \
+    do {                                                                                                \
+        if (p->prof_mode == 2 || (p->prof_mode == 1 && ((i) == 4 || (i) == 5))) {                        \
+            GM_HIP(hipEventRecord(p->ev[i], s));                                                        \
+            p->ev_rec[i] = true;                                                                        \
+        }                                                                                               \
+    } while (0)
 
+    STAGE_MARK(0);
     // 1. digits
     hipLaunchKernelGGL(k_digits, dim3(ceil_div(N, 256)), dim3(256), 0, s,
                        reinterpret_cast<const uint32_t*>(d_scalars), p->digits, N, p->d_log, p->y0, p->nwin);
     GM_LAUNCH_CHECK();
+    STAGE_MARK(1);
     // 2. histogram per (window, chunk), scan over chunks, row offsets
     const uint64_t ntasks = (uint64_t)p->nwin * p->nchunks;
     const uint32_t waves = 4;
     hipLaunchKernelGGL(k_hist, dim3(ceil_div(ntasks, waves)), dim3(64 * waves), waves * nd * sizeof(uint32_t), s,
                        p->digits, p->hist, N, nd, p->nchunks, p->chunk, ntasks);
     GM_LAUNCH_CHECK();
+    STAGE_MARK(2);
     hipLaunchKernelGGL(k_scan_chunks, dim3(ceil_div(nrows, 256)), dim3(256), 0, s, p->hist, p->row_len, nd,
                        p->nchunks, nrows);
     GM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_offsets_from_len, dim3(1), dim3(1024), 0, s, p->row_len, p->off[0], nrows);
     GM_LAUNCH_CHECK();
+    STAGE_MARK(3);
     // 3. stable scatter
     hipLaunchKernelGGL(k_rank_scatter, dim3(ceil_div(ntasks, waves)), dim3(64 * waves),
                        waves * nd * sizeof(uint32_t), s, p->digits, p->hist, p->off[0], p->counter, p->cells, N,
@@ -513,9 +553,11 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     } else {
         hipLaunchKernelGGL(k_offsets_next, dim3(1), dim3(1024), 0, s, p->off[0], p->off[1], nrows);
         GM_LAUNCH_CHECK();
+        STAGE_MARK(4);
         hipLaunchKernelGGL(k_add_level0, dim3(ceil_div(cap_out, 128)), dim3(128), 0, s, pts, p->cells, p->off[0],
                            p->off[1], nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2]);
         GM_LAUNCH_CHECK();
+        STAGE_MARK(5);
         cur_off = 1;
         int cur_lvl = 0;
         uint64_t cells_cur = cap_out;
@@ -536,6 +578,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
                            p->off[cur_off], nrows, p->bsum[0], p->bsum[1], p->bsum[2]);
         GM_LAUNCH_CHECK();
     }
+    STAGE_MARK(6);
     // 5. bucket reduction per window
     const size_t lds = 2 * (size_t)nd * sizeof(Point3);
     const dim3 tb(nd < 256 ? (nd < 64 ? 64 : nd) : 256);
@@ -547,6 +590,8 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
                            p->d_log, p->nwin, p->win_pts, reinterpret_cast<Point3*>(p->tri_scratch));
     }
     GM_LAUNCH_CHECK();
+    STAGE_MARK(7);
+#undef STAGE_MARK
     return GM_OK;
 }
 

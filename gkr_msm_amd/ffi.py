@@ -49,6 +49,7 @@ _SIGS = {
     "gm_free": (C.c_int32, [vp]),
     "gm_memcpy_h2d": (C.c_int32, [vp, vp, C.c_size_t, vp]),
     "gm_memcpy_d2h": (C.c_int32, [vp, vp, C.c_size_t, vp]),
+    "gm_memcpy_d2d": (C.c_int32, [vp, vp, C.c_size_t, vp]),
     "gm_fn_shape": (C.c_int32, [C.POINTER(GmFn), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gm_fr_batch": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64, vp]),
     "gm_fr_host": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64]),
@@ -60,6 +61,8 @@ _SIGS = {
     "gm_msm_bucket_sums": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]),
     "gm_msm_window_points": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gm_msm_digits": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "gm_msm_profile": (C.c_int32, [vp, C.c_int32]),
+    "gm_msm_profile_read": (C.c_int32, [vp, C.POINTER(C.c_float), C.c_int32]),
     "gm_msm_combine_host": (C.c_int32, [vp, C.c_uint32, C.c_uint32, vp]),
     "gm_msm_te": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "gm_bs_scalars_into_bigint": (C.c_int32, [vp, vp, C.c_uint64, vp]),

@@ -41,6 +41,7 @@ int32_t gm_malloc(void** out_d_ptr, size_t bytes);
 int32_t gm_free(void* d_ptr);
 int32_t gm_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
 int32_t gm_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int32_t gm_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream); /* asynchronous */
 
 /* ---------------------------------------------------------------- AlgFn descriptors
  * Replaces the Rust generics `Fun: AlgFn<F>` (src/cleanup/utils/algfn.rs:21-34).  A function is a
@@ -114,6 +115,13 @@ int32_t gm_msm_window_points(const gm_msm_plan* plan, const uint64_t** d_cols, u
                              uint64_t* col_len);
 int32_t gm_msm_digits(const gm_msm_plan* plan, const uint16_t** d_digits, const uint32_t** d_counter,
                       const uint32_t** d_row_len);
+
+/* Bench instrumentation: HIP events on the launch stream around the stages of gm_msm_run.
+ * mode 0 off, 1 = only the dominant kernel (level-0 bucket add), 2 = every stage.
+ * gm_msm_profile_read returns ms per stage of the last run (7 floats: digits, histogram, chunk scan +
+ * offsets, scatter, level-0 add, levels >= 1, bucket reduction; -1 where not recorded). */
+int32_t gm_msm_profile(gm_msm_plan* plan, int32_t mode);
+int32_t gm_msm_profile_read(gm_msm_plan* plan, float* h_ms, int32_t n);
 
 /* Final recombination acc = sum_w 2^(d*w) sum_{i>=1} 2^(i-1) P[i][w] on the host from the window points
  * of ALL windows (h_cols: 3*(d+1) columns x n_windows, Montgomery); writes affine (x,y), 8 x u64. */

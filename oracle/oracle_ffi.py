@@ -1,0 +1,89 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes view of oracle/liboracle.so (the C restatement).
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liboracle.so")
+
+
+class OrFn(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("prim", C.c_int32 * 4), ("count", C.c_int32 * 4)]
+
+
+def make_fn(*segs):
+    f = OrFn()
+    f.nseg = len(segs)
+    for i, (p, c) in enumerate(segs):
+        f.prim[i] = p
+        f.count[i] = c
+    return f
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.or_msm.restype = C.c_int
+        _lib.or_msm.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                C.c_int] + [C.c_void_p] * 7
+        _lib.or_msm_combine.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        _lib.or_fr_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        _lib.or_fn_exec.argtypes = [C.POINTER(OrFn), C.c_void_p, C.c_void_p]
+        _lib.or_fn_n_ins.argtypes = [C.POINTER(OrFn)]
+        _lib.or_fn_n_outs.argtypes = [C.POINTER(OrFn)]
+        _lib.or_dense_bind.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        _lib.or_dense_bind21.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        _lib.or_dense_make21.argtypes = [C.c_void_p, C.c_uint64]
+        _lib.or_eq_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.or_coeff_d.argtypes = [C.c_void_p]
+    return _lib
+
+
+def msm(points_mont, scalars, x_log, d_log, y_size, y0=0, y1=None, threads=1, want_aux=True):
+    """points_mont (N,8) u64, scalars (N,4) u64 canonical -> dict of numpy outputs (Montgomery limbs)"""
+    L = lib()
+    y1 = y_size if y1 is None else y1
+    n = 1 << x_log
+    nwin = y1 - y0
+    nrows = nwin << d_log
+    pts = np.ascontiguousarray(points_mont, dtype=np.uint64)
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = {
+        "digits": np.zeros((nwin, n), dtype=np.uint16) if want_aux else None,
+        "counter": np.zeros((nwin, n), dtype=np.uint32) if want_aux else None,
+        "row_len": np.zeros(nrows, dtype=np.uint32),
+        "bx": np.zeros((nrows, 4), dtype=np.uint64),
+        "by": np.zeros((nrows, 4), dtype=np.uint64),
+        "bz": np.zeros((nrows, 4), dtype=np.uint64),
+        "window_cols": np.zeros((3 * (d_log + 1), nwin, 4), dtype=np.uint64),
+    }
+
+    def p(a):
+        return a.ctypes.data if a is not None else None
+    rc = L.or_msm(pts.ctypes.data, sc.ctypes.data, x_log, d_log, y_size, y0, y1, threads, p(out["digits"]),
+                  p(out["counter"]), p(out["row_len"]), p(out["bx"]), p(out["by"]), p(out["bz"]),
+                  p(out["window_cols"]))
+    if rc != 0:
+        raise ValueError("or_msm rejected the shape (rc=%d)" % rc)
+    return out
+
+
+def msm_combine(window_cols, d_log):
+    L = lib()
+    w = np.ascontiguousarray(window_cols, dtype=np.uint64)
+    out = np.zeros((2, 4), dtype=np.uint64)
+    L.or_msm_combine(w.ctypes.data, d_log, w.shape[1], out.ctypes.data)
+    return out
