@@ -1,0 +1,52 @@
+// Cross-translation-unit declarations inside libgkrmsm_hip.so (not part of the ABI).
+#pragma once
+#include <vector>
+
+#include "common.hpp"
+#include "segfn.cuh"
+
+namespace gm {
+
+int32_t to_gmfn(const gm_fn* f, GmFn* g);
+int32_t launch_dense_map(const SegPlan& sp, const Fr* const* in, Fr* const* out, uint64_t n, hipStream_t s);
+int32_t launch_dense_map_split(const SegPlan& sp, const Fr* const* in, Fr* const* out, uint64_t n, uint32_t lo_bit,
+                               uint32_t bundle, hipStream_t s);
+int32_t launch_dense_fold(const Fr* const* in, Fr* const* out, int k, uint64_t n_out, const Fr& t, hipStream_t s);
+int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s);
+
+int32_t launch_offsets_next(const uint32_t* off_in, uint32_t* off_out, uint32_t nrows, hipStream_t s);
+int32_t launch_offsets_from_len(const uint32_t* len, uint32_t* off, uint32_t nrows, hipStream_t s);
+
+// ---- host-side univariate helpers (liblasso UniPoly::from_evals = interpolation on 0..D; un-vendored
+// dependency, git 925a7a74; call sites sumcheck.rs:220,327, vecvec_eq.rs:209)
+std::vector<Fr> unipoly_from_evals(const std::vector<Fr>& evals);
+Fr evaluate_univar(const std::vector<Fr>& coeffs, const Fr& x);                 // sumcheck.rs:33-44
+std::vector<Fr> from12(const Fr& p1, const Fr& p2, const Fr& eq1, const Fr& prev_claim);  // vecvec_eq.rs:197-216
+Fr eq_bind_factor(const Fr& q, const Fr& t);                                    // 1 - q - t + 2qt
+Fr eq_sum_host(const Fr* pt, uint32_t n, uint64_t k);                           // utils.rs:265-291
+
+// device buffer owned by a handle
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int32_t alloc(size_t b) {
+        free();
+        if (b == 0) b = 32;
+        hipError_t e = hipMalloc(&p, b);
+        if (e != hipSuccess) return set_err(GM_ERR_HIP, "hipMalloc(%zu): %s", b, hipGetErrorString(e));
+        bytes = b;
+        return GM_OK;
+    }
+    void free() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    ~DevBuf() { free(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    Fr* fr() const { return reinterpret_cast<Fr*>(p); }
+};
+
+}  // namespace gm

@@ -19,10 +19,11 @@
 // witness builder in witness.hip, which the sumcheck needs; the MSM does not).
 #include "algfn.cuh"
 #include "common.hpp"
+#include "msm_plan.hpp"
+#include "ragged.cuh"
 
 namespace gm {
 
-static constexpr uint32_t PAD_IDX = 0xffffffffu;
 static constexpr int CHUNK = 1024;  // x-range handled by one wave in the scatter passes
 
 struct Point3 {
@@ -229,16 +230,6 @@ __global__ void k_pad_cells(const uint32_t* __restrict__ row_len, const uint32_t
     if (l & 1u) cells[(uint64_t)off[r] + l] = PAD_IDX;
 }
 
-__device__ __forceinline__ uint32_t find_row(const uint32_t* __restrict__ off, uint32_t nrows, uint32_t j) {
-    // largest r with off[r] <= j  (j < off[nrows])
-    uint32_t lo = 0, hi = nrows;  // invariant: off[lo] <= j < off[hi]
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (off[mid] <= j) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 // bintree level 0: gather affine points by index, add pairs (2p, 2p+1) of every row
 __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* __restrict__ cells,
                              const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
@@ -392,27 +383,18 @@ __global__ void k_triangle(const Fr* __restrict__ bx, const Fr* __restrict__ by,
 
 using namespace gm;
 
-#define GM_MSM_NSTAGE 7
-struct gm_msm_plan {
-    uint32_t x_log, d_log, y_size, y0, y1, nwin, nd, nrows, nchunks, chunk;
-    uint64_t N;
-    uint16_t* digits = nullptr;
-    uint32_t* counter = nullptr;
-    uint32_t* hist = nullptr;
-    uint32_t* row_len = nullptr;
-    uint32_t* off[2] = {nullptr, nullptr};
-    uint32_t* cells = nullptr;
-    Fr* lvl[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    Fr* bsum[3] = {nullptr, nullptr, nullptr};
-    Fr* win_pts = nullptr;
-    Fr* tri_scratch = nullptr;
-    uint64_t cap0, cap1;  // cell capacity of level buffers
-    size_t bytes = 0;
-    // stage timing (bench only): events bracket the stages of gm_msm_run on the launch stream
-    int prof_mode = 0;  // 0 off, 1 dominant kernel only (level-0 add), 2 all stages
-    hipEvent_t ev[GM_MSM_NSTAGE + 1] = {};
-    bool ev_rec[GM_MSM_NSTAGE + 1] = {};
-};
+namespace gm {
+int32_t launch_offsets_next(const uint32_t* off_in, uint32_t* off_out, uint32_t nrows, hipStream_t s) {
+    hipLaunchKernelGGL(k_offsets_next, dim3(1), dim3(1024), 0, s, off_in, off_out, nrows);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+int32_t launch_offsets_from_len(const uint32_t* len, uint32_t* off, uint32_t nrows, hipStream_t s) {
+    hipLaunchKernelGGL(k_offsets_from_len, dim3(1), dim3(1024), 0, s, len, off, nrows);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+}  // namespace gm
 
 template <typename T>
 static int32_t plan_alloc(gm_msm_plan* p, T** ptr, uint64_t count) {
@@ -451,6 +433,7 @@ extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, ui
     ALLOC(p->row_len, p->nrows);
     ALLOC(p->off[0], p->nrows + 1);
     ALLOC(p->off[1], p->nrows + 1);
+    ALLOC(p->off[2], p->nrows + 1);
     ALLOC(p->cells, cells_in + 2);
     for (int c = 0; c < 3; c++) {
         ALLOC(p->lvl[0][c], p->cap0);
@@ -467,7 +450,7 @@ extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, ui
 extern "C" int32_t gm_msm_plan_destroy(gm_msm_plan* p) {
     if (!p) return GM_OK;
     (void)hipFree(p->digits); (void)hipFree(p->counter); (void)hipFree(p->hist); (void)hipFree(p->row_len);
-    (void)hipFree(p->off[0]); (void)hipFree(p->off[1]); (void)hipFree(p->cells);
+    (void)hipFree(p->off[0]); (void)hipFree(p->off[1]); (void)hipFree(p->off[2]); (void)hipFree(p->cells);
     for (int c = 0; c < 3; c++) { (void)hipFree(p->lvl[0][c]); (void)hipFree(p->lvl[1][c]); (void)hipFree(p->bsum[c]); }
     (void)hipFree(p->win_pts);
     (void)hipFree(p->tri_scratch);
@@ -563,13 +546,14 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
         uint64_t cells_cur = cap_out;
         for (uint32_t level = 1; level + 1 < p->x_log; level++) {
             const uint64_t cells_next = cells_cur / 2 + nrows + 2;
-            hipLaunchKernelGGL(k_offsets_next, dim3(1), dim3(1024), 0, s, p->off[cur_off], p->off[cur_off ^ 1], nrows);
+            const int nxt_off = (cur_off == 1) ? 2 : 1;
+            hipLaunchKernelGGL(k_offsets_next, dim3(1), dim3(1024), 0, s, p->off[cur_off], p->off[nxt_off], nrows);
             GM_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_add_level, dim3(ceil_div(cells_next, 128)), dim3(128), 0, s, p->lvl[cur_lvl][0],
-                               p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[cur_off], p->off[cur_off ^ 1], nrows,
+                               p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[cur_off], p->off[nxt_off], nrows,
                                p->lvl[cur_lvl ^ 1][0], p->lvl[cur_lvl ^ 1][1], p->lvl[cur_lvl ^ 1][2]);
             GM_LAUNCH_CHECK();
-            cur_off ^= 1;
+            cur_off = nxt_off;
             cur_lvl ^= 1;
             cells_cur = cells_next;
         }

@@ -1,0 +1,29 @@
+// The MSM plan (workspaces of gm_msm_run); shared with the witness builders that start from the bucket image.
+#pragma once
+#include "common.hpp"
+#include "fr.cuh"
+
+using gm::Fr;
+
+#define GM_MSM_NSTAGE 7
+struct gm_msm_plan {
+    uint32_t x_log, d_log, y_size, y0, y1, nwin, nd, nrows, nchunks, chunk;
+    uint64_t N;
+    uint16_t* digits = nullptr;
+    uint32_t* counter = nullptr;
+    uint32_t* hist = nullptr;
+    uint32_t* row_len = nullptr;
+    uint32_t* off[3] = {nullptr, nullptr, nullptr};  // [0] = image rows (kept), [1],[2] ping-pong over levels
+    uint32_t* cells = nullptr;
+    Fr* lvl[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    Fr* bsum[3] = {nullptr, nullptr, nullptr};
+    Fr* win_pts = nullptr;
+    Fr* tri_scratch = nullptr;
+    uint64_t cap0, cap1;  // cell capacity of level buffers
+    size_t bytes = 0;
+    // stage timing (bench only): events bracket the stages of gm_msm_run on the launch stream
+    int prof_mode = 0;  // 0 off, 1 dominant kernel only (level-0 add), 2 all stages
+    hipEvent_t ev[GM_MSM_NSTAGE + 1] = {};
+    bool ev_rec[GM_MSM_NSTAGE + 1] = {};
+};
+

@@ -1,0 +1,199 @@
+// Dense multilinear polynomials on the device: pointwise layer maps (with or without a split),
+// LSB fold, eq tables.  Restates (semantics only)
+//   Vec::algfn_map / algfn_map_split   /root/reference/src/cleanup/polys/dense.rs:115-184
+//   bind_dense_poly                     /root/reference/src/cleanup/protocols/sumcheck.rs:160-163
+//   bind_21 (same values, see below)    /root/reference/src/cleanup/polys/dense.rs:54-61
+//   eq_poly_sequence_from_multiplier    /root/reference/src/utils.rs:222-250
+// Columns are separate device arrays of 32-byte Montgomery elements (struct-of-columns, AoS inside a
+// column): a lane moves whole elements with two 16-byte accesses and consecutive lanes touch consecutive
+// elements, so every wave-level load covers one contiguous 2 KiB span.
+#include "common.hpp"
+#include "segfn.cuh"
+
+namespace gm {
+
+__device__ __forceinline__ void seg_eval(const Seg& g, const Fr* a, Fr* o) { prim_exec(g.prim, a, o); }
+
+__global__ void __launch_bounds__(256) k_dense_map(SegPlan sp, ColPtrs in, ColPtrsMut out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int s = 0; s < sp.nseg; s++) {
+        const Seg g = sp.seg[s];
+        Fr a[6], o[4];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + i);
+        seg_eval(g, a, o);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q < g.n_out) fr_store(out.p[g.out0 + q] + i, o[q]);
+    }
+}
+
+// element i goes to half (i >> lo_bit) & 1 at position ((i >> (lo_bit+1)) << lo_bit) | (i & (2^lo_bit - 1));
+// output o of half h lands in column 2*(o/bundle)*bundle + h*bundle + o%bundle   (dense.rs:126-138)
+__global__ void __launch_bounds__(256) k_dense_map_split(SegPlan sp, ColPtrs in, ColPtrsMut out, uint64_t n,
+                                                          uint32_t lo_bit, uint32_t bundle) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t half = (uint32_t)(i >> lo_bit) & 1u;
+    const uint64_t pos = ((i >> (lo_bit + 1)) << lo_bit) | (i & ((1ull << lo_bit) - 1));
+    for (int s = 0; s < sp.nseg; s++) {
+        const Seg g = sp.seg[s];
+        Fr a[6], o[4];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + i);
+        seg_eval(g, a, o);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q < g.n_out) {
+                const uint32_t oc = g.out0 + q;
+                const uint32_t col = 2 * (oc / bundle) * bundle + half * bundle + oc % bundle;
+                fr_store(out.p[col] + pos, o[q]);
+            }
+    }
+}
+
+// out[c][i] = in[c][2i] + t * (in[c][2i+1] - in[c][2i]);  blockIdx.y = column
+__global__ void __launch_bounds__(256) k_dense_fold(ColPtrs in, ColPtrsMut out, uint64_t n_out, Fr t) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const Fr* src = in.p[blockIdx.y];
+    Fr p0 = fr_load(src + 2 * i), p1 = fr_load(src + 2 * i + 1);
+    fr_store(out.p[blockIdx.y] + i, fr_add(p0, fr_mul(t, fr_sub(p1, p0))));
+}
+
+// one level of the eq table: next[2j] = w - r*w, next[2j+1] = r*w
+__global__ void __launch_bounds__(256) k_eq_level(const Fr* __restrict__ prev, Fr* __restrict__ next, Fr r,
+                                                   uint64_t n_prev) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_prev) return;
+    Fr w = fr_load(prev + j);
+    Fr m = fr_mul(r, w);
+    fr_store(next + 2 * j, fr_sub(w, m));
+    fr_store(next + 2 * j + 1, m);
+}
+
+__global__ void k_set1(Fr* dst, Fr v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) fr_store(dst, v);
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+namespace gm {
+
+int32_t to_gmfn(const gm_fn* f, GmFn* g) {
+    if (!f || f->nseg < 1 || f->nseg > GM_FN_MAX_SEG) return set_err(GM_ERR_INVALID, "bad gm_fn");
+    g->nseg = f->nseg;
+    for (int s = 0; s < f->nseg; s++) {
+        if (f->prim[s] < 1 || f->prim[s] > 10 || f->count[s] < 0) return set_err(GM_ERR_INVALID, "bad gm_fn segment %d", s);
+        g->prim[s] = f->prim[s];
+        g->count[s] = f->count[s];
+    }
+    return GM_OK;
+}
+
+int32_t launch_dense_map(const SegPlan& sp, const Fr* const* in, Fr* const* out, uint64_t n, hipStream_t s) {
+    ColPtrs ci;
+    ColPtrsMut co;
+    for (int i = 0; i < sp.n_ins; i++) ci.p[i] = in[i];
+    for (int i = 0; i < sp.n_outs; i++) co.p[i] = out[i];
+    if (n == 0) return GM_OK;
+    hipLaunchKernelGGL(k_dense_map, dim3(ceil_div(n, 256)), dim3(256), 0, s, sp, ci, co, n);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int32_t launch_dense_map_split(const SegPlan& sp, const Fr* const* in, Fr* const* out, uint64_t n, uint32_t lo_bit,
+                               uint32_t bundle, hipStream_t s) {
+    ColPtrs ci;
+    ColPtrsMut co;
+    for (int i = 0; i < sp.n_ins; i++) ci.p[i] = in[i];
+    for (int i = 0; i < 2 * sp.n_outs; i++) co.p[i] = out[i];
+    if (n == 0) return GM_OK;
+    hipLaunchKernelGGL(k_dense_map_split, dim3(ceil_div(n, 256)), dim3(256), 0, s, sp, ci, co, n, lo_bit, bundle);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int32_t launch_dense_fold(const Fr* const* in, Fr* const* out, int k, uint64_t n_out, const Fr& t, hipStream_t s) {
+    if (n_out == 0 || k == 0) return GM_OK;
+    for (int base = 0; base < k; base += GM_MAX_COLS) {
+        ColPtrs ci;
+        ColPtrsMut co;
+        int cnt = (k - base < GM_MAX_COLS) ? k - base : GM_MAX_COLS;
+        for (int i = 0; i < cnt; i++) { ci.p[i] = in[base + i]; co.p[i] = out[base + i]; }
+        hipLaunchKernelGGL(k_dense_fold, dim3(ceil_div(n_out, 256), cnt), dim3(256), 0, s, ci, co, n_out, t);
+        GM_LAUNCH_CHECK();
+    }
+    return GM_OK;
+}
+
+// levels[i] must hold 2^i elements (i = 0..nvars); level i = eq(pt[0..i], .) * mult   (pt[0] = MSB)
+int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s) {
+    hipLaunchKernelGGL(k_set1, dim3(1), dim3(64), 0, s, levels[0], mult);
+    GM_LAUNCH_CHECK();
+    for (uint32_t i = 1; i <= nvars; i++) {
+        const uint64_t np = 1ull << (i - 1);
+        hipLaunchKernelGGL(k_eq_level, dim3(ceil_div(np, 256)), dim3(256), 0, s, levels[i - 1], levels[i], pt[i - 1], np);
+        GM_LAUNCH_CHECK();
+    }
+    return GM_OK;
+}
+
+}  // namespace gm
+
+// ------------------------------------------------------------------------------------------- C ABI
+extern "C" int32_t gm_dense_map(const gm_fn* f, const uint64_t* const* d_in, uint64_t* const* d_out, uint64_t len,
+                                void* stream) {
+    GmFn g;
+    int32_t rc = to_gmfn(f, &g);
+    if (rc) return rc;
+    SegPlan sp;
+    GM_REQUIRE(seg_plan_build(g, &sp), "function too wide (max %d columns / %d segments)", GM_MAX_COLS, GM_MAX_SEGS);
+    GM_REQUIRE(d_in && d_out, "null argument");
+    return launch_dense_map(sp, reinterpret_cast<const Fr* const*>(d_in), reinterpret_cast<Fr* const*>(d_out), len,
+                            as_stream(stream));
+}
+
+extern "C" int32_t gm_dense_map_split(const gm_fn* f, const uint64_t* const* d_in, uint64_t* const* d_out,
+                                      uint64_t len, uint32_t split_lo_bit, uint32_t bundle, void* stream) {
+    GmFn g;
+    int32_t rc = to_gmfn(f, &g);
+    if (rc) return rc;
+    SegPlan sp;
+    GM_REQUIRE(seg_plan_build(g, &sp), "function too wide");
+    GM_REQUIRE(d_in && d_out && bundle >= 1, "bad argument");
+    GM_REQUIRE(2 * sp.n_outs <= GM_MAX_COLS, "too many output columns");
+    GM_REQUIRE((len & (len - 1)) == 0 && (2ull << split_lo_bit) <= len, "len must be a power of two > 2^split_lo_bit");
+    GM_REQUIRE(sp.n_outs % (int)bundle == 0, "n_outs must be a multiple of the bundle size");
+    return launch_dense_map_split(sp, reinterpret_cast<const Fr* const*>(d_in), reinterpret_cast<Fr* const*>(d_out),
+                                  len, split_lo_bit, bundle, as_stream(stream));
+}
+
+extern "C" int32_t gm_dense_bind(const uint64_t* const* d_in, uint64_t* const* d_out, uint32_t k, uint64_t len,
+                                 const uint64_t* h_t, void* stream) {
+    GM_REQUIRE(d_in && d_out && h_t && len % 2 == 0, "bad argument");
+    Fr t;
+    memcpy(&t, h_t, 32);
+    return launch_dense_fold(reinterpret_cast<const Fr* const*>(d_in), reinterpret_cast<Fr* const*>(d_out), (int)k,
+                             len / 2, t, as_stream(stream));
+}
+
+extern "C" int32_t gm_eq_table(const uint64_t* h_multiplier, const uint64_t* h_point, uint32_t nvars,
+                               uint64_t* d_scratch, uint64_t* d_out, void* stream) {
+    GM_REQUIRE(h_multiplier && h_point && d_out && nvars <= 30, "bad argument");
+    GM_REQUIRE(nvars == 0 || d_scratch, "scratch (2^nvars elements) required");
+    Fr mult, pt[32];
+    memcpy(&mult, h_multiplier, 32);
+    memcpy(pt, h_point, 32 * (size_t)nvars);
+    // levels 0..nvars-1 packed in scratch at offsets 2^i - 1, last level in d_out
+    Fr* lv[33];
+    Fr* sc = reinterpret_cast<Fr*>(d_scratch);
+    for (uint32_t i = 0; i < nvars; i++) lv[i] = sc + ((1ull << i) - 1);
+    lv[nvars] = reinterpret_cast<Fr*>(d_out);
+    return launch_eq_sequence(mult, pt, nvars, lv, as_stream(stream));
+}

@@ -1,0 +1,996 @@
+// Sumcheck objects on the device: the `Sumcheckable::{unipoly, bind, final_evals}` seam
+// (/root/reference/src/cleanup/protocols/sumchecks/vecvec_eq.rs:218-225) for
+//   DenseDeg2SumcheckObjectSO       dense_eq.rs:61-173          (degree-2 layer function, eq factored out)
+//   VecVecDeg2SumcheckObjectSO      vecvec_eq.rs:72-398         (same over ragged rows, then handover to dense)
+//   DenseSumcheckObjectSO           sumcheck.rs:237-347         (generic degree D; with EqWrapper/GammaWrapper :706-829)
+//
+// What runs where.  Per round the device does the two data-parallel passes: the round sums (every pair
+// of every column is read once, the layer function is evaluated at "1" and "2", weighted by eq and the
+// gamma powers and reduced to two field elements) and the fold.  The host only does the O(1) scalar
+// tail (pads, multiplier, from12 / interpolation, claim update) with the same Fr code.
+//
+// Values.  The reference rewrites polynomials into "21 form" (make_21: p[2i] <- 2 p[2i+1] - p[2i]) and binds
+// with bind_21.  Both are exact field identities of the plain pair (p0, p1): value-at-2 = 2 p1 - p0 and
+// bind_21 = p1 + (t-1)(p2 - p1) = p0 + t (p1 - p0).  The device keeps plain form, computes value-at-2 in
+// registers and folds with the plain formula: every round polynomial, folded polynomial and final evaluation
+// is the same canonical field element as in the reference (sums in a field do not depend on their order).
+#include "internal.hpp"
+#include "ragged.cuh"
+#include "vecvec.hpp"
+
+namespace gm {
+
+// ------------------------------------------------------------------------------------------ host math
+Fr eq_bind_factor(const Fr& q, const Fr& t) {
+    // 1 - q - t + 2 q t   (dense_eq.rs:100, vecvec.rs:122)
+    return fr_add(fr_sub(fr_sub(fr_one(), q), t), fr_dbl(fr_mul(q, t)));
+}
+
+std::vector<Fr> unipoly_from_evals(const std::vector<Fr>& evals) {
+    const int n = (int)evals.size();
+    std::vector<Fr> coeffs(n, fr_zero());
+    for (int i = 0; i < n; i++) {
+        std::vector<Fr> num(1, fr_one());
+        Fr den = fr_one();
+        for (int j = 0; j < n; j++) {
+            if (j == i) continue;
+            // num *= (x - j)
+            std::vector<Fr> nx(num.size() + 1, fr_zero());
+            const Fr fj = fr_from_u64((uint64_t)j);
+            for (size_t k = 0; k < num.size(); k++) {
+                nx[k + 1] = fr_add(nx[k + 1], num[k]);
+                nx[k] = fr_sub(nx[k], fr_mul(fj, num[k]));
+            }
+            num.swap(nx);
+            const Fr d = (i > j) ? fr_from_u64((uint64_t)(i - j)) : fr_neg(fr_from_u64((uint64_t)(j - i)));
+            den = fr_mul(den, d);
+        }
+        const Fr sc = fr_mul(evals[i], fr_inv(den));
+        for (int k = 0; k < n; k++) coeffs[k] = fr_add(coeffs[k], fr_mul(num[k], sc));
+    }
+    return coeffs;
+}
+
+Fr evaluate_univar(const std::vector<Fr>& c, const Fr& x) {
+    Fr r = fr_zero();
+    for (int i = (int)c.size() - 1; i >= 0; i--) r = fr_add(fr_mul(r, x), c[i]);
+    return r;
+}
+
+std::vector<Fr> from12(const Fr& p1, const Fr& p2, const Fr& eq1, const Fr& prev_claim) {
+    const Fr eq0 = fr_sub(fr_one(), eq1);
+    const Fr eq2 = fr_sub(fr_dbl(eq1), eq0);
+    const Fr eq3 = fr_sub(fr_dbl(eq2), eq1);
+    const Fr prod1 = fr_mul(p1, eq1);
+    const Fr prod0 = fr_sub(prev_claim, prod1);
+    const Fr p0 = fr_mul(prod0, fr_inv(eq0));  // undefined in the reference if eq0 == 0 (unwrap panics)
+    const Fr p3 = fr_add(fr_sub(fr_sub(fr_add(fr_dbl(p2), p2), fr_dbl(p1)), p1), p0);
+    std::vector<Fr> ev = {prod0, prod1, fr_mul(p2, eq2), fr_mul(p3, eq3)};
+    return unipoly_from_evals(ev);
+}
+
+Fr eq_sum_host(const Fr* pt, uint32_t n, uint64_t k) {
+    if (k >= (1ull << n)) return fr_one();
+    Fr mult = fr_one(), acc = fr_zero();
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t left = k >> (n - i - 1);
+        const Fr prev = mult;
+        if (left == 1) {
+            mult = fr_mul(mult, pt[i]);
+            acc = fr_add(acc, fr_sub(prev, mult));
+        } else {
+            mult = fr_mul(mult, fr_sub(fr_one(), pt[i]));
+        }
+        k -= left << (n - i - 1);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------ kernels
+#define SC_THREADS 256
+
+// block-wide sum of NACC field elements per thread -> partial[blockIdx.x * NACC + a]
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store(Fr* acc, Fr* __restrict__ partial) {
+    __shared__ Fr red[SC_THREADS];
+    for (int a = 0; a < NACC; a++) {
+        red[threadIdx.x] = acc[a];
+        __syncthreads();
+        for (int s = SC_THREADS / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] = fr_add(red[threadIdx.x], red[threadIdx.x + s]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) fr_store(partial + (uint64_t)blockIdx.x * NACC + a, red[0]);
+        __syncthreads();
+    }
+}
+
+// sum the per-block partials: out[a] = sum_b partial[b*NACC + a]   (single block)
+__global__ void __launch_bounds__(SC_THREADS) k_reduce_partials(const Fr* __restrict__ partial, uint32_t nblocks,
+                                                                 int nacc, Fr* __restrict__ out) {
+    __shared__ Fr red[SC_THREADS];
+    for (int a = 0; a < nacc; a++) {
+        Fr s = fr_zero();
+        for (uint32_t b = threadIdx.x; b < nblocks; b += SC_THREADS) s = fr_add(s, fr_load(partial + (uint64_t)b * nacc + a));
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int st = SC_THREADS / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] = fr_add(red[threadIdx.x], red[threadIdx.x + st]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) fr_store(out + a, red[0]);
+        __syncthreads();
+    }
+}
+
+struct GammaPows {
+    Fr g[GM_MAX_COLS];  // g[o] = gamma^o, g[0] = 1
+};
+
+// gamma-combined layer function at the "1" and "2" points of one pair:
+//   A1 = sum_o gamma^o f_o(p1),  A2 = sum_o gamma^o f_o(2 p1 - p0)
+__device__ __forceinline__ void eval_pair_12(const SegPlan& sp, const ColPtrs& cols, const Fr* __restrict__ gp,
+                                             uint64_t cell0, Fr& A1, Fr& A2) {
+    A1 = fr_zero();
+    A2 = fr_zero();
+    for (int s = 0; s < sp.nseg; s++) {
+        const Seg g = sp.seg[s];
+        Fr v1[6], v2[6], o1[4], o2[4];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (q < g.n_in) {
+                const Fr p0 = fr_load(cols.p[g.in[q]] + cell0);
+                const Fr p1 = fr_load(cols.p[g.in[q]] + cell0 + 1);
+                v1[q] = p1;
+                v2[q] = fr_sub(fr_dbl(p1), p0);
+            }
+        prim_exec(g.prim, v1, o1);
+        prim_exec(g.prim, v2, o2);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q < g.n_out) {
+                const int oc = g.out0 + q;
+                if (oc == 0) {
+                    A1 = fr_add(A1, o1[q]);
+                    A2 = fr_add(A2, o2[q]);
+                } else {
+                    const Fr gm_ = fr_load(gp + oc);
+                    A1 = fr_add(A1, fr_mul(gm_, o1[q]));
+                    A2 = fr_add(A2, fr_mul(gm_, o2[q]));
+                }
+            }
+    }
+}
+
+// DenseDeg2 round sums (dense_eq.rs:121-139): S1 = sum_i eq[i] A1(i), S2 = sum_i eq[i] A2(i)
+__global__ void __launch_bounds__(SC_THREADS) k_round_deg2_dense(SegPlan sp, ColPtrs cols, const Fr* __restrict__ eq,
+                                                                  const Fr* __restrict__ gp, uint64_t npairs,
+                                                                  Fr* __restrict__ partial) {
+    Fr acc[2] = {fr_zero(), fr_zero()};
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+        Fr A1, A2;
+        eval_pair_12(sp, cols, gp, 2 * i, A1, A2);
+        const Fr e = fr_load(eq + i);
+        acc[0] = fr_add(acc[0], fr_mul(A1, e));
+        acc[1] = fr_add(acc[1], fr_mul(A2, e));
+    }
+    block_reduce_store<2>(acc, partial);
+}
+
+// VecVecDeg2 round sums (vecvec_eq.rs:320-361): cells of all rows in one flat pass;
+// weight of pair idx of row r = eq_row[idx] * row_eq_coefs[r]
+__global__ void __launch_bounds__(SC_THREADS) k_round_deg2_vecvec(SegPlan sp, ColPtrs cols, const uint32_t* __restrict__ off,
+                                                                   uint32_t nrows, const Fr* __restrict__ eq_row,
+                                                                   const Fr* __restrict__ row_coef,
+                                                                   const Fr* __restrict__ gp, Fr* __restrict__ partial) {
+    Fr acc[2] = {fr_zero(), fr_zero()};
+    const uint64_t npairs = off[nrows] >> 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+        const uint32_t cell0 = (uint32_t)(2 * i);
+        const uint32_t r = find_row(off, nrows, cell0);
+        const uint32_t idx = (cell0 - off[r]) >> 1;
+        Fr A1, A2;
+        eval_pair_12(sp, cols, gp, cell0, A1, A2);
+        const Fr w = fr_mul(fr_load(eq_row + idx), fr_load(row_coef + r));
+        acc[0] = fr_add(acc[0], fr_mul(A1, w));
+        acc[1] = fr_add(acc[1], fr_mul(A2, w));
+    }
+    block_reduce_store<2>(acc, partial);
+}
+
+// per-row tail weight of the VecVec round: W = sum_r row_coef[r] * (1 - sum_{idx < seg_r} eq_row[idx])
+// (get_trailing_sum, vecvec.rs:144-146).  eq prefix sums come from a scan of the current eq level.
+__global__ void __launch_bounds__(SC_THREADS) k_vv_tail_weight(const uint32_t* __restrict__ off, uint32_t nrows,
+                                                                const Fr* __restrict__ eq_prefix /* prefix[k] = sum_{i<k} */,
+                                                                const Fr* __restrict__ row_coef, Fr* __restrict__ partial) {
+    Fr acc[1] = {fr_zero()};
+    for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < nrows; r += gridDim.x * SC_THREADS) {
+        const uint32_t seg = (off[r + 1] - off[r]) >> 1;
+        const Fr tr = fr_sub(fr_one(), fr_load(eq_prefix + seg));
+        acc[0] = fr_add(acc[0], fr_mul(fr_load(row_coef + r), tr));
+    }
+    block_reduce_store<1>(acc, partial);
+}
+
+// inclusive->exclusive prefix sums of a (short) eq level: prefix[0] = 0, prefix[k] = sum_{i<k} v[i]; single block
+__global__ void __launch_bounds__(SC_THREADS) k_prefix_sums(const Fr* __restrict__ v, uint32_t n, Fr* __restrict__ prefix) {
+    __shared__ Fr part[SC_THREADS];
+    __shared__ Fr carry;
+    if (threadIdx.x == 0) { carry = fr_zero(); fr_store(prefix, fr_zero()); }
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += SC_THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        part[threadIdx.x] = (i < n) ? fr_load(v + i) : fr_zero();
+        __syncthreads();
+        for (uint32_t s = 1; s < SC_THREADS; s <<= 1) {
+            Fr t = (threadIdx.x >= s) ? part[threadIdx.x - s] : fr_zero();
+            __syncthreads();
+            part[threadIdx.x] = fr_add(part[threadIdx.x], t);
+            __syncthreads();
+        }
+        if (i < n) fr_store(prefix + i + 1, fr_add(carry, part[threadIdx.x]));
+        __syncthreads();
+        if (threadIdx.x == SC_THREADS - 1) carry = fr_add(carry, part[threadIdx.x]);
+        __syncthreads();
+    }
+}
+
+// VecVec fold: out row = pad2(len/2) cells, cell p < len/2 = p0 + t (p1 - p0), the extra cell = row pad
+// (bind_21, vecvec.rs:420-441); blockIdx.y = column
+struct PadCols {
+    Fr v[16];
+};
+__global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut out, const uint32_t* __restrict__ off_in,
+                                                         const uint32_t* __restrict__ off_out, uint32_t nrows, Fr t,
+                                                         PadCols pad) {
+    const uint32_t j = blockIdx.x * SC_THREADS + threadIdx.x;
+    if (j >= off_out[nrows]) return;
+    const uint32_t r = find_row(off_out, nrows, j);
+    const uint32_t p = j - off_out[r];
+    const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
+    const int c = blockIdx.y;
+    Fr v;
+    if (p < half) {
+        const Fr p0 = fr_load(in.p[c] + in0 + 2 * p), p1 = fr_load(in.p[c] + in0 + 2 * p + 1);
+        v = fr_add(p0, fr_mul(t, fr_sub(p1, p0)));
+    } else {
+        v = pad.v[c];
+    }
+    fr_store(out.p[c] + j, v);
+}
+
+// bind_into_dense (vecvec_eq.rs:157-175): rows of 0 or 2 cells -> one dense value per row
+__global__ void __launch_bounds__(SC_THREADS) k_vv_fold_to_dense(ColPtrs in, ColPtrsMut out, const uint32_t* __restrict__ off_in,
+                                                                  uint32_t nrows, uint32_t nrows_dense, Fr t,
+                                                                  PadCols row_pad, PadCols col_pad) {
+    const uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x;
+    if (r >= nrows_dense) return;
+    const int c = blockIdx.y;
+    Fr v;
+    if (r >= nrows) v = col_pad.v[c];
+    else {
+        const uint32_t in0 = off_in[r], len = off_in[r + 1] - in0;
+        if (len == 0) v = row_pad.v[c];
+        else {
+            const Fr p0 = fr_load(in.p[c] + in0), p1 = fr_load(in.p[c] + in0 + 1);
+            v = fr_add(p0, fr_mul(t, fr_sub(p1, p0)));
+        }
+    }
+    fr_store(out.p[c] + r, v);
+}
+
+// Generic dense round (sumcheck.rs:283-316) for F = EqWrapper(GammaWrapper(f)) [kind 0: last column is eq]
+// or Prod3 [kind 1]: acc[s] += F(p1 + s * (p1 - p0)), s = 0..D-1.
+template <int D>
+__global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan sp, ColPtrs cols, int ncols,
+                                                               const Fr* __restrict__ gp, uint64_t npairs,
+                                                               Fr* __restrict__ partial) {
+    Fr acc[D];
+#pragma unroll
+    for (int s = 0; s < D; s++) acc[s] = fr_zero();
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+        if (kind == 1) {
+            Fr a[3], d[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const Fr p0 = fr_load(cols.p[q] + 2 * i), p1 = fr_load(cols.p[q] + 2 * i + 1);
+                a[q] = p1;
+                d[q] = fr_sub(p1, p0);
+            }
+#pragma unroll
+            for (int s = 0; s < D; s++) {
+                if (s) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) a[q] = fr_add(a[q], d[q]);
+                }
+                acc[s] = fr_add(acc[s], fr_mul(fr_mul(a[0], a[1]), a[2]));
+            }
+        } else {
+            // eq column (last) at the D points
+            const Fr e0 = fr_load(cols.p[ncols - 1] + 2 * i), e1 = fr_load(cols.p[ncols - 1] + 2 * i + 1);
+            const Fr ed = fr_sub(e1, e0);
+            Fr G[D];
+#pragma unroll
+            for (int s = 0; s < D; s++) G[s] = fr_zero();
+            for (int sg = 0; sg < sp.nseg; sg++) {
+                const Seg g = sp.seg[sg];
+                Fr a[6], d[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if (q < g.n_in) {
+                        const Fr p0 = fr_load(cols.p[g.in[q]] + 2 * i), p1 = fr_load(cols.p[g.in[q]] + 2 * i + 1);
+                        a[q] = p1;
+                        d[q] = fr_sub(p1, p0);
+                    }
+#pragma unroll
+                for (int s = 0; s < D; s++) {
+                    if (s) {
+#pragma unroll
+                        for (int q = 0; q < 6; q++)
+                            if (q < g.n_in) a[q] = fr_add(a[q], d[q]);
+                    }
+                    Fr o[4];
+                    prim_exec(g.prim, a, o);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (q < g.n_out) {
+                            const int oc = g.out0 + q;
+                            G[s] = fr_add(G[s], oc == 0 ? o[q] : fr_mul(fr_load(gp + oc), o[q]));
+                        }
+                }
+            }
+            Fr e = e1;
+#pragma unroll
+            for (int s = 0; s < D; s++) {
+                if (s) e = fr_add(e, ed);
+                acc[s] = fr_add(acc[s], fr_mul(G[s], e));
+            }
+        }
+    }
+    block_reduce_store<D>(acc, partial);
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+// ============================================================================================ objects
+static constexpr uint32_t SC_MAX_BLOCKS = 2048;
+
+struct gm_sc {
+    virtual ~gm_sc() {}
+    virtual int32_t unipoly(std::vector<Fr>* coeffs) = 0;
+    virtual int32_t bind(const Fr& t) = 0;
+    virtual int32_t final_evals(std::vector<Fr>* out) = 0;
+    virtual Fr claim() const = 0;
+    hipStream_t stream = nullptr;
+};
+
+namespace {
+
+struct RoundScratch {
+    DevBuf partial, result;
+    Fr* h_result = nullptr;  // pinned
+    int32_t init() {
+        int32_t rc = partial.alloc((size_t)SC_MAX_BLOCKS * 4 * sizeof(Fr));
+        if (rc) return rc;
+        rc = result.alloc(8 * sizeof(Fr));
+        if (rc) return rc;
+        GM_HIP(hipHostMalloc((void**)&h_result, 8 * sizeof(Fr)));
+        return GM_OK;
+    }
+    ~RoundScratch() {
+        if (h_result) (void)hipHostFree(h_result);
+    }
+    // reduce `nacc` accumulators over `nblocks` partial rows and fetch them
+    int32_t finish(uint32_t nblocks, int nacc, hipStream_t s, Fr* out) {
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(SC_THREADS), 0, s, partial.fr(), nblocks, nacc, result.fr());
+        GM_LAUNCH_CHECK();
+        GM_HIP(hipMemcpyAsync(h_result, result.p, (size_t)nacc * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        GM_HIP(hipStreamSynchronize(s));
+        for (int a = 0; a < nacc; a++) out[a] = h_result[a];
+        return GM_OK;
+    }
+};
+
+static uint32_t blocks_for(uint64_t work) {
+    uint64_t b = (work + SC_THREADS - 1) / SC_THREADS;
+    if (b < 1) b = 1;
+    return (uint32_t)(b > SC_MAX_BLOCKS ? SC_MAX_BLOCKS : b);
+}
+
+// ---- columns with ping-pong fold buffers --------------------------------------------------------
+struct FoldCols {
+    int k = 0;
+    std::vector<const Fr*> cur;            // current columns (input columns on round 0)
+    std::vector<std::unique_ptr<DevBuf>> a, b;  // scratch: a holds len/2, b holds len/4
+    bool cur_is_a = false, started = false;
+    int32_t init(int k_, const Fr* const* in, uint64_t len_elems) {
+        k = k_;
+        cur.assign(in, in + k);
+        for (int i = 0; i < k; i++) {
+            a.emplace_back(new DevBuf());
+            b.emplace_back(new DevBuf());
+            int32_t rc = a.back()->alloc((size_t)(len_elems / 2 + 2) * sizeof(Fr));
+            if (rc) return rc;
+            rc = b.back()->alloc((size_t)(len_elems / 4 + 2) * sizeof(Fr));
+            if (rc) return rc;
+        }
+        return GM_OK;
+    }
+    // destination columns of the next fold
+    void next(std::vector<Fr*>* dst) {
+        dst->resize(k);
+        const bool to_a = !started || !cur_is_a;
+        for (int i = 0; i < k; i++) (*dst)[i] = to_a ? a[i]->fr() : b[i]->fr();
+    }
+    void commit(const std::vector<Fr*>& dst) {
+        cur_is_a = !started || !cur_is_a;
+        started = true;
+        for (int i = 0; i < k; i++) cur[i] = dst[i];
+    }
+};
+
+// gamma powers on the device: g[o] = gamma^o   (make_gamma_pows, utils.rs:126-135)
+static int32_t upload_gamma(const std::vector<Fr>& gp, DevBuf* d, hipStream_t s) {
+    int32_t rc = d->alloc(gp.size() * sizeof(Fr) + 32);
+    if (rc) return rc;
+    GM_HIP(hipMemcpyAsync(d->p, gp.data(), gp.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+    GM_HIP(hipStreamSynchronize(s));
+    return GM_OK;
+}
+
+static std::vector<Fr> make_gamma_pows(const Fr& gamma, int count) {
+    std::vector<Fr> g = {fr_one(), gamma};
+    for (int i = 2; i < count; i++) g.push_back(fr_mul(g[i - 1], gamma));
+    return g;
+}
+
+// ---- DenseSumcheckObjectSO (sumcheck.rs:237-347) ------------------------------------------------
+struct ScDense : gm_sc {
+    int kind = 0;  // 0: EqWrapper(GammaWrapper(f, gamma)) with the eq column last; 1: Prod3
+    SegPlan sp{};
+    int D = 3;
+    uint32_t num_vars = 0, round_idx = 0;
+    FoldCols cols;
+    DevBuf d_gamma;
+    RoundScratch rs;
+    Fr claim_;
+    std::vector<Fr> cached;
+    bool has_cached = false;
+    std::vector<std::unique_ptr<DevBuf>> owned;  // columns built by a handover
+
+    Fr claim() const override { return claim_; }
+
+    int32_t unipoly(std::vector<Fr>* coeffs) override {
+        if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended (sumcheck.rs:279)");
+        if (!has_cached) {
+            const uint64_t npairs = 1ull << (num_vars - round_idx - 1);
+            const uint32_t nb = blocks_for(npairs);
+            ColPtrs cp;
+            for (int i = 0; i < cols.k; i++) cp.p[i] = cols.cur[i];
+            if (D == 3)
+                hipLaunchKernelGGL((k_round_generic<3>), dim3(nb), dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                                   d_gamma.fr(), npairs, rs.partial.fr());
+            else if (D == 2)
+                hipLaunchKernelGGL((k_round_generic<2>), dim3(nb), dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                                   d_gamma.fr(), npairs, rs.partial.fr());
+            else
+                return set_err(GM_ERR_INVALID, "unsupported degree %d", D);
+            GM_LAUNCH_CHECK();
+            Fr acc[4];
+            int32_t rc = rs.finish(nb, D, stream, acc);
+            if (rc) return rc;
+            std::vector<Fr> total(D + 1);
+            for (int s = 0; s < D; s++) total[s + 1] = acc[s];
+            total[0] = fr_sub(claim_, total[1]);  // sumcheck.rs:325
+            cached = unipoly_from_evals(total);
+            has_cached = true;
+        }
+        *coeffs = cached;
+        return GM_OK;
+    }
+
+    int32_t bind(const Fr& t) override {
+        if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended (sumcheck.rs:264)");
+        if (!has_cached) return set_err(GM_ERR_STATE, "should evaluate unipoly before binding (sumcheck.rs:271)");
+        std::vector<Fr*> dst;
+        cols.next(&dst);
+        const uint64_t n_out = 1ull << (num_vars - round_idx - 1);
+        int32_t rc = launch_dense_fold(cols.cur.data(), dst.data(), cols.k, n_out, t, stream);
+        if (rc) return rc;
+        cols.commit(dst);
+        round_idx++;
+        claim_ = evaluate_univar(cached, t);
+        has_cached = false;
+        return GM_OK;
+    }
+
+    int32_t final_evals(std::vector<Fr>* out) override {
+        if (round_idx != num_vars) return set_err(GM_ERR_STATE, "can only call final evals after the last round (sumcheck.rs:338)");
+        out->resize(cols.k);
+        for (int i = 0; i < cols.k; i++) GM_HIP(hipMemcpyAsync(&(*out)[i], cols.cur[i], sizeof(Fr), hipMemcpyDeviceToHost, stream));
+        GM_HIP(hipStreamSynchronize(stream));
+        return GM_OK;
+    }
+};
+
+// ---- DenseDeg2SumcheckObjectSO (dense_eq.rs:61-173) ---------------------------------------------
+struct ScDenseDeg2 : gm_sc {
+    SegPlan sp{};
+    uint32_t num_vars = 0, round_idx = 0;
+    FoldCols cols;
+    std::vector<Fr> gamma_pows, point;
+    DevBuf d_gamma, d_eq;           // eq levels 0..num_vars-1 packed: level i at offset 2^i - 1
+    RoundScratch rs;
+    Fr claim_, multiplier;
+    std::vector<Fr> cached;
+    bool has_cached = false;
+
+    Fr claim() const override { return claim_; }
+    const Fr* eq_level(uint32_t i) const { return d_eq.fr() + ((1ull << i) - 1); }
+
+    int32_t unipoly(std::vector<Fr>* coeffs) override {
+        if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (dense_eq.rs:109-111)");
+        if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended");
+        const uint64_t npairs = 1ull << (num_vars - round_idx - 1);
+        const uint32_t nb = blocks_for(npairs);
+        ColPtrs cp;
+        for (int i = 0; i < cols.k; i++) cp.p[i] = cols.cur[i];
+        hipLaunchKernelGGL(k_round_deg2_dense, dim3(nb), dim3(SC_THREADS), 0, stream, sp, cp,
+                           eq_level(num_vars - 1 - round_idx), d_gamma.fr(), npairs, rs.partial.fr());
+        GM_LAUNCH_CHECK();
+        Fr acc[4];
+        int32_t rc = rs.finish(nb, 2, stream, acc);
+        if (rc) return rc;
+        // full-length dense columns: sum of eq = 1, the trailing pad term (dense_eq.rs:141-146) vanishes
+        const Fr total1 = fr_mul(acc[0], multiplier), total2 = fr_mul(acc[1], multiplier);
+        cached = from12(total1, total2, point.back(), claim_);
+        has_cached = true;
+        *coeffs = cached;
+        return GM_OK;
+    }
+
+    int32_t bind(const Fr& t) override {
+        if (!has_cached) return set_err(GM_ERR_STATE, "bind before unipoly (dense_eq.rs:105 unwrap)");
+        multiplier = fr_mul(multiplier, eq_bind_factor(point.back(), t));
+        std::vector<Fr*> dst;
+        cols.next(&dst);
+        const uint64_t n_out = 1ull << (num_vars - round_idx - 1);
+        int32_t rc = launch_dense_fold(cols.cur.data(), dst.data(), cols.k, n_out, t, stream);
+        if (rc) return rc;
+        cols.commit(dst);
+        point.pop_back();
+        round_idx++;
+        claim_ = evaluate_univar(cached, t);
+        has_cached = false;
+        return GM_OK;
+    }
+
+    int32_t final_evals(std::vector<Fr>* out) override {
+        out->resize(cols.k);
+        for (int i = 0; i < cols.k; i++) GM_HIP(hipMemcpyAsync(&(*out)[i], cols.cur[i], sizeof(Fr), hipMemcpyDeviceToHost, stream));
+        GM_HIP(hipStreamSynchronize(stream));
+        return GM_OK;
+    }
+};
+
+// ---- VecVecDeg2SumcheckObjectSO (vecvec_eq.rs:72-398) -------------------------------------------
+struct ScVecVecDeg2 : gm_sc {
+    SegPlan sp{};
+    GmFn fn{};
+    uint32_t nrows = 0, col_logsize = 0, row_logsize = 0;  // row_logsize shrinks with every sparse bind
+    uint32_t n_row_vars0 = 0;                               // row variables at creation
+    uint32_t already_bound = 0;
+    int k = 0;
+    std::vector<const Fr*> cur;
+    std::vector<std::unique_ptr<DevBuf>> bufA, bufB;
+    bool cur_is_a = false, started = false;
+    const uint32_t* off_cur = nullptr;
+    DevBuf off_a, off_b;
+    uint32_t cap_a = 0, cap_b = 0;
+    std::vector<Fr> row_pad, col_pad, gamma_pows, point;
+    int binding_var_idx = 0;
+    uint32_t padded_vars = 0;  // leading row variables every row is shorter than (EQPolyPointParts)
+    DevBuf d_gamma, d_row_coef, d_eq_seq, d_prefix;
+    std::vector<uint64_t> eq_level_off;  // offset of level i of the padded eq sequence inside d_eq_seq
+    std::vector<uint32_t> eq_level_len;
+    std::vector<Fr> row_coef_tail;       // row_eq_coefs_tail_sums (host)
+    RoundScratch rs;
+    Fr claim_, multiplier;
+    std::vector<Fr> cached;
+    bool has_cached = false;
+    std::unique_ptr<ScDense> dense;
+
+    Fr claim() const override { return dense ? dense->claim() : claim_; }
+
+    int32_t unipoly(std::vector<Fr>* coeffs) override {
+        if (dense) return dense->unipoly(coeffs);
+        if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (vecvec_eq.rs:305-307)");
+        // current eq level: row_eq_poly_seq[len - 1 - already_bound]  (vecvec.rs:129-135)
+        const size_t lvl = eq_level_len.size() - 1 - already_bound;
+        const Fr* eq_row = d_eq_seq.fr() + eq_level_off[lvl];
+        const uint32_t eq_len = eq_level_len[lvl];
+        hipLaunchKernelGGL(k_prefix_sums, dim3(1), dim3(SC_THREADS), 0, stream, eq_row, eq_len, d_prefix.fr());
+        GM_LAUNCH_CHECK();
+        ColPtrs cp;
+        for (int i = 0; i < k; i++) cp.p[i] = cur[i];
+        // grid from the capacity bound: the exact cell count lives on the device (off[nrows])
+        const uint64_t cap_pairs = ((uint64_t)1 << (row_logsize + col_logsize)) / 2;
+        uint64_t bound = cells_bound / 2 + 1;
+        if (bound > cap_pairs) bound = cap_pairs;
+        const uint32_t nb = blocks_for(bound);
+        hipLaunchKernelGGL(k_round_deg2_vecvec, dim3(nb), dim3(SC_THREADS), 0, stream, sp, cp, off_cur, nrows, eq_row,
+                           d_row_coef.fr(), d_gamma.fr(), rs.partial.fr());
+        GM_LAUNCH_CHECK();
+        Fr acc[4];
+        int32_t rc = rs.finish(nb, 2, stream, acc);
+        if (rc) return rc;
+        const uint32_t nb2 = blocks_for(nrows);
+        hipLaunchKernelGGL(k_vv_tail_weight, dim3(nb2), dim3(SC_THREADS), 0, stream, off_cur, nrows, d_prefix.fr(),
+                           d_row_coef.fr(), rs.partial.fr());
+        GM_LAUNCH_CHECK();
+        Fr w[4];
+        rc = rs.finish(nb2, 1, stream, w);
+        if (rc) return rc;
+        // pads: f(row_pad..) weighted by W, f(col_pad..) by the coefficient tail (vecvec_eq.rs:309-315, 345-371)
+        Fr in[GM_MAX_COLS], pr[GM_MAX_COLS], pc[GM_MAX_COLS];
+        for (int i = 0; i < k; i++) in[i] = row_pad[i];
+        seg_plan_exec_host(sp, in, pr);
+        for (int i = 0; i < k; i++) in[i] = col_pad[i];
+        seg_plan_exec_host(sp, in, pc);
+        Fr padsum = fr_zero(), colsum = fr_zero();
+        for (int o = 0; o < sp.n_outs; o++) {
+            padsum = fr_add(padsum, o == 0 ? pr[o] : fr_mul(pr[o], gamma_pows[o]));
+            colsum = fr_add(colsum, o == 0 ? pc[o] : fr_mul(pc[o], gamma_pows[o]));
+        }
+        Fr extra = fr_mul(padsum, w[0]);
+        if (nrows < (1u << col_logsize)) extra = fr_add(extra, fr_mul(colsum, row_coef_tail[nrows]));
+        const Fr total1 = fr_mul(fr_add(acc[0], extra), multiplier);
+        const Fr total2 = fr_mul(fr_add(acc[1], extra), multiplier);
+        cached = from12(total1, total2, point[binding_var_idx], claim_);
+        has_cached = true;
+        *coeffs = cached;
+        return GM_OK;
+    }
+
+    uint64_t cells_bound = 0;  // upper bound of off_cur[nrows]
+
+    int32_t bind(const Fr& t) override {
+        if (dense) return dense->bind(t);
+        if (!has_cached) return set_err(GM_ERR_STATE, "bind before unipoly (vecvec_eq.rs:299 unwrap)");
+        if ((uint32_t)binding_var_idx > col_logsize) {
+            // sparse bind (vecvec_eq.rs:295-300)
+            const bool to_a = !started || !cur_is_a;
+            DevBuf& off_dst = to_a ? off_a : off_b;
+            int32_t rc = launch_offsets_next(off_cur, reinterpret_cast<uint32_t*>(off_dst.p), nrows, stream);
+            if (rc) return rc;
+            const uint64_t new_bound = cells_bound / 2 + nrows;
+            ColPtrs ci;
+            ColPtrsMut co;
+            PadCols pd;
+            if (k > 16) return set_err(GM_ERR_INVALID, "VecVec sumcheck supports at most 16 polynomials");
+            for (int i = 0; i < k; i++) {
+                ci.p[i] = cur[i];
+                co.p[i] = to_a ? bufA[i]->fr() : bufB[i]->fr();
+                pd.v[i] = row_pad[i];
+            }
+            hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(new_bound, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co,
+                               off_cur, reinterpret_cast<const uint32_t*>(off_dst.p), nrows, t, pd);
+            GM_LAUNCH_CHECK();
+            for (int i = 0; i < k; i++) cur[i] = co.p[i];
+            off_cur = reinterpret_cast<const uint32_t*>(off_dst.p);
+            cur_is_a = to_a;
+            started = true;
+            cells_bound = new_bound;
+            row_logsize--;
+            multiplier = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));
+            binding_var_idx--;
+            already_bound++;
+            claim_ = evaluate_univar(cached, t);
+            has_cached = false;
+            return GM_OK;
+        }
+        return bind_into_dense(t);
+    }
+
+    // vecvec_eq.rs:157-190
+    int32_t bind_into_dense(const Fr& t) {
+        std::unique_ptr<ScDense> d(new ScDense());
+        d->stream = stream;
+        d->kind = 0;
+        d->sp = sp;
+        d->D = 3;
+        d->num_vars = col_logsize;
+        const uint32_t nd = 1u << col_logsize;
+        std::vector<const Fr*> cptr;
+        ColPtrs ci;
+        ColPtrsMut co;
+        PadCols rp, cpad;
+        for (int i = 0; i < k; i++) {
+            d->owned.emplace_back(new DevBuf());
+            int32_t rc = d->owned.back()->alloc((size_t)nd * sizeof(Fr));
+            if (rc) return rc;
+            ci.p[i] = cur[i];
+            co.p[i] = d->owned.back()->fr();
+            rp.v[i] = row_pad[i];
+            cpad.v[i] = col_pad[i];
+            cptr.push_back(d->owned.back()->fr());
+        }
+        hipLaunchKernelGGL(k_vv_fold_to_dense, dim3(ceil_div(nd, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co,
+                           off_cur, nrows, nd, t, rp, cpad);
+        GM_LAUNCH_CHECK();
+        // eq over the vertical variables, scaled by the multiplier after this bind (vecvec_eq.rs:177-180)
+        const Fr mult = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));
+        d->owned.emplace_back(new DevBuf());
+        int32_t rc = d->owned.back()->alloc((size_t)2 * nd * sizeof(Fr));
+        if (rc) return rc;
+        Fr* base = d->owned.back()->fr();
+        std::vector<Fr*> lv(col_logsize + 1);
+        for (uint32_t i = 0; i <= col_logsize; i++) lv[i] = base + ((1ull << i) - 1);
+        rc = launch_eq_sequence(mult, point.data(), col_logsize, lv.data(), stream);
+        if (rc) return rc;
+        cptr.push_back(lv[col_logsize]);
+        rc = d->cols.init(k + 1, cptr.data(), nd);
+        if (rc) return rc;
+        // GammaWrapper::new(func, gamma_pows[1])  (vecvec_eq.rs:185-187): same powers gamma^o
+        rc = upload_gamma(gamma_pows, &d->d_gamma, stream);
+        if (rc) return rc;
+        rc = d->rs.init();
+        if (rc) return rc;
+        d->claim_ = evaluate_univar(cached, t);
+        has_cached = false;
+        dense = std::move(d);
+        return GM_OK;
+    }
+
+    int32_t final_evals(std::vector<Fr>* out) override {
+        if (!dense) return set_err(GM_ERR_STATE, "final_evals in the sparse stage (vecvec_eq.rs:391 unreachable!)");
+        return dense->final_evals(out);
+    }
+};
+
+}  // namespace
+
+// ============================================================================================ C ABI
+static int32_t parse_fn(const gm_fn* f, GmFn* g, SegPlan* sp) {
+    int32_t rc = to_gmfn(f, g);
+    if (rc) return rc;
+    if (!seg_plan_build(*g, sp)) return set_err(GM_ERR_INVALID, "function too wide");
+    return GM_OK;
+}
+
+static Fr rlc_claims(const std::vector<Fr>& gp, const uint64_t* h_claims, int n) {
+    // claim = claims[0] + sum_{i>=1} gamma^i claims[i]   (dense_eq.rs:45-49, vecvec_eq.rs:57-61)
+    Fr c;
+    memcpy(&c, h_claims, 32);
+    for (int i = 1; i < n; i++) {
+        Fr ci;
+        memcpy(&ci, h_claims + 4 * i, 32);
+        c = fr_add(c, fr_mul(gp[i], ci));
+    }
+    return c;
+}
+
+extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, const uint64_t* const* d_cols,
+                                           const uint64_t* h_point, const uint64_t* h_gamma, const uint64_t* h_claims,
+                                           gm_sc** out, void* stream) {
+    GM_REQUIRE(out && d_cols && h_point && h_gamma && h_claims && num_vars >= 1 && num_vars <= 30, "bad argument");
+    std::unique_ptr<ScDenseDeg2> so(new ScDenseDeg2());
+    GmFn g;
+    int32_t rc = parse_fn(f, &g, &so->sp);
+    if (rc) return rc;
+    GM_REQUIRE(so->sp.deg == 2, "DenseDeg2Sumcheck needs a degree-2 function (dense_eq.rs:200)");
+    so->stream = as_stream(stream);
+    so->num_vars = num_vars;
+    Fr gamma;
+    memcpy(&gamma, h_gamma, 32);
+    so->gamma_pows = make_gamma_pows(gamma, so->sp.n_outs);
+    so->claim_ = rlc_claims(so->gamma_pows, h_claims, so->sp.n_outs);
+    so->point.resize(num_vars);
+    memcpy(so->point.data(), h_point, 32 * (size_t)num_vars);
+    so->multiplier = fr_one();
+    rc = so->cols.init(so->sp.n_ins, reinterpret_cast<const Fr* const*>(d_cols), 1ull << num_vars);
+    if (rc) return rc;
+    rc = upload_gamma(so->gamma_pows, &so->d_gamma, so->stream);
+    if (rc) return rc;
+    // eq_poly_sequence(point[0 .. n-1])  (dense_eq.rs:85): levels 0..n-1, level i has 2^i entries
+    rc = so->d_eq.alloc(((size_t)1 << num_vars) * sizeof(Fr));
+    if (rc) return rc;
+    std::vector<Fr*> lv(num_vars);
+    for (uint32_t i = 0; i < num_vars; i++) lv[i] = so->d_eq.fr() + ((1ull << i) - 1);
+    rc = launch_eq_sequence(fr_one(), so->point.data(), num_vars - 1, lv.data(), so->stream);
+    if (rc) return rc;
+    rc = so->rs.init();
+    if (rc) return rc;
+    *out = so.release();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, const uint64_t* h_point,
+                                            const uint64_t* h_gamma, const uint64_t* h_claims, gm_sc** out,
+                                            void* stream) {
+    GM_REQUIRE(out && polys && h_point && h_gamma && h_claims, "bad argument");
+    std::unique_ptr<ScVecVecDeg2> so(new ScVecVecDeg2());
+    int32_t rc = parse_fn(f, &so->fn, &so->sp);
+    if (rc) return rc;
+    GM_REQUIRE(so->sp.deg == 2, "VecVecDeg2Sumcheck needs a degree-2 function (vecvec_eq.rs:426)");
+    GM_REQUIRE((int)polys->k == so->sp.n_ins, "%u polys for a %d-input function", polys->k, so->sp.n_ins);
+    GM_REQUIRE(polys->k <= 16, "VecVec sumcheck supports at most 16 polynomials");
+    GM_REQUIRE(polys->row_logsize >= 1, "row_logsize must be >= 1");
+    GM_REQUIRE(polys->max_row_len >= 2, "all rows empty (log_2(0), vecvec.rs:86)");
+    hipStream_t s = as_stream(stream);
+    so->stream = s;
+    so->k = polys->k;
+    so->nrows = polys->nrows;
+    so->col_logsize = polys->col_logsize;
+    so->row_logsize = polys->row_logsize;
+    so->n_row_vars0 = polys->row_logsize;
+    so->row_pad = polys->row_pad;
+    so->col_pad = polys->col_pad;
+    so->cells_bound = polys->total;
+    const uint32_t nvars = polys->row_logsize + polys->col_logsize;
+    Fr gamma;
+    memcpy(&gamma, h_gamma, 32);
+    so->gamma_pows = make_gamma_pows(gamma, so->sp.n_outs);
+    so->claim_ = rlc_claims(so->gamma_pows, h_claims, so->sp.n_outs);
+    so->point.resize(nvars);
+    memcpy(so->point.data(), h_point, 32 * (size_t)nvars);
+    so->multiplier = fr_one();
+    so->binding_var_idx = (int)nvars - 1;
+    for (uint32_t i = 0; i < polys->k; i++) so->cur.push_back(polys->cols[i]->fr());
+    so->off_cur = reinterpret_cast<const uint32_t*>(polys->off->p);
+    rc = so->off_a.alloc((size_t)(so->nrows + 1) * 4);
+    if (rc) return rc;
+    rc = so->off_b.alloc((size_t)(so->nrows + 1) * 4);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < polys->k; i++) {
+        so->bufA.emplace_back(new DevBuf());
+        so->bufB.emplace_back(new DevBuf());
+        rc = so->bufA.back()->alloc((size_t)(polys->total / 2 + so->nrows + 2) * sizeof(Fr));
+        if (rc) return rc;
+        rc = so->bufB.back()->alloc((size_t)(polys->total / 4 + 2 * so->nrows + 2) * sizeof(Fr));
+        if (rc) return rc;
+    }
+    rc = upload_gamma(so->gamma_pows, &so->d_gamma, s);
+    if (rc) return rc;
+    // EQPolyData::new (vecvec.rs:85-119)
+    uint32_t max_seg_log = 0;
+    {   // liblasso log_2: exact for powers of two, else bit length
+        uint32_t m = polys->max_row_len, bl = 0;
+        while ((1u << bl) < m) bl++;
+        max_seg_log = bl;
+    }
+    GM_REQUIRE(max_seg_log <= polys->row_logsize, "row longer than 2^row_logsize");
+    const uint32_t segment_vars_idx = nvars - max_seg_log;
+    const uint32_t padded = segment_vars_idx - polys->col_logsize;       // padded_vars_range().len()
+    const uint32_t n_seq_vars = (nvars - 1) - polys->col_logsize;        // row_vars_range().len()
+    so->padded_vars = padded;
+    // row_eq_coefs = eq(point[0..col_logsize]) and its tail sums
+    {
+        rc = so->d_row_coef.alloc(((size_t)2 << polys->col_logsize) * sizeof(Fr));
+        if (rc) return rc;
+        std::vector<Fr*> lv(polys->col_logsize + 1);
+        Fr* scratch = so->d_row_coef.fr() + ((size_t)1 << polys->col_logsize);
+        for (uint32_t i = 0; i < polys->col_logsize; i++) lv[i] = scratch + ((1ull << i) - 1);
+        lv[polys->col_logsize] = so->d_row_coef.fr();
+        rc = launch_eq_sequence(fr_one(), so->point.data(), polys->col_logsize, lv.data(), s);
+        if (rc) return rc;
+        std::vector<Fr> coefs((size_t)1 << polys->col_logsize);
+        GM_HIP(hipMemcpyAsync(coefs.data(), so->d_row_coef.p, coefs.size() * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        GM_HIP(hipStreamSynchronize(s));
+        so->row_coef_tail.assign(coefs.size() + 1, fr_zero());
+        for (int64_t i = (int64_t)coefs.size() - 1; i >= 0; i--) so->row_coef_tail[i] = fr_add(so->row_coef_tail[i + 1], coefs[i]);
+    }
+    // padded_eq_poly_sequence(padded, point[row vars])  (utils.rs:189-220): levels 0..n_seq_vars
+    {
+        so->eq_level_off.resize(n_seq_vars + 1);
+        so->eq_level_len.resize(n_seq_vars + 1);
+        uint64_t tot = 0;
+        for (uint32_t i = 0; i <= n_seq_vars; i++) {
+            so->eq_level_len[i] = (i <= padded) ? 1u : (1u << (i - padded));
+            so->eq_level_off[i] = tot;
+            tot += so->eq_level_len[i];
+        }
+        rc = so->d_eq_seq.alloc((size_t)tot * sizeof(Fr));
+        if (rc) return rc;
+        // the first `padded` variables only scale: level i (i <= padded) = prod_{j<i} (1 - pt[j])
+        const Fr* pt = so->point.data() + polys->col_logsize;
+        Fr m = fr_one();
+        for (uint32_t i = 1; i <= padded; i++) m = fr_mul(m, fr_sub(fr_one(), pt[i - 1]));
+        // upload scalar levels 0..padded
+        Fr acc = fr_one();
+        std::vector<Fr> scal(padded + 1);
+        scal[0] = fr_one();
+        for (uint32_t i = 1; i <= padded; i++) { acc = fr_mul(acc, fr_sub(fr_one(), pt[i - 1])); scal[i] = acc; }
+        GM_HIP(hipMemcpyAsync(so->d_eq_seq.p, scal.data(), scal.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+        GM_HIP(hipStreamSynchronize(s));
+        std::vector<Fr*> lv(n_seq_vars - padded + 1);
+        for (uint32_t i = padded; i <= n_seq_vars; i++) lv[i - padded] = so->d_eq_seq.fr() + so->eq_level_off[i];
+        // levels padded..n_seq_vars are the ordinary doubling levels started from the scalar m
+        rc = launch_eq_sequence(m, pt + padded, n_seq_vars - padded, lv.data(), s);
+        if (rc) return rc;
+        rc = so->d_prefix.alloc(((size_t)so->eq_level_len[n_seq_vars] + 2) * sizeof(Fr));
+        if (rc) return rc;
+    }
+    rc = so->rs.init();
+    if (rc) return rc;
+    *out = so.release();
+    return GM_OK;
+}
+
+// DenseSumcheckObjectSO with F = EqWrapper(GammaWrapper(f, gamma)) (kind 0: d_cols = f.n_ins columns + the eq column)
+// or Prod3Fn (kind 1: 3 columns, f ignored); claim_hint as in sumcheck.rs:250.
+extern "C" int32_t gm_sc_dense_create(int32_t kind, const gm_fn* f, uint32_t num_vars, const uint64_t* const* d_cols,
+                                      const uint64_t* h_gamma, const uint64_t* h_claim, gm_sc** out, void* stream) {
+    GM_REQUIRE(out && d_cols && h_claim && num_vars >= 1 && num_vars <= 30 && (kind == 0 || kind == 1), "bad argument");
+    std::unique_ptr<ScDense> so(new ScDense());
+    so->stream = as_stream(stream);
+    so->kind = kind;
+    so->num_vars = num_vars;
+    int ncols = 3;
+    std::vector<Fr> gp = {fr_one()};
+    if (kind == 0) {
+        GM_REQUIRE(h_gamma, "gamma required");
+        GmFn g;
+        int32_t rc = parse_fn(f, &g, &so->sp);
+        if (rc) return rc;
+        GM_REQUIRE(so->sp.n_outs > 1, "GammaWrapper needs n_outs > 1 (sumcheck.rs:714)");
+        so->D = so->sp.deg + 1;
+        ncols = so->sp.n_ins + 1;
+        Fr gamma;
+        memcpy(&gamma, h_gamma, 32);
+        gp = make_gamma_pows(gamma, so->sp.n_outs);
+    } else {
+        so->D = 3;
+    }
+    GM_REQUIRE(so->D == 2 || so->D == 3, "unsupported degree %d", so->D);
+    memcpy(&so->claim_, h_claim, 32);
+    int32_t rc = so->cols.init(ncols, reinterpret_cast<const Fr* const*>(d_cols), 1ull << num_vars);
+    if (rc) return rc;
+    rc = upload_gamma(gp, &so->d_gamma, so->stream);
+    if (rc) return rc;
+    rc = so->rs.init();
+    if (rc) return rc;
+    *out = so.release();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_sc_unipoly(gm_sc* so, uint64_t* h_coeffs, uint32_t* n_coeffs) {
+    GM_REQUIRE(so && h_coeffs, "null argument");
+    std::vector<Fr> c;
+    int32_t rc = so->unipoly(&c);
+    if (rc) return rc;
+    memcpy(h_coeffs, c.data(), c.size() * sizeof(Fr));
+    if (n_coeffs) *n_coeffs = (uint32_t)c.size();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_sc_bind(gm_sc* so, const uint64_t* h_t) {
+    GM_REQUIRE(so && h_t, "null argument");
+    Fr t;
+    memcpy(&t, h_t, 32);
+    return so->bind(t);
+}
+
+extern "C" int32_t gm_sc_final_evals(gm_sc* so, uint64_t* h_evals, uint32_t* n_evals) {
+    GM_REQUIRE(so && h_evals, "null argument");
+    std::vector<Fr> e;
+    int32_t rc = so->final_evals(&e);
+    if (rc) return rc;
+    memcpy(h_evals, e.data(), e.size() * sizeof(Fr));
+    if (n_evals) *n_evals = (uint32_t)e.size();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_sc_claim(const gm_sc* so, uint64_t* h_claim) {
+    GM_REQUIRE(so && h_claim, "null argument");
+    Fr c = so->claim();
+    memcpy(h_claim, &c, 32);
+    return GM_OK;
+}
+
+extern "C" int32_t gm_sc_destroy(gm_sc* so) {
+    delete so;
+    return GM_OK;
+}

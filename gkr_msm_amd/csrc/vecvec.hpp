@@ -1,0 +1,25 @@
+// gm_vv: k VecVec polynomials over one shared ragged row structure (host-side handle).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "internal.hpp"
+
+struct gm_vv {
+    uint32_t k = 0;
+    uint32_t nrows = 0;        // stored rows (data.len() in the reference); rows past it are col_pad
+    uint64_t total = 0;        // cells = sum of (even) stored row lengths
+    uint32_t row_logsize = 0;  // low variables: index inside a row; the ones a sumcheck runs over
+    uint32_t col_logsize = 0;  // high variables: row index
+    uint32_t max_row_len = 0;  // EQPolyData::new needs it (vecvec.rs:86)
+    std::shared_ptr<gm::DevBuf> off;                // u32[nrows + 1]
+    std::vector<std::shared_ptr<gm::DevBuf>> cols;  // k arrays of `total` elements
+    std::vector<gm::Fr> row_pad, col_pad;
+    int32_t alloc_cols(uint32_t k_, uint64_t total_);
+};
+
+namespace gm {
+int32_t vv_map(const SegPlan& sp, const gm_vv* in, gm_vv** out, hipStream_t s);
+int32_t vv_map_split(const SegPlan& sp, const gm_vv* in, uint32_t bundle, gm_vv** out, hipStream_t s);
+int32_t vv_map_split_to_dense(const SegPlan& sp, const gm_vv* in, uint32_t bundle, Fr* const* d_out, hipStream_t s);
+}  // namespace gm

@@ -54,6 +54,30 @@ _SIGS = {
     "gm_fr_batch": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64, vp]),
     "gm_fr_host": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64]),
     "gm_fn_host": (C.c_int32, [C.POINTER(GmFn), vp, vp, C.c_uint64]),
+    "gm_dense_map": (C.c_int32, [C.POINTER(GmFn), vp, vp, C.c_uint64, vp]),
+    "gm_dense_map_split": (C.c_int32, [C.POINTER(GmFn), vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
+    "gm_dense_bind": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint64, vp, vp]),
+    "gm_eq_table": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, vp]),
+    "gm_vv_from_host": (C.c_int32, [C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp), vp]),
+    "gm_vv_from_msm": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(vp), vp]),
+    "gm_vv_map": (C.c_int32, [C.POINTER(GmFn), vp, C.POINTER(vp), vp]),
+    "gm_vv_map_split": (C.c_int32, [C.POINTER(GmFn), vp, C.c_uint32, C.POINTER(vp), vp]),
+    "gm_vv_map_split_to_dense": (C.c_int32, [C.POINTER(GmFn), vp, C.c_uint32, vp, vp]),
+    "gm_vv_slice": (C.c_int32, [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "gm_vv_concat": (C.c_int32, [vp, vp, C.POINTER(vp)]),
+    "gm_vv_to_dense": (C.c_int32, [vp, vp, vp]),
+    "gm_vv_info": (C.c_int32, [vp, u32p, u32p, u64p, u32p, u32p]),
+    "gm_vv_read": (C.c_int32, [vp, C.c_uint32, vp, vp, vp]),
+    "gm_vv_pads": (C.c_int32, [vp, vp, vp]),
+    "gm_vv_destroy": (C.c_int32, [vp]),
+    "gm_sc_dense_deg2_create": (C.c_int32, [C.POINTER(GmFn), C.c_uint32, vp, vp, vp, vp, C.POINTER(vp), vp]),
+    "gm_sc_vecvec_deg2_create": (C.c_int32, [C.POINTER(GmFn), vp, vp, vp, vp, C.POINTER(vp), vp]),
+    "gm_sc_dense_create": (C.c_int32, [C.c_int32, C.POINTER(GmFn), C.c_uint32, vp, vp, vp, C.POINTER(vp), vp]),
+    "gm_sc_unipoly": (C.c_int32, [vp, vp, u32p]),
+    "gm_sc_bind": (C.c_int32, [vp, vp]),
+    "gm_sc_final_evals": (C.c_int32, [vp, vp, u32p]),
+    "gm_sc_claim": (C.c_int32, [vp, vp]),
+    "gm_sc_destroy": (C.c_int32, [vp]),
     "gm_msm_plan_create": (C.c_int32, [C.c_uint32] * 5 + [C.POINTER(vp)]),
     "gm_msm_plan_destroy": (C.c_int32, [vp]),
     "gm_msm_plan_workspace_bytes": (C.c_size_t, [vp]),

@@ -100,3 +100,221 @@ def combine_host(raw_cols, d_logsize):
     ffi.check(ffi.lib().gm_msm_combine_host(raw.ctypes.data, d_logsize, raw.shape[1], out.ctypes.data))
     x, y = codec.from_mont_limbs(out.reshape(2, 4))
     return (x, y)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense columns / VecVec / sumcheck object wrappers (test + bench plumbing over the C ABI)
+def ptr_array(tensors):
+    """host array of device pointers for `const uint64_t* const*` arguments; keeps nothing alive"""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if hasattr(t, "data_ptr") else t
+    return arr
+
+
+def cols_to_dev(cols):
+    """list of lists of canonical ints -> list of device tensors (Montgomery)"""
+    return [to_dev(codec.to_mont_limbs(c)) for c in cols]
+
+
+def cols_to_host(tensors):
+    return [codec.from_mont_limbs(to_host(t)) for t in tensors]
+
+
+def fr_arg(vals):
+    """canonical ints -> contiguous (n,4) uint64 Montgomery array (keep a reference while it is in use)"""
+    return codec.to_mont_limbs(list(vals))
+
+
+def dense_map(fn, cols, n_outs):
+    n = cols[0].numel() // 4
+    outs = [dev_empty(n * 4) for _ in range(n_outs)]
+    ffi.check(ffi.lib().gm_dense_map(C.byref(fn), ptr_array(cols), ptr_array(outs), n, cur_stream()))
+    return outs
+
+
+def dense_map_split(fn, cols, n_outs, lo_bit, bundle):
+    n = cols[0].numel() // 4
+    outs = [dev_empty((n // 2) * 4) for _ in range(2 * n_outs)]
+    ffi.check(ffi.lib().gm_dense_map_split(C.byref(fn), ptr_array(cols), ptr_array(outs), n, lo_bit, bundle,
+                                           cur_stream()))
+    return outs
+
+
+def dense_bind(cols, t):
+    n = cols[0].numel() // 4
+    outs = [dev_empty((n // 2) * 4) for _ in cols]
+    ta = fr_arg([t])
+    ffi.check(ffi.lib().gm_dense_bind(ptr_array(cols), ptr_array(outs), len(cols), n, ta.ctypes.data, cur_stream()))
+    return outs
+
+
+def eq_table(mult, point):
+    nv = len(point)
+    out = dev_empty((1 << nv) * 4)
+    scratch = dev_empty((1 << nv) * 4)
+    m, p = fr_arg([mult]), fr_arg(point if nv else [0])
+    ffi.check(ffi.lib().gm_eq_table(m.ctypes.data, p.ctypes.data, nv, C.c_void_p(scratch.data_ptr()),
+                                    C.c_void_p(out.data_ptr()), cur_stream()))
+    return out
+
+
+class VV:
+    """owner of a gm_vv handle"""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.L = ffi.lib()
+
+    @staticmethod
+    def from_host(rows_per_poly, row_pads, col_pads, row_logsize, col_logsize):
+        """rows_per_poly[c] = list of rows (lists of canonical ints); all polys share the row lengths"""
+        k = len(rows_per_poly)
+        nrows = len(rows_per_poly[0])
+        lens = np.array([len(r) for r in rows_per_poly[0]], dtype=np.uint32)
+        datas = [codec.to_mont_limbs([v for r in rows for v in r]) if sum(len(r) for r in rows) else
+                 np.zeros((1, 4), dtype=np.uint64) for rows in rows_per_poly]
+        dptr = (C.c_void_p * k)(*[d.ctypes.data for d in datas])
+        rp, cp = fr_arg(row_pads), fr_arg(col_pads)
+        h = C.c_void_p()
+        ffi.check(ffi.lib().gm_vv_from_host(k, nrows, lens.ctypes.data if nrows else None, dptr, rp.ctypes.data,
+                                            cp.ctypes.data, row_logsize, col_logsize, C.byref(h), cur_stream()))
+        return VV(h)
+
+    @staticmethod
+    def from_msm(plan, d_points, y_logsize):
+        h = C.c_void_p()
+        ffi.check(ffi.lib().gm_vv_from_msm(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, C.byref(h),
+                                           cur_stream()))
+        return VV(h)
+
+    def close(self):
+        if self.h:
+            self.L.gm_vv_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        k, nr, rl, cl = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        tot = C.c_uint64()
+        ffi.check(self.L.gm_vv_info(self.h, C.byref(k), C.byref(nr), C.byref(tot), C.byref(rl), C.byref(cl)))
+        return dict(k=k.value, nrows=nr.value, total=tot.value, row_logsize=rl.value, col_logsize=cl.value)
+
+    def map(self, fn):
+        h = C.c_void_p()
+        ffi.check(self.L.gm_vv_map(C.byref(fn), self.h, C.byref(h), cur_stream()))
+        return VV(h)
+
+    def map_split(self, fn, bundle):
+        h = C.c_void_p()
+        ffi.check(self.L.gm_vv_map_split(C.byref(fn), self.h, bundle, C.byref(h), cur_stream()))
+        return VV(h)
+
+    def map_split_to_dense(self, fn, bundle, n_outs):
+        n = 1 << self.info()["col_logsize"]
+        outs = [dev_empty(n * 4) for _ in range(2 * n_outs)]
+        ffi.check(self.L.gm_vv_map_split_to_dense(C.byref(fn), self.h, bundle, ptr_array(outs), cur_stream()))
+        return outs
+
+    def slice(self, first, count):
+        h = C.c_void_p()
+        ffi.check(self.L.gm_vv_slice(self.h, first, count, C.byref(h)))
+        return VV(h)
+
+    def concat(self, other):
+        h = C.c_void_p()
+        ffi.check(self.L.gm_vv_concat(self.h, other.h, C.byref(h)))
+        return VV(h)
+
+    def to_dense(self):
+        inf = self.info()
+        n = 1 << (inf["row_logsize"] + inf["col_logsize"])
+        outs = [dev_empty(n * 4) for _ in range(inf["k"])]
+        ffi.check(self.L.gm_vv_to_dense(self.h, ptr_array(outs), cur_stream()))
+        return cols_to_host(outs)
+
+    def rows(self):
+        """[(poly c) -> list of stored rows (canonical ints)], plus pads"""
+        inf = self.info()
+        off = np.zeros(inf["nrows"] + 1, dtype=np.uint32)
+        res = []
+        for c in range(inf["k"]):
+            cells = np.zeros((max(inf["total"], 1), 4), dtype=np.uint64)
+            ffi.check(self.L.gm_vv_read(self.h, c, off.ctypes.data, cells.ctypes.data, cur_stream()))
+            vals = codec.from_mont_limbs(cells[: inf["total"]]) if inf["total"] else []
+            res.append([vals[off[r]:off[r + 1]] for r in range(inf["nrows"])])
+        rp = np.zeros((inf["k"], 4), dtype=np.uint64)
+        cp = np.zeros((inf["k"], 4), dtype=np.uint64)
+        ffi.check(self.L.gm_vv_pads(self.h, rp.ctypes.data, cp.ctypes.data))
+        return res, codec.from_mont_limbs(rp), codec.from_mont_limbs(cp)
+
+
+class Sumcheckable:
+    """`Sumcheckable` (vecvec_eq.rs:218-225) over a gm_sc handle; values are canonical ints"""
+
+    def __init__(self, handle, keep=()):
+        self.h = handle
+        self.L = ffi.lib()
+        self.keep = keep  # device tensors / VV the object reads from
+
+    @staticmethod
+    def dense_deg2(fn, num_vars, cols, point, gamma, claims):
+        h = C.c_void_p()
+        p, g, c = fr_arg(point), fr_arg([gamma]), fr_arg(claims)
+        ffi.check(ffi.lib().gm_sc_dense_deg2_create(C.byref(fn), num_vars, ptr_array(cols), p.ctypes.data,
+                                                    g.ctypes.data, c.ctypes.data, C.byref(h), cur_stream()))
+        return Sumcheckable(h, keep=tuple(cols))
+
+    @staticmethod
+    def vecvec_deg2(fn, vv, point, gamma, claims):
+        h = C.c_void_p()
+        p, g, c = fr_arg(point), fr_arg([gamma]), fr_arg(claims)
+        ffi.check(ffi.lib().gm_sc_vecvec_deg2_create(C.byref(fn), vv.h, p.ctypes.data, g.ctypes.data, c.ctypes.data,
+                                                     C.byref(h), cur_stream()))
+        return Sumcheckable(h, keep=(vv,))
+
+    @staticmethod
+    def dense(kind, fn, num_vars, cols, gamma, claim):
+        h = C.c_void_p()
+        g, c = fr_arg([gamma]), fr_arg([claim])
+        ffi.check(ffi.lib().gm_sc_dense_create(kind, C.byref(fn) if fn is not None else None, num_vars,
+                                               ptr_array(cols), g.ctypes.data, c.ctypes.data, C.byref(h),
+                                               cur_stream()))
+        return Sumcheckable(h, keep=tuple(cols))
+
+    def close(self):
+        if self.h:
+            self.L.gm_sc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def unipoly(self):
+        buf = np.zeros((8, 4), dtype=np.uint64)
+        n = C.c_uint32()
+        ffi.check(self.L.gm_sc_unipoly(self.h, buf.ctypes.data, C.byref(n)))
+        return codec.from_mont_limbs(buf[: n.value])
+
+    def bind(self, t):
+        ta = fr_arg([t])
+        ffi.check(self.L.gm_sc_bind(self.h, ta.ctypes.data))
+
+    def final_evals(self):
+        buf = np.zeros((64, 4), dtype=np.uint64)
+        n = C.c_uint32()
+        ffi.check(self.L.gm_sc_final_evals(self.h, buf.ctypes.data, C.byref(n)))
+        return codec.from_mont_limbs(buf[: n.value])
+
+    def claim(self):
+        buf = np.zeros((1, 4), dtype=np.uint64)
+        ffi.check(self.L.gm_sc_claim(self.h, buf.ctypes.data))
+        return codec.from_mont_limbs(buf)[0]

@@ -79,6 +79,80 @@ int32_t gm_fr_host(int32_t op, const uint64_t* h_a, const uint64_t* h_b, uint64_
 /* exec an AlgFn on host rows: h_in = n rows x n_ins elements, h_out = n rows x n_outs elements */
 int32_t gm_fn_host(const gm_fn* f, const uint64_t* h_in, uint64_t* h_out, uint64_t n);
 
+/* ---------------------------------------------------------------- dense polynomials (a2, a3, a4, a5)
+ * Columns are separate device arrays of 2^n elements; `d_in` / `d_out` are HOST arrays of device pointers.
+ *   gm_dense_map        Vec::algfn_map                 cleanup/polys/dense.rs:141-184   (AlgFnUtils::map algfn.rs:55-80)
+ *   gm_dense_map_split  Vec::algfn_map_split           cleanup/polys/dense.rs:115-139   split on index bit
+ *                       `split_lo_bit` (= SplitIdx::lo_usize), outputs 2*n_outs columns of len/2 in the
+ *                       bundle-interleaved order [L-bundle, R-bundle, ...] of dense.rs:137-138
+ *   gm_dense_bind       bind_dense_poly                cleanup/protocols/sumcheck.rs:160-163 (== bind_21 on 21-form,
+ *                       dense.rs:54-61): out[c][i] = in[c][2i] + t (in[c][2i+1] - in[c][2i]) for k columns
+ *   gm_eq_table         eq_poly_sequence_from_multiplier(..).last()   utils.rs:222-250; point[0] is the MSB;
+ *                       d_scratch: 2^nvars elements of workspace (holds the lower levels) */
+int32_t gm_dense_map(const gm_fn* f, const uint64_t* const* d_in, uint64_t* const* d_out, uint64_t len, void* stream);
+int32_t gm_dense_map_split(const gm_fn* f, const uint64_t* const* d_in, uint64_t* const* d_out, uint64_t len,
+                           uint32_t split_lo_bit, uint32_t bundle, void* stream);
+int32_t gm_dense_bind(const uint64_t* const* d_in, uint64_t* const* d_out, uint32_t k, uint64_t len,
+                      const uint64_t* h_t, void* stream);
+int32_t gm_eq_table(const uint64_t* h_multiplier, const uint64_t* h_point, uint32_t nvars, uint64_t* d_scratch,
+                    uint64_t* d_out, void* stream);
+
+/* ---------------------------------------------------------------- VecVec polynomials (a2, a3, a12)
+ * gm_vv = k `VecVecPolynomial`s sharing one row structure (cleanup/polys/vecvec.rs:149-160): rows stored back to
+ * back on the device, odd rows padded with row_pad (vecvec.rs:181-186).
+ *   gm_vv_from_host           VecVecPolynomial::new for k polys (h_data[c] = rows of poly c concatenated, unpadded)
+ *   gm_vv_from_msm            the bucket image of PushForwardState::new (pushforward.rs:342-349, 380-381, 411-426,
+ *                             477-487) from the last gm_msm_run: polys (x, y, z), pads (0, 1, 0)
+ *   gm_vv_map                 vecvec_map                    vecvec.rs:480-540
+ *   gm_vv_map_split           vecvec_map_split, LO(0)       vecvec.rs:542-606   (output: 2*n_outs polys, bundled)
+ *   gm_vv_map_split_to_dense  vecvec_map_split_to_dense     vecvec.rs:608-654   (d_out: 2*n_outs columns of 2^col_logsize)
+ *   gm_vv_slice / gm_vv_concat  &polys[a..b] / Vec::extend as used by GlueSplit::witness (splits.rs:172-176)
+ *   gm_vv_to_dense            Densify::to_dense             vecvec.rs:446-476 */
+typedef struct gm_vv gm_vv;
+int32_t gm_vv_from_host(uint32_t k, uint32_t nrows, const uint32_t* h_row_len, const uint64_t* const* h_data,
+                        const uint64_t* h_row_pad, const uint64_t* h_col_pad, uint32_t row_logsize,
+                        uint32_t col_logsize, gm_vv** out, void* stream);
+int32_t gm_vv_from_msm(const struct gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize, gm_vv** out,
+                       void* stream);
+int32_t gm_vv_map(const gm_fn* f, const gm_vv* in, gm_vv** out, void* stream);
+int32_t gm_vv_map_split(const gm_fn* f, const gm_vv* in, uint32_t bundle, gm_vv** out, void* stream);
+int32_t gm_vv_map_split_to_dense(const gm_fn* f, const gm_vv* in, uint32_t bundle, uint64_t* const* d_out,
+                                 void* stream);
+int32_t gm_vv_slice(const gm_vv* in, uint32_t first, uint32_t count, gm_vv** out);
+int32_t gm_vv_concat(const gm_vv* a, const gm_vv* b, gm_vv** out);
+int32_t gm_vv_to_dense(const gm_vv* v, uint64_t* const* d_out, void* stream);
+int32_t gm_vv_info(const gm_vv* v, uint32_t* k, uint32_t* nrows, uint64_t* total_cells, uint32_t* row_logsize,
+                   uint32_t* col_logsize);
+int32_t gm_vv_read(const gm_vv* v, uint32_t col, uint32_t* h_off, uint64_t* h_cells, void* stream);
+int32_t gm_vv_pads(const gm_vv* v, uint64_t* h_row_pad, uint64_t* h_col_pad);
+int32_t gm_vv_destroy(gm_vv* v);
+
+/* ---------------------------------------------------------------- sumcheck objects (a6-a9)
+ * The `Sumcheckable::{unipoly, bind, final_evals}` seam (cleanup/protocols/sumchecks/vecvec_eq.rs:218-225) called
+ * by GenericSumcheckProtocol::prove (cleanup/protocols/sumcheck.rs:101-123):
+ *   gm_sc_dense_deg2_create   DenseDeg2SumcheckObject::new + rlc(gamma)   dense_eq.rs:27-59  -> ..ObjectSO :61-173
+ *   gm_sc_vecvec_deg2_create  VecVecDeg2SumcheckObject::new + rlc(gamma)  vecvec_eq.rs:35-70 -> ..ObjectSO :72-398
+ *                             (sparse rounds, then bind_into_dense :157-190 and the dense rounds)
+ *   gm_sc_dense_create        DenseSumcheckObjectSO::new                  sumcheck.rs:248-257; kind 0: F = EqWrapper(
+ *                             GammaWrapper(f, gamma)) over f.n_ins columns + the eq column (:706-829), kind 1: Prod3Fn
+ *                             (pushforward.rs:27-49)
+ * h_claims: n_outs evaluation claims (folded with gamma as in rlc); h_point: num_vars elements, point[0] = MSB.
+ * Input columns are read, never written.  gm_sc_unipoly returns the deg+1 coefficients (low to high) of the
+ * round polynomial, i.e. `unipoly().as_vec()`; the caller drops the linear one (compress_coefficients :27-31). */
+typedef struct gm_sc gm_sc;
+int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, const uint64_t* const* d_cols,
+                                const uint64_t* h_point, const uint64_t* h_gamma, const uint64_t* h_claims, gm_sc** out,
+                                void* stream);
+int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, const uint64_t* h_point, const uint64_t* h_gamma,
+                                 const uint64_t* h_claims, gm_sc** out, void* stream);
+int32_t gm_sc_dense_create(int32_t kind, const gm_fn* f, uint32_t num_vars, const uint64_t* const* d_cols,
+                           const uint64_t* h_gamma, const uint64_t* h_claim, gm_sc** out, void* stream);
+int32_t gm_sc_unipoly(gm_sc* so, uint64_t* h_coeffs, uint32_t* n_coeffs);
+int32_t gm_sc_bind(gm_sc* so, const uint64_t* h_t);
+int32_t gm_sc_final_evals(gm_sc* so, uint64_t* h_evals, uint32_t* n_evals);
+int32_t gm_sc_claim(const gm_sc* so, uint64_t* h_claim);
+int32_t gm_sc_destroy(gm_sc* so);
+
 /* ---------------------------------------------------------------- Pippenger MSM (a11, a12, a14)
  * The reference's bucketed MSM over Bandersnatch:
  *   digits + bucket scatter      PushForwardState::new      pushforward/pushforward.rs:351-361, 401-429
