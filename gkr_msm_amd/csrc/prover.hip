@@ -1,0 +1,518 @@
+// Host side above the kernels, mirroring the reference's prover for the "image part" of the Pippenger
+// protocol (the reference is Rust; no Rust toolchain exists here, so the drivers are C++ with the same
+// names and the same call order):
+//
+//   GlueSplit::witness                       cleanup/protocols/splits.rs:172-176
+//   bintree_add::builder::witness::build     cleanup/protocols/gkrs/bintree_add.rs:137-239     (+ last_step :128-135)
+//   triangle_add::builder::witness::build    cleanup/protocols/gkrs/triangle_add.rs:101-158    (+ last_step :88-99)
+//   PippengerEndingWG::new                   cleanup/protocols/pippenger_ending.rs:32-95  (the reference builds the
+//                                            bintree witness twice, :40-45 and :67-72; one build is kept)
+//   bintree / triangle protocol layer lists  bintree_add.rs:247-375, triangle_add.rs:173-232
+//   SimpleGKR::prove                         cleanup/protocols/gkrs/gkr.rs:45-50
+//   GenericSumcheckProtocol::prove           cleanup/protocols/sumcheck.rs:101-123
+//   DenseDeg2Sumcheck / VecVecDeg2Sumcheck   sumchecks/dense_eq.rs:198-229, sumchecks/vecvec_eq.rs:424-456
+//   SplitAt / ZeroCheck / GlueSplit prove    splits.rs:121-143, zero_check.rs:24-28, splits.rs:185-197
+//   PippengerBucketed::prove                 pippenger_ending.rs:142-149, Pippenger::prove "prove image part" pippenger.rs:138-141
+//
+// The Fiat-Shamir transcript (merlin) stays with the caller: challenges are taken from a tape
+// the caller provides, prover messages are returned in order.
+#include <memory>
+#include <vector>
+
+#include "internal.hpp"
+#include "msm_plan.hpp"
+#include "vecvec.hpp"
+
+using namespace gm;
+
+// C ABI pieces of the other translation units used here
+extern "C" {
+int32_t gm_vv_from_msm(const gm_msm_plan* p, const uint64_t* d_points_xy, uint32_t y_logsize, gm_vv** out, void* stream);
+int32_t gm_vv_slice(const gm_vv* in, uint32_t first, uint32_t count, gm_vv** out);
+int32_t gm_vv_concat(const gm_vv* a, const gm_vv* b, gm_vv** out);
+int32_t gm_vv_destroy(gm_vv* v);
+struct gm_sc;
+int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, const uint64_t* const* d_cols, const uint64_t* h_point,
+                                const uint64_t* h_gamma, const uint64_t* h_claims, gm_sc** out, void* stream);
+int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, const uint64_t* h_point, const uint64_t* h_gamma,
+                                 const uint64_t* h_claims, gm_sc** out, void* stream);
+int32_t gm_sc_unipoly(gm_sc* so, uint64_t* h_coeffs, uint32_t* n_coeffs);
+int32_t gm_sc_bind(gm_sc* so, const uint64_t* h_t);
+int32_t gm_sc_final_evals(gm_sc* so, uint64_t* h_evals, uint32_t* n_evals);
+int32_t gm_sc_claim(const gm_sc* so, uint64_t* h_claim);
+int32_t gm_sc_destroy(gm_sc* so);
+}
+
+namespace {
+
+#define TRY(x)                      \
+    do {                            \
+        int32_t rc__ = (x);         \
+        if (rc__) return rc__;      \
+    } while (0)
+
+gm_fn mkfn(int p0, int c0, int p1 = 0, int c1 = 0) {
+    gm_fn f;
+    memset(&f, 0, sizeof(f));
+    f.nseg = p1 ? 2 : 1;
+    f.prim[0] = p0; f.count[0] = c0;
+    f.prim[1] = p1; f.count[1] = c1;
+    return f;
+}
+
+SegPlan plan_of(const gm_fn& f) {
+    GmFn g;
+    to_gmfn(&f, &g);
+    SegPlan sp;
+    seg_plan_build(g, &sp);
+    return sp;
+}
+
+struct VVHolder {
+    gm_vv* v = nullptr;
+    VVHolder() = default;
+    explicit VVHolder(gm_vv* p) : v(p) {}
+    VVHolder(const VVHolder&) = delete;
+    VVHolder& operator=(const VVHolder&) = delete;
+    ~VVHolder() { if (v) gm_vv_destroy(v); }
+};
+
+// one layer input ("advice", split_map_gkr.rs:75-81)
+struct Advice {
+    enum Kind { VECVEC, DENSE, EMPTY } kind = EMPTY;
+    std::shared_ptr<VVHolder> vv;
+    std::vector<std::shared_ptr<DevBuf>> cols;
+    uint64_t len = 0;
+    std::vector<const uint64_t*> col_ptrs() const {
+        std::vector<const uint64_t*> p;
+        for (auto& c : cols) p.push_back(reinterpret_cast<const uint64_t*>(c->p));
+        return p;
+    }
+};
+
+int32_t dense_alloc(int n, uint64_t len, std::vector<std::shared_ptr<DevBuf>>* out) {
+    out->clear();
+    for (int i = 0; i < n; i++) {
+        out->emplace_back(new DevBuf());
+        TRY(out->back()->alloc((size_t)len * sizeof(Fr)));
+    }
+    return GM_OK;
+}
+
+int32_t dense_map_adv(const gm_fn& f, const Advice& in, Advice* out, hipStream_t s) {
+    SegPlan sp = plan_of(f);
+    out->kind = Advice::DENSE;
+    out->len = in.len;
+    TRY(dense_alloc(sp.n_outs, in.len, &out->cols));
+    std::vector<const Fr*> ci;
+    std::vector<Fr*> co;
+    for (auto& c : in.cols) ci.push_back(c->fr());
+    for (auto& c : out->cols) co.push_back(c->fr());
+    return launch_dense_map(sp, ci.data(), co.data(), in.len, s);
+}
+
+int32_t dense_map_split_adv(const gm_fn& f, const Advice& in, uint32_t lo_bit, uint32_t bundle, Advice* out, hipStream_t s) {
+    SegPlan sp = plan_of(f);
+    out->kind = Advice::DENSE;
+    out->len = in.len / 2;
+    TRY(dense_alloc(2 * sp.n_outs, in.len / 2, &out->cols));
+    std::vector<const Fr*> ci;
+    std::vector<Fr*> co;
+    for (auto& c : in.cols) ci.push_back(c->fr());
+    for (auto& c : out->cols) co.push_back(c->fr());
+    return launch_dense_map_split(sp, ci.data(), co.data(), in.len, lo_bit, bundle, s);
+}
+
+int32_t adv_map(const gm_fn& f, const Advice& in, Advice* out, hipStream_t s) {
+    if (in.kind == Advice::DENSE) return dense_map_adv(f, in, out, s);
+    SegPlan sp = plan_of(f);
+    gm_vv* o = nullptr;
+    TRY(vv_map(sp, in.vv->v, &o, s));
+    out->kind = Advice::VECVEC;
+    out->vv.reset(new VVHolder(o));
+    return GM_OK;
+}
+
+// advice_map_split (bintree_add.rs:186-205): VecVec -> dense when layer_idx + 2 == row_logsize
+int32_t adv_map_split_lo0(const gm_fn& f, const Advice& in, uint32_t layer_idx, uint32_t row_logsize, uint32_t bundle,
+                          Advice* out, hipStream_t s) {
+    if (in.kind == Advice::DENSE) return dense_map_split_adv(f, in, 0, bundle, out, s);
+    SegPlan sp = plan_of(f);
+    if (layer_idx + 2 == row_logsize) {
+        out->kind = Advice::DENSE;
+        out->len = 1ull << in.vv->v->col_logsize;
+        TRY(dense_alloc(2 * sp.n_outs, out->len, &out->cols));
+        std::vector<Fr*> co;
+        for (auto& c : out->cols) co.push_back(c->fr());
+        return vv_map_split_to_dense(sp, in.vv->v, bundle, co.data(), s);
+    }
+    gm_vv* o = nullptr;
+    TRY(vv_map_split(sp, in.vv->v, bundle, &o, s));
+    out->kind = Advice::VECVEC;
+    out->vv.reset(new VVHolder(o));
+    return GM_OK;
+}
+
+struct Claims {
+    std::vector<Fr> point, evs;
+};
+
+struct Tape {
+    const uint64_t* tape;
+    uint64_t n, pos = 0;
+    std::vector<Fr>* msgs;
+    uint64_t rounds = 0;
+    int32_t challenge(Fr* out) {
+        if (pos >= n) return set_err(GM_ERR_INVALID, "challenge tape exhausted after %llu challenges", (unsigned long long)pos);
+        Fr c;
+        memcpy(&c, tape + 4 * pos, 32);  // canonical value < 2^128 (transcript.challenge(128), proof_transcript.rs:37-39)
+        pos++;
+        *out = fr_to_mont(c);
+        return GM_OK;
+    }
+    void write_scalars(const std::vector<Fr>& v) { msgs->insert(msgs->end(), v.begin(), v.end()); }
+};
+
+// GenericSumcheckProtocol::prove (sumcheck.rs:101-123)
+int32_t generic_sumcheck_prove(Tape* tr, gm_sc* so, uint32_t num_rounds, uint32_t degree, std::vector<Fr>* point,
+                               std::vector<Fr>* final_evals) {
+    std::vector<Fr> r;
+    for (uint32_t rd = 0; rd < num_rounds; rd++) {
+        Fr coeffs[8];
+        uint32_t nc = 0;
+        TRY(gm_sc_unipoly(so, reinterpret_cast<uint64_t*>(coeffs), &nc));
+        if (nc != degree + 1) return set_err(GM_ERR_STATE, "round polynomial has %u coefficients, expected %u", nc, degree + 1);
+        std::vector<Fr> msg;  // compress_coefficients: drop the linear term (sumcheck.rs:27-31)
+        msg.push_back(coeffs[0]);
+        for (uint32_t i = 2; i < nc; i++) msg.push_back(coeffs[i]);
+        tr->write_scalars(msg);
+        Fr x;
+        TRY(tr->challenge(&x));
+        r.push_back(x);
+        TRY(gm_sc_bind(so, reinterpret_cast<const uint64_t*>(&x)));
+        tr->rounds++;
+    }
+    point->assign(r.rbegin(), r.rend());
+    Fr ev[GM_MAX_COLS + 1];
+    uint32_t ne = 0;
+    TRY(gm_sc_final_evals(so, reinterpret_cast<uint64_t*>(ev), &ne));
+    final_evals->assign(ev, ev + ne);
+    return GM_OK;
+}
+
+struct ScHolder {
+    gm_sc* so = nullptr;
+    ~ScHolder() { if (so) gm_sc_destroy(so); }
+};
+
+// DenseDeg2Sumcheck::prove (dense_eq.rs:198-229)
+int32_t dense_deg2_prove(Tape* tr, const gm_fn& f, uint32_t num_vars, Claims* claims, const Advice& adv, hipStream_t s) {
+    if (adv.kind != Advice::DENSE) return set_err(GM_ERR_STATE, "dense layer got a non-dense advice");
+    Fr gamma;
+    TRY(tr->challenge(&gamma));
+    ScHolder h;
+    auto ptrs = adv.col_ptrs();
+    TRY(gm_sc_dense_deg2_create(&f, num_vars, ptrs.data(), reinterpret_cast<const uint64_t*>(claims->point.data()),
+                                reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(claims->evs.data()),
+                                &h.so, s));
+    std::vector<Fr> pt, evs;
+    TRY(generic_sumcheck_prove(tr, h.so, num_vars, 3, &pt, &evs));
+    tr->write_scalars(evs);
+    claims->point = pt;
+    claims->evs = evs;
+    return GM_OK;
+}
+
+// VecVecDeg2Sumcheck::prove (vecvec_eq.rs:424-456)
+int32_t vecvec_deg2_prove(Tape* tr, const gm_fn& f, uint32_t num_vars, Claims* claims, const Advice& adv, hipStream_t s) {
+    if (adv.kind != Advice::VECVEC) return set_err(GM_ERR_STATE, "vecvec layer got a non-vecvec advice");
+    Fr gamma;
+    TRY(tr->challenge(&gamma));
+    ScHolder h;
+    TRY(gm_sc_vecvec_deg2_create(&f, adv.vv->v, reinterpret_cast<const uint64_t*>(claims->point.data()),
+                                 reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(claims->evs.data()),
+                                 &h.so, s));
+    std::vector<Fr> pt, evs;
+    TRY(generic_sumcheck_prove(tr, h.so, num_vars, 3, &pt, &evs));
+    evs.pop_back();  // the eq column (vecvec_eq.rs:451)
+    tr->write_scalars(evs);
+    claims->point = pt;
+    claims->evs = evs;
+    return GM_OK;
+}
+
+// SplitAt::prove (splits.rs:121-143); HI(x): insert at x, LO(x): insert at len - x
+int32_t split_at_prove(Tape* tr, Claims* c, bool hi, uint32_t idx, uint32_t bundle) {
+    Fr r;
+    TRY(tr->challenge(&r));
+    std::vector<Fr> l, rr;
+    for (size_t base = 0; base < c->evs.size(); base += bundle) {
+        std::vector<Fr>& dst = ((base / bundle) % 2 == 0) ? l : rr;
+        for (size_t i = base; i < base + bundle && i < c->evs.size(); i++) dst.push_back(c->evs[i]);
+    }
+    std::vector<Fr> nw;
+    for (size_t i = 0; i < l.size() && i < rr.size(); i++) nw.push_back(fr_add(l[i], fr_mul(r, fr_sub(rr[i], l[i]))));
+    const size_t pos = hi ? idx : c->point.size() - idx;
+    c->point.insert(c->point.begin() + pos, r);
+    c->evs = nw;
+    return GM_OK;
+}
+
+struct Layer {
+    enum Kind { VECVEC, DENSE, SPLIT, ZEROCHECK } kind;
+    gm_fn f;
+    uint32_t num_vars = 0;
+    bool split_hi = false;
+    uint32_t split_idx = 0, bundle = 3;
+};
+
+// SimpleGKR::prove (gkr.rs:45-50)
+int32_t simple_gkr_prove(Tape* tr, const std::vector<Layer>& layers, const std::vector<Advice>& advices, Claims* claims,
+                         hipStream_t s) {
+    if (layers.size() != advices.size()) return set_err(GM_ERR_STATE, "%zu layers vs %zu advices (zip_eq)", layers.size(), advices.size());
+    for (size_t k = layers.size(); k-- > 0;) {
+        const Layer& L = layers[k];
+        const Advice& a = advices[k];
+        switch (L.kind) {
+            case Layer::VECVEC: TRY(vecvec_deg2_prove(tr, L.f, L.num_vars, claims, a, s)); break;
+            case Layer::DENSE: TRY(dense_deg2_prove(tr, L.f, L.num_vars, claims, a, s)); break;
+            case Layer::SPLIT: TRY(split_at_prove(tr, claims, L.split_hi, L.split_idx, L.bundle)); break;
+            case Layer::ZEROCHECK:  // zero_check.rs:24-28
+                claims->evs.push_back(fr_zero());
+                claims->evs.push_back(fr_zero());
+                break;
+        }
+    }
+    return GM_OK;
+}
+
+}  // namespace
+
+struct gm_pip_witness {
+    uint32_t x_log, y_log, d_log;
+    hipStream_t stream;
+    std::vector<Advice> bintree_advices, triangle_advices;
+    Advice bucket_sums;   // bintree last_step
+    Advice dense_output;  // triangle last_step: 3*(d+1) columns of 2^y_log
+};
+
+// bintree_add::builder::witness::build (bintree_add.rs:137-184)
+static int32_t bintree_witness_build(Advice advice, uint32_t row_logsize, uint32_t num_adds, bool do_bitcheck,
+                                     std::vector<Advice>* advices, hipStream_t s) {
+    GM_REQUIRE(num_adds > 0, "num_adds must be positive (bintree_add.rs:143)");
+    for (uint32_t add = 0; add < num_adds; add++) {
+        const bool last = add + 1 == num_adds;
+        for (int step = 0; step < 3; step++) {
+            Advice next;
+            bool have_next = true;
+            if (step == 0) TRY(adv_map(mkfn(add == 0 ? GM_FN_AFF_L1 : GM_FN_PROJ_L1, 1), advice, &next, s));
+            else if (step == 1) TRY(adv_map(mkfn(add == 0 ? GM_FN_AFF_L2 : GM_FN_PROJ_L2, 1), advice, &next, s));
+            else if (last) have_next = false;
+            else TRY(adv_map_split_lo0(mkfn(add == 0 ? GM_FN_AFF_L3 : GM_FN_PROJ_L3, 1), advice, add, row_logsize, 3, &next, s));
+            advices->push_back(advice);
+            if (add == 0 && step == 0 && do_bitcheck) advices->push_back(Advice());
+            if (have_next) advice = next;
+        }
+        if (!last) advices->push_back(Advice());
+    }
+    return GM_OK;
+}
+
+// bintree_add::builder::protocol::build (bintree_add.rs:247-375)
+static std::vector<Layer> bintree_layers(uint32_t num_vars, uint32_t num_adds, uint32_t row_logsize, bool do_bitcheck) {
+    std::vector<Layer> layers;
+    for (uint32_t i = 0; i < num_adds; i++) {
+        for (int step = 0; step < 3; step++) {
+            Layer L;
+            L.kind = (i == 0 || i + 1 < row_logsize) ? Layer::VECVEC : Layer::DENSE;
+            L.num_vars = num_vars - i - 1;
+            const int prim = (i == 0) ? (step == 0 ? GM_FN_AFF_L1 : step == 1 ? GM_FN_AFF_L2 : GM_FN_AFF_L3)
+                                      : (step == 0 ? GM_FN_PROJ_L1 : step == 1 ? GM_FN_PROJ_L2 : GM_FN_PROJ_L3);
+            L.f = (i == 0 && step == 0 && do_bitcheck) ? mkfn(GM_FN_AFF_L1, 1, GM_FN_BITCHECK, 2) : mkfn(prim, 1);
+            layers.push_back(L);
+            if (i == 0 && step == 0 && do_bitcheck) {
+                Layer Z;
+                Z.kind = Layer::ZEROCHECK;
+                layers.push_back(Z);
+            }
+        }
+        if (i != num_adds - 1) {
+            Layer S;
+            S.kind = Layer::SPLIT; S.split_hi = false; S.split_idx = 0; S.bundle = 3;
+            layers.push_back(S);
+        }
+    }
+    return layers;
+}
+
+// triangle_add::builder::witness::build (triangle_add.rs:101-158); split index HI(hi_idx)
+static int32_t triangle_witness_build(Advice advice, uint32_t num_vars, uint32_t hi_idx, std::vector<Advice>* advices,
+                                      hipStream_t s) {
+    const uint32_t num_layers = num_vars - hi_idx;
+    for (uint32_t l = 0; l <= num_layers; l++) {
+        for (int step = 0; step < 3; step++) {
+            Advice next;
+            bool have_next = true;
+            if (step == 0) TRY(dense_map_adv(mkfn(GM_FN_TRI_L1, 1, GM_FN_PROJ_L1, (int)l), advice, &next, s));
+            else if (step == 1) TRY(dense_map_adv(mkfn(GM_FN_PROJ_L2, (int)l + 3), advice, &next, s));
+            else if (l == num_layers) have_next = false;
+            else {
+                // the arrays at layer l have num_vars - l variables; HI(hi_idx) = index bit (num_vars - l) - 1 - hi_idx
+                const uint32_t lo_bit = (num_vars - l) - 1 - hi_idx;
+                TRY(dense_map_split_adv(mkfn(GM_FN_PROJ_L3, (int)l + 3), advice, lo_bit, 3, &next, s));
+            }
+            advices->push_back(advice);
+            if (have_next) advice = next;
+        }
+        if (l < num_layers) advices->push_back(Advice());
+    }
+    return GM_OK;
+}
+
+// triangle_add::builder::protocol::build (triangle_add.rs:173-232)
+static std::vector<Layer> triangle_layers(uint32_t num_vars, uint32_t hi_idx) {
+    std::vector<Layer> layers;
+    const uint32_t num_layers = num_vars - hi_idx;
+    for (uint32_t l = 0; l <= num_layers; l++) {
+        Layer a, b, c;
+        a.kind = b.kind = c.kind = Layer::DENSE;
+        a.num_vars = b.num_vars = c.num_vars = num_vars - l;
+        a.f = mkfn(GM_FN_TRI_L1, 1, GM_FN_PROJ_L1, (int)l);
+        b.f = mkfn(GM_FN_PROJ_L2, (int)l + 3);
+        c.f = mkfn(GM_FN_PROJ_L3, (int)l + 3);
+        layers.push_back(a); layers.push_back(b); layers.push_back(c);
+        if (l < num_layers) {
+            Layer S;
+            S.kind = Layer::SPLIT; S.split_hi = true; S.split_idx = hi_idx; S.bundle = 3;
+            layers.push_back(S);
+        }
+    }
+    return layers;
+}
+
+// ------------------------------------------------------------------------------------------- C ABI
+// PippengerWG::new without the G1 commitments (pippenger.rs:37-70): image -> GlueSplit::witness -> PippengerEndingWG::new
+extern "C" int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                         gm_pip_witness** out, void* stream) {
+    GM_REQUIRE(plan && d_points_xy && out, "null argument");
+    GM_REQUIRE(plan->x_log >= plan->d_log, "x_logsize >= d_logsize required (pippenger.rs:93)");
+    GM_REQUIRE(plan->x_log >= 2, "x_logsize >= 2 required");
+    hipStream_t s = as_stream(stream);
+    std::unique_ptr<gm_pip_witness> w(new gm_pip_witness());
+    w->x_log = plan->x_log; w->y_log = y_logsize; w->d_log = plan->d_log; w->stream = s;
+    gm_vv* image = nullptr;
+    TRY(gm_vv_from_msm(plan, d_points_xy, y_logsize, &image, stream));
+    VVHolder img(image);
+    // GlueSplit::witness (splits.rs:172-176)
+    gm_vv *xy = nullptr, *z = nullptr, *xy_s = nullptr, *z_s = nullptr, *glued = nullptr;
+    TRY(gm_vv_slice(image, 0, 2, &xy));
+    VVHolder hxy(xy);
+    TRY(gm_vv_slice(image, 2, 1, &z));
+    VVHolder hz(z);
+    TRY(vv_map_split(plan_of(mkfn(GM_FN_ID, 2)), xy, 2, &xy_s, s));
+    VVHolder hxys(xy_s);
+    TRY(vv_map_split(plan_of(mkfn(GM_FN_ID, 1)), z, 1, &z_s, s));
+    VVHolder hzs(z_s);
+    TRY(gm_vv_concat(xy_s, z_s, &glued));
+    Advice in;
+    in.kind = Advice::VECVEC;
+    in.vv.reset(new VVHolder(glued));
+    // PippengerEndingWG::new (pippenger_ending.rs:32-95)
+    const uint32_t horizontal = plan->x_log, multirow = y_logsize, bucket = plan->d_log;
+    TRY(bintree_witness_build(in, horizontal, horizontal, true, &w->bintree_advices, s));
+    // last_step (bintree_add.rs:128-135)
+    TRY(adv_map(mkfn(horizontal - 1 == 0 ? GM_FN_AFF_L3 : GM_FN_PROJ_L3, 1), w->bintree_advices.back(), &w->bucket_sums, s));
+    GM_REQUIRE(w->bucket_sums.kind == Advice::DENSE, "bucket sums are not dense");
+    const uint32_t nv = multirow + bucket;
+    Advice s1, s2;
+    TRY(dense_map_split_adv(mkfn(GM_FN_ID, 3), w->bucket_sums, nv - 1 - multirow, 3, &s1, s));
+    TRY(dense_map_split_adv(mkfn(GM_FN_ID, 6), s1, (nv - 1) - 1 - multirow, 3, &s2, s));
+    TRY(triangle_witness_build(s2, nv - 2, multirow, &w->triangle_advices, s));
+    // pippenger.rs:531-534: last_step(ending.last(), num_layers) with num_layers = d - 2
+    TRY(dense_map_adv(mkfn(GM_FN_PROJ_L3, (int)(bucket - 2) + 3), w->triangle_advices.back(), &w->dense_output, s));
+    GM_HIP(hipStreamSynchronize(s));
+    *out = w.release();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_pip_witness_destroy(gm_pip_witness* w) {
+    delete w;
+    return GM_OK;
+}
+
+// device columns of the dense output (3*(d+1) columns of 2^y_logsize) and of the bucket sums (3 x 2^(y_log+d))
+extern "C" int32_t gm_pip_witness_outputs(const gm_pip_witness* w, const uint64_t** d_output_cols, uint32_t* n_output_cols,
+                                          uint64_t* output_len, const uint64_t** d_bucket_sum_cols) {
+    GM_REQUIRE(w, "null witness");
+    if (d_output_cols)
+        for (size_t i = 0; i < w->dense_output.cols.size(); i++)
+            d_output_cols[i] = reinterpret_cast<const uint64_t*>(w->dense_output.cols[i]->p);
+    if (n_output_cols) *n_output_cols = (uint32_t)w->dense_output.cols.size();
+    if (output_len) *output_len = w->dense_output.len;
+    if (d_bucket_sum_cols)
+        for (int i = 0; i < 3; i++) d_bucket_sum_cols[i] = reinterpret_cast<const uint64_t*>(w->bucket_sums.cols[i]->p);
+    return GM_OK;
+}
+
+// bytes of witness trace held on the device
+extern "C" uint64_t gm_pip_witness_bytes(const gm_pip_witness* w) {
+    if (!w) return 0;
+    uint64_t b = 0;
+    auto add = [&](const Advice& a) {
+        if (a.kind == Advice::DENSE) for (auto& c : a.cols) b += c->bytes;
+        if (a.kind == Advice::VECVEC) for (auto& c : a.vv->v->cols) b += c->bytes;
+    };
+    for (auto& a : w->bintree_advices) add(a);
+    for (auto& a : w->triangle_advices) add(a);
+    return b;
+}
+
+// PippengerBucketed::prove + GlueSplit::prove = "prove image part" (pippenger.rs:138-141).
+//   h_claim_point: y_logsize elements; h_claim_evs: 3*(d+1) evaluations of the dense output at that point
+//   h_tape: n_tape challenges, canonical 4 x u64 (values < 2^128)
+//   outputs: prover messages in order (h_msgs, capacity msgs_cap elements), final claims (point of
+//   y_log + d + x_log elements, 3 evaluations: x, y, z of the image), challenges consumed, sumcheck rounds run.
+extern "C" int32_t gm_pip_prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim_point,
+                                           const uint64_t* h_claim_evs, const uint64_t* h_tape, uint64_t n_tape,
+                                           uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_final_point,
+                                           uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* tape_used,
+                                           uint64_t* rounds) {
+    GM_REQUIRE(w && h_claim_point && h_claim_evs && h_tape, "null argument");
+    const uint32_t multirow = w->y_log, bucket = w->d_log, horizontal = w->x_log;
+    std::vector<Fr> msgs;
+    Tape tr{h_tape, n_tape, 0, &msgs, 0};
+    Claims c;
+    c.point.resize(multirow);
+    memcpy(c.point.data(), h_claim_point, 32 * (size_t)multirow);
+    c.evs.resize(3 * (bucket + 1));
+    memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
+    hipStream_t s = w->stream;
+    // PippengerBucketed::prove (pippenger_ending.rs:142-149)
+    TRY(simple_gkr_prove(&tr, triangle_layers(multirow + bucket - 2, multirow), w->triangle_advices, &c, s));
+    TRY(split_at_prove(&tr, &c, true, multirow, 3));
+    TRY(split_at_prove(&tr, &c, true, multirow, 3));
+    TRY(simple_gkr_prove(&tr, bintree_layers(multirow + bucket + horizontal, horizontal, horizontal, true),
+                         w->bintree_advices, &c, s));
+    // GlueSplit::prove (splits.rs:185-197)
+    {
+        Fr r;
+        TRY(tr.challenge(&r));
+        GM_REQUIRE(c.evs.size() == 6, "GlueSplit expects 6 evaluations, got %zu", c.evs.size());
+        std::vector<Fr> nw = {fr_add(c.evs[0], fr_mul(r, fr_sub(c.evs[2], c.evs[0]))),
+                              fr_add(c.evs[1], fr_mul(r, fr_sub(c.evs[3], c.evs[1]))),
+                              fr_add(c.evs[4], fr_mul(r, fr_sub(c.evs[5], c.evs[4])))};
+        c.point.push_back(r);
+        c.evs = nw;
+    }
+    if (n_msgs) *n_msgs = msgs.size();
+    if (h_msgs) {
+        GM_REQUIRE(msgs.size() <= msgs_cap, "message buffer too small: %zu > %llu", msgs.size(), (unsigned long long)msgs_cap);
+        memcpy(h_msgs, msgs.data(), msgs.size() * sizeof(Fr));
+    }
+    if (n_final_point) *n_final_point = (uint32_t)c.point.size();
+    if (h_final_point) memcpy(h_final_point, c.point.data(), c.point.size() * sizeof(Fr));
+    if (h_final_evs) memcpy(h_final_evs, c.evs.data(), c.evs.size() * sizeof(Fr));
+    if (tape_used) *tape_used = tr.pos;
+    if (rounds) *rounds = tr.rounds;
+    return GM_OK;
+}

@@ -193,7 +193,9 @@ static void pads_through(const SegPlan& sp, const gm_vv* in, std::vector<Fr>* rp
 namespace gm {
 
 int32_t vv_map(const SegPlan& sp, const gm_vv* in, gm_vv** out, hipStream_t s) {
-    GM_REQUIRE((int)in->k == sp.n_ins, "vecvec_map: %u polys for a %d-input function", in->k, sp.n_ins);
+    // exec reads args[0..n_ins): extra trailing polys are ignored, as in the reference
+    // (bintree level 0 maps affine l1 over the 6-poly GlueSplit output, bintree_add.rs:213-215)
+    GM_REQUIRE((int)in->k >= sp.n_ins, "vecvec_map: %u polys for a %d-input function", in->k, sp.n_ins);
     std::unique_ptr<gm_vv> o(new gm_vv());
     o->nrows = in->nrows; o->row_logsize = in->row_logsize; o->col_logsize = in->col_logsize;
     o->max_row_len = in->max_row_len;

@@ -78,6 +78,11 @@ _SIGS = {
     "gm_sc_final_evals": (C.c_int32, [vp, vp, u32p]),
     "gm_sc_claim": (C.c_int32, [vp, vp]),
     "gm_sc_destroy": (C.c_int32, [vp]),
+    "gm_pip_witness_create": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(vp), vp]),
+    "gm_pip_witness_destroy": (C.c_int32, [vp]),
+    "gm_pip_witness_outputs": (C.c_int32, [vp, vp, u32p, u64p, vp]),
+    "gm_pip_witness_bytes": (C.c_uint64, [vp]),
+    "gm_pip_prove_image_part": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, u32p, vp, u64p, u64p]),
     "gm_msm_plan_create": (C.c_int32, [C.c_uint32] * 5 + [C.POINTER(vp)]),
     "gm_msm_plan_destroy": (C.c_int32, [vp]),
     "gm_msm_plan_workspace_bytes": (C.c_size_t, [vp]),

@@ -318,3 +318,51 @@ class Sumcheckable:
         buf = np.zeros((1, 4), dtype=np.uint64)
         ffi.check(self.L.gm_sc_claim(self.h, buf.ctypes.data))
         return codec.from_mont_limbs(buf)[0]
+
+
+class PipWitness:
+    """gm_pip_witness: the witness of the image part (bintree + triangle traces) on the device"""
+
+    def __init__(self, plan, d_points, y_logsize):
+        self.L = ffi.lib()
+        self.plan, self.y_logsize = plan, y_logsize
+        self.h = C.c_void_p()
+        ffi.check(self.L.gm_pip_witness_create(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, C.byref(self.h),
+                                               cur_stream()))
+
+    def close(self):
+        if self.h:
+            self.L.gm_pip_witness_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def outputs(self):
+        """(dense output columns, bucket sum columns) as canonical ints"""
+        d = self.plan.d_logsize
+        ncol = 3 * (d + 1)
+        out_ptrs = (C.c_void_p * ncol)()
+        bs_ptrs = (C.c_void_p * 3)()
+        n, ln = C.c_uint32(), C.c_uint64()
+        ffi.check(self.L.gm_pip_witness_outputs(self.h, out_ptrs, C.byref(n), C.byref(ln), bs_ptrs))
+        outs = [codec.from_mont_limbs(read_dev(out_ptrs[i], ln.value * 32)) for i in range(n.value)]
+        nb = 1 << (self.y_logsize + d)
+        bs = [codec.from_mont_limbs(read_dev(bs_ptrs[i], nb * 32)) for i in range(3)]
+        return outs, bs
+
+    def prove_image_part(self, claim_point, claim_evs, tape, msgs_cap=1 << 16):
+        cp, ce = fr_arg(claim_point), fr_arg(claim_evs)
+        tp = codec.ints_to_limbs(tape)
+        msgs = np.zeros((msgs_cap, 4), dtype=np.uint64)
+        fpt = np.zeros((64, 4), dtype=np.uint64)
+        fev = np.zeros((8, 4), dtype=np.uint64)
+        nm, used, rounds, npt = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        ffi.check(self.L.gm_pip_prove_image_part(self.h, cp.ctypes.data, ce.ctypes.data, tp.ctypes.data, len(tape),
+                                                 msgs.ctypes.data, msgs_cap, C.byref(nm), fpt.ctypes.data,
+                                                 C.byref(npt), fev.ctypes.data, C.byref(used), C.byref(rounds)))
+        return dict(msgs=codec.from_mont_limbs(msgs[: nm.value]), point=codec.from_mont_limbs(fpt[: npt.value]),
+                    evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value, rounds=rounds.value)

@@ -206,6 +206,27 @@ int32_t gm_msm_combine_host(const uint64_t* h_cols, uint32_t d_logsize, uint32_t
 int32_t gm_msm_te(const uint64_t* d_points_xy, const uint64_t* d_scalars, uint32_t x_logsize,
                   uint32_t d_logsize, uint32_t nbits, uint64_t* h_out_xy, void* stream);
 
+/* ---------------------------------------------------------------- "prove image part" (a10, a11)
+ * Host-side driver over the kernels, mirroring PippengerWG::new (pippenger.rs:37-70, without the BLS12-381 G1
+ * commitments: SURVEY 8f-1) and Pippenger::prove's "prove image part" span (pippenger.rs:138-141):
+ *   gm_pip_witness_create    image (gm_vv_from_msm) -> GlueSplit::witness (splits.rs:172-176) -> PippengerEndingWG::new
+ *                            (pippenger_ending.rs:32-95): bintree witness, last_step, two HI splits, triangle witness,
+ *                            and the dense output of pippenger.rs:531-534
+ *   gm_pip_prove_image_part  PippengerBucketed::prove (pippenger_ending.rs:142-149) + GlueSplit::prove (splits.rs:185-197).
+ * The Fiat-Shamir transcript stays with the caller: h_tape holds the challenges in the order the protocol draws
+ * them (canonical 4 x u64, values < 2^128 as `challenge(128)` yields); prover messages come back in write order. */
+typedef struct gm_pip_witness gm_pip_witness;
+int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                              gm_pip_witness** out, void* stream);
+int32_t gm_pip_witness_destroy(gm_pip_witness* w);
+int32_t gm_pip_witness_outputs(const gm_pip_witness* w, const uint64_t** d_output_cols, uint32_t* n_output_cols,
+                               uint64_t* output_len, const uint64_t** d_bucket_sum_cols);
+uint64_t gm_pip_witness_bytes(const gm_pip_witness* w);
+int32_t gm_pip_prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_msgs, uint64_t msgs_cap,
+                                uint64_t* n_msgs, uint64_t* h_final_point, uint32_t* n_final_point,
+                                uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds);
+
 /* Bandersnatch ScalarField (Montgomery, as stored by ark `Fr` of ark-ed-on-bls12-381-bandersnatch)
  * -> canonical bigint: the `into_bigint()` of pushforward.rs:352 / msm_nonaffine.rs:21-23. */
 int32_t gm_bs_scalars_into_bigint(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream);
