@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--nbits", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-sumcheck", action="store_true")
+    ap.add_argument("--cpu-sumcheck-xlog", type=int, default=14)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,11 +165,51 @@ def main():
         "result_x": hex(result[0]),
     }
 
+    # ---- second headline: sumcheck rounds/sec of the image-part prover (triangle + bintree GKR) at the same config
+    P = codec.P
+
+    def claims_for(w_, y_log_, seed):
+        outs, _ = w_.outputs()
+        pr = np.random.default_rng(seed)
+        r = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(y_log_)]
+
+        def ev(poly):
+            cur = list(poly)
+            for f in reversed(r):
+                cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
+            return cur[0]
+        tape = [int.from_bytes(pr.bytes(16), "little") for _ in range(4000)]
+        return r, [ev(o) for o in outs], tape
+
+    if world == 1 and not args.no_sumcheck:
+        y_log = (y_size - 1).bit_length()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        w = harness.PipWitness(plan, d_pts, y_log)
+        torch.cuda.synchronize()
+        wit_ms = (time.perf_counter() - t1) * 1e3
+        r_pt, r_evs, tape = claims_for(w, y_log, 7)
+        w.prove_image_part(r_pt, r_evs, tape)          # warmup
+        reps = 3
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            res = w.prove_image_part(r_pt, r_evs, tape)
+        prove_dt = (time.perf_counter() - t1) / reps
+        out["sumcheck"] = {"metric": "sumcheck_rounds_per_sec", "value": round(res["rounds"] / prove_dt, 1),
+                           "rounds": res["rounds"], "prove_ms": round(prove_dt * 1e3, 2),
+                           "witness_build_ms": round(wit_ms, 2),
+                           "witness_trace_GiB": round(L.gm_pip_witness_bytes(w.h) / 2 ** 30, 2),
+                           "workload": "prove image part (triangle + bintree GKR) x_logsize=%d d_logsize=%d nbits=%d" % (
+                               x_log, d_log, nbits)}
+        w.close()
+        del w
+
     # ---- CPU baseline + in-run parity (rank 0, N = 1)
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_ffi as O
-        threads = args.cpu_threads or (os.cpu_count() or 1)
+        threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
         pts_h = harness.to_host(d_pts).reshape(n, 8)
         # bounded sample: the first 2^xs points of the same inputs, all windows
         xs = min(x_log, 20)
@@ -183,6 +225,34 @@ def main():
             out["parity"] = "bit-exact vs oracle (window points, %d x %d Fr)" % raw.shape[:2] if ok else "MISMATCH"
             assert ok, "GPU window points differ from the CPU oracle"
         out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        if not args.no_sumcheck:
+            # bounded sumcheck sample: the same prover at x_logsize = 16 on the CPU oracle and on the GPU
+            xs2 = min(x_log, args.cpu_sumcheck_xlog)
+            y_log = (y_size - 1).bit_length()
+            n2 = 1 << xs2
+            plan2 = harness.MsmPlan(xs2, d_log, y_size)
+            d_pts2, d_sc2 = harness.to_dev(pts_h[:n2]), harness.to_dev(sc[:n2])
+            plan2.run(d_pts2, d_sc2)
+            w2 = harness.PipWitness(plan2, d_pts2, y_log)
+            r_pt, r_evs, tape = claims_for(w2, y_log, 8)
+            w2.prove_image_part(r_pt, r_evs, tape)
+            t1 = time.perf_counter()
+            g = w2.prove_image_part(r_pt, r_evs, tape)
+            gpu_dt = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            cw = O.PipWitness(pts_h[:n2], sc[:n2], xs2, d_log, y_size, y_log, threads)
+            cpu_wit = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            c = cw.prove_image_part(codec.to_mont_limbs(r_pt), codec.to_mont_limbs(r_evs), codec.ints_to_limbs(tape))
+            cpu_prove = time.perf_counter() - t1
+            same = codec.from_mont_limbs(c["msgs"]) == g["msgs"] and codec.from_mont_limbs(c["evs"]) == g["evs"]
+            assert same, "GPU prover messages differ from the CPU oracle"
+            out["sumcheck"]["cpu_baseline"] = {
+                "value": round(c["rounds"] / cpu_prove, 1), "unit": "rounds/s", "cores": threads, "kind": "port",
+                "sample": "same prover at x_logsize=%d (%d rounds): cpu witness %.2f s + prove %.2f s" % (
+                    xs2, c["rounds"], cpu_wit, cpu_prove),
+                "gpu_same_sample_rounds_per_sec": round(g["rounds"] / gpu_dt, 1),
+                "parity": "bit-exact (%d prover messages + final claims)" % len(g["msgs"])}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -69,4 +69,25 @@ void or_msm_combine(const or_fr* window_cols, uint32_t d_logsize, uint32_t n_win
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- "prove image part" on the CPU (added after the first header block; same restatement rules):
+ *   PippengerWG::new (Fr part)  pippenger.rs:37-70, splits.rs:172-176, pippenger_ending.rs:32-95
+ *   PippengerBucketed::prove + GlueSplit::prove   pippenger_ending.rs:142-149, splits.rs:185-197
+ * with the sumcheck objects of sumchecks/dense_eq.rs:61-173, sumchecks/vecvec_eq.rs:72-398, sumcheck.rs:237-347.
+ * Challenges come from a tape (canonical 4 x u64 each, < 2^128); messages are returned in write order. */
+#ifdef __cplusplus
+extern "C" {
 #endif
+typedef struct or_pip_witness or_pip_witness;
+or_pip_witness* or_pip_witness_create(const or_fr* points_xy, const uint64_t* scalars, uint32_t x_logsize,
+                                      uint32_t d_logsize, uint32_t y_size, uint32_t y_logsize, int threads);
+void or_pip_witness_destroy(or_pip_witness* w);
+/* dense output (pippenger.rs:531-534): 3*(d+1) columns of 2^y_logsize, written column-major into out */
+void or_pip_witness_output(const or_pip_witness* w, or_fr* out);
+int or_pip_prove_image_part(or_pip_witness* w, const or_fr* claim_point, const or_fr* claim_evs, const uint64_t* tape,
+                            uint64_t n_tape, or_fr* msgs, uint64_t msgs_cap, uint64_t* n_msgs, or_fr* final_point,
+                            uint32_t* n_final_point, or_fr* final_evs, uint64_t* tape_used, uint64_t* rounds, int threads);
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKRMSM_ORACLE_H */

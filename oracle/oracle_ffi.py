@@ -87,3 +87,57 @@ def msm_combine(window_cols, d_log):
     out = np.zeros((2, 4), dtype=np.uint64)
     L.or_msm_combine(w.ctypes.data, d_log, w.shape[1], out.ctypes.data)
     return out
+
+
+class PipWitness:
+    """or_pip_witness: CPU witness + image-part prover of the C oracle"""
+
+    def __init__(self, points_mont, scalars, x_log, d_log, y_size, y_log, threads=1):
+        L = lib()
+        L.or_pip_witness_create.restype = C.c_void_p
+        L.or_pip_witness_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.or_pip_witness_destroy.argtypes = [C.c_void_p]
+        L.or_pip_witness_output.argtypes = [C.c_void_p, C.c_void_p]
+        L.or_pip_prove_image_part.restype = C.c_int
+        L.or_pip_prove_image_part.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                              C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int]
+        self.L, self.d_log, self.y_log, self.threads = L, d_log, y_log, threads
+        pts = np.ascontiguousarray(points_mont, dtype=np.uint64)
+        sc = np.ascontiguousarray(scalars, dtype=np.uint64)
+        self.h = L.or_pip_witness_create(pts.ctypes.data, sc.ctypes.data, x_log, d_log, y_size, y_log, threads)
+        if not self.h:
+            raise ValueError("or_pip_witness_create rejected the shape")
+
+    def close(self):
+        if self.h:
+            self.L.or_pip_witness_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def output(self):
+        out = np.zeros((3 * (self.d_log + 1), 1 << self.y_log, 4), dtype=np.uint64)
+        self.L.or_pip_witness_output(self.h, out.ctypes.data)
+        return out
+
+    def prove_image_part(self, claim_point_mont, claim_evs_mont, tape_limbs, msgs_cap=1 << 16):
+        cp = np.ascontiguousarray(claim_point_mont, dtype=np.uint64)
+        ce = np.ascontiguousarray(claim_evs_mont, dtype=np.uint64)
+        tp = np.ascontiguousarray(tape_limbs, dtype=np.uint64)
+        msgs = np.zeros((msgs_cap, 4), dtype=np.uint64)
+        fpt = np.zeros((80, 4), dtype=np.uint64)
+        fev = np.zeros((3, 4), dtype=np.uint64)
+        nm, used, rounds = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        npt = C.c_uint32()
+        rc = self.L.or_pip_prove_image_part(self.h, cp.ctypes.data, ce.ctypes.data, tp.ctypes.data, tp.shape[0],
+                                            msgs.ctypes.data, msgs_cap, C.addressof(nm), fpt.ctypes.data,
+                                            C.addressof(npt), fev.ctypes.data, C.addressof(used), C.addressof(rounds),
+                                            self.threads)
+        if rc != 0:
+            raise ValueError("or_pip_prove_image_part failed (rc=%d)" % rc)
+        return dict(msgs=msgs[: nm.value], point=fpt[: npt.value], evs=fev, tape_used=used.value, rounds=rounds.value)
