@@ -29,6 +29,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from gkr_msm_amd import codec, ffi, harness  # noqa: E402
+from gkr_msm_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -48,7 +49,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-sumcheck", action="store_true")
-    ap.add_argument("--cpu-sumcheck-xlog", type=int, default=14)
+    ap.add_argument("--cpu-sumcheck-xlog", type=int, default=17)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,9 +69,8 @@ def main():
     d_log, nbits = args.d_logsize, args.nbits
     x_log = args.x_logsize if args.x_logsize is not None else 20 + int(round(math.log2(world)))
     y_size = (nbits + d_log - 1) // d_log
-    assert y_size % world == 0, "windows (%d) must divide over %d ranks" % (y_size, world)
-    wpr = y_size // world
-    y0, y1 = rank * wpr, (rank + 1) * wpr
+    y0, y1 = gdist.window_range(rank, world, y_size)
+    wpr = y1 - y0
     n = 1 << x_log
 
     # ---- synthetic inputs, identical on every rank (replicated operands)
@@ -90,7 +90,6 @@ def main():
     d_sc = harness.to_dev(sc)
     plan = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
     ncols = 3 * (d_log + 1)
-    gathered = torch.empty((world, ncols, wpr, 4), dtype=torch.int64, device="cuda") if world > 1 else None
 
     def step():
         plan.run(d_pts, d_sc)
@@ -99,9 +98,7 @@ def main():
         if world > 1:
             mine = torch.empty((ncols, wpr, 4), dtype=torch.int64, device="cuda")
             ffi.check(L.gm_memcpy_d2d(C.c_void_p(mine.data_ptr()), p, ncols * wpr * 32, harness.cur_stream()))
-            dist.all_gather_into_tensor(gathered, mine)
-            raw = gathered.cpu().numpy().view(np.uint64)          # (world, ncols, wpr, 4)
-            raw = np.ascontiguousarray(np.transpose(raw, (1, 0, 2, 3)).reshape(ncols, y_size, 4))
+            raw = gdist.gather_window_points(dist, mine, world)
         else:
             raw = harness.read_dev(p, ncols * wpr * 32).reshape(ncols, wpr, 4)
         return harness.combine_host(raw, d_log), raw

@@ -147,3 +147,31 @@ def test_fr_batch_ops():
     assert all(x * y % F.P == 1 for x, y in zip(a[1:], inv[1:]))
     assert run(7) == [F.mul_by_a(x) for x in a]
     assert run(8) == [F.mul_by_d(x) for x in a]
+
+
+@pytest.mark.parametrize("name", ["msm_x4_d2_n12.json", "msm_x5_d3_n24.json"])
+def test_golden_fixture_msm_and_prover(name):
+    """the committed fixtures (tests/golden) through the HIP path: MSM outputs and the image-part prover"""
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)))
+    ints = lambda xs: [int(x, 16) for x in xs]  # noqa: E731
+    x_log, d_log, y_size, y_log = fx["x_logsize"], fx["d_logsize"], fx["y_size"], fx["y_logsize"]
+    d_pts = harness.to_dev(codec.points_to_mont([(int(p[0], 16), int(p[1], 16)) for p in fx["points"]]))
+    d_sc = harness.to_dev(codec.ints_to_limbs(ints(fx["scalars"])))
+    plan = harness.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, d_sc)
+    dg, ct, _ = plan.digits_counter_rowlen()
+    assert dg.tolist() == fx["digits"] and ct.tolist() == fx["counter"]
+    bs = plan.bucket_sums()
+    for c in range(3):
+        assert bs[c] == ints(fx["bucket_sums"][c])
+    wp = plan.window_points()
+    for c in range(3 * (d_log + 1)):
+        assert wp[c] == ints(fx["window_points"][c])[:y_size]
+    assert list(harness.combine_host(plan.window_points_raw(), d_log)) == ints(fx["msm_result"])
+    w = harness.PipWitness(plan, d_pts, y_log)
+    res = w.prove_image_part(ints(fx["claim_point"]), ints(fx["claim_evs"]), ints(fx["tape"]))
+    assert res["tape_used"] == len(fx["tape"])
+    assert res["msgs"] == ints(fx["prover_messages"])
+    assert res["point"] == ints(fx["final_point"]) and res["evs"] == ints(fx["final_evs"])
