@@ -25,20 +25,66 @@ std::vector<Fr> from12(const Fr& p1, const Fr& p2, const Fr& eq1, const Fr& prev
 Fr eq_bind_factor(const Fr& q, const Fr& t);                                    // 1 - q - t + 2qt
 Fr eq_sum_host(const Fr* pt, uint32_t n, uint64_t k);                           // utils.rs:265-291
 
-// device buffer owned by a handle
+// Bump allocator over one device allocation.  The image-part prover creates ~65 short-lived sumcheck objects;
+// hipMalloc/hipFree per buffer (hipFree synchronises the device) dominated the per-round cost, so the driver opens
+// an ArenaScope around each layer and resets the arena afterwards.  DevBuf::alloc carves from the current arena
+// when one is active on the calling thread, otherwise it owns a hipMalloc.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0, high = 0;
+    int32_t init(size_t bytes) {
+        hipError_t e = hipMalloc((void**)&base, bytes);
+        if (e != hipSuccess) return set_err(GM_ERR_HIP, "hipMalloc(arena %zu): %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return GM_OK;
+    }
+    void* carve(size_t b) {
+        const size_t a = (used + 255) & ~(size_t)255;
+        if (a + b > cap) return nullptr;
+        used = a + b;
+        if (used > high) high = used;
+        return base + a;
+    }
+    void reset() { used = 0; }
+    ~Arena() { if (base) (void)hipFree(base); }
+};
+inline Arena*& current_arena() {
+    static thread_local Arena* a = nullptr;
+    return a;
+}
+inline Fr*& shared_pinned() {  // pinned host staging (>= 8 Fr) shared by the round objects of one driver
+    static thread_local Fr* p = nullptr;
+    return p;
+}
+struct ArenaScope {
+    Arena* prev;
+    explicit ArenaScope(Arena* a) : prev(current_arena()) { current_arena() = a; }
+    ~ArenaScope() { current_arena() = prev; }
+};
+
+// device buffer owned by a handle (or borrowed from the current arena)
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool owned = true;
     int32_t alloc(size_t b) {
         free();
         if (b == 0) b = 32;
+        if (Arena* a = current_arena()) {
+            p = a->carve(b);
+            if (!p) return set_err(GM_ERR_HIP, "workspace arena exhausted (%zu + %zu > %zu)", a->used, b, a->cap);
+            owned = false;
+            bytes = b;
+            return GM_OK;
+        }
         hipError_t e = hipMalloc(&p, b);
         if (e != hipSuccess) return set_err(GM_ERR_HIP, "hipMalloc(%zu): %s", b, hipGetErrorString(e));
+        owned = true;
         bytes = b;
         return GM_OK;
     }
     void free() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
     }

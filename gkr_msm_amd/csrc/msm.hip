@@ -125,58 +125,48 @@ __global__ void k_scan_chunks(uint32_t* __restrict__ hist, uint32_t* __restrict_
     row_len[r] = acc;
 }
 
-// off[r] = sum_{r' < r} f(len[r']),  f = pad-to-even (image) ; single block
-__global__ void k_offsets_from_len(const uint32_t* __restrict__ len, uint32_t* __restrict__ off,
-                                   uint32_t nrows) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nrows; base += blockDim.x) {
-        uint32_t r = base + threadIdx.x;
-        uint32_t v = 0;
-        if (r < nrows) { uint32_t l = len[r]; v = l + (l & 1u); }
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t s = 1; s < blockDim.x; s <<= 1) {
-            uint32_t t = (threadIdx.x >= s) ? part[threadIdx.x - s] : 0;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (r < nrows) off[r] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) carry += part[threadIdx.x];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) off[nrows] = carry;
+// Exclusive scan of per-row lengths into row offsets, one 1024-thread block: every thread sums a contiguous
+// chunk of rows serially, the 1024 chunk sums are scanned with wave shuffles, then the chunk is written out.
+//   MODE 0: v(r) = pad2(len[r])                      image rows (vecvec.rs:181-186)
+//   MODE 1: v(r) = pad2((off_in[r+1] - off_in[r])/2)  next level / next round (vecvec.rs:579-594, 420-441)
+template <int MODE>
+__device__ __forceinline__ uint32_t row_value(const uint32_t* __restrict__ src, uint32_t r) {
+    if (MODE == 0) { const uint32_t l = src[r]; return l + (l & 1u); }
+    const uint32_t h = (src[r + 1] - src[r]) >> 1;
+    return h + (h & 1u);
 }
 
-// off_out[r] from off_in: len_out = pad2(len_in / 2)    (vecvec.rs:579-594: split by LSB, re-pad)
-__global__ void k_offsets_next(const uint32_t* __restrict__ off_in, uint32_t* __restrict__ off_out,
-                               uint32_t nrows) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nrows; base += blockDim.x) {
-        uint32_t r = base + threadIdx.x;
-        uint32_t v = 0;
-        if (r < nrows) { uint32_t h = (off_in[r + 1] - off_in[r]) >> 1; v = h + (h & 1u); }
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t s = 1; s < blockDim.x; s <<= 1) {
-            uint32_t t = (threadIdx.x >= s) ? part[threadIdx.x - s] : 0;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (r < nrows) off_out[r] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) carry += part[threadIdx.x];
-        __syncthreads();
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_offsets_scan(const uint32_t* __restrict__ src, uint32_t* __restrict__ off,
+                                                        uint32_t nrows) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per = (nrows + 1023) / 1024;
+    const uint32_t r0 = tid * per;
+    const uint32_t r1 = (r0 + per < nrows) ? r0 + per : nrows;
+    uint32_t sum = 0;
+    for (uint32_t r = r0; r < r1; r++) sum += row_value<MODE>(src, r);
+    // inclusive scan inside the wave
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if ((int)lane >= d) inc += t;
     }
-    if (threadIdx.x == 0) off_out[nrows] = carry;
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
+    uint32_t run = base + inc - sum;  // exclusive prefix of this thread's chunk
+    for (uint32_t r = r0; r < r1; r++) {
+        off[r] = run;
+        run += row_value<MODE>(src, r);
+    }
+    if (tid == 1023) {
+        uint32_t tot = 0;
+        for (int w = 0; w < 16; w++) tot += wave_tot[w];
+        off[nrows] = tot;
+    }
 }
 
 // Stable rank of every x inside its bucket row: counter[w][x] = #{x' < x : digit[w][x'] == digit[w][x]}
@@ -385,12 +375,12 @@ using namespace gm;
 
 namespace gm {
 int32_t launch_offsets_next(const uint32_t* off_in, uint32_t* off_out, uint32_t nrows, hipStream_t s) {
-    hipLaunchKernelGGL(k_offsets_next, dim3(1), dim3(1024), 0, s, off_in, off_out, nrows);
+    hipLaunchKernelGGL((k_offsets_scan<1>), dim3(1), dim3(1024), 0, s, off_in, off_out, nrows);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
 int32_t launch_offsets_from_len(const uint32_t* len, uint32_t* off, uint32_t nrows, hipStream_t s) {
-    hipLaunchKernelGGL(k_offsets_from_len, dim3(1), dim3(1024), 0, s, len, off, nrows);
+    hipLaunchKernelGGL((k_offsets_scan<0>), dim3(1), dim3(1024), 0, s, len, off, nrows);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -514,7 +504,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     hipLaunchKernelGGL(k_scan_chunks, dim3(ceil_div(nrows, 256)), dim3(256), 0, s, p->hist, p->row_len, nd,
                        p->nchunks, nrows);
     GM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_offsets_from_len, dim3(1), dim3(1024), 0, s, p->row_len, p->off[0], nrows);
+    hipLaunchKernelGGL((k_offsets_scan<0>), dim3(1), dim3(1024), 0, s, p->row_len, p->off[0], nrows);
     GM_LAUNCH_CHECK();
     STAGE_MARK(3);
     // 3. stable scatter
@@ -534,7 +524,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
                            p->bsum[1], p->bsum[2]);
         GM_LAUNCH_CHECK();
     } else {
-        hipLaunchKernelGGL(k_offsets_next, dim3(1), dim3(1024), 0, s, p->off[0], p->off[1], nrows);
+        hipLaunchKernelGGL((k_offsets_scan<1>), dim3(1), dim3(1024), 0, s, p->off[0], p->off[1], nrows);
         GM_LAUNCH_CHECK();
         STAGE_MARK(4);
         hipLaunchKernelGGL(k_add_level0, dim3(ceil_div(cap_out, 128)), dim3(128), 0, s, pts, p->cells, p->off[0],
@@ -547,7 +537,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
         for (uint32_t level = 1; level + 1 < p->x_log; level++) {
             const uint64_t cells_next = cells_cur / 2 + nrows + 2;
             const int nxt_off = (cur_off == 1) ? 2 : 1;
-            hipLaunchKernelGGL(k_offsets_next, dim3(1), dim3(1024), 0, s, p->off[cur_off], p->off[nxt_off], nrows);
+            hipLaunchKernelGGL((k_offsets_scan<1>), dim3(1), dim3(1024), 0, s, p->off[cur_off], p->off[nxt_off], nrows);
             GM_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_add_level, dim3(ceil_div(cells_next, 128)), dim3(128), 0, s, p->lvl[cur_lvl][0],
                                p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[cur_off], p->off[nxt_off], nrows,

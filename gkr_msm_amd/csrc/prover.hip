@@ -268,11 +268,15 @@ struct Layer {
 
 // SimpleGKR::prove (gkr.rs:45-50)
 int32_t simple_gkr_prove(Tape* tr, const std::vector<Layer>& layers, const std::vector<Advice>& advices, Claims* claims,
-                         hipStream_t s) {
+                         Arena* arena, hipStream_t s) {
     if (layers.size() != advices.size()) return set_err(GM_ERR_STATE, "%zu layers vs %zu advices (zip_eq)", layers.size(), advices.size());
     for (size_t k = layers.size(); k-- > 0;) {
         const Layer& L = layers[k];
         const Advice& a = advices[k];
+        // every buffer of this layer's sumcheck object comes out of the arena; the object is gone when the layer
+        // returns (its kernels are complete: final_evals synchronised), so the arena can be rewound
+        arena->reset();
+        ArenaScope scope(arena);
         switch (L.kind) {
             case Layer::VECVEC: TRY(vecvec_deg2_prove(tr, L.f, L.num_vars, claims, a, s)); break;
             case Layer::DENSE: TRY(dense_deg2_prove(tr, L.f, L.num_vars, claims, a, s)); break;
@@ -291,6 +295,9 @@ int32_t simple_gkr_prove(Tape* tr, const std::vector<Layer>& layers, const std::
 struct gm_pip_witness {
     uint32_t x_log, y_log, d_log;
     hipStream_t stream;
+    Arena arena;            // per-layer workspace of the sumcheck objects (reset after every layer)
+    Fr* pinned = nullptr;   // host staging for the per-round results
+    ~gm_pip_witness() { if (pinned) (void)hipHostFree(pinned); }
     std::vector<Advice> bintree_advices, triangle_advices;
     Advice bucket_sums;   // bintree last_step
     Advice dense_output;  // triangle last_step: 3*(d+1) columns of 2^y_log
@@ -430,6 +437,14 @@ extern "C" int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t
     TRY(triangle_witness_build(s2, nv - 2, multirow, &w->triangle_advices, s));
     // pippenger.rs:531-534: last_step(ending.last(), num_layers) with num_layers = d - 2
     TRY(dense_map_adv(mkfn(GM_FN_PROJ_L3, (int)(bucket - 2) + 3), w->triangle_advices.back(), &w->dense_output, s));
+    // workspace for the largest layer (bintree level 0: 6 polys over the glue-split image):
+    // fold buffers of 1/2 and 1/4 of the cells per polynomial + tables
+    {
+        const uint64_t T = glued->total, nr = glued->nrows;
+        const size_t bytes = (size_t)6 * 32 * (T / 2 + T / 4 + 4 * nr + 64) + ((size_t)48 << 20);
+        TRY(w->arena.init(bytes));
+        GM_HIP(hipHostMalloc((void**)&w->pinned, 16 * sizeof(Fr)));
+    }
     GM_HIP(hipStreamSynchronize(s));
     *out = w.release();
     return GM_OK;
@@ -488,11 +503,14 @@ extern "C" int32_t gm_pip_prove_image_part(const gm_pip_witness* w, const uint64
     memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
     hipStream_t s = w->stream;
     // PippengerBucketed::prove (pippenger_ending.rs:142-149)
-    TRY(simple_gkr_prove(&tr, triangle_layers(multirow + bucket - 2, multirow), w->triangle_advices, &c, s));
+    gm_pip_witness* wm = const_cast<gm_pip_witness*>(w);
+    shared_pinned() = wm->pinned;
+    struct PinnedReset { ~PinnedReset() { shared_pinned() = nullptr; } } pinned_reset;
+    TRY(simple_gkr_prove(&tr, triangle_layers(multirow + bucket - 2, multirow), w->triangle_advices, &c, &wm->arena, s));
     TRY(split_at_prove(&tr, &c, true, multirow, 3));
     TRY(split_at_prove(&tr, &c, true, multirow, 3));
     TRY(simple_gkr_prove(&tr, bintree_layers(multirow + bucket + horizontal, horizontal, horizontal, true),
-                         w->bintree_advices, &c, s));
+                         w->bintree_advices, &c, &wm->arena, s));
     // GlueSplit::prove (splits.rs:185-197)
     {
         Fr r;

@@ -26,16 +26,20 @@ Fr eq_bind_factor(const Fr& q, const Fr& t) {
     return fr_add(fr_sub(fr_sub(fr_one(), q), t), fr_dbl(fr_mul(q, t)));
 }
 
-std::vector<Fr> unipoly_from_evals(const std::vector<Fr>& evals) {
-    const int n = (int)evals.size();
-    std::vector<Fr> coeffs(n, fr_zero());
+// Lagrange basis on the nodes 0..n-1 in coefficient form: coeffs[k] = sum_i M[i][k] * evals[i].
+// The nodes are fixed, so the matrix (and its n field inversions) is computed once per n.
+static const std::vector<std::vector<Fr>>& lagrange_matrix(int n) {
+    static thread_local std::vector<std::vector<std::vector<Fr>>> cache(9);
+    if (n < 1 || n > 8) n = 8;
+    std::vector<std::vector<Fr>>& M = cache[n];
+    if (!M.empty()) return M;
+    M.assign(n, std::vector<Fr>(n, fr_zero()));
     for (int i = 0; i < n; i++) {
         std::vector<Fr> num(1, fr_one());
         Fr den = fr_one();
         for (int j = 0; j < n; j++) {
             if (j == i) continue;
-            // num *= (x - j)
-            std::vector<Fr> nx(num.size() + 1, fr_zero());
+            std::vector<Fr> nx(num.size() + 1, fr_zero());  // num *= (x - j)
             const Fr fj = fr_from_u64((uint64_t)j);
             for (size_t k = 0; k < num.size(); k++) {
                 nx[k + 1] = fr_add(nx[k + 1], num[k]);
@@ -45,9 +49,18 @@ std::vector<Fr> unipoly_from_evals(const std::vector<Fr>& evals) {
             const Fr d = (i > j) ? fr_from_u64((uint64_t)(i - j)) : fr_neg(fr_from_u64((uint64_t)(j - i)));
             den = fr_mul(den, d);
         }
-        const Fr sc = fr_mul(evals[i], fr_inv(den));
-        for (int k = 0; k < n; k++) coeffs[k] = fr_add(coeffs[k], fr_mul(num[k], sc));
+        const Fr di = fr_inv(den);
+        for (int k = 0; k < n; k++) M[i][k] = fr_mul(num[k], di);
     }
+    return M;
+}
+
+std::vector<Fr> unipoly_from_evals(const std::vector<Fr>& evals) {
+    const int n = (int)evals.size();
+    const std::vector<std::vector<Fr>>& M = lagrange_matrix(n);
+    std::vector<Fr> coeffs(n, fr_zero());
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < n; k++) coeffs[k] = fr_add(coeffs[k], fr_mul(M[i][k], evals[i]));
     return coeffs;
 }
 
@@ -55,6 +68,36 @@ Fr evaluate_univar(const std::vector<Fr>& c, const Fr& x) {
     Fr r = fr_zero();
     for (int i = (int)c.size() - 1; i >= 0; i--) r = fr_add(fr_mul(r, x), c[i]);
     return r;
+}
+
+// inverses of (1 - q) for all coordinates of a point with one field inversion (Montgomery's trick);
+// a coordinate equal to 1 yields 0 here (the reference would panic on `inverse().unwrap()`, vecvec_eq.rs:205)
+std::vector<Fr> batch_inv_one_minus(const std::vector<Fr>& pt) {
+    const size_t n = pt.size();
+    std::vector<Fr> v(n), pre(n + 1, fr_one()), out(n, fr_zero());
+    for (size_t i = 0; i < n; i++) {
+        v[i] = fr_sub(fr_one(), pt[i]);
+        pre[i + 1] = fr_is_zero(v[i]) ? pre[i] : fr_mul(pre[i], v[i]);
+    }
+    Fr inv = fr_inv(pre[n]);
+    for (size_t i = n; i-- > 0;) {
+        if (fr_is_zero(v[i])) continue;
+        out[i] = fr_mul(inv, pre[i]);
+        inv = fr_mul(inv, v[i]);
+    }
+    return out;
+}
+
+std::vector<Fr> from12_inv(const Fr& p1, const Fr& p2, const Fr& eq1, const Fr& inv_eq0, const Fr& prev_claim) {
+    const Fr eq0 = fr_sub(fr_one(), eq1);
+    const Fr eq2 = fr_sub(fr_dbl(eq1), eq0);
+    const Fr eq3 = fr_sub(fr_dbl(eq2), eq1);
+    const Fr prod1 = fr_mul(p1, eq1);
+    const Fr prod0 = fr_sub(prev_claim, prod1);
+    const Fr p0 = fr_mul(prod0, inv_eq0);
+    const Fr p3 = fr_add(fr_sub(fr_sub(fr_add(fr_dbl(p2), p2), fr_dbl(p1)), p1), p0);
+    std::vector<Fr> ev = {prod0, prod1, fr_mul(p2, eq2), fr_mul(p3, eq3)};
+    return unipoly_from_evals(ev);
 }
 
 std::vector<Fr> from12(const Fr& p1, const Fr& p2, const Fr& eq1, const Fr& prev_claim) {
@@ -89,10 +132,22 @@ Fr eq_sum_host(const Fr* pt, uint32_t n, uint64_t k) {
 // ------------------------------------------------------------------------------------------ kernels
 #define SC_THREADS 256
 
-// block-wide sum of NACC field elements per thread -> partial[blockIdx.x * NACC + a]
+// Block-wide sum of NACC field elements per thread, then the cross-block sum inside the same launch:
+// every block publishes its partial, the block that arrives last (agent-scope release / acquire around one
+// device counter) adds the partials up and writes the NACC results straight into pinned host memory, so a round is
+// ONE kernel + ONE stream synchronisation.  Field addition is exact, the order of the blocks does not matter.
+struct FinishCtx {
+    Fr* partial;         // gridDim.x * gridDim.y rows of NACC elements
+    uint32_t* counter;   // zero between launches (the last block resets it)
+    Fr* out;             // pinned host memory (device-visible)
+};
+
 template <int NACC>
-__device__ __forceinline__ void block_reduce_store(Fr* acc, Fr* __restrict__ partial) {
+__device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc) {
     __shared__ Fr red[SC_THREADS];
+    __shared__ uint32_t is_last;
+    const uint32_t nblk = gridDim.x * gridDim.y;
+    const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
     for (int a = 0; a < NACC; a++) {
         red[threadIdx.x] = acc[a];
         __syncthreads();
@@ -100,116 +155,117 @@ __device__ __forceinline__ void block_reduce_store(Fr* acc, Fr* __restrict__ par
             if ((int)threadIdx.x < s) red[threadIdx.x] = fr_add(red[threadIdx.x], red[threadIdx.x + s]);
             __syncthreads();
         }
-        if (threadIdx.x == 0) fr_store(partial + (uint64_t)blockIdx.x * NACC + a, red[0]);
+        if (threadIdx.x == 0) fr_store(fc.partial + (uint64_t)bid * NACC + a, red[0]);
         __syncthreads();
     }
-}
-
-// sum the per-block partials: out[a] = sum_b partial[b*NACC + a]   (single block)
-__global__ void __launch_bounds__(SC_THREADS) k_reduce_partials(const Fr* __restrict__ partial, uint32_t nblocks,
-                                                                 int nacc, Fr* __restrict__ out) {
-    __shared__ Fr red[SC_THREADS];
-    for (int a = 0; a < nacc; a++) {
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t prev = atomicAdd(fc.counter, 1u);
+        const uint32_t last = (prev == nblk - 1) ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    for (int a = 0; a < NACC; a++) {
         Fr s = fr_zero();
-        for (uint32_t b = threadIdx.x; b < nblocks; b += SC_THREADS) s = fr_add(s, fr_load(partial + (uint64_t)b * nacc + a));
+        for (uint32_t b2 = threadIdx.x; b2 < nblk; b2 += SC_THREADS) s = fr_add(s, fr_load(fc.partial + (uint64_t)b2 * NACC + a));
         red[threadIdx.x] = s;
         __syncthreads();
         for (int st = SC_THREADS / 2; st > 0; st >>= 1) {
             if ((int)threadIdx.x < st) red[threadIdx.x] = fr_add(red[threadIdx.x], red[threadIdx.x + st]);
             __syncthreads();
         }
-        if (threadIdx.x == 0) fr_store(out + a, red[0]);
+        if (threadIdx.x == 0) fr_store(fc.out + a, red[0]);
         __syncthreads();
     }
+    if (threadIdx.x == 0) *fc.counter = 0;
 }
 
-struct GammaPows {
-    Fr g[GM_MAX_COLS];  // g[o] = gamma^o, g[0] = 1
+struct SmallVals {
+    Fr v[48];
+};
+__global__ void k_upload_small(SmallVals sv, int n, Fr* __restrict__ dst) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) fr_store(dst + i, sv.v[i]);
+}
+
+// One segment of the gamma-combined layer function at the "1" point (h = 0: p1) or the "2" point (h = 1: 2 p1 - p0)
+// of the pair starting at cell0:  sum_{o in segment} gamma^o f_o(.)
+__device__ __forceinline__ Fr eval_seg(const Seg& g, const ColPtrs& cols, const Fr* __restrict__ gp, uint64_t cell0, int h) {
+    Fr v[6], o[4];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+        if (q < g.n_in) {
+            const Fr p1 = fr_load(cols.p[g.in[q]] + cell0 + 1);
+            v[q] = h ? fr_sub(fr_dbl(p1), fr_load(cols.p[g.in[q]] + cell0)) : p1;
+        }
+    prim_exec(g.prim, v, o);
+    Fr A = fr_zero();
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q < g.n_out) {
+            const int oc = g.out0 + q;
+            A = fr_add(A, oc == 0 ? o[q] : fr_mul(fr_load(gp + oc), o[q]));
+        }
+    return A;
+}
+
+// Deg-2 round sums with eq factored out.
+//   dense  (dense_eq.rs:121-139):  S_h = sum_i eq[i] * A_h(i)
+//   VecVec (vecvec_eq.rs:320-361): S_h = sum_r coef[r] sum_idx eq_row[idx] * A_h(r, idx), plus acc[2] = the tail
+//          weight W = sum_r coef[r] * (1 - sum_{idx < seg_r} eq_row[idx])  (get_trailing_sum, vecvec.rs:144-146)
+// SPLIT = false: one thread per pair walks all segments and both points (large layers: every element is loaded once).
+// SPLIT = true : blockIdx.y = 2 * segment + h; one thread per (pair, segment, point).  Small layers are latency bound
+//                (a lone wave needs ~1 us per field multiplication), so the serial chain per thread is what matters.
+struct VVArgs {
+    const uint32_t* off;
+    uint32_t nrows;
+    const Fr* row_coef;
+    const Fr* eq_prefix;
 };
 
-// gamma-combined layer function at the "1" and "2" points of one pair:
-//   A1 = sum_o gamma^o f_o(p1),  A2 = sum_o gamma^o f_o(2 p1 - p0)
-__device__ __forceinline__ void eval_pair_12(const SegPlan& sp, const ColPtrs& cols, const Fr* __restrict__ gp,
-                                             uint64_t cell0, Fr& A1, Fr& A2) {
-    A1 = fr_zero();
-    A2 = fr_zero();
-    for (int s = 0; s < sp.nseg; s++) {
-        const Seg g = sp.seg[s];
-        Fr v1[6], v2[6], o1[4], o2[4];
-#pragma unroll
-        for (int q = 0; q < 6; q++)
-            if (q < g.n_in) {
-                const Fr p0 = fr_load(cols.p[g.in[q]] + cell0);
-                const Fr p1 = fr_load(cols.p[g.in[q]] + cell0 + 1);
-                v1[q] = p1;
-                v2[q] = fr_sub(fr_dbl(p1), p0);
-            }
-        prim_exec(g.prim, v1, o1);
-        prim_exec(g.prim, v2, o2);
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (q < g.n_out) {
-                const int oc = g.out0 + q;
-                if (oc == 0) {
-                    A1 = fr_add(A1, o1[q]);
-                    A2 = fr_add(A2, o2[q]);
-                } else {
-                    const Fr gm_ = fr_load(gp + oc);
-                    A1 = fr_add(A1, fr_mul(gm_, o1[q]));
-                    A2 = fr_add(A2, fr_mul(gm_, o2[q]));
-                }
-            }
+template <bool VECVEC, bool SPLIT>
+__global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs cols, const Fr* __restrict__ eq,
+                                                            const Fr* __restrict__ gp, uint64_t npairs_dense, VVArgs vv,
+                                                            FinishCtx fc) {
+    constexpr int NACC = VECVEC ? 3 : 2;
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    if (VECVEC && blockIdx.y == 0) {
+        for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
+            const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+        }
     }
-}
-
-// DenseDeg2 round sums (dense_eq.rs:121-139): S1 = sum_i eq[i] A1(i), S2 = sum_i eq[i] A2(i)
-__global__ void __launch_bounds__(SC_THREADS) k_round_deg2_dense(SegPlan sp, ColPtrs cols, const Fr* __restrict__ eq,
-                                                                  const Fr* __restrict__ gp, uint64_t npairs,
-                                                                  Fr* __restrict__ partial) {
-    Fr acc[2] = {fr_zero(), fr_zero()};
+    const uint64_t npairs = VECVEC ? (uint64_t)(vv.off[vv.nrows] >> 1) : npairs_dense;
     for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
-        Fr A1, A2;
-        eval_pair_12(sp, cols, gp, 2 * i, A1, A2);
-        const Fr e = fr_load(eq + i);
-        acc[0] = fr_add(acc[0], fr_mul(A1, e));
-        acc[1] = fr_add(acc[1], fr_mul(A2, e));
+        Fr w;
+        if (VECVEC) {
+            const uint32_t cell0 = (uint32_t)(2 * i);
+            const uint32_t r = find_row(vv.off, vv.nrows, cell0);
+            w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
+        } else {
+            w = fr_load(eq + i);
+        }
+        if (SPLIT) {
+            const int sgi = blockIdx.y >> 1, h = blockIdx.y & 1;
+            const Seg g = sp.seg[sgi];
+            acc[h] = fr_add(acc[h], fr_mul(eval_seg(g, cols, gp, 2 * i, h), w));
+        } else {
+            Fr A1 = fr_zero(), A2 = fr_zero();
+            for (int sgi = 0; sgi < sp.nseg; sgi++) {
+                const Seg g = sp.seg[sgi];
+                A1 = fr_add(A1, eval_seg(g, cols, gp, 2 * i, 0));
+                A2 = fr_add(A2, eval_seg(g, cols, gp, 2 * i, 1));
+            }
+            acc[0] = fr_add(acc[0], fr_mul(A1, w));
+            acc[1] = fr_add(acc[1], fr_mul(A2, w));
+        }
     }
-    block_reduce_store<2>(acc, partial);
-}
-
-// VecVecDeg2 round sums (vecvec_eq.rs:320-361): cells of all rows in one flat pass;
-// weight of pair idx of row r = eq_row[idx] * row_eq_coefs[r]
-__global__ void __launch_bounds__(SC_THREADS) k_round_deg2_vecvec(SegPlan sp, ColPtrs cols, const uint32_t* __restrict__ off,
-                                                                   uint32_t nrows, const Fr* __restrict__ eq_row,
-                                                                   const Fr* __restrict__ row_coef,
-                                                                   const Fr* __restrict__ gp, Fr* __restrict__ partial) {
-    Fr acc[2] = {fr_zero(), fr_zero()};
-    const uint64_t npairs = off[nrows] >> 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
-        const uint32_t cell0 = (uint32_t)(2 * i);
-        const uint32_t r = find_row(off, nrows, cell0);
-        const uint32_t idx = (cell0 - off[r]) >> 1;
-        Fr A1, A2;
-        eval_pair_12(sp, cols, gp, cell0, A1, A2);
-        const Fr w = fr_mul(fr_load(eq_row + idx), fr_load(row_coef + r));
-        acc[0] = fr_add(acc[0], fr_mul(A1, w));
-        acc[1] = fr_add(acc[1], fr_mul(A2, w));
-    }
-    block_reduce_store<2>(acc, partial);
-}
-
-// per-row tail weight of the VecVec round: W = sum_r row_coef[r] * (1 - sum_{idx < seg_r} eq_row[idx])
-// (get_trailing_sum, vecvec.rs:144-146).  eq prefix sums come from a scan of the current eq level.
-__global__ void __launch_bounds__(SC_THREADS) k_vv_tail_weight(const uint32_t* __restrict__ off, uint32_t nrows,
-                                                                const Fr* __restrict__ eq_prefix /* prefix[k] = sum_{i<k} */,
-                                                                const Fr* __restrict__ row_coef, Fr* __restrict__ partial) {
-    Fr acc[1] = {fr_zero()};
-    for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < nrows; r += gridDim.x * SC_THREADS) {
-        const uint32_t seg = (off[r + 1] - off[r]) >> 1;
-        const Fr tr = fr_sub(fr_one(), fr_load(eq_prefix + seg));
-        acc[0] = fr_add(acc[0], fr_mul(fr_load(row_coef + r), tr));
-    }
-    block_reduce_store<1>(acc, partial);
+    block_reduce_finish<NACC>(acc, fc);
 }
 
 // inclusive->exclusive prefix sums of a (short) eq level: prefix[0] = 0, prefix[k] = sum_{i<k} v[i]; single block
@@ -281,14 +337,15 @@ __global__ void __launch_bounds__(SC_THREADS) k_vv_fold_to_dense(ColPtrs in, Col
 
 // Generic dense round (sumcheck.rs:283-316) for F = EqWrapper(GammaWrapper(f)) [kind 0: last column is eq]
 // or Prod3 [kind 1]: acc[s] += F(p1 + s * (p1 - p0)), s = 0..D-1.
-template <int D>
+// SPLIT: blockIdx.y = D * segment + s (kind 1: = s); one thread per (pair, segment, evaluation point).
+template <int D, bool SPLIT>
 __global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan sp, ColPtrs cols, int ncols,
-                                                               const Fr* __restrict__ gp, uint64_t npairs,
-                                                               Fr* __restrict__ partial) {
+                                                               const Fr* __restrict__ gp, uint64_t npairs, FinishCtx fc) {
     Fr acc[D];
 #pragma unroll
     for (int s = 0; s < D; s++) acc[s] = fr_zero();
     for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+        const int s_lo = SPLIT ? (int)(blockIdx.y % D) : 0, s_hi = SPLIT ? s_lo + 1 : D;
         if (kind == 1) {
             Fr a[3], d[3];
 #pragma unroll
@@ -297,22 +354,21 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan 
                 a[q] = p1;
                 d[q] = fr_sub(p1, p0);
             }
-#pragma unroll
-            for (int s = 0; s < D; s++) {
+            for (int s = 0; s < s_hi; s++) {
                 if (s) {
 #pragma unroll
                     for (int q = 0; q < 3; q++) a[q] = fr_add(a[q], d[q]);
                 }
-                acc[s] = fr_add(acc[s], fr_mul(fr_mul(a[0], a[1]), a[2]));
+                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul(fr_mul(a[0], a[1]), a[2]));
             }
         } else {
-            // eq column (last) at the D points
             const Fr e0 = fr_load(cols.p[ncols - 1] + 2 * i), e1 = fr_load(cols.p[ncols - 1] + 2 * i + 1);
             const Fr ed = fr_sub(e1, e0);
             Fr G[D];
 #pragma unroll
             for (int s = 0; s < D; s++) G[s] = fr_zero();
-            for (int sg = 0; sg < sp.nseg; sg++) {
+            const int g_lo = SPLIT ? (int)(blockIdx.y / D) : 0, g_hi = SPLIT ? g_lo + 1 : sp.nseg;
+            for (int sg = g_lo; sg < g_hi; sg++) {
                 const Seg g = sp.seg[sg];
                 Fr a[6], d[6];
 #pragma unroll
@@ -322,13 +378,13 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan 
                         a[q] = p1;
                         d[q] = fr_sub(p1, p0);
                     }
-#pragma unroll
-                for (int s = 0; s < D; s++) {
+                for (int s = 0; s < s_hi; s++) {
                     if (s) {
 #pragma unroll
                         for (int q = 0; q < 6; q++)
                             if (q < g.n_in) a[q] = fr_add(a[q], d[q]);
                     }
+                    if (s < s_lo) continue;
                     Fr o[4];
                     prim_exec(g.prim, a, o);
 #pragma unroll
@@ -340,14 +396,13 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan 
                 }
             }
             Fr e = e1;
-#pragma unroll
-            for (int s = 0; s < D; s++) {
+            for (int s = 0; s < s_hi; s++) {
                 if (s) e = fr_add(e, ed);
-                acc[s] = fr_add(acc[s], fr_mul(G[s], e));
+                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul(G[s], e));
             }
         }
     }
-    block_reduce_store<D>(acc, partial);
+    block_reduce_finish<D>(acc, fc);
 }
 
 }  // namespace gm
@@ -355,7 +410,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan 
 using namespace gm;
 
 // ============================================================================================ objects
-static constexpr uint32_t SC_MAX_BLOCKS = 2048;
+static constexpr uint32_t SC_MAX_BLOCKS = 4096;
 
 struct gm_sc {
     virtual ~gm_sc() {}
@@ -369,34 +424,45 @@ struct gm_sc {
 namespace {
 
 struct RoundScratch {
-    DevBuf partial, result;
-    Fr* h_result = nullptr;  // pinned
-    int32_t init() {
-        int32_t rc = partial.alloc((size_t)SC_MAX_BLOCKS * 4 * sizeof(Fr));
+    DevBuf partial, counter;
+    Fr* h_result = nullptr;  // pinned, device-visible
+    bool own_pinned = false;
+    int32_t init(hipStream_t s) {
+        int32_t rc = partial.alloc((size_t)SC_MAX_BLOCKS * 3 * sizeof(Fr));
         if (rc) return rc;
-        rc = result.alloc(8 * sizeof(Fr));
+        rc = counter.alloc(64);
         if (rc) return rc;
-        GM_HIP(hipHostMalloc((void**)&h_result, 8 * sizeof(Fr)));
+        GM_HIP(hipMemsetAsync(counter.p, 0, 64, s));
+        if (shared_pinned()) {
+            h_result = shared_pinned();
+            own_pinned = false;
+        } else {
+            GM_HIP(hipHostMalloc((void**)&h_result, 8 * sizeof(Fr)));
+            own_pinned = true;
+        }
         return GM_OK;
     }
     ~RoundScratch() {
-        if (h_result) (void)hipHostFree(h_result);
+        if (h_result && own_pinned) (void)hipHostFree(h_result);
     }
-    // reduce `nacc` accumulators over `nblocks` partial rows and fetch them
-    int32_t finish(uint32_t nblocks, int nacc, hipStream_t s, Fr* out) {
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(SC_THREADS), 0, s, partial.fr(), nblocks, nacc, result.fr());
-        GM_LAUNCH_CHECK();
-        GM_HIP(hipMemcpyAsync(h_result, result.p, (size_t)nacc * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    FinishCtx ctx() const { return FinishCtx{partial.fr(), reinterpret_cast<uint32_t*>(counter.p), h_result}; }
+    // the launch wrote `nacc` results into the pinned buffer; wait for it and copy them out
+    int32_t finish(int nacc, hipStream_t s, Fr* out) {
         GM_HIP(hipStreamSynchronize(s));
         for (int a = 0; a < nacc; a++) out[a] = h_result[a];
         return GM_OK;
     }
 };
 
-static uint32_t blocks_for(uint64_t work) {
-    uint64_t b = (work + SC_THREADS - 1) / SC_THREADS;
-    if (b < 1) b = 1;
-    return (uint32_t)(b > SC_MAX_BLOCKS ? SC_MAX_BLOCKS : b);
+// grid for a round: x over pairs (grid-stride beyond the cap), y = sub-units in split mode
+static constexpr uint64_t SC_SPLIT_MAX_PAIRS = 1ull << 14;
+static dim3 round_grid(uint64_t npairs, int ny) {
+    uint64_t bx = (npairs + SC_THREADS - 1) / SC_THREADS;
+    if (bx < 1) bx = 1;
+    const uint64_t cap = SC_MAX_BLOCKS / (uint64_t)(ny > 0 ? ny : 1);
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)ny);
 }
 
 // ---- columns with ping-pong fold buffers --------------------------------------------------------
@@ -432,12 +498,21 @@ struct FoldCols {
 };
 
 // gamma powers on the device: g[o] = gamma^o   (make_gamma_pows, utils.rs:126-135)
+// small host -> device uploads ride in kernel arguments: asynchronous, no staging copy, no sync
+static int32_t upload_small(const Fr* v, size_t n, Fr* dst, hipStream_t s) {
+    for (size_t base = 0; base < n; base += 48) {
+        SmallVals sv;
+        const int cnt = (int)((n - base < 48) ? n - base : 48);
+        for (int i = 0; i < cnt; i++) sv.v[i] = v[base + i];
+        hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(64), 0, s, sv, cnt, dst + base);
+        GM_LAUNCH_CHECK();
+    }
+    return GM_OK;
+}
 static int32_t upload_gamma(const std::vector<Fr>& gp, DevBuf* d, hipStream_t s) {
     int32_t rc = d->alloc(gp.size() * sizeof(Fr) + 32);
     if (rc) return rc;
-    GM_HIP(hipMemcpyAsync(d->p, gp.data(), gp.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
-    GM_HIP(hipStreamSynchronize(s));
-    return GM_OK;
+    return upload_small(gp.data(), gp.size(), d->fr(), s);
 }
 
 static std::vector<Fr> make_gamma_pows(const Fr& gamma, int count) {
@@ -466,20 +541,29 @@ struct ScDense : gm_sc {
         if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended (sumcheck.rs:279)");
         if (!has_cached) {
             const uint64_t npairs = 1ull << (num_vars - round_idx - 1);
-            const uint32_t nb = blocks_for(npairs);
             ColPtrs cp;
             for (int i = 0; i < cols.k; i++) cp.p[i] = cols.cur[i];
-            if (D == 3)
-                hipLaunchKernelGGL((k_round_generic<3>), dim3(nb), dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
-                                   d_gamma.fr(), npairs, rs.partial.fr());
+            const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
+            const int ny = split ? D * (kind == 1 ? 1 : sp.nseg) : 1;
+            const dim3 grid = round_grid(npairs, ny);
+            const FinishCtx fc = rs.ctx();
+            if (D == 3 && split)
+                hipLaunchKernelGGL((k_round_generic<3, true>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                                   d_gamma.fr(), npairs, fc);
+            else if (D == 3)
+                hipLaunchKernelGGL((k_round_generic<3, false>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                                   d_gamma.fr(), npairs, fc);
+            else if (D == 2 && split)
+                hipLaunchKernelGGL((k_round_generic<2, true>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                                   d_gamma.fr(), npairs, fc);
             else if (D == 2)
-                hipLaunchKernelGGL((k_round_generic<2>), dim3(nb), dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
-                                   d_gamma.fr(), npairs, rs.partial.fr());
+                hipLaunchKernelGGL((k_round_generic<2, false>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                                   d_gamma.fr(), npairs, fc);
             else
                 return set_err(GM_ERR_INVALID, "unsupported degree %d", D);
             GM_LAUNCH_CHECK();
             Fr acc[4];
-            int32_t rc = rs.finish(nb, D, stream, acc);
+            int32_t rc = rs.finish(D, stream, acc);
             if (rc) return rc;
             std::vector<Fr> total(D + 1);
             for (int s = 0; s < D; s++) total[s + 1] = acc[s];
@@ -524,7 +608,7 @@ struct ScDenseDeg2 : gm_sc {
     DevBuf d_gamma, d_eq;           // eq levels 0..num_vars-1 packed: level i at offset 2^i - 1
     RoundScratch rs;
     Fr claim_, multiplier;
-    std::vector<Fr> cached;
+    std::vector<Fr> cached, inv_eq0;
     bool has_cached = false;
 
     Fr claim() const override { return claim_; }
@@ -534,18 +618,25 @@ struct ScDenseDeg2 : gm_sc {
         if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (dense_eq.rs:109-111)");
         if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended");
         const uint64_t npairs = 1ull << (num_vars - round_idx - 1);
-        const uint32_t nb = blocks_for(npairs);
         ColPtrs cp;
         for (int i = 0; i < cols.k; i++) cp.p[i] = cols.cur[i];
-        hipLaunchKernelGGL(k_round_deg2_dense, dim3(nb), dim3(SC_THREADS), 0, stream, sp, cp,
-                           eq_level(num_vars - 1 - round_idx), d_gamma.fr(), npairs, rs.partial.fr());
+        const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
+        const dim3 grid = round_grid(npairs, split ? 2 * sp.nseg : 1);
+        const VVArgs none{nullptr, 0, nullptr, nullptr};
+        if (split)
+            hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp,
+                               eq_level(num_vars - 1 - round_idx), d_gamma.fr(), npairs, none, rs.ctx());
+        else
+            hipLaunchKernelGGL((k_round_deg2<false, false>), grid, dim3(SC_THREADS), 0, stream, sp, cp,
+                               eq_level(num_vars - 1 - round_idx), d_gamma.fr(), npairs, none, rs.ctx());
         GM_LAUNCH_CHECK();
         Fr acc[4];
-        int32_t rc = rs.finish(nb, 2, stream, acc);
+        int32_t rc = rs.finish(2, stream, acc);
         if (rc) return rc;
         // full-length dense columns: sum of eq = 1, the trailing pad term (dense_eq.rs:141-146) vanishes
         const Fr total1 = fr_mul(acc[0], multiplier), total2 = fr_mul(acc[1], multiplier);
-        cached = from12(total1, total2, point.back(), claim_);
+        if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);  // first round: point is still complete
+        cached = from12_inv(total1, total2, point.back(), inv_eq0[point.size() - 1], claim_);
         has_cached = true;
         *coeffs = cached;
         return GM_OK;
@@ -598,7 +689,7 @@ struct ScVecVecDeg2 : gm_sc {
     std::vector<Fr> row_coef_tail;       // row_eq_coefs_tail_sums (host)
     RoundScratch rs;
     Fr claim_, multiplier;
-    std::vector<Fr> cached;
+    std::vector<Fr> cached, inv_eq0;
     bool has_cached = false;
     std::unique_ptr<ScDense> dense;
 
@@ -607,32 +698,29 @@ struct ScVecVecDeg2 : gm_sc {
     int32_t unipoly(std::vector<Fr>* coeffs) override {
         if (dense) return dense->unipoly(coeffs);
         if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (vecvec_eq.rs:305-307)");
-        // current eq level: row_eq_poly_seq[len - 1 - already_bound]  (vecvec.rs:129-135)
+        // current eq level: row_eq_poly_seq[len - 1 - already_bound]  (vecvec.rs:129-135) and its prefix sums
         const size_t lvl = eq_level_len.size() - 1 - already_bound;
         const Fr* eq_row = d_eq_seq.fr() + eq_level_off[lvl];
-        const uint32_t eq_len = eq_level_len[lvl];
-        hipLaunchKernelGGL(k_prefix_sums, dim3(1), dim3(SC_THREADS), 0, stream, eq_row, eq_len, d_prefix.fr());
-        GM_LAUNCH_CHECK();
+        const Fr* eq_pre = d_prefix.fr() + eq_level_off[lvl] + lvl;  // level l has len+1 prefix entries
         ColPtrs cp;
         for (int i = 0; i < k; i++) cp.p[i] = cur[i];
         // grid from the capacity bound: the exact cell count lives on the device (off[nrows])
-        const uint64_t cap_pairs = ((uint64_t)1 << (row_logsize + col_logsize)) / 2;
-        uint64_t bound = cells_bound / 2 + 1;
-        if (bound > cap_pairs) bound = cap_pairs;
-        const uint32_t nb = blocks_for(bound);
-        hipLaunchKernelGGL(k_round_deg2_vecvec, dim3(nb), dim3(SC_THREADS), 0, stream, sp, cp, off_cur, nrows, eq_row,
-                           d_row_coef.fr(), d_gamma.fr(), rs.partial.fr());
+        const uint64_t bound_pairs = cells_bound / 2 + 1;
+        const bool split = bound_pairs <= SC_SPLIT_MAX_PAIRS;
+        const uint64_t gx = bound_pairs > nrows ? bound_pairs : nrows;  // the tail-weight loop runs over rows
+        const dim3 grid = round_grid(gx, split ? 2 * sp.nseg : 1);
+        const VVArgs va{off_cur, nrows, d_row_coef.fr(), eq_pre};
+        if (split)
+            hipLaunchKernelGGL((k_round_deg2<true, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
+                               (uint64_t)0, va, rs.ctx());
+        else
+            hipLaunchKernelGGL((k_round_deg2<true, false>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
+                               (uint64_t)0, va, rs.ctx());
         GM_LAUNCH_CHECK();
         Fr acc[4];
-        int32_t rc = rs.finish(nb, 2, stream, acc);
+        int32_t rc = rs.finish(3, stream, acc);
         if (rc) return rc;
-        const uint32_t nb2 = blocks_for(nrows);
-        hipLaunchKernelGGL(k_vv_tail_weight, dim3(nb2), dim3(SC_THREADS), 0, stream, off_cur, nrows, d_prefix.fr(),
-                           d_row_coef.fr(), rs.partial.fr());
-        GM_LAUNCH_CHECK();
-        Fr w[4];
-        rc = rs.finish(nb2, 1, stream, w);
-        if (rc) return rc;
+        const Fr* w = acc + 2;
         // pads: f(row_pad..) weighted by W, f(col_pad..) by the coefficient tail (vecvec_eq.rs:309-315, 345-371)
         Fr in[GM_MAX_COLS], pr[GM_MAX_COLS], pc[GM_MAX_COLS];
         for (int i = 0; i < k; i++) in[i] = row_pad[i];
@@ -648,7 +736,8 @@ struct ScVecVecDeg2 : gm_sc {
         if (nrows < (1u << col_logsize)) extra = fr_add(extra, fr_mul(colsum, row_coef_tail[nrows]));
         const Fr total1 = fr_mul(fr_add(acc[0], extra), multiplier);
         const Fr total2 = fr_mul(fr_add(acc[1], extra), multiplier);
-        cached = from12(total1, total2, point[binding_var_idx], claim_);
+        if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);
+        cached = from12_inv(total1, total2, point[binding_var_idx], inv_eq0[binding_var_idx], claim_);
         has_cached = true;
         *coeffs = cached;
         return GM_OK;
@@ -736,7 +825,7 @@ struct ScVecVecDeg2 : gm_sc {
         // GammaWrapper::new(func, gamma_pows[1])  (vecvec_eq.rs:185-187): same powers gamma^o
         rc = upload_gamma(gamma_pows, &d->d_gamma, stream);
         if (rc) return rc;
-        rc = d->rs.init();
+        rc = d->rs.init(stream);
         if (rc) return rc;
         d->claim_ = evaluate_univar(cached, t);
         has_cached = false;
@@ -801,7 +890,7 @@ extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, co
     for (uint32_t i = 0; i < num_vars; i++) lv[i] = so->d_eq.fr() + ((1ull << i) - 1);
     rc = launch_eq_sequence(fr_one(), so->point.data(), num_vars - 1, lv.data(), so->stream);
     if (rc) return rc;
-    rc = so->rs.init();
+    rc = so->rs.init(so->stream);
     if (rc) return rc;
     *out = so.release();
     return GM_OK;
@@ -876,11 +965,9 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         lv[polys->col_logsize] = so->d_row_coef.fr();
         rc = launch_eq_sequence(fr_one(), so->point.data(), polys->col_logsize, lv.data(), s);
         if (rc) return rc;
-        std::vector<Fr> coefs((size_t)1 << polys->col_logsize);
-        GM_HIP(hipMemcpyAsync(coefs.data(), so->d_row_coef.p, coefs.size() * sizeof(Fr), hipMemcpyDeviceToHost, s));
-        GM_HIP(hipStreamSynchronize(s));
-        so->row_coef_tail.assign(coefs.size() + 1, fr_zero());
-        for (int64_t i = (int64_t)coefs.size() - 1; i >= 0; i--) so->row_coef_tail[i] = fr_add(so->row_coef_tail[i + 1], coefs[i]);
+        // row_eq_coefs_tail_sums[nrows] = sum_{j >= nrows} eq(point[0..col], j) = 1 - eq_sum(point[0..col], nrows)
+        so->row_coef_tail.assign(((size_t)1 << polys->col_logsize) + 1, fr_zero());
+        so->row_coef_tail[so->nrows] = fr_sub(fr_one(), eq_sum_host(so->point.data(), polys->col_logsize, so->nrows));
     }
     // padded_eq_poly_sequence(padded, point[row vars])  (utils.rs:189-220): levels 0..n_seq_vars
     {
@@ -903,17 +990,23 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         std::vector<Fr> scal(padded + 1);
         scal[0] = fr_one();
         for (uint32_t i = 1; i <= padded; i++) { acc = fr_mul(acc, fr_sub(fr_one(), pt[i - 1])); scal[i] = acc; }
-        GM_HIP(hipMemcpyAsync(so->d_eq_seq.p, scal.data(), scal.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
-        GM_HIP(hipStreamSynchronize(s));
+        rc = upload_small(scal.data(), scal.size(), so->d_eq_seq.fr(), s);
+        if (rc) return rc;
         std::vector<Fr*> lv(n_seq_vars - padded + 1);
         for (uint32_t i = padded; i <= n_seq_vars; i++) lv[i - padded] = so->d_eq_seq.fr() + so->eq_level_off[i];
         // levels padded..n_seq_vars are the ordinary doubling levels started from the scalar m
         rc = launch_eq_sequence(m, pt + padded, n_seq_vars - padded, lv.data(), s);
         if (rc) return rc;
-        rc = so->d_prefix.alloc(((size_t)so->eq_level_len[n_seq_vars] + 2) * sizeof(Fr));
+        // row_eq_poly_prefix_seq (vecvec.rs:101-109): level l -> len_l + 1 prefix sums, packed at offset off_l + l
+        rc = so->d_prefix.alloc((size_t)(tot + n_seq_vars + 2) * sizeof(Fr));
         if (rc) return rc;
+        for (uint32_t i = 0; i <= n_seq_vars; i++) {
+            hipLaunchKernelGGL(k_prefix_sums, dim3(1), dim3(SC_THREADS), 0, s, so->d_eq_seq.fr() + so->eq_level_off[i],
+                               so->eq_level_len[i], so->d_prefix.fr() + so->eq_level_off[i] + i);
+            GM_LAUNCH_CHECK();
+        }
     }
-    rc = so->rs.init();
+    rc = so->rs.init(so->stream);
     if (rc) return rc;
     *out = so.release();
     return GM_OK;
@@ -950,7 +1043,7 @@ extern "C" int32_t gm_sc_dense_create(int32_t kind, const gm_fn* f, uint32_t num
     if (rc) return rc;
     rc = upload_gamma(gp, &so->d_gamma, so->stream);
     if (rc) return rc;
-    rc = so->rs.init();
+    rc = so->rs.init(so->stream);
     if (rc) return rc;
     *out = so.release();
     return GM_OK;

@@ -6,7 +6,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gkr_msm_amd import codec, ffi, harness
 
 x_log = int(sys.argv[1]) if len(sys.argv) > 1 else 20
