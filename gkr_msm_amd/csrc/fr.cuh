@@ -153,7 +153,27 @@ GM_HD uint32_t fr_addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t* cout) {
 // limb of t (a*b + t_j never overflows 64 bits); the high halves are then folded in with one 32-bit
 // add-with-carry chain per row.  This keeps the operands of each mad in place (no 64-bit zero-extension
 // shuffles), which is worth ~1.4x over the textbook running-carry loop with hipcc 7.2.
-GM_HD Fr fr_mul(const Fr& a, const Fr& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GM_FR_MUL_ASM)
+// Device path: hand-laid-out instruction stream with fixed VGPRs (scripts/gen/gen_fr_mul_asm.py explains the
+// register plan).  Bit-identical to the C formulation below (scripts/ubench/fr_mul_asm_test.hip checks 2^20 random
+// pairs + edge cases on the device against it, and the C formulation is what the host/oracle tests pin).
+__device__ __forceinline__ Fr fr_mul_asm(const Fr& a, const Fr& b) {
+    Fr r;
+    asm volatile(
+#include "fr_mul_asm.inc"
+        : "={v16}"(r.l[0]), "={v18}"(r.l[1]), "={v20}"(r.l[2]), "={v22}"(r.l[3]), "={v24}"(r.l[4]), "={v26}"(r.l[5]),
+          "={v28}"(r.l[6]), "={v30}"(r.l[7])
+        : "{v0}"(a.l[0]), "{v1}"(a.l[1]), "{v2}"(a.l[2]), "{v3}"(a.l[3]), "{v4}"(a.l[4]), "{v5}"(a.l[5]), "{v6}"(a.l[6]),
+          "{v7}"(a.l[7]), "{v8}"(b.l[0]), "{v9}"(b.l[1]), "{v10}"(b.l[2]), "{v11}"(b.l[3]), "{v12}"(b.l[4]),
+          "{v13}"(b.l[5]), "{v14}"(b.l[6]), "{v15}"(b.l[7])
+        : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "v17", "v19", "v21", "v23", "v25", "v27", "v29", "v31", "v32",
+          "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
+          "v49", "v50");
+    return r;
+}
+#endif
+
+GM_HD Fr fr_mul_c(const Fr& a, const Fr& b) {
     uint32_t t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) t[i] = 0;
@@ -198,6 +218,14 @@ GM_HD Fr fr_mul(const Fr& a, const Fr& b) {
     for (int i = 0; i < 8; i++) r.l[i] = t[i];
     // result < 2p and < 2^256 (t[8] == 0 since 2p < 2^256)
     return fr_reduce_once(r);
+}
+
+GM_HD Fr fr_mul(const Fr& a, const Fr& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GM_FR_MUL_ASM)
+    return fr_mul_asm(a, b);
+#else
+    return fr_mul_c(a, b);
+#endif
 }
 
 GM_HD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
