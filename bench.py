@@ -142,11 +142,15 @@ def main():
     cells0 = wpr * n // 2
     alg_bytes = cells0 * (128 + 8 + 96)
     fr_mul0 = cells0 * 9
+    # HBM traffic per k_add_level0 launch from the committed PMC passes (profiles/r01/msm_bench_pmc_hbm.csv, config B,
+    # 32 windows on this GPU): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction.
+    # Raw (uncorrected) it is 3.68e9; the gather pattern is uncalibrated, the truth lies between the two.
+    pmc_traffic = 5740748531 if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None
     roofline = None
     if dom:
         ach = alg_bytes / (dom * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_add_level0", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic,
                     "avg_launch_ms": round(dom, 4), "algorithmic_bytes_per_launch": alg_bytes,
                     "fr_mul_per_launch": fr_mul0, "fr_mul_per_s": round(fr_mul0 / (dom * 1e-3), 1)}
 

@@ -17,6 +17,8 @@
 // finds its row by binary search in the offsets table.  Each level is one launch; the three layer
 // functions l1/l2/l3 are fused in registers (the per-layer outputs are only materialised by the
 // witness builder in witness.hip, which the sumcheck needs; the MSM does not).
+#include <vector>
+
 #include "algfn.cuh"
 #include "common.hpp"
 #include "msm_plan.hpp"
@@ -595,4 +597,103 @@ extern "C" int32_t gm_msm_digits(const gm_msm_plan* p, const uint16_t** d_digits
     if (d_counter) *d_counter = p->counter;
     if (d_row_len) *d_row_len = p->row_len;
     return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fr-side data of the pushforward argument derived from the bucketing (PushForwardState, pushforward.rs:489-510 and
+// second_phase :572-596): c / d as field elements, negated access counts, and the eq "pullbacks".
+namespace gm {
+
+__global__ void __launch_bounds__(256) k_u_to_fr(const uint16_t* __restrict__ dg, const uint32_t* __restrict__ ct,
+                                                  uint64_t n, Fr* __restrict__ d_out, Fr* __restrict__ c_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(d_out + i, fr_from_u64(dg[i]));
+    fr_store(c_out + i, fr_from_u64(ct[i]));
+}
+
+__global__ void __launch_bounds__(256) k_access_counts(const uint16_t* __restrict__ dg, const uint32_t* __restrict__ ct,
+                                                        uint64_t n, uint32_t* __restrict__ cnt_d, uint32_t* __restrict__ cnt_c) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atomicAdd(&cnt_d[dg[i]], 1u);
+    atomicAdd(&cnt_c[ct[i]], 1u);
+}
+
+__global__ void __launch_bounds__(256) k_neg_count_to_fr(const uint32_t* __restrict__ cnt, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(out + i, fr_neg(fr_from_u64(cnt[i])));
+}
+
+__global__ void __launch_bounds__(256) k_pull(const uint16_t* __restrict__ dg, const uint32_t* __restrict__ ct, uint64_t n,
+                                               const Fr* __restrict__ eq_d, const Fr* __restrict__ eq_c,
+                                               Fr* __restrict__ d_pull, Fr* __restrict__ c_pull) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(d_pull + i, fr_load(eq_d + dg[i]));
+    fr_store(c_pull + i, fr_load(eq_c + ct[i]));
+}
+
+int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s);
+
+}  // namespace gm
+
+// d_c, d_d: y_size * 2^x elements each ([y][x]); d_ac_c: 2^x_logsize, d_ac_d: 2^d_logsize elements
+extern "C" int32_t gm_msm_phase1_polys(const gm_msm_plan* p, uint64_t* d_c, uint64_t* d_d, uint64_t* d_ac_c,
+                                       uint64_t* d_ac_d, void* stream) {
+    GM_REQUIRE(p && d_c && d_d && d_ac_c && d_ac_d, "null argument");
+    hipStream_t s = as_stream(stream);
+    const uint64_t n = (uint64_t)p->nwin * p->N;
+    hipLaunchKernelGGL(k_u_to_fr, dim3(ceil_div(n, 256)), dim3(256), 0, s, p->digits, p->counter, n,
+                       reinterpret_cast<Fr*>(d_d), reinterpret_cast<Fr*>(d_c));
+    GM_LAUNCH_CHECK();
+    uint32_t* cnt = nullptr;
+    const uint64_t nc = p->N + p->nd;
+    GM_HIP(hipMalloc((void**)&cnt, nc * 4));
+    GM_HIP(hipMemsetAsync(cnt, 0, nc * 4, s));
+    hipLaunchKernelGGL(k_access_counts, dim3(ceil_div(n, 256)), dim3(256), 0, s, p->digits, p->counter, n, cnt + p->N, cnt);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_neg_count_to_fr, dim3(ceil_div(p->N, 256)), dim3(256), 0, s, cnt, p->N, reinterpret_cast<Fr*>(d_ac_c));
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_neg_count_to_fr, dim3(ceil_div(p->nd, 256)), dim3(256), 0, s, cnt + p->N, (uint64_t)p->nd,
+                       reinterpret_cast<Fr*>(d_ac_d));
+    GM_LAUNCH_CHECK();
+    GM_HIP(hipStreamSynchronize(s));
+    GM_HIP(hipFree(cnt));
+    return GM_OK;
+}
+
+// h_r: y_logsize + d_logsize + x_logsize elements, layout [r_y | r_d | r_c] (pushforward.rs:574-580)
+extern "C" int32_t gm_msm_second_phase(const gm_msm_plan* p, const uint64_t* h_r, uint32_t y_logsize, uint64_t* d_c_pull,
+                                       uint64_t* d_d_pull, void* stream) {
+    GM_REQUIRE(p && h_r && d_c_pull && d_d_pull, "null argument");
+    hipStream_t s = as_stream(stream);
+    const uint32_t dl = p->d_log, xl = p->x_log;
+    std::vector<Fr> r(y_logsize + dl + xl);
+    memcpy(r.data(), h_r, r.size() * sizeof(Fr));
+    Fr* buf = nullptr;
+    const uint64_t tot = (2ull << xl) + (2ull << dl);
+    GM_HIP(hipMalloc((void**)&buf, tot * sizeof(Fr)));
+    Fr* eq_c = buf;                       // 2^xl, scratch 2^xl after it
+    Fr* eq_d = buf + (2ull << xl);        // 2^dl, scratch after it
+    std::vector<Fr*> lv(xl + 1);
+    for (uint32_t i = 0; i < xl; i++) lv[i] = eq_c + (1ull << xl) + ((1ull << i) - 1);
+    lv[xl] = eq_c;
+    int32_t rc = launch_eq_sequence(fr_one(), r.data() + y_logsize + dl, xl, lv.data(), s);
+    if (rc == GM_OK) {
+        lv.assign(dl + 1, nullptr);
+        for (uint32_t i = 0; i < dl; i++) lv[i] = eq_d + (1ull << dl) + ((1ull << i) - 1);
+        lv[dl] = eq_d;
+        rc = launch_eq_sequence(fr_one(), r.data() + y_logsize, dl, lv.data(), s);
+    }
+    if (rc == GM_OK) {
+        const uint64_t n = (uint64_t)p->nwin * p->N;
+        hipLaunchKernelGGL(k_pull, dim3(ceil_div(n, 256)), dim3(256), 0, s, p->digits, p->counter, n, eq_d, eq_c,
+                           reinterpret_cast<Fr*>(d_d_pull), reinterpret_cast<Fr*>(d_c_pull));
+        if (hipGetLastError() != hipSuccess) rc = set_err(GM_ERR_HIP, "k_pull launch failed");
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(buf);
+    return rc;
 }

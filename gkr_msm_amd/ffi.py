@@ -90,6 +90,8 @@ _SIGS = {
     "gm_msm_bucket_sums": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]),
     "gm_msm_window_points": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gm_msm_digits": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "gm_msm_phase1_polys": (C.c_int32, [vp, vp, vp, vp, vp, vp]),
+    "gm_msm_second_phase": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, vp]),
     "gm_msm_profile": (C.c_int32, [vp, C.c_int32]),
     "gm_msm_profile_read": (C.c_int32, [vp, C.POINTER(C.c_float), C.c_int32]),
     "gm_msm_combine_host": (C.c_int32, [vp, C.c_uint32, C.c_uint32, vp]),

@@ -190,6 +190,16 @@ int32_t gm_msm_window_points(const gm_msm_plan* plan, const uint64_t** d_cols, u
 int32_t gm_msm_digits(const gm_msm_plan* plan, const uint16_t** d_digits, const uint32_t** d_counter,
                       const uint32_t** d_row_len);
 
+/* Fr-side data of the pushforward argument derived from the bucketing of the last run (a12/a13):
+ *   gm_msm_phase1_polys  PushForwardState::new   pushforward.rs:489-510  c, d ([y][x] as field elements), ac_c, ac_d
+ *                        (negated access counts, 2^x_logsize and 2^d_logsize elements)
+ *   gm_msm_second_phase  PushForwardState::second_phase  pushforward.rs:572-596  c_pull = eq_c[counter], d_pull = eq_d[digit]
+ *                        for the point h_r = [r_y | r_d | r_c]  (the G1 commitments of these columns are SURVEY 8f-1) */
+int32_t gm_msm_phase1_polys(const gm_msm_plan* plan, uint64_t* d_c, uint64_t* d_d, uint64_t* d_ac_c, uint64_t* d_ac_d,
+                            void* stream);
+int32_t gm_msm_second_phase(const gm_msm_plan* plan, const uint64_t* h_r, uint32_t y_logsize, uint64_t* d_c_pull,
+                            uint64_t* d_d_pull, void* stream);
+
 /* Bench instrumentation: HIP events on the launch stream around the stages of gm_msm_run.
  * mode 0 off, 1 = only the dominant kernel (level-0 bucket add), 2 = every stage.
  * gm_msm_profile_read returns ms per stage of the last run (7 floats: digits, histogram, chunk scan +

@@ -288,3 +288,32 @@ def prove_image_part(transcript, y_logsize, d_logsize, x_logsize, claims, wg, re
     """pippenger.rs:138-141 : ending.prove + GlueSplit.prove"""
     claims = pippenger_bucketed_prove(transcript, y_logsize, d_logsize, x_logsize, claims, wg, record)
     return glue_split_prove(transcript, claims)
+
+
+# ------------------------------------------------------------------ pushforward phase data (Fr part)
+def pushforward_phase1_polys(digits, counter, x_logsize, d_logsize):
+    """pushforward.rs:489-510 : c, d as field elements (flattened [y][x]) and the negated access counts"""
+    d = [v % P for row in digits for v in row]
+    c = [v % P for row in counter for v in row]
+    ac_d = [0] * (1 << d_logsize)
+    ac_c = [0] * (1 << x_logsize)
+    for row in digits:
+        for v in row:
+            ac_d[v] += 1
+    for row in counter:
+        for v in row:
+            ac_c[v] += 1
+    return c, d, [(-v) % P for v in ac_c], [(-v) % P for v in ac_d]
+
+
+def pushforward_second_phase(digits, counter, r, y_logsize, d_logsize, x_logsize):
+    """pushforward.rs:572-596 : point layout [r_y | r_d | r_c]; c_pull = eq_c[counter], d_pull = eq_d[digit]"""
+    from .polys import eq_poly_sequence_last
+    assert len(r) == y_logsize + d_logsize + x_logsize
+    r_d = r[y_logsize:y_logsize + d_logsize]
+    r_c = r[y_logsize + d_logsize:]
+    eq_c = eq_poly_sequence_last(r_c)
+    eq_d = eq_poly_sequence_last(r_d)
+    c_pull = [eq_c[v] for row in counter for v in row]
+    d_pull = [eq_d[v] for row in digits for v in row]
+    return c_pull, d_pull

@@ -175,3 +175,36 @@ def test_golden_fixture_msm_and_prover(name):
     assert res["tape_used"] == len(fx["tape"])
     assert res["msgs"] == ints(fx["prover_messages"])
     assert res["point"] == ints(fx["final_point"]) and res["evs"] == ints(fx["final_evs"])
+
+
+def test_phase1_polys_and_second_phase():
+    """a12/a13: c, d, ac_c, ac_d (pushforward.rs:489-510) and c_pull / d_pull (second_phase, pushforward.rs:572-596)"""
+    import ctypes as C
+    from gkr_msm_amd import ffi
+    x_log, d_log, nbits = 7, 4, 24
+    y_size = 6
+    y_log = 3
+    n = 1 << x_log
+    pts = F.random_points(n, 31)
+    sc = F.random_scalars(n, nbits, 32)
+    _, digits, counter = G.bucketing_image(pts, sc, y_size, y_log, d_log, x_log)
+    d_pts = harness.to_dev(codec.points_to_mont(pts))
+    d_sc = harness.to_dev(codec.ints_to_limbs(sc))
+    plan = harness.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, d_sc)
+    L = ffi.lib()
+    tot = y_size * n
+    dc, dd = harness.dev_empty(tot * 4), harness.dev_empty(tot * 4)
+    dac, dad = harness.dev_empty(n * 4), harness.dev_empty((1 << d_log) * 4)
+    ffi.check(L.gm_msm_phase1_polys(plan.h, C.c_void_p(dc.data_ptr()), C.c_void_p(dd.data_ptr()), C.c_void_p(dac.data_ptr()),
+                                    C.c_void_p(dad.data_ptr()), harness.cur_stream()))
+    c, d, ac_c, ac_d = G.pushforward_phase1_polys(digits, counter, x_log, d_log)
+    assert harness.cols_to_host([dc, dd, dac, dad]) == [c, d, ac_c, ac_d]
+    rng = F.SplitMix64(5)
+    r = [rng.next_fr() for _ in range(y_log + d_log + x_log)]
+    cp, dp = harness.dev_empty(tot * 4), harness.dev_empty(tot * 4)
+    ra = harness.fr_arg(r)
+    ffi.check(L.gm_msm_second_phase(plan.h, ra.ctypes.data, y_log, C.c_void_p(cp.data_ptr()), C.c_void_p(dp.data_ptr()),
+                                    harness.cur_stream()))
+    e_c, e_d = G.pushforward_second_phase(digits, counter, r, y_log, d_log, x_log)
+    assert harness.cols_to_host([cp, dp]) == [e_c, e_d]
