@@ -133,10 +133,43 @@ int32_t launch_dense_fold(const Fr* const* in, Fr* const* out, int k, uint64_t n
 }
 
 // levels[i] must hold 2^i elements (i = 0..nvars); level i = eq(pt[0..i], .) * mult   (pt[0] = MSB)
+// Small tables dominate the prover (one per layer, 2^13 entries and below): all their levels are built by ONE
+// single-workgroup launch (a launch costs more than the arithmetic); larger levels continue one launch per level.
+#define EQ_SMALL_LEVELS 14
+struct EqSmallArgs {
+    Fr* level[EQ_SMALL_LEVELS + 1];
+    Fr pt[EQ_SMALL_LEVELS];
+    Fr mult;
+    uint32_t nlev;  // levels 1..nlev are computed here
+};
+__global__ void __launch_bounds__(1024) k_eq_small(EqSmallArgs a) {
+    if (threadIdx.x == 0) fr_store(a.level[0], a.mult);
+    __syncthreads();
+    for (uint32_t i = 1; i <= a.nlev; i++) {
+        const uint32_t np = 1u << (i - 1);
+        const Fr r = a.pt[i - 1];
+        for (uint32_t j = threadIdx.x; j < np; j += blockDim.x) {
+            const Fr w = fr_load(a.level[i - 1] + j);
+            const Fr m = fr_mul(r, w);
+            fr_store(a.level[i] + 2 * j, fr_sub(w, m));
+            fr_store(a.level[i] + 2 * j + 1, m);
+        }
+        __syncthreads();  // same workgroup: the stores above are visible to the loads of the next level
+    }
+}
+
 int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s) {
-    hipLaunchKernelGGL(k_set1, dim3(1), dim3(64), 0, s, levels[0], mult);
-    GM_LAUNCH_CHECK();
-    for (uint32_t i = 1; i <= nvars; i++) {
+    const uint32_t small = nvars < EQ_SMALL_LEVELS ? nvars : EQ_SMALL_LEVELS;
+    {
+        EqSmallArgs a;
+        a.mult = mult;
+        a.nlev = small;
+        for (uint32_t i = 0; i <= small; i++) a.level[i] = levels[i];
+        for (uint32_t i = 0; i < small; i++) a.pt[i] = pt[i];
+        hipLaunchKernelGGL(k_eq_small, dim3(1), dim3(small >= 10 ? 1024 : 256), 0, s, a);
+        GM_LAUNCH_CHECK();
+    }
+    for (uint32_t i = small + 1; i <= nvars; i++) {
         const uint64_t np = 1ull << (i - 1);
         hipLaunchKernelGGL(k_eq_level, dim3(ceil_div(np, 256)), dim3(256), 0, s, levels[i - 1], levels[i], pt[i - 1], np);
         GM_LAUNCH_CHECK();

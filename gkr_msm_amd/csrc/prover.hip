@@ -443,7 +443,8 @@ extern "C" int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t
         const uint64_t T = glued->total, nr = glued->nrows;
         const size_t bytes = (size_t)6 * 32 * (T / 2 + T / 4 + 4 * nr + 64) + ((size_t)48 << 20);
         TRY(w->arena.init(bytes));
-        GM_HIP(hipHostMalloc((void**)&w->pinned, 16 * sizeof(Fr)));
+        GM_HIP(hipHostMalloc((void**)&w->pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
+        memset(w->pinned, 0, 16 * sizeof(Fr));
     }
     GM_HIP(hipStreamSynchronize(s));
     *out = w.release();

@@ -14,6 +14,8 @@
 // bind_21 = p1 + (t-1)(p2 - p1) = p0 + t (p1 - p0).  The device keeps plain form, computes value-at-2 in
 // registers and folds with the plain formula: every round polynomial, folded polynomial and final evaluation
 // is the same canonical field element as in the reference (sums in a field do not depend on their order).
+#include <atomic>
+
 #include "internal.hpp"
 #include "ragged.cuh"
 #include "vecvec.hpp"
@@ -139,7 +141,8 @@ Fr eq_sum_host(const Fr* pt, uint32_t n, uint64_t k) {
 struct FinishCtx {
     Fr* partial;         // gridDim.x * gridDim.y rows of NACC elements
     uint32_t* counter;   // zero between launches (the last block resets it)
-    Fr* out;             // pinned host memory (device-visible)
+    Fr* out;             // pinned host memory (device-visible); element 7 doubles as the sequence slot
+    uint32_t seq;        // written (system scope) after the results: the host polls it instead of a stream sync
 };
 
 template <int NACC>
@@ -183,7 +186,11 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
         if (threadIdx.x == 0) fr_store(fc.out + a, red[0]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) *fc.counter = 0;
+    if (threadIdx.x == 0) {
+        *fc.counter = 0;
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(fc.out + 7), fc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 struct SmallVals {
@@ -288,6 +295,38 @@ __global__ void __launch_bounds__(SC_THREADS) k_prefix_sums(const Fr* __restrict
         __syncthreads();
         if (threadIdx.x == SC_THREADS - 1) carry = fr_add(carry, part[threadIdx.x]);
         __syncthreads();
+    }
+}
+
+// all levels of the padded eq sequence in one launch: level i has len_i = (i <= padded ? 1 : 2^(i - padded))
+// entries at offset off_i = sum_{j<i} len_j; its len_i + 1 prefix sums go to prefix + off_i + i
+__global__ void __launch_bounds__(SC_THREADS) k_prefix_sums_levels(const Fr* __restrict__ seq, Fr* __restrict__ prefix,
+                                                                    uint32_t padded, uint32_t nlevels_minus1) {
+    __shared__ Fr part[SC_THREADS];
+    __shared__ Fr carry;
+    uint64_t off = 0;
+    for (uint32_t lv = 0; lv <= nlevels_minus1; lv++) {
+        const uint32_t n = (lv <= padded) ? 1u : (1u << (lv - padded));
+        const Fr* v = seq + off;
+        Fr* pre = prefix + off + lv;
+        if (threadIdx.x == 0) { carry = fr_zero(); fr_store(pre, fr_zero()); }
+        __syncthreads();
+        for (uint32_t base = 0; base < n; base += SC_THREADS) {
+            const uint32_t i = base + threadIdx.x;
+            part[threadIdx.x] = (i < n) ? fr_load(v + i) : fr_zero();
+            __syncthreads();
+            for (uint32_t st = 1; st < SC_THREADS; st <<= 1) {
+                Fr t = (threadIdx.x >= st) ? part[threadIdx.x - st] : fr_zero();
+                __syncthreads();
+                part[threadIdx.x] = fr_add(part[threadIdx.x], t);
+                __syncthreads();
+            }
+            if (i < n) fr_store(pre + i + 1, fr_add(carry, part[threadIdx.x]));
+            __syncthreads();
+            if (threadIdx.x == SC_THREADS - 1) carry = fr_add(carry, part[threadIdx.x]);
+            __syncthreads();
+        }
+        off += n;
     }
 }
 
@@ -437,7 +476,8 @@ struct RoundScratch {
             h_result = shared_pinned();
             own_pinned = false;
         } else {
-            GM_HIP(hipHostMalloc((void**)&h_result, 8 * sizeof(Fr)));
+            GM_HIP(hipHostMalloc((void**)&h_result, 8 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
+            memset(h_result, 0, 8 * sizeof(Fr));
             own_pinned = true;
         }
         return GM_OK;
@@ -445,10 +485,28 @@ struct RoundScratch {
     ~RoundScratch() {
         if (h_result && own_pinned) (void)hipHostFree(h_result);
     }
-    FinishCtx ctx() const { return FinishCtx{partial.fr(), reinterpret_cast<uint32_t*>(counter.p), h_result}; }
-    // the launch wrote `nacc` results into the pinned buffer; wait for it and copy them out
+    static uint32_t& seq_counter() {
+        static thread_local uint32_t c = 0;
+        return c;
+    }
+    uint32_t expect = 0;
+    FinishCtx ctx() {
+        expect = ++seq_counter();
+        if (expect == 0) expect = ++seq_counter();
+        return FinishCtx{partial.fr(), reinterpret_cast<uint32_t*>(counter.p), h_result, expect};
+    }
+    // The launch writes `nacc` results and then the sequence number into the pinned buffer.  Poll the sequence
+    // slot (a PCIe write lands in ~2 us; hipStreamSynchronize costs 10-20 us per round); fall back to the stream
+    // synchronisation if it has not shown up after a bounded spin.
     int32_t finish(int nacc, hipStream_t s, Fr* out) {
-        GM_HIP(hipStreamSynchronize(s));
+        volatile uint32_t* slot = reinterpret_cast<volatile uint32_t*>(h_result + 7);
+        bool seen = false;
+        for (int spin = 0; spin < 200000; spin++) {
+            if (*slot == expect) { seen = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!seen) GM_HIP(hipStreamSynchronize(s));
+        std::atomic_thread_fence(std::memory_order_acquire);
         for (int a = 0; a < nacc; a++) out[a] = h_result[a];
         return GM_OK;
     }
@@ -1000,11 +1058,9 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         // row_eq_poly_prefix_seq (vecvec.rs:101-109): level l -> len_l + 1 prefix sums, packed at offset off_l + l
         rc = so->d_prefix.alloc((size_t)(tot + n_seq_vars + 2) * sizeof(Fr));
         if (rc) return rc;
-        for (uint32_t i = 0; i <= n_seq_vars; i++) {
-            hipLaunchKernelGGL(k_prefix_sums, dim3(1), dim3(SC_THREADS), 0, s, so->d_eq_seq.fr() + so->eq_level_off[i],
-                               so->eq_level_len[i], so->d_prefix.fr() + so->eq_level_off[i] + i);
-            GM_LAUNCH_CHECK();
-        }
+        hipLaunchKernelGGL(k_prefix_sums_levels, dim3(1), dim3(SC_THREADS), 0, s, so->d_eq_seq.fr(), so->d_prefix.fr(),
+                           padded, n_seq_vars);
+        GM_LAUNCH_CHECK();
     }
     rc = so->rs.init(so->stream);
     if (rc) return rc;
