@@ -83,6 +83,8 @@ _SIGS = {
     "gm_pip_witness_outputs": (C.c_int32, [vp, vp, u32p, u64p, vp]),
     "gm_pip_witness_bytes": (C.c_uint64, [vp]),
     "gm_pip_prove_image_part": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, u32p, vp, u64p, u64p]),
+    "gm_gkr_msm_prove": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u32p, vp,
+                                     u64p, u64p, C.POINTER(C.c_double), vp]),
     "gm_msm_plan_create": (C.c_int32, [C.c_uint32] * 5 + [C.POINTER(vp)]),
     "gm_msm_plan_destroy": (C.c_int32, [vp]),
     "gm_msm_plan_workspace_bytes": (C.c_size_t, [vp]),

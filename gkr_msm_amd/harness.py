@@ -366,3 +366,23 @@ class PipWitness:
                                                  C.byref(npt), fev.ctypes.data, C.byref(used), C.byref(rounds)))
         return dict(msgs=codec.from_mont_limbs(msgs[: nm.value]), point=codec.from_mont_limbs(fpt[: npt.value]),
                     evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value, rounds=rounds.value)
+
+
+def gkr_msm_prove(d_points, d_bits_u8, log_num_points, log_num_scalar_bits, tape, msgs_cap=1 << 18):
+    """gen-1 gkr_msm_prove through the C ABI; d_bits_u8: uint8 CUDA tensor of 2^lp * 2^lb entries"""
+    L = ffi.lib()
+    tp = codec.ints_to_limbs(tape)
+    msgs = np.zeros((msgs_cap, 4), dtype=np.uint64)
+    nout = 1 << log_num_scalar_bits
+    outp = np.zeros((3 * nout, 4), dtype=np.uint64)
+    fpt = np.zeros((64, 4), dtype=np.uint64)
+    fev = np.zeros((8, 4), dtype=np.uint64)
+    nm, used, rounds, npt, wms = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_double()
+    ffi.check(L.gm_gkr_msm_prove(C.c_void_p(d_points.data_ptr()), C.c_void_p(d_bits_u8.data_ptr()), log_num_points,
+                                 log_num_scalar_bits, tp.ctypes.data, len(tape), msgs.ctypes.data, msgs_cap, C.byref(nm),
+                                 outp.ctypes.data, fpt.ctypes.data, C.byref(npt), fev.ctypes.data, C.byref(used),
+                                 C.byref(rounds), C.byref(wms), cur_stream()))
+    return dict(msgs=codec.from_mont_limbs(msgs[: nm.value]), output=[codec.from_mont_limbs(outp[c * nout:(c + 1) * nout])
+                                                                        for c in range(3)],
+                point=codec.from_mont_limbs(fpt[: npt.value]), evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value,
+                rounds=rounds.value, witness_ms=wms.value)

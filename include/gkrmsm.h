@@ -237,6 +237,21 @@ int32_t gm_pip_prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim
                                 uint64_t* n_msgs, uint64_t* h_final_point, uint32_t* n_final_point,
                                 uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds);
 
+/* ---------------------------------------------------------------- gen-1 prover (a6, a16)
+ * gkr_msm_prove (src/gkr_msm_simple.rs:86-338) without the BLS12-381 G1 column commitments: base polys
+ * (bit, px, py) over index point*2^lb + bit, BintreeProtocol::witness (protocol/bintree.rs:168-184) over the layer list of
+ * gkr_msm_simple.rs:248-269, output claims, and the BintreeProver::round loop (bintree.rs:213-288) with
+ * SumcheckPolyMapProver / SplitProver (protocol/sumcheck.rs:185-257, protocol/split.rs:66-82).
+ *   d_scalar_bits: 2^lp * 2^lb bytes, the flattened Vec<Vec<bool>> (1 = true);  h_tape: challenges in draw order, canonical
+ *   field elements (gen-1 challenges are 64 bytes reduced mod p, transcript.rs:96-101);  h_msgs: everything the prover appends
+ *   to the transcript, in order (output polys, round polynomials as full coefficient vectors, final evaluations);
+ *   h_output: the three output polys (3 * 2^lb);  final EvalClaim: point (lp + lb elements) and 3 evaluations (bit, px, py). */
+int32_t gm_gkr_msm_prove(const uint64_t* d_points_xy, const uint8_t* d_scalar_bits, uint32_t log_num_points,
+                         uint32_t log_num_scalar_bits, const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_msgs,
+                         uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_output, uint64_t* h_final_point,
+                         uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds,
+                         double* witness_ms, void* stream);
+
 /* Bandersnatch ScalarField (Montgomery, as stored by ark `Fr` of ark-ed-on-bls12-381-bandersnatch)
  * -> canonical bigint: the `into_bigint()` of pushforward.rs:352 / msm_nonaffine.rs:21-23. */
 int32_t gm_bs_scalars_into_bigint(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream);
