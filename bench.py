@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-sumcheck", action="store_true")
     ap.add_argument("--cpu-sumcheck-xlog", type=int, default=17)
+    ap.add_argument("--gen1-log-points", type=int, default=18, help="gen-1 gkr_msm_prove size (0 = skip; 20 needs ~210 GiB)")
+    ap.add_argument("--cpu-gen1-log-points", type=int, default=12)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,6 +208,28 @@ def main():
         w.close()
         del w
 
+    # ---- gen-1 prover (gkr_msm_simple.rs gkr_msm_prove, Fr part): BASELINE.json configs[2]
+    if world == 1 and not args.no_sumcheck and args.gen1_log_points > 0:
+        plan.close()
+        torch.cuda.empty_cache()
+        lp, lb = args.gen1_log_points, 8
+        g_rng = np.random.default_rng(11)
+        d_bits = torch.from_numpy(g_rng.integers(0, 2, size=(1 << (lp + lb)), dtype=np.uint8)).cuda()
+        g_tape = [int.from_bytes(g_rng.bytes(64), "little") % P for _ in range(6000)]
+        d_pts_g = d_pts[: (1 << lp) * 8] if lp <= x_log else None
+        if d_pts_g is None:
+            d_pts_g = harness.dev_empty((1 << lp) * 8)
+            ffi.check(L.gm_gen_points(C.c_void_p(d_pts_g.data_ptr()), 1 << lp, 0x474B524D534D, harness.cur_stream()))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        g1 = harness.gkr_msm_prove(d_pts_g, d_bits, lp, lb, g_tape, msgs_cap=1 << 16)
+        g_dt = time.perf_counter() - t1
+        out["gen1"] = {"workload": "gkr_msm_prove log_num_points=%d log_num_scalar_bits=%d (witness + prover)" % (lp, lb),
+                       "total_ms": round(g_dt * 1e3, 2), "witness_ms": round(g1["witness_ms"], 2), "rounds": g1["rounds"],
+                       "rounds_per_sec": round(g1["rounds"] / max(g_dt - g1["witness_ms"] * 1e-3, 1e-9), 1),
+                       "points_per_sec": round((1 << lp) / g_dt, 1)}
+        del d_bits
+
     # ---- CPU baseline + in-run parity (rank 0, N = 1)
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -248,6 +272,25 @@ def main():
             cpu_prove = time.perf_counter() - t1
             same = codec.from_mont_limbs(c["msgs"]) == g["msgs"] and codec.from_mont_limbs(c["evs"]) == g["evs"]
             assert same, "GPU prover messages differ from the CPU oracle"
+            if "gen1" in out:
+                lp2, lb2 = min(args.cpu_gen1_log_points, args.gen1_log_points), 8
+                b8 = np.random.default_rng(12).integers(0, 2, size=(1 << (lp2 + lb2)), dtype=np.uint8)
+                r13 = np.random.default_rng(13)
+                tape2 = [int.from_bytes(r13.bytes(64), "little") % P for _ in range(4000)]
+                t1 = time.perf_counter()
+                cg = O.gkr_msm_prove(pts_h[: 1 << lp2], b8, lp2, lb2, codec.ints_to_limbs(tape2), threads, msgs_cap=1 << 16)
+                cpu_g = time.perf_counter() - t1
+                gg = harness.gkr_msm_prove(harness.to_dev(pts_h[: 1 << lp2]), torch.from_numpy(b8).cuda(), lp2, lb2, tape2,
+                                           msgs_cap=1 << 16)
+                t1 = time.perf_counter()
+                gg = harness.gkr_msm_prove(harness.to_dev(pts_h[: 1 << lp2]), torch.from_numpy(b8).cuda(), lp2, lb2, tape2,
+                                           msgs_cap=1 << 16)
+                gpu_g = time.perf_counter() - t1
+                assert codec.from_mont_limbs(cg["msgs"]) == gg["msgs"], "gen-1 GPU transcript differs from the CPU oracle"
+                out["gen1"]["cpu_baseline"] = {"value": round((1 << lp2) / cpu_g, 1), "unit": "points/s", "cores": threads,
+                                               "kind": "port", "sample": "gkr_msm_prove log_num_points=%d: cpu %.2f s" % (lp2, cpu_g),
+                                               "gpu_same_sample_points_per_sec": round((1 << lp2) / gpu_g, 1),
+                                               "parity": "bit-exact (%d transcript messages)" % len(gg["msgs"])}
             out["sumcheck"]["cpu_baseline"] = {
                 "value": round(c["rounds"] / cpu_prove, 1), "unit": "rounds/s", "cores": threads, "kind": "port",
                 "sample": "same prover at x_logsize=%d (%d rounds): cpu witness %.2f s + prove %.2f s" % (

@@ -87,6 +87,10 @@ void or_pip_witness_output(const or_pip_witness* w, or_fr* out);
 int or_pip_prove_image_part(or_pip_witness* w, const or_fr* claim_point, const or_fr* claim_evs, const uint64_t* tape,
                             uint64_t n_tape, or_fr* msgs, uint64_t msgs_cap, uint64_t* n_msgs, or_fr* final_point,
                             uint32_t* n_final_point, or_fr* final_evs, uint64_t* tape_used, uint64_t* rounds, int threads);
+/* gen-1 prover gkr_msm_prove, Fr part (gkr_msm_simple.rs:86-338); bits: 2^lp * 2^lb bytes; tape: canonical field elements */
+int or_gkr_msm_prove(const or_fr* points_xy, const uint8_t* bits, uint32_t lp, uint32_t lb, const uint64_t* tape,
+                     uint64_t n_tape, or_fr* msgs, uint64_t msgs_cap, uint64_t* n_msgs, or_fr* output, or_fr* final_point,
+                     uint32_t* n_final_point, or_fr* final_evs, uint64_t* tape_used, uint64_t* rounds, int threads);
 #ifdef __cplusplus
 }
 #endif

@@ -740,3 +740,136 @@ int or_pip_prove_image_part(or_pip_witness* w, const or_fr* claim_point, const o
     if (rounds) *rounds = tr.rounds;
     return tr.err;
 }
+
+/* ================================================================================================
+ * gen-1 prover gkr_msm_prove (Fr part), full shapes.  Restates
+ *   src/gkr_msm_simple.rs:82-338, src/protocol/bintree.rs:81-123, 168-288,
+ *   src/protocol/sumcheck.rs:67-257, 659-701, src/protocol/split.rs:37-82, src/polynomial/fragmented.rs:676-761,
+ *   src/copoly.rs:457-633 (EqPoly on a full shape = the eq table), src/utils.rs:104-113, 167-173.
+ */
+typedef struct { int is_map; or_fn f; int n_split; uint32_t nv; } g1_layer;
+
+int or_gkr_msm_prove(const or_fr* points_xy, const uint8_t* bits, uint32_t lp, uint32_t lb, const uint64_t* tape,
+                     uint64_t n_tape, or_fr* msgs, uint64_t msgs_cap, uint64_t* n_msgs, or_fr* output /* 3 * 2^lb */,
+                     or_fr* final_point, uint32_t* n_final_point, or_fr* final_evs, uint64_t* tape_used, uint64_t* rounds,
+                     int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    if (lp < 1 || lb < 1 || lp + lb > 30) return 1;
+    const uint32_t nv0 = lp + lb;
+    const uint64_t n0 = 1ULL << nv0;
+    g1_layer layers[4 * 32 + 8];
+    int nl = 0;
+    {
+        uint32_t nv = nv0;
+        g1_layer L;
+        memset(&L, 0, sizeof(L));
+#define G1_MAP(id) do { L.is_map = 1; L.f = mkfn(id, 1, 0, 0); L.n_split = 0; L.nv = nv; layers[nl++] = L; } while (0)
+#define G1_SPLIT(n) do { L.is_map = 0; L.f = mkfn(8, n, 0, 0); L.n_split = n; L.nv = nv; layers[nl++] = L; nv--; } while (0)
+        G1_MAP(10); G1_SPLIT(2); G1_MAP(1); G1_MAP(2); G1_MAP(3);
+        for (uint32_t i = 0; i + 1 < lp; i++) { G1_SPLIT(3); G1_MAP(4); G1_MAP(5); G1_MAP(6); }
+    }
+    /* base layer: index = point * 2^lb + bit (gkr_msm_simple.rs:120, 150-186) */
+    dset** trace = (dset**)calloc((size_t)nl + 1, sizeof(dset*));
+    dset* cur = d_new(3, n0);
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < n0; i++) {
+        cur->col[0][i] = bits[i] ? ONE : ZERO;
+        cur->col[1][i] = points_xy[2 * (i >> lb)];
+        cur->col[2][i] = points_xy[2 * (i >> lb) + 1];
+    }
+    for (int li = 0; li < nl; li++) {
+        trace[li] = cur;
+        cur = layers[li].is_map ? dn_map(&layers[li].f, cur) : dn_map_split(&layers[li].f, cur, 0, layers[li].n_split);
+    }
+    tape_t tr = {tape, n_tape, 0, msgs, msgs_cap, 0, 0, 0};
+    const uint64_t nout = 1ULL << lb;
+    for (int c = 0; c < 3; c++) {
+        tp_write(&tr, cur->col[c], (int)nout);
+        if (output) memcpy(output + (size_t)c * nout, cur->col[c], nout * sizeof(or_fr));
+    }
+    /* gen-1 challenges are full field elements: the tape holds canonical values < p */
+    claims_t cl;
+    for (uint32_t i = 0; i < lb; i++) cl.point[i] = tp_challenge(&tr);
+    cl.npoint = (int)lb;
+    for (int c = 0; c < 3; c++) { /* FragmentedPoly::evaluate */
+        or_fr* v = (or_fr*)malloc(nout * sizeof(or_fr));
+        memcpy(v, cur->col[c], nout * sizeof(or_fr));
+        uint64_t len = nout;
+        for (int k = (int)lb - 1; k >= 0; k--) { or_dense_bind(v, len, &cl.point[k], v); len /= 2; }
+        cl.evs[c] = v[0];
+        free(v);
+    }
+    cl.nevs = 3;
+    d_free(cur);
+    for (int li = nl - 1; li >= 0; li--) {
+        const g1_layer* L = &layers[li];
+        or_fr c0 = tp_challenge(&tr);
+        if (!L->is_map) { /* SplitProver::round */
+            int h = cl.nevs / 2;
+            for (int i = 0; i < h; i++) cl.evs[i] = f_add(cl.evs[i], f_mul(c0, f_sub(cl.evs[h + i], cl.evs[i])));
+            cl.nevs = h;
+            cl.point[cl.npoint++] = c0; /* fix_var_top */
+            continue;
+        }
+        const or_fn* f = &L->f;
+        int ni = or_fn_n_ins(f), no = or_fn_n_outs(f);
+        uint32_t nv = L->nv;
+        or_fr gp[64];
+        gp[0] = ONE; gp[1] = c0;
+        for (int i = 2; i < no; i++) gp[i] = f_mul(gp[i - 1], c0);
+        uint64_t n = 1ULL << nv;
+        or_fr** cols = (or_fr**)malloc(sizeof(or_fr*) * (size_t)(ni + 1));
+        for (int c = 0; c < ni; c++) { cols[c] = (or_fr*)malloc(n * sizeof(or_fr)); memcpy(cols[c], trace[li]->col[c], n * sizeof(or_fr)); }
+        cols[ni] = (or_fr*)malloc(n * sizeof(or_fr));
+        or_eq_table(&ONE, cl.point, nv, cols[ni]);
+        or_fr rs[64];
+        for (uint32_t rd = 0; rd < nv; rd++) {
+            uint64_t half = 1ULL << (nv - rd - 1);
+            or_fr S[4] = {ZERO, ZERO, ZERO, ZERO};
+#pragma omp parallel
+            {
+                or_fr loc[4] = {ZERO, ZERO, ZERO, ZERO};
+#pragma omp for schedule(static) nowait
+                for (uint64_t i = 0; i < half; i++) {
+                    or_fr a[64], d[64], o[64];
+                    for (int c = 0; c <= ni; c++) { a[c] = cols[c][2 * i]; d[c] = f_sub(cols[c][2 * i + 1], cols[c][2 * i]); }
+                    for (int k = 0; k < 4; k++) { /* evaluations at 0, 1, 2, 3 (sumcheck.rs:99-151) */
+                        if (k) for (int c = 0; c <= ni; c++) a[c] = f_add(a[c], d[c]);
+                        or_fn_exec(f, a, o);
+                        or_fr g = o[0];
+                        for (int q = 1; q < no; q++) g = f_add(g, f_mul(gp[q], o[q]));
+                        loc[k] = f_add(loc[k], f_mul(g, a[ni]));
+                    }
+                }
+#pragma omp critical
+                for (int k = 0; k < 4; k++) S[k] = f_add(S[k], loc[k]);
+            }
+            or_fr co[4];
+            unipoly_from_evals(S, 4, co);
+            tp_write(&tr, co, 4); /* full coefficient vector (sumcheck.rs:250) */
+            or_fr r = tp_challenge(&tr);
+            rs[rd] = r;
+#pragma omp parallel for schedule(static)
+            for (int c = 0; c <= ni; c++) or_dense_bind(cols[c], 2 * half, &r, cols[c]);
+            tr.rounds++;
+        }
+        for (uint32_t i = 0; i < nv; i++) cl.point[i] = rs[nv - 1 - i]; /* fix_var_bot */
+        cl.npoint = (int)nv;
+        for (int c = 0; c < ni; c++) cl.evs[c] = cols[c][0];
+        cl.nevs = ni;
+        tp_write(&tr, cl.evs, ni);
+        for (int c = 0; c <= ni; c++) free(cols[c]);
+        free(cols);
+    }
+    for (int li = 0; li < nl; li++) d_free(trace[li]);
+    free(trace);
+    if (n_msgs) *n_msgs = tr.nmsgs;
+    if (final_point) memcpy(final_point, cl.point, (size_t)cl.npoint * sizeof(or_fr));
+    if (n_final_point) *n_final_point = (uint32_t)cl.npoint;
+    if (final_evs) memcpy(final_evs, cl.evs, 3 * sizeof(or_fr));
+    if (tape_used) *tape_used = tr.pos;
+    if (rounds) *rounds = tr.rounds;
+    return tr.err;
+}

@@ -141,3 +141,29 @@ class PipWitness:
         if rc != 0:
             raise ValueError("or_pip_prove_image_part failed (rc=%d)" % rc)
         return dict(msgs=msgs[: nm.value], point=fpt[: npt.value], evs=fev, tape_used=used.value, rounds=rounds.value)
+
+
+def gkr_msm_prove(points_mont, bits_u8, lp, lb, tape_limbs, threads=1, msgs_cap=1 << 18):
+    """C oracle gen-1 prover (or_gkr_msm_prove); returns Montgomery limb arrays"""
+    L = lib()
+    L.or_gkr_msm_prove.restype = C.c_int
+    L.or_gkr_msm_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
+                                   C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int]
+    pts = np.ascontiguousarray(points_mont, dtype=np.uint64)
+    bits = np.ascontiguousarray(bits_u8, dtype=np.uint8)
+    tp = np.ascontiguousarray(tape_limbs, dtype=np.uint64)
+    msgs = np.zeros((msgs_cap, 4), dtype=np.uint64)
+    nout = 1 << lb
+    outp = np.zeros((3 * nout, 4), dtype=np.uint64)
+    fpt = np.zeros((80, 4), dtype=np.uint64)
+    fev = np.zeros((3, 4), dtype=np.uint64)
+    nm, used, rounds = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    npt = C.c_uint32()
+    rc = L.or_gkr_msm_prove(pts.ctypes.data, bits.ctypes.data, lp, lb, tp.ctypes.data, tp.shape[0], msgs.ctypes.data,
+                            msgs_cap, C.addressof(nm), outp.ctypes.data, fpt.ctypes.data, C.addressof(npt),
+                            fev.ctypes.data, C.addressof(used), C.addressof(rounds), threads)
+    if rc != 0:
+        raise ValueError("or_gkr_msm_prove failed (rc=%d)" % rc)
+    return dict(msgs=msgs[: nm.value], output=outp, point=fpt[: npt.value], evs=fev, tape_used=used.value,
+                rounds=rounds.value)

@@ -41,3 +41,23 @@ def test_c_prover_matches_pyref(x_log, d_log, nbits, threads):
     assert codec.from_mont_limbs(res["evs"]) == fin[1]
     for i in range(3):
         assert PL.evaluate_poly(image[i].to_dense(), fin[0]) == fin[1][i]
+
+
+@pytest.mark.parametrize("lp,lb,threads", [(1, 1, 1), (2, 1, 2), (3, 2, 1), (4, 3, 3), (3, 5, 2)])
+def test_c_gen1_prover_matches_pyref(lp, lb, threads):
+    """gen-1 gkr_msm_prove: C oracle vs the Python restatement (+ Pattern A on the final claim)"""
+    import numpy as np
+    from pyref import gen1 as G1
+    pts = F.random_points(1 << lp, 3 + lp)
+    rng = F.SplitMix64(40 + lb)
+    bits = [[bool(rng.next() & 1) for _ in range(1 << lb)] for _ in range(1 << lp)]
+    tape = [rng.next_fr() for _ in range(3000)]
+    claim, out, tr = G1.gkr_msm_prove(bits, pts, lp, lb, tape)
+    b8 = np.array([[1 if b else 0 for b in s] for s in bits], dtype=np.uint8).reshape(-1)
+    res = O.gkr_msm_prove(codec.points_to_mont(pts), b8, lp, lb, codec.ints_to_limbs(tape), threads)
+    assert res["tape_used"] == tr.pos
+    assert codec.from_mont_limbs(res["msgs"]) == tr.msgs
+    assert codec.from_mont_limbs(res["output"]) == [v for p in out for v in p]
+    assert codec.from_mont_limbs(res["point"]) == claim[0] and codec.from_mont_limbs(res["evs"]) == claim[1]
+    base = G1.base_layer(bits, pts, lp, lb)
+    assert [G1.evaluate(b, claim[0]) for b in base] == claim[1]
