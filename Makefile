@@ -1,7 +1,7 @@
 # Builds the product library (HIP, gfx950 only) and the test oracle.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -DGM_FR_MUL_ASM -mllvm -enable-misched=0
 SRC := $(wildcard gkr_msm_amd/csrc/*.hip)
 OBJ := $(patsubst gkr_msm_amd/csrc/%.hip,build/%.o,$(SRC))
 HDR := $(wildcard gkr_msm_amd/csrc/*.inc) $(wildcard gkr_msm_amd/csrc/*.cuh) $(wildcard gkr_msm_amd/csrc/*.hpp) include/gkrmsm.h

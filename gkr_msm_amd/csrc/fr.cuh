@@ -220,11 +220,63 @@ GM_HD Fr fr_mul_c(const Fr& a, const Fr& b) {
     return fr_reduce_once(r);
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host path (scalar glue of the drivers: recombination, interpolation, claims): 4 x 64-bit CIOS with 128-bit products.
+inline Fr fr_mul_host64(const Fr& a, const Fr& b) {
+    typedef unsigned __int128 u128;
+    static const uint64_t Pm[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    uint64_t x[4], y[4], t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        x[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+        y[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+    }
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)x[j] * y[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * 0xfffffffeffffffffULL;  // -p^-1 mod 2^64
+        c = ((u128)m * Pm[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * Pm[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    // conditional subtraction
+    uint64_t d[4];
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 v = (u128)t[i] - Pm[i] - br;
+        d[i] = (uint64_t)v;
+        br = (v >> 64) & 1;
+    }
+    const bool ge = t[4] != 0 || br == 0;
+    Fr r;
+    for (int i = 0; i < 4; i++) {
+        const uint64_t v = ge ? d[i] : t[i];
+        r.l[2 * i] = (uint32_t)v;
+        r.l[2 * i + 1] = (uint32_t)(v >> 32);
+    }
+    return r;
+}
+#endif
+
 GM_HD Fr fr_mul(const Fr& a, const Fr& b) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GM_FR_MUL_ASM)
     return fr_mul_asm(a, b);
-#else
+#elif defined(__HIP_DEVICE_COMPILE__)
     return fr_mul_c(a, b);
+#else
+    return fr_mul_host64(a, b);
 #endif
 }
 

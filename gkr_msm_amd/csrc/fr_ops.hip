@@ -40,6 +40,7 @@ static Fr fr_op_host(int op, const Fr& a, const Fr& b) {
         case 5: return fr_to_mont(a);
         case 6: return fr_from_mont(a);
         case 7: return fr_mul_by_a(a);
+        case 9: return fr_mul_c(a, b);  // the 32-bit-limb formulation the device compiles when the asm path is off
         default: return fr_mul_by_d(a);
     }
 }
@@ -200,12 +201,12 @@ extern "C" int32_t gm_fr_batch(int32_t op, const uint64_t* d_a, const uint64_t* 
 }
 
 extern "C" int32_t gm_fr_host(int32_t op, const uint64_t* h_a, const uint64_t* h_b, uint64_t* h_out, uint64_t n) {
-    GM_REQUIRE(op >= 0 && op <= 8, "bad op %d", op);
-    GM_REQUIRE(h_a && h_out && (op > 2 || h_b), "null argument");
+    GM_REQUIRE(op >= 0 && op <= 9, "bad op %d", op);
+    GM_REQUIRE(h_a && h_out && ((op > 2 && op != 9) || h_b), "null argument");
     for (uint64_t i = 0; i < n; i++) {
         Fr a, b;
         memcpy(&a, h_a + 4 * i, 32);
-        if (op <= 2) memcpy(&b, h_b + 4 * i, 32); else b = a;
+        if (op <= 2 || op == 9) memcpy(&b, h_b + 4 * i, 32); else b = a;
         Fr r = fr_op_host(op, a, b);
         memcpy(h_out + 4 * i, &r, 32);
     }

@@ -40,27 +40,35 @@ __device__ __forceinline__ Point3 pt_identity() {
     return p;
 }
 
-// (x1,y1) + (x2,y2) through affine l1 -> l2 -> l3 (bintree level 0)
+// The MSM only needs the OUTPUT of l3(l2(l1(.))) -- the per-layer polynomials are materialised by the witness builder,
+// not here -- so the composition is evaluated with fewer multiplications while producing the same field elements:
+//   x1y2 + x2y1 = (x1 + y1)(x2 + y2) - x1x2 - y1y2          (one product instead of two)
+//   (x1y2)(x2y1) = (x1x2)(y1y2)                              (reuses the two products l1 needs anyway)
+// Field arithmetic is exact, so X, Y, Z are bit-identical to the layer-by-layer evaluation
+// (twisted_edwards_ops.rs:10-65); 8 instead of 9 multiplications (affine), 12 instead of 13 (projective).
+
+// (x1,y1) + (x2,y2) = affine l3(l2(l1(.)))  (bintree level 0)
 __device__ __forceinline__ Point3 aff_add(const Fr& x1, const Fr& y1, const Fr& x2, const Fr& y2) {
-    Fr in[4] = {x1, y1, x2, y2};
-    Fr a[3], b[3], c[3];
-    aff_l1(in, a);
-    aff_l2(a, b);
-    aff_l3(b, c);
+    const Fr A = fr_mul(x1, x2), B = fr_mul(y1, y2);
+    const Fr s = fr_sub(fr_sub(fr_mul(fr_add(x1, y1), fr_add(x2, y2)), A), B);  // x1y2 + x2y1
+    const Fr t = fr_sub(B, fr_mul_by_a(A));                                     // y1y2 - a x1x2
+    const Fr dxy = fr_mul_by_d(fr_mul(A, B));                                   // d (x1y2)(x2y1)
+    const Fr m = fr_sub(fr_one(), dxy), q = fr_add(fr_one(), dxy);
     Point3 r;
-    r.x = c[0]; r.y = c[1]; r.z = c[2];
+    r.x = fr_mul(m, s); r.y = fr_mul(q, t); r.z = fr_mul(m, q);
     return r;
 }
 
-// projective l1 -> l2 -> l3 (bintree levels >= 1, triangle)
-__device__ __forceinline__ Point3 proj_add(const Point3& p, const Point3& q) {
-    Fr in[6] = {p.x, p.y, p.z, q.x, q.y, q.z};
-    Fr a[4], b[4], c[3];
-    proj_l1(in, a);
-    proj_l2(a, b);
-    proj_l3(b, c);
+// projective l3(l2(l1(.)))  (bintree levels >= 1, triangle)
+__device__ __forceinline__ Point3 proj_add(const Point3& p, const Point3& g) {
+    const Fr A = fr_mul(p.x, g.x), B = fr_mul(p.y, g.y), zz = fr_mul(p.z, g.z);
+    const Fr s = fr_sub(fr_sub(fr_mul(fr_add(p.x, p.y), fr_add(g.x, g.y)), A), B);  // x1y2 + x2y1
+    const Fr t = fr_sub(B, fr_mul_by_a(A));
+    const Fr X = fr_mul(s, zz), Y = fr_mul(t, zz), z2 = fr_sqr(zz);
+    const Fr dxy = fr_mul_by_d(fr_mul(A, B));
+    const Fr m = fr_sub(z2, dxy), q = fr_add(z2, dxy);
     Point3 r;
-    r.x = c[0]; r.y = c[1]; r.z = c[2];
+    r.x = fr_mul(m, X); r.y = fr_mul(q, Y); r.z = fr_mul(m, q);
     return r;
 }
 
@@ -227,8 +235,9 @@ __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* _
                              const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
                              uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= off_out[nrows]) return;
-    const uint32_t r = find_row(off_out, nrows, j);
+    const uint32_t total = off_out[nrows];
+    const uint32_t r = find_row_block(off_out, nrows, j, j < total, total);
+    if (j >= total) return;
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
     Point3 res;
@@ -257,8 +266,9 @@ __global__ void k_add_level(const Fr* __restrict__ ix, const Fr* __restrict__ iy
                             const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
                             uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= off_out[nrows]) return;
-    const uint32_t r = find_row(off_out, nrows, j);
+    const uint32_t total = off_out[nrows];
+    const uint32_t r = find_row_block(off_out, nrows, j, j < total, total);
+    if (j >= total) return;
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
     Point3 res;
@@ -274,6 +284,115 @@ __global__ void k_add_level(const Fr* __restrict__ ix, const Fr* __restrict__ iy
     fr_store(ox + j, res.x);
     fr_store(oy + j, res.y);
     fr_store(oz + j, res.z);
+}
+
+// Offsets of every level in one launch: level 0 from the bucket populations, level l+1 from level l.
+// off_all[l * (nrows + 1) + r]; single 1024-thread block, same scan as k_offsets_scan.
+__global__ void __launch_bounds__(1024) k_offsets_all_levels(const uint32_t* __restrict__ row_len, uint32_t* __restrict__ off_all,
+                                                              uint32_t nrows, uint32_t nlevels) {
+    __shared__ uint32_t wave_tot[2][16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per = (nrows + 1023) / 1024;
+    const uint32_t r0 = tid * per;
+    const uint32_t r1 = (r0 + per < nrows) ? r0 + per : nrows;
+    constexpr uint32_t PER_MAX = 16;  // row lengths of this thread's chunk stay in registers across levels
+    uint32_t cur[PER_MAX];
+    const bool in_regs = per <= PER_MAX;
+    if (in_regs) {
+#pragma unroll
+        for (uint32_t k = 0; k < PER_MAX; k++) {
+            const uint32_t r = r0 + k;
+            uint32_t l = (k < per && r < r1) ? row_len[r] : 0u;
+            cur[k] = l + (l & 1u);
+        }
+    }
+    for (uint32_t lvl = 0; lvl < nlevels; lvl++) {
+        const uint32_t* src = lvl ? off_all + (uint64_t)(lvl - 1) * (nrows + 1) : row_len;
+        uint32_t* off = off_all + (uint64_t)lvl * (nrows + 1);
+        uint32_t sum = 0;
+        if (in_regs) {
+            if (lvl) {
+#pragma unroll
+                for (uint32_t k = 0; k < PER_MAX; k++) { const uint32_t h = cur[k] >> 1; cur[k] = h + (h & 1u); }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < PER_MAX; k++) sum += cur[k];
+        } else {
+            for (uint32_t r = r0; r < r1; r++) sum += lvl ? row_value<1>(src, r) : row_value<0>(src, r);
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d, 64);
+            if ((int)lane >= d) inc += t;
+        }
+        if (lane == 63) wave_tot[lvl & 1][wave] = inc;
+        __syncthreads();  // double-buffered totals: one barrier per level is enough when lengths live in registers
+        uint32_t base = 0, tot = 0;
+        for (uint32_t w = 0; w < 16; w++) { const uint32_t v = wave_tot[lvl & 1][w]; tot += v; if (w < wave) base += v; }
+        uint32_t run = base + inc - sum;
+        if (in_regs) {
+#pragma unroll
+            for (uint32_t k = 0; k < PER_MAX; k++) {
+                if (k < per && r0 + k < r1) off[r0 + k] = run;
+                run += cur[k];
+            }
+        } else {
+            for (uint32_t r = r0; r < r1; r++) {
+                off[r] = run;
+                run += lvl ? row_value<1>(src, r) : row_value<0>(src, r);
+            }
+        }
+        if (tid == 1023) off[nrows] = tot;
+        if (!in_regs) __syncthreads();  // the next level re-reads this level's offsets from memory
+    }
+}
+
+// Tail of the bucket-sum tree: once rows are short, one 64-lane workgroup owns one row and runs ALL remaining levels
+// for it, ping-ponging between the two level buffers (rows are independent, so no cross-workgroup dependency).
+// Levels first_level .. x_log - 1; the last one writes the dense bucket sum (same semantics as k_add_last).
+__global__ void __launch_bounds__(64) k_add_tail(Fr* __restrict__ ax, Fr* __restrict__ ay, Fr* __restrict__ az,
+                                                  Fr* __restrict__ bx_, Fr* __restrict__ by_, Fr* __restrict__ bz_,
+                                                  const uint32_t* __restrict__ off_all, uint32_t nrows, uint32_t first_level,
+                                                  uint32_t x_log, Fr* __restrict__ sx, Fr* __restrict__ sy, Fr* __restrict__ sz) {
+    const uint32_t r = blockIdx.x, lane = threadIdx.x;
+    Fr *ix = ax, *iy = ay, *iz = az, *ox = bx_, *oy = by_, *oz = bz_;
+    for (uint32_t lvl = first_level; lvl < x_log; lvl++) {
+        const uint32_t* offi = off_all + (uint64_t)lvl * (nrows + 1);
+        const uint32_t in0 = offi[r], len = offi[r + 1] - in0, half = len >> 1;
+        if (lvl + 1 == x_log) {
+            if (lane == 0) {
+                Point3 P = pt_identity(), Q = pt_identity();
+                if (len) {
+                    P.x = fr_load(ix + in0); P.y = fr_load(iy + in0); P.z = fr_load(iz + in0);
+                    Q.x = fr_load(ix + in0 + 1); Q.y = fr_load(iy + in0 + 1); Q.z = fr_load(iz + in0 + 1);
+                }
+                const Point3 res = proj_add(P, Q);
+                fr_store(sx + r, res.x); fr_store(sy + r, res.y); fr_store(sz + r, res.z);
+            }
+        } else {
+            const uint32_t* offo = off_all + (uint64_t)(lvl + 1) * (nrows + 1);
+            const uint32_t out0 = offo[r], olen = offo[r + 1] - out0;
+            for (uint32_t p = lane; p < olen; p += 64) {
+                Point3 res;
+                if (p < half) {
+                    const uint64_t a = (uint64_t)in0 + 2 * p;
+                    Point3 P, Q;
+                    P.x = fr_load(ix + a); P.y = fr_load(iy + a); P.z = fr_load(iz + a);
+                    Q.x = fr_load(ix + a + 1); Q.y = fr_load(iy + a + 1); Q.z = fr_load(iz + a + 1);
+                    res = proj_add(P, Q);
+                } else {
+                    res = pt_identity();
+                }
+                fr_store(ox + out0 + p, res.x); fr_store(oy + out0 + p, res.y); fr_store(oz + out0 + p, res.z);
+            }
+            __syncthreads();  // single-wave workgroup: orders this level's stores before the next level's loads
+            Fr* t;
+            t = ix; ix = ox; ox = t;
+            t = iy; iy = oy; oy = t;
+            t = iz; iz = oz; oz = t;
+        }
+    }
 }
 
 // last bintree level: every row has 0 or 2 cells; output is dense over rows
@@ -423,9 +542,8 @@ extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, ui
     ALLOC(p->counter, (uint64_t)p->nwin * p->N);
     ALLOC(p->hist, (uint64_t)p->nwin * p->nchunks * p->nd);
     ALLOC(p->row_len, p->nrows);
-    ALLOC(p->off[0], p->nrows + 1);
-    ALLOC(p->off[1], p->nrows + 1);
-    ALLOC(p->off[2], p->nrows + 1);
+    // off[0] holds the offsets of ALL levels: level l at off[0] + l * (nrows + 1); level 0 = the image rows
+    ALLOC(p->off[0], (uint64_t)(x_logsize + 1) * (p->nrows + 1));
     ALLOC(p->cells, cells_in + 2);
     for (int c = 0; c < 3; c++) {
         ALLOC(p->lvl[0][c], p->cap0);
@@ -506,7 +624,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     hipLaunchKernelGGL(k_scan_chunks, dim3(ceil_div(nrows, 256)), dim3(256), 0, s, p->hist, p->row_len, nd,
                        p->nchunks, nrows);
     GM_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_offsets_scan<0>), dim3(1), dim3(1024), 0, s, p->row_len, p->off[0], nrows);
+    hipLaunchKernelGGL(k_offsets_all_levels, dim3(1), dim3(1024), 0, s, p->row_len, p->off[0], nrows, p->x_log);
     GM_LAUNCH_CHECK();
     STAGE_MARK(3);
     // 3. stable scatter
@@ -517,41 +635,40 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     hipLaunchKernelGGL(k_pad_cells, dim3(ceil_div(nrows, 256)), dim3(256), 0, s, p->row_len, p->off[0], p->cells,
                        nrows);
     GM_LAUNCH_CHECK();
-    // 4. bucket sums: x_log levels of pairwise adds
+    // 4. bucket sums: x_log levels of pairwise adds.  Level l reads the layout off_all[l] and writes off_all[l + 1];
+    //    the first levels are flat launches over all cells, the short-row tail is one launch (k_add_tail).
     uint64_t cap_out = p->cap0;
-    int cur_off = 0;
+    const uint32_t stride = nrows + 1;
     if (p->x_log == 1) {
         hipLaunchKernelGGL((k_add_last<true>), dim3(ceil_div(nrows, 128)), dim3(128), 0, s, pts, p->cells,
                            (const Fr*)nullptr, (const Fr*)nullptr, (const Fr*)nullptr, p->off[0], nrows, p->bsum[0],
                            p->bsum[1], p->bsum[2]);
         GM_LAUNCH_CHECK();
     } else {
-        hipLaunchKernelGGL((k_offsets_scan<1>), dim3(1), dim3(1024), 0, s, p->off[0], p->off[1], nrows);
-        GM_LAUNCH_CHECK();
         STAGE_MARK(4);
         hipLaunchKernelGGL(k_add_level0, dim3(ceil_div(cap_out, 128)), dim3(128), 0, s, pts, p->cells, p->off[0],
-                           p->off[1], nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2]);
+                           p->off[0] + stride, nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2]);
         GM_LAUNCH_CHECK();
         STAGE_MARK(5);
-        cur_off = 1;
+        // The row-owned tail kernel can take over any number of trailing levels in one launch.  Measured on MI355X
+        // (config B) it does not pay before the last level: a lone wave needs ~1 us per field multiplication, so 14
+        // fused levels cost as much as 14 small launches; it is used for the last level only.
+        const uint32_t tail_level = p->x_log - 1;
         int cur_lvl = 0;
         uint64_t cells_cur = cap_out;
-        for (uint32_t level = 1; level + 1 < p->x_log; level++) {
+        for (uint32_t level = 1; level < tail_level; level++) {
             const uint64_t cells_next = cells_cur / 2 + nrows + 2;
-            const int nxt_off = (cur_off == 1) ? 2 : 1;
-            hipLaunchKernelGGL((k_offsets_scan<1>), dim3(1), dim3(1024), 0, s, p->off[cur_off], p->off[nxt_off], nrows);
-            GM_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_add_level, dim3(ceil_div(cells_next, 128)), dim3(128), 0, s, p->lvl[cur_lvl][0],
-                               p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[cur_off], p->off[nxt_off], nrows,
-                               p->lvl[cur_lvl ^ 1][0], p->lvl[cur_lvl ^ 1][1], p->lvl[cur_lvl ^ 1][2]);
+                               p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[0] + (uint64_t)level * stride,
+                               p->off[0] + (uint64_t)(level + 1) * stride, nrows, p->lvl[cur_lvl ^ 1][0],
+                               p->lvl[cur_lvl ^ 1][1], p->lvl[cur_lvl ^ 1][2]);
             GM_LAUNCH_CHECK();
-            cur_off = nxt_off;
             cur_lvl ^= 1;
             cells_cur = cells_next;
         }
-        hipLaunchKernelGGL((k_add_last<false>), dim3(ceil_div(nrows, 128)), dim3(128), 0, s, (const Fr*)nullptr,
-                           (const uint32_t*)nullptr, p->lvl[cur_lvl][0], p->lvl[cur_lvl][1], p->lvl[cur_lvl][2],
-                           p->off[cur_off], nrows, p->bsum[0], p->bsum[1], p->bsum[2]);
+        hipLaunchKernelGGL(k_add_tail, dim3(nrows), dim3(64), 0, s, p->lvl[cur_lvl][0], p->lvl[cur_lvl][1], p->lvl[cur_lvl][2],
+                           p->lvl[cur_lvl ^ 1][0], p->lvl[cur_lvl ^ 1][1], p->lvl[cur_lvl ^ 1][2], p->off[0], nrows,
+                           tail_level, p->x_log, p->bsum[0], p->bsum[1], p->bsum[2]);
         GM_LAUNCH_CHECK();
     }
     STAGE_MARK(6);

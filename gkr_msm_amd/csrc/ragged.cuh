@@ -19,4 +19,27 @@ __device__ __forceinline__ uint32_t find_row(const uint32_t* __restrict__ off, u
     return lo;
 }
 
+// Block-cooperative row lookup for a block whose threads own consecutive cells [j0, j0 + blockDim.x): two lanes
+// bracket the block's row range with a full binary search, every thread then searches only inside that bracket
+// (usually one or two rows).  This replaces log2(nrows) dependent global loads per thread by ~1.
+// Every thread of the block must call it (it contains a barrier); `valid` = this thread's j is in range.
+__device__ __forceinline__ uint32_t find_row_block(const uint32_t* __restrict__ off, uint32_t nrows, uint32_t j, bool valid,
+                                                   uint32_t total) {
+    __shared__ uint32_t s_range[2];
+    const uint32_t j0 = blockIdx.x * blockDim.x;
+    if (threadIdx.x < 2 && j0 < total) {
+        uint32_t jj = threadIdx.x == 0 ? j0 : j0 + blockDim.x - 1;
+        if (jj >= total) jj = total - 1;
+        s_range[threadIdx.x] = find_row(off, nrows, jj);
+    }
+    __syncthreads();
+    if (!valid) return 0;
+    uint32_t lo = s_range[0], hi = s_range[1] + 1;  // off[lo] <= j < off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 }  // namespace gm

@@ -79,6 +79,22 @@ int main() {
         hipEventElapsedTime(&ms, e0, e1);
         printf("asm : %.3f ms  %.1f G mul/s\n", ms, muls / ms / 1e6);
     }
+    // occupancy sweep: dynamic LDS limits resident 256-thread blocks per CU (= waves per SIMD)
+    for (int occ : {1, 2, 3, 4, 6, 8}) {
+        const size_t lds = (160 * 1024) / occ - 512;
+        hipFuncSetAttribute((const void*)k_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        float msC, msA;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_chain<false>), dim3(blocks), dim3(threads), lds, 0, da, o1, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&msC, e0, e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_chain<true>), dim3(blocks), dim3(threads), lds, 0, da, o2, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&msA, e0, e1);
+        double muls = (double)blocks * threads * iters * 2;
+        printf("waves/SIMD %d : C %.1f G mul/s   asm %.1f G mul/s\n", occ, muls / msC / 1e6, muls / msA / 1e6);
+    }
     hipMemcpy(h1, o1, 4096 * 32, hipMemcpyDeviceToHost); hipMemcpy(h2, o2, 4096 * 32, hipMemcpyDeviceToHost);
     printf("chain results equal: %s\n", memcmp(h1, h2, 4096 * 32) ? "NO" : "yes");
     return bad != 0;

@@ -64,6 +64,7 @@ def test_host_field_glue_vs_bigint():
     assert run(0) == [(x + y) % F.P for x, y in zip(a, b)]
     assert run(1) == [(x - y) % F.P for x, y in zip(a, b)]
     assert run(2) == [(x * y) % F.P for x, y in zip(a, b)]
+    assert run(9) == [(x * y) % F.P for x, y in zip(a, b)]   # the 32-bit-limb formulation of the device code
     assert run(3) == [(-x) % F.P for x in a]
     assert run(7) == [F.mul_by_a(x) for x in a]
     assert run(8) == [F.mul_by_d(x) for x in a]
