@@ -89,12 +89,12 @@ struct ScHolder {
 // h_tape: challenges in draw order, canonical field elements (4 x u64 each, < p: gen-1 reduces 64 bytes mod p);
 // outputs: h_msgs = everything appended to the transcript in order (output polys, round polynomials as full coefficient
 // vectors, final evaluations); h_output = the 3 output polys (3 * 2^lb elements); final claim (point of lp + lb, 3 evs).
-extern "C" int32_t gm_gkr_msm_prove(const uint64_t* d_points_xy, const uint8_t* d_scalar_bits, uint32_t log_num_points,
-                                    uint32_t log_num_scalar_bits, const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_msgs,
-                                    uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_output, uint64_t* h_final_point,
-                                    uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds,
-                                    double* witness_ms, void* stream) {
-    GM_REQUIRE(d_points_xy && d_scalar_bits && h_tape, "null argument");
+static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_scalar_bits, uint32_t log_num_points,
+                                  uint32_t log_num_scalar_bits, const uint64_t* h_tape, uint64_t n_tape, const gm_transcript* cb,
+                                  uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_output,
+                                  uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* tape_used,
+                                  uint64_t* rounds, double* witness_ms, void* stream) {
+    GM_REQUIRE(d_points_xy && d_scalar_bits && (h_tape || cb), "null argument");
     GM_REQUIRE(log_num_points >= 1 && log_num_scalar_bits >= 1 && log_num_points + log_num_scalar_bits <= 30, "bad sizes");
     hipStream_t s = as_stream(stream);
     const uint32_t lp = log_num_points, lb = log_num_scalar_bits, nv0 = lp + lb;
@@ -163,15 +163,26 @@ extern "C" int32_t gm_gkr_msm_prove(const uint64_t* d_points_xy, const uint8_t* 
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    int32_t cb_rc = 0;
+    auto emit = [&](const Fr* v, size_t n) {  // transcript.append_scalars
+        msgs.insert(msgs.end(), v, v + n);
+        if (cb && cb->write_scalars && !cb_rc && n) cb_rc = cb->write_scalars(cb->ctx, reinterpret_cast<const uint64_t*>(v), n);
+    };
     for (int c = 0; c < 3; c++) {
-        msgs.insert(msgs.end(), out[c].begin(), out[c].end());
+        emit(out[c].data(), out[c].size());
         if (h_output) memcpy(h_output + (size_t)c * nout * 4, out[c].data(), nout * sizeof(Fr));
     }
     uint64_t pos = 0, nrounds = 0;
     auto challenge = [&](Fr* c) -> int32_t {
-        if (pos >= n_tape) return set_err(GM_ERR_INVALID, "challenge tape exhausted after %llu challenges", (unsigned long long)pos);
         Fr v;
-        memcpy(&v, h_tape + 4 * pos, 32);
+        if (cb) {
+            if (cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", cb_rc);
+            const int32_t rc = cb->challenge(cb->ctx, reinterpret_cast<uint64_t*>(&v));
+            if (rc) return set_err(GM_ERR_STATE, "transcript challenge callback failed with %d", rc);
+        } else {
+            if (pos >= n_tape) return set_err(GM_ERR_INVALID, "challenge tape exhausted after %llu challenges", (unsigned long long)pos);
+            memcpy(&v, h_tape + 4 * pos, 32);
+        }
         pos++;
         *c = fr_to_mont(v);
         return GM_OK;
@@ -240,7 +251,7 @@ extern "C" int32_t gm_gkr_msm_prove(const uint64_t* d_points_xy, const uint8_t* 
             Fr co[8];
             uint32_t nc = 0;
             TRY(gm_sc_unipoly(h.so, reinterpret_cast<uint64_t*>(co), &nc));
-            msgs.insert(msgs.end(), co, co + nc);  // transcript.append_scalars(b"poly", &round_uni_poly.as_vec())
+            emit(co, nc);  // transcript.append_scalars(b"poly", &round_uni_poly.as_vec())
             Fr r;
             TRY(challenge(&r));
             rs.insert(rs.begin(), r);              // fix_var_bot
@@ -251,7 +262,7 @@ extern "C" int32_t gm_gkr_msm_prove(const uint64_t* d_points_xy, const uint8_t* 
         uint32_t ne = 0;
         TRY(gm_sc_final_evals(h.so, reinterpret_cast<uint64_t*>(fe), &ne));
         evs.assign(fe, fe + sp.n_ins);             // final_evaluations[0..num_i]
-        msgs.insert(msgs.end(), evs.begin(), evs.end());
+        emit(evs.data(), evs.size());
         point = rs;
     }
     if (n_msgs) *n_msgs = msgs.size();
@@ -262,7 +273,30 @@ extern "C" int32_t gm_gkr_msm_prove(const uint64_t* d_points_xy, const uint8_t* 
     if (n_final_point) *n_final_point = (uint32_t)point.size();
     if (h_final_point) memcpy(h_final_point, point.data(), point.size() * sizeof(Fr));
     if (h_final_evs) memcpy(h_final_evs, evs.data(), evs.size() * sizeof(Fr));
+    if (cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", cb_rc);
     if (tape_used) *tape_used = pos;
     if (rounds) *rounds = nrounds;
     return GM_OK;
+}
+
+extern "C" int32_t gm_gkr_msm_prove(const uint64_t* d_points_xy, const uint8_t* d_scalar_bits, uint32_t log_num_points,
+                                    uint32_t log_num_scalar_bits, const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_msgs,
+                                    uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_output, uint64_t* h_final_point,
+                                    uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds,
+                                    double* witness_ms, void* stream) {
+    GM_REQUIRE(h_tape, "null argument");
+    return gkr_msm_prove_impl(d_points_xy, d_scalar_bits, log_num_points, log_num_scalar_bits, h_tape, n_tape, nullptr, h_msgs,
+                              msgs_cap, n_msgs, h_output, h_final_point, n_final_point, h_final_evs, tape_used, rounds,
+                              witness_ms, stream);
+}
+
+// gkr_msm_prove against the caller's live transcript (gen-1 TranscriptReceiver/TranscriptSender, transcript.rs:70-101)
+extern "C" int32_t gm_gkr_msm_prove_tr(const uint64_t* d_points_xy, const uint8_t* d_scalar_bits, uint32_t log_num_points,
+                                       uint32_t log_num_scalar_bits, const gm_transcript* tr, uint64_t* h_output,
+                                       uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs,
+                                       uint64_t* n_challenges, uint64_t* rounds, void* stream) {
+    GM_REQUIRE(tr && tr->challenge, "null transcript");
+    return gkr_msm_prove_impl(d_points_xy, d_scalar_bits, log_num_points, log_num_scalar_bits, nullptr, 0, tr, nullptr, 0,
+                              nullptr, h_output, h_final_point, n_final_point, h_final_evs, n_challenges, rounds, nullptr,
+                              stream);
 }

@@ -15,6 +15,7 @@ int32_t launch_dense_fold(const Fr* const* in, Fr* const* out, int k, uint64_t n
 int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s);
 
 int32_t launch_offsets_next(const uint32_t* off_in, uint32_t* off_out, uint32_t nrows, hipStream_t s);
+int32_t launch_offsets_all_from_off(const uint32_t* off0, uint32_t* off_all, uint32_t nrows, uint32_t nlevels, hipStream_t s);
 int32_t launch_offsets_from_len(const uint32_t* len, uint32_t* off, uint32_t nrows, hipStream_t s);
 
 // ---- host-side univariate helpers (liblasso UniPoly::from_evals = interpolation on 0..D; un-vendored

@@ -288,6 +288,9 @@ __global__ void k_add_level(const Fr* __restrict__ ix, const Fr* __restrict__ iy
 
 // Offsets of every level in one launch: level 0 from the bucket populations, level l+1 from level l.
 // off_all[l * (nrows + 1) + r]; single 1024-thread block, same scan as k_offsets_scan.
+// FROM_OFF: `row_len` is an offsets table (nrows + 1 entries, even row lengths) and level 0 reproduces it -- the
+// VecVec sumcheck precomputes the row layouts of all its sparse rounds this way (bind_21, vecvec.rs:420-441).
+template <bool FROM_OFF>
 __global__ void __launch_bounds__(1024) k_offsets_all_levels(const uint32_t* __restrict__ row_len, uint32_t* __restrict__ off_all,
                                                               uint32_t nrows, uint32_t nlevels) {
     __shared__ uint32_t wave_tot[2][16];
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(1024) k_offsets_all_levels(const uint32_t* __r
 #pragma unroll
         for (uint32_t k = 0; k < PER_MAX; k++) {
             const uint32_t r = r0 + k;
-            uint32_t l = (k < per && r < r1) ? row_len[r] : 0u;
+            uint32_t l = (k < per && r < r1) ? (FROM_OFF ? row_len[r + 1] - row_len[r] : row_len[r]) : 0u;
             cur[k] = l + (l & 1u);
         }
     }
@@ -318,7 +321,7 @@ __global__ void __launch_bounds__(1024) k_offsets_all_levels(const uint32_t* __r
 #pragma unroll
             for (uint32_t k = 0; k < PER_MAX; k++) sum += cur[k];
         } else {
-            for (uint32_t r = r0; r < r1; r++) sum += lvl ? row_value<1>(src, r) : row_value<0>(src, r);
+            for (uint32_t r = r0; r < r1; r++) sum += lvl ? row_value<1>(src, r) : (FROM_OFF ? src[r + 1] - src[r] : row_value<0>(src, r));
         }
         uint32_t inc = sum;
 #pragma unroll
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(1024) k_offsets_all_levels(const uint32_t* __r
         } else {
             for (uint32_t r = r0; r < r1; r++) {
                 off[r] = run;
-                run += lvl ? row_value<1>(src, r) : row_value<0>(src, r);
+                run += lvl ? row_value<1>(src, r) : (FROM_OFF ? src[r + 1] - src[r] : row_value<0>(src, r));
             }
         }
         if (tid == 1023) off[nrows] = tot;
@@ -500,6 +503,12 @@ int32_t launch_offsets_next(const uint32_t* off_in, uint32_t* off_out, uint32_t 
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
+// off_all: nlevels tables of nrows + 1 entries; table 0 = off0, table l + 1 = the row layout after one more fold
+int32_t launch_offsets_all_from_off(const uint32_t* off0, uint32_t* off_all, uint32_t nrows, uint32_t nlevels, hipStream_t s) {
+    hipLaunchKernelGGL((k_offsets_all_levels<true>), dim3(1), dim3(1024), 0, s, off0, off_all, nrows, nlevels);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
 int32_t launch_offsets_from_len(const uint32_t* len, uint32_t* off, uint32_t nrows, hipStream_t s) {
     hipLaunchKernelGGL((k_offsets_scan<0>), dim3(1), dim3(1024), 0, s, len, off, nrows);
     GM_LAUNCH_CHECK();
@@ -624,7 +633,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     hipLaunchKernelGGL(k_scan_chunks, dim3(ceil_div(nrows, 256)), dim3(256), 0, s, p->hist, p->row_len, nd,
                        p->nchunks, nrows);
     GM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_offsets_all_levels, dim3(1), dim3(1024), 0, s, p->row_len, p->off[0], nrows, p->x_log);
+    hipLaunchKernelGGL((k_offsets_all_levels<false>), dim3(1), dim3(1024), 0, s, p->row_len, p->off[0], nrows, p->x_log);
     GM_LAUNCH_CHECK();
     STAGE_MARK(3);
     // 3. stable scatter

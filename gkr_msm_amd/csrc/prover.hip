@@ -162,15 +162,27 @@ struct Tape {
     uint64_t n, pos = 0;
     std::vector<Fr>* msgs;
     uint64_t rounds = 0;
+    const gm_transcript* cb = nullptr;  // the caller's live transcript; replaces the tape when set
+    int32_t cb_rc = 0;
     int32_t challenge(Fr* out) {
-        if (pos >= n) return set_err(GM_ERR_INVALID, "challenge tape exhausted after %llu challenges", (unsigned long long)pos);
         Fr c;
-        memcpy(&c, tape + 4 * pos, 32);  // canonical value < 2^128 (transcript.challenge(128), proof_transcript.rs:37-39)
+        if (cb) {
+            if (cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", cb_rc);
+            const int32_t rc = cb->challenge(cb->ctx, reinterpret_cast<uint64_t*>(&c));
+            if (rc) return set_err(GM_ERR_STATE, "transcript challenge callback failed with %d", rc);
+        } else {
+            if (pos >= n) return set_err(GM_ERR_INVALID, "challenge tape exhausted after %llu challenges", (unsigned long long)pos);
+            memcpy(&c, tape + 4 * pos, 32);  // canonical value < 2^128 (transcript.challenge(128), proof_transcript.rs:37-39)
+        }
         pos++;
         *out = fr_to_mont(c);
         return GM_OK;
     }
-    void write_scalars(const std::vector<Fr>& v) { msgs->insert(msgs->end(), v.begin(), v.end()); }
+    void write_scalars(const std::vector<Fr>& v) {
+        msgs->insert(msgs->end(), v.begin(), v.end());
+        if (cb && cb->write_scalars && !cb_rc && !v.empty())
+            cb_rc = cb->write_scalars(cb->ctx, reinterpret_cast<const uint64_t*>(v.data()), v.size());
+    }
 };
 
 // GenericSumcheckProtocol::prove (sumcheck.rs:101-123)
@@ -488,15 +500,13 @@ extern "C" uint64_t gm_pip_witness_bytes(const gm_pip_witness* w) {
 //   h_tape: n_tape challenges, canonical 4 x u64 (values < 2^128)
 //   outputs: prover messages in order (h_msgs, capacity msgs_cap elements), final claims (point of
 //   y_log + d + x_log elements, 3 evaluations: x, y, z of the image), challenges consumed, sumcheck rounds run.
-extern "C" int32_t gm_pip_prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim_point,
-                                           const uint64_t* h_claim_evs, const uint64_t* h_tape, uint64_t n_tape,
-                                           uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_final_point,
-                                           uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* tape_used,
-                                           uint64_t* rounds) {
-    GM_REQUIRE(w && h_claim_point && h_claim_evs && h_tape, "null argument");
+static int32_t prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                const uint64_t* h_tape, uint64_t n_tape, const gm_transcript* cb, uint64_t* h_msgs,
+                                uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_final_point, uint32_t* n_final_point,
+                                uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds) {
     const uint32_t multirow = w->y_log, bucket = w->d_log, horizontal = w->x_log;
     std::vector<Fr> msgs;
-    Tape tr{h_tape, n_tape, 0, &msgs, 0};
+    Tape tr{h_tape, n_tape, 0, &msgs, 0, cb, 0};
     Claims c;
     c.point.resize(multirow);
     memcpy(c.point.data(), h_claim_point, 32 * (size_t)multirow);
@@ -531,7 +541,29 @@ extern "C" int32_t gm_pip_prove_image_part(const gm_pip_witness* w, const uint64
     if (n_final_point) *n_final_point = (uint32_t)c.point.size();
     if (h_final_point) memcpy(h_final_point, c.point.data(), c.point.size() * sizeof(Fr));
     if (h_final_evs) memcpy(h_final_evs, c.evs.data(), c.evs.size() * sizeof(Fr));
+    if (tr.cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", tr.cb_rc);
     if (tape_used) *tape_used = tr.pos;
     if (rounds) *rounds = tr.rounds;
     return GM_OK;
+}
+
+extern "C" int32_t gm_pip_prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim_point,
+                                           const uint64_t* h_claim_evs, const uint64_t* h_tape, uint64_t n_tape,
+                                           uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_final_point,
+                                           uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* tape_used,
+                                           uint64_t* rounds) {
+    GM_REQUIRE(w && h_claim_point && h_claim_evs && h_tape, "null argument");
+    return prove_image_part(w, h_claim_point, h_claim_evs, h_tape, n_tape, nullptr, h_msgs, msgs_cap, n_msgs, h_final_point,
+                            n_final_point, h_final_evs, tape_used, rounds);
+}
+
+// Same prover driven by the caller's live Fiat-Shamir transcript (ProofTranscript2, proof_transcript.rs:85-147): every
+// write_scalars of the reference reaches tr->write_scalars in order, every challenge(128) is drawn through tr->challenge.
+extern "C" int32_t gm_pip_prove_image_part_tr(const gm_pip_witness* w, const uint64_t* h_claim_point,
+                                              const uint64_t* h_claim_evs, const gm_transcript* tr, uint64_t* h_final_point,
+                                              uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* n_challenges,
+                                              uint64_t* rounds) {
+    GM_REQUIRE(w && h_claim_point && h_claim_evs && tr && tr->challenge, "null argument");
+    return prove_image_part(w, h_claim_point, h_claim_evs, nullptr, 0, tr, nullptr, 0, nullptr, h_final_point, n_final_point,
+                            h_final_evs, n_challenges, rounds);
 }

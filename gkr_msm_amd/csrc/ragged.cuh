@@ -42,4 +42,21 @@ __device__ __forceinline__ uint32_t find_row_block(const uint32_t* __restrict__ 
     return lo;
 }
 
+// Same idea for a block whose threads own the cells j_first .. j_last (block-uniform bounds, j_first <= j <= j_last for
+// every valid thread), usable inside grid-stride loops: two barriers per call, every thread of the block must call it.
+__device__ __forceinline__ uint32_t find_row_span(const uint32_t* __restrict__ off, uint32_t nrows, uint32_t j, bool valid,
+                                                  uint32_t j_first, uint32_t j_last) {
+    __shared__ uint32_t s_span[2];
+    __syncthreads();  // the previous call's readers are done with s_span
+    if (threadIdx.x < 2) s_span[threadIdx.x] = find_row(off, nrows, threadIdx.x == 0 ? j_first : j_last);
+    __syncthreads();
+    if (!valid) return 0;
+    uint32_t lo = s_span[0], hi = s_span[1] + 1;  // off[lo] <= j < off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 }  // namespace gm

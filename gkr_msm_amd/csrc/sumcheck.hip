@@ -145,22 +145,48 @@ struct FinishCtx {
     uint32_t seq;        // written (system scope) after the results: the host polls it instead of a stream sync
 };
 
+// sum of `v` over the 64 lanes of the wave; the result is valid in lane 0
+__device__ __forceinline__ Fr wave_sum(Fr v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        Fr t;
+#pragma unroll
+        for (int l = 0; l < 8; l++) t.l[l] = __shfl_down(v.l[l], d, 64);
+        v = fr_add(v, t);
+    }
+    return v;
+}
+
+// block-wide sums of acc[0..NACC): wave shuffles, then one pass over the SC_THREADS / 64 wave totals.
+// Valid in thread a (a < NACC) as the return value; one barrier.
+template <int NACC>
+__device__ __forceinline__ Fr block_sum(Fr* acc, Fr (*red)[NACC]) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        const Fr w = wave_sum(acc[a]);
+        if (lane == 0) red[wave][a] = w;
+    }
+    __syncthreads();
+    Fr tot = fr_zero();
+    if (threadIdx.x < NACC) {
+#pragma unroll
+        for (int w = 0; w < SC_THREADS / 64; w++) tot = fr_add(tot, red[w][threadIdx.x]);
+    }
+    return tot;
+}
+
 template <int NACC>
 __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc) {
-    __shared__ Fr red[SC_THREADS];
+    __shared__ Fr red[SC_THREADS / 64][NACC];
     __shared__ uint32_t is_last;
     const uint32_t nblk = gridDim.x * gridDim.y;
     const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
-    for (int a = 0; a < NACC; a++) {
-        red[threadIdx.x] = acc[a];
-        __syncthreads();
-        for (int s = SC_THREADS / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] = fr_add(red[threadIdx.x], red[threadIdx.x + s]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) fr_store(fc.partial + (uint64_t)bid * NACC + a, red[0]);
-        __syncthreads();
+    {
+        const Fr tot = block_sum<NACC>(acc, red);
+        if (threadIdx.x < NACC) fr_store(fc.partial + (uint64_t)bid * NACC + threadIdx.x, tot);
     }
+    __syncthreads();  // all partial stores of this block are issued (and waited for below) before the counter moves
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -174,18 +200,18 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
     }
     __syncthreads();
     if (!is_last) return;
+    Fr s2[NACC];
+#pragma unroll
     for (int a = 0; a < NACC; a++) {
         Fr s = fr_zero();
         for (uint32_t b2 = threadIdx.x; b2 < nblk; b2 += SC_THREADS) s = fr_add(s, fr_load(fc.partial + (uint64_t)b2 * NACC + a));
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int st = SC_THREADS / 2; st > 0; st >>= 1) {
-            if ((int)threadIdx.x < st) red[threadIdx.x] = fr_add(red[threadIdx.x], red[threadIdx.x + st]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) fr_store(fc.out + a, red[0]);
-        __syncthreads();
+        s2[a] = s;
     }
+    {
+        const Fr tot = block_sum<NACC>(s2, red);
+        if (threadIdx.x < NACC) fr_store(fc.out + threadIdx.x, tot);
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         *fc.counter = 0;
         __threadfence_system();
@@ -248,13 +274,18 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs c
         }
     }
     const uint64_t npairs = VECVEC ? (uint64_t)(vv.off[vv.nrows] >> 1) : npairs_dense;
-    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+    for (uint64_t base = (uint64_t)blockIdx.x * SC_THREADS; base < npairs; base += (uint64_t)gridDim.x * SC_THREADS) {
+        const uint64_t i = base + threadIdx.x;
+        const bool valid = i < npairs;
         Fr w;
         if (VECVEC) {
             const uint32_t cell0 = (uint32_t)(2 * i);
-            const uint32_t r = find_row(vv.off, vv.nrows, cell0);
+            const uint64_t last_pair = (base + SC_THREADS - 1 < npairs) ? base + SC_THREADS - 1 : npairs - 1;
+            const uint32_t r = find_row_span(vv.off, vv.nrows, cell0, valid, (uint32_t)(2 * base), (uint32_t)(2 * last_pair));
+            if (!valid) continue;
             w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
         } else {
+            if (!valid) continue;
             w = fr_load(eq + i);
         }
         if (SPLIT) {
@@ -298,36 +329,33 @@ __global__ void __launch_bounds__(SC_THREADS) k_prefix_sums(const Fr* __restrict
     }
 }
 
-// all levels of the padded eq sequence in one launch: level i has len_i = (i <= padded ? 1 : 2^(i - padded))
-// entries at offset off_i = sum_{j<i} len_j; its len_i + 1 prefix sums go to prefix + off_i + i
+// Prefix sums of every level of the padded eq sequence in one launch, without a scan.  Level i has
+// len_i = (i <= padded ? 1 : 2^(i - padded)) entries at offset off_i = sum_{j<i} len_j; its len_i + 1 prefix sums go to
+// prefix + off_i + i.  An eq level splits every entry of the level below into two that add up to it exactly
+// (next[2j] = w - r w, next[2j+1] = r w, utils.rs:222-250), so
+//   P_i[2t] = P_{i-1}[t],  P_i[2t+1] = P_{i-1}[t] + E_i[2t]   =>   P_i[n] = sum_{b : bit b of n set} E_{i-b}[(n >> b) - 1]
+// -- the same field elements as the running sums of vecvec.rs:101-109.  blockIdx.y = level.
 __global__ void __launch_bounds__(SC_THREADS) k_prefix_sums_levels(const Fr* __restrict__ seq, Fr* __restrict__ prefix,
                                                                     uint32_t padded, uint32_t nlevels_minus1) {
-    __shared__ Fr part[SC_THREADS];
-    __shared__ Fr carry;
-    uint64_t off = 0;
-    for (uint32_t lv = 0; lv <= nlevels_minus1; lv++) {
-        const uint32_t n = (lv <= padded) ? 1u : (1u << (lv - padded));
-        const Fr* v = seq + off;
-        Fr* pre = prefix + off + lv;
-        if (threadIdx.x == 0) { carry = fr_zero(); fr_store(pre, fr_zero()); }
-        __syncthreads();
-        for (uint32_t base = 0; base < n; base += SC_THREADS) {
-            const uint32_t i = base + threadIdx.x;
-            part[threadIdx.x] = (i < n) ? fr_load(v + i) : fr_zero();
-            __syncthreads();
-            for (uint32_t st = 1; st < SC_THREADS; st <<= 1) {
-                Fr t = (threadIdx.x >= st) ? part[threadIdx.x - st] : fr_zero();
-                __syncthreads();
-                part[threadIdx.x] = fr_add(part[threadIdx.x], t);
-                __syncthreads();
+    const uint32_t lv = blockIdx.y;
+    if (lv > nlevels_minus1) return;
+    const uint32_t j = lv > padded ? lv - padded : 0;
+    const uint32_t len = 1u << j;
+    const uint32_t n = blockIdx.x * SC_THREADS + threadIdx.x;
+    if (n > len) return;
+    // offset of level l >= padded: padded - 1 + 2^(l - padded); of level l < padded: l
+    const uint64_t off_lv = lv >= padded ? (uint64_t)padded - 1 + len : lv;
+    Fr s = fr_zero();
+    if (lv <= padded) {
+        if (n) s = fr_load(seq + off_lv);
+    } else {
+        for (uint32_t b = 0; b <= j; b++)
+            if ((n >> b) & 1u) {
+                const uint64_t off_b = (uint64_t)padded - 1 + (1u << (j - b));
+                s = fr_add(s, fr_load(seq + off_b + ((n >> b) - 1)));
             }
-            if (i < n) fr_store(pre + i + 1, fr_add(carry, part[threadIdx.x]));
-            __syncthreads();
-            if (threadIdx.x == SC_THREADS - 1) carry = fr_add(carry, part[threadIdx.x]);
-            __syncthreads();
-        }
-        off += n;
     }
+    fr_store(prefix + off_lv + lv + n, s);
 }
 
 // VecVec fold: out row = pad2(len/2) cells, cell p < len/2 = p0 + t (p1 - p0), the extra cell = row pad
@@ -339,8 +367,9 @@ __global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut o
                                                          const uint32_t* __restrict__ off_out, uint32_t nrows, Fr t,
                                                          PadCols pad) {
     const uint32_t j = blockIdx.x * SC_THREADS + threadIdx.x;
-    if (j >= off_out[nrows]) return;
-    const uint32_t r = find_row(off_out, nrows, j);
+    const uint32_t total = off_out[nrows];
+    const uint32_t r = find_row_block(off_out, nrows, j, j < total, total);
+    if (j >= total) return;
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
     const int c = blockIdx.y;
@@ -736,7 +765,7 @@ struct ScVecVecDeg2 : gm_sc {
     std::vector<std::unique_ptr<DevBuf>> bufA, bufB;
     bool cur_is_a = false, started = false;
     const uint32_t* off_cur = nullptr;
-    DevBuf off_a, off_b;
+    DevBuf off_all;  // row layouts of all sparse rounds: table l at off_all + l * (nrows + 1), table 0 = the input layout
     uint32_t cap_a = 0, cap_b = 0;
     std::vector<Fr> row_pad, col_pad, gamma_pows, point;
     int binding_var_idx = 0;
@@ -802,6 +831,7 @@ struct ScVecVecDeg2 : gm_sc {
     }
 
     uint64_t cells_bound = 0;  // upper bound of off_cur[nrows]
+    uint32_t n_off_tables = 0;
 
     int32_t bind(const Fr& t) override {
         if (dense) return dense->bind(t);
@@ -809,9 +839,8 @@ struct ScVecVecDeg2 : gm_sc {
         if ((uint32_t)binding_var_idx > col_logsize) {
             // sparse bind (vecvec_eq.rs:295-300)
             const bool to_a = !started || !cur_is_a;
-            DevBuf& off_dst = to_a ? off_a : off_b;
-            int32_t rc = launch_offsets_next(off_cur, reinterpret_cast<uint32_t*>(off_dst.p), nrows, stream);
-            if (rc) return rc;
+            if (already_bound + 1 >= n_off_tables) return set_err(GM_ERR_STATE, "more sparse binds than row variables");
+            const uint32_t* off_next = reinterpret_cast<const uint32_t*>(off_all.p) + (uint64_t)(already_bound + 1) * (nrows + 1);
             const uint64_t new_bound = cells_bound / 2 + nrows;
             ColPtrs ci;
             ColPtrsMut co;
@@ -823,10 +852,10 @@ struct ScVecVecDeg2 : gm_sc {
                 pd.v[i] = row_pad[i];
             }
             hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(new_bound, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co,
-                               off_cur, reinterpret_cast<const uint32_t*>(off_dst.p), nrows, t, pd);
+                               off_cur, off_next, nrows, t, pd);
             GM_LAUNCH_CHECK();
             for (int i = 0; i < k; i++) cur[i] = co.p[i];
-            off_cur = reinterpret_cast<const uint32_t*>(off_dst.p);
+            off_cur = off_next;
             cur_is_a = to_a;
             started = true;
             cells_bound = new_bound;
@@ -987,9 +1016,10 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
     so->binding_var_idx = (int)nvars - 1;
     for (uint32_t i = 0; i < polys->k; i++) so->cur.push_back(polys->cols[i]->fr());
     so->off_cur = reinterpret_cast<const uint32_t*>(polys->off->p);
-    rc = so->off_a.alloc((size_t)(so->nrows + 1) * 4);
+    so->n_off_tables = polys->row_logsize + 1;
+    rc = so->off_all.alloc((size_t)so->n_off_tables * (so->nrows + 1) * 4);
     if (rc) return rc;
-    rc = so->off_b.alloc((size_t)(so->nrows + 1) * 4);
+    rc = launch_offsets_all_from_off(so->off_cur, reinterpret_cast<uint32_t*>(so->off_all.p), so->nrows, so->n_off_tables, s);
     if (rc) return rc;
     for (uint32_t i = 0; i < polys->k; i++) {
         so->bufA.emplace_back(new DevBuf());
@@ -1058,8 +1088,9 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         // row_eq_poly_prefix_seq (vecvec.rs:101-109): level l -> len_l + 1 prefix sums, packed at offset off_l + l
         rc = so->d_prefix.alloc((size_t)(tot + n_seq_vars + 2) * sizeof(Fr));
         if (rc) return rc;
-        hipLaunchKernelGGL(k_prefix_sums_levels, dim3(1), dim3(SC_THREADS), 0, s, so->d_eq_seq.fr(), so->d_prefix.fr(),
-                           padded, n_seq_vars);
+        const uint32_t top_len = 1u << (n_seq_vars - padded);
+        hipLaunchKernelGGL(k_prefix_sums_levels, dim3(ceil_div((uint64_t)top_len + 1, SC_THREADS), n_seq_vars + 1), dim3(SC_THREADS),
+                           0, s, so->d_eq_seq.fr(), so->d_prefix.fr(), padded, n_seq_vars);
         GM_LAUNCH_CHECK();
     }
     rc = so->rs.init(so->stream);

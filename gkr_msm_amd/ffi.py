@@ -39,6 +39,15 @@ u32p = C.POINTER(C.c_uint32)
 u16p = C.POINTER(C.c_uint16)
 vp = C.c_void_p
 
+WRITE_SCALARS_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64)
+CHALLENGE_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64))
+
+
+class GmTranscript(C.Structure):
+    """gm_transcript: the caller's live Fiat-Shamir transcript as two callbacks"""
+    _fields_ = [("ctx", C.c_void_p), ("write_scalars", WRITE_SCALARS_CB), ("challenge", CHALLENGE_CB)]
+
+
 _SIGS = {
     "gm_last_error": (C.c_char_p, []),
     "gm_version": (C.c_char_p, []),
@@ -83,6 +92,9 @@ _SIGS = {
     "gm_pip_witness_outputs": (C.c_int32, [vp, vp, u32p, u64p, vp]),
     "gm_pip_witness_bytes": (C.c_uint64, [vp]),
     "gm_pip_prove_image_part": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, u32p, vp, u64p, u64p]),
+    "gm_pip_prove_image_part_tr": (C.c_int32, [vp, vp, vp, C.POINTER(GmTranscript), vp, u32p, vp, u64p, u64p]),
+    "gm_gkr_msm_prove_tr": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(GmTranscript), vp, vp, u32p, vp, u64p, u64p,
+                                        vp]),
     "gm_gkr_msm_prove": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u32p, vp,
                                      u64p, u64p, C.POINTER(C.c_double), vp]),
     "gm_msm_plan_create": (C.c_int32, [C.c_uint32] * 5 + [C.POINTER(vp)]),

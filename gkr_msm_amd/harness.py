@@ -368,6 +368,59 @@ class PipWitness:
                     evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value, rounds=rounds.value)
 
 
+class LiveTranscript:
+    """A gm_transcript whose callbacks run Python code: `on_write(list of canonical ints)` and `draw() -> int`.
+    Stands in for the Rust shim's wrappers over ProofTranscript2 (tests drive it from a tape or a hash)."""
+
+    def __init__(self, draw, on_write=None):
+        self.writes, self.n_challenges = [], 0
+
+        def _w(ctx, ptr, n):
+            arr = np.ctypeslib.as_array(ptr, shape=(n * 4,)).reshape(n, 4).copy()
+            vals = codec.from_mont_limbs(arr)
+            self.writes.append(vals)
+            if on_write:
+                on_write(vals)
+            return 0
+
+        def _c(ctx, out):
+            v = draw()
+            if v is None:
+                return 7
+            self.n_challenges += 1
+            for i in range(4):
+                out[i] = (v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+            return 0
+        self._w, self._c = ffi.WRITE_SCALARS_CB(_w), ffi.CHALLENGE_CB(_c)   # keep the thunks alive
+        self.c = ffi.GmTranscript(None, self._w, self._c)
+
+
+def prove_image_part_tr(w, claim_point, claim_evs, transcript):
+    cp, ce = fr_arg(claim_point), fr_arg(claim_evs)
+    fpt = np.zeros((64, 4), dtype=np.uint64)
+    fev = np.zeros((8, 4), dtype=np.uint64)
+    used, rounds, npt = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    ffi.check(w.L.gm_pip_prove_image_part_tr(w.h, cp.ctypes.data, ce.ctypes.data, C.byref(transcript.c), fpt.ctypes.data,
+                                             C.byref(npt), fev.ctypes.data, C.byref(used), C.byref(rounds)))
+    return dict(point=codec.from_mont_limbs(fpt[: npt.value]), evs=codec.from_mont_limbs(fev[:3]), n_challenges=used.value,
+                rounds=rounds.value)
+
+
+def gkr_msm_prove_tr(d_points, d_bits_u8, log_num_points, log_num_scalar_bits, transcript):
+    L = ffi.lib()
+    nout = 1 << log_num_scalar_bits
+    outp = np.zeros((3 * nout, 4), dtype=np.uint64)
+    fpt = np.zeros((64, 4), dtype=np.uint64)
+    fev = np.zeros((8, 4), dtype=np.uint64)
+    used, rounds, npt = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    ffi.check(L.gm_gkr_msm_prove_tr(C.c_void_p(d_points.data_ptr()), C.c_void_p(d_bits_u8.data_ptr()), log_num_points,
+                                    log_num_scalar_bits, C.byref(transcript.c), outp.ctypes.data, fpt.ctypes.data,
+                                    C.byref(npt), fev.ctypes.data, C.byref(used), C.byref(rounds), cur_stream()))
+    return dict(output=[codec.from_mont_limbs(outp[c * nout:(c + 1) * nout]) for c in range(3)],
+                point=codec.from_mont_limbs(fpt[: npt.value]), evs=codec.from_mont_limbs(fev[:3]), n_challenges=used.value,
+                rounds=rounds.value)
+
+
 def gkr_msm_prove(d_points, d_bits_u8, log_num_points, log_num_scalar_bits, tape, msgs_cap=1 << 18):
     """gen-1 gkr_msm_prove through the C ABI; d_bits_u8: uint8 CUDA tensor of 2^lp * 2^lb entries"""
     L = ffi.lib()

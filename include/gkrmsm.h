@@ -216,6 +216,21 @@ int32_t gm_msm_combine_host(const uint64_t* h_cols, uint32_t d_logsize, uint32_t
 int32_t gm_msm_te(const uint64_t* d_points_xy, const uint64_t* d_scalars, uint32_t x_logsize,
                   uint32_t d_logsize, uint32_t nbits, uint64_t* h_out_xy, void* stream);
 
+/* ---------------------------------------------------------------- Fiat-Shamir seam
+ * The transcript (merlin/STROBE hashing, sequential) stays with the caller.  The whole-protocol drivers below come in
+ * two forms: `*_tr` takes the caller's live transcript as two callbacks (what the Rust shim passes: thin wrappers over
+ * TProofTranscript2::write_scalars / challenge(128), cleanup/proof_transcript.rs:109-136, or gen-1
+ * TranscriptReceiver::append_scalars / TranscriptSender::challenge_scalar, transcript.rs:70-101); the tape form takes
+ * pre-drawn challenges and returns the messages (tests, benches, replay).
+ *   write_scalars: n field elements in the reference's in-memory form (Montgomery, 4 x u64), in write order; may be NULL
+ *   challenge:     one field element, canonical 4 x u64 LE (gen-2: < 2^128; gen-1: 64 bytes reduced mod p)
+ * A non-zero return from either aborts the prover with GM_ERR_STATE. */
+typedef struct gm_transcript {
+    void* ctx;
+    int32_t (*write_scalars)(void* ctx, const uint64_t* elems, uint64_t n);
+    int32_t (*challenge)(void* ctx, uint64_t* out);
+} gm_transcript;
+
 /* ---------------------------------------------------------------- "prove image part" (a10, a11)
  * Host-side driver over the kernels, mirroring PippengerWG::new (pippenger.rs:37-70, without the BLS12-381 G1
  * commitments: SURVEY 8f-1) and Pippenger::prove's "prove image part" span (pippenger.rs:138-141):
@@ -237,6 +252,10 @@ int32_t gm_pip_prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim
                                 uint64_t* n_msgs, uint64_t* h_final_point, uint32_t* n_final_point,
                                 uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds);
 
+int32_t gm_pip_prove_image_part_tr(const gm_pip_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                   const gm_transcript* tr, uint64_t* h_final_point, uint32_t* n_final_point,
+                                   uint64_t* h_final_evs, uint64_t* n_challenges, uint64_t* rounds);
+
 /* ---------------------------------------------------------------- gen-1 prover (a6, a16)
  * gkr_msm_prove (src/gkr_msm_simple.rs:86-338) without the BLS12-381 G1 column commitments: base polys
  * (bit, px, py) over index point*2^lb + bit, BintreeProtocol::witness (protocol/bintree.rs:168-184) over the layer list of
@@ -251,6 +270,11 @@ int32_t gm_gkr_msm_prove(const uint64_t* d_points_xy, const uint8_t* d_scalar_bi
                          uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_output, uint64_t* h_final_point,
                          uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds,
                          double* witness_ms, void* stream);
+
+int32_t gm_gkr_msm_prove_tr(const uint64_t* d_points_xy, const uint8_t* d_scalar_bits, uint32_t log_num_points,
+                            uint32_t log_num_scalar_bits, const gm_transcript* tr, uint64_t* h_output,
+                            uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* n_challenges,
+                            uint64_t* rounds, void* stream);
 
 /* Bandersnatch ScalarField (Montgomery, as stored by ark `Fr` of ark-ed-on-bls12-381-bandersnatch)
  * -> canonical bigint: the `into_bigint()` of pushforward.rs:352 / msm_nonaffine.rs:21-23. */

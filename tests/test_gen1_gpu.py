@@ -27,3 +27,29 @@ def test_gkr_msm_prove_matches_oracle(lp, lb):
     assert res["point"] == claim[0] and res["evs"] == claim[1]
     base = G1.base_layer(bits, pts, lp, lb)
     assert [G1.evaluate(b, res["point"]) for b in base] == res["evs"]
+
+
+def test_gen1_live_transcript_matches_tape():
+    lp, lb = 4, 2
+    pts = F.random_points(1 << lp, 9)
+    rng = F.SplitMix64(77)
+    bits = [[bool(rng.next() & 1) for _ in range(1 << lb)] for _ in range(1 << lp)]
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    d_bits = torch.from_numpy(np.array([[1 if b else 0 for b in s] for s in bits], dtype=np.uint8).reshape(-1)).cuda()
+    acc = [12345]
+    drawn = []
+
+    def on_write(vals):
+        for v in vals:
+            acc[0] = (acc[0] * 1000003 + v) % F.P
+
+    def draw():
+        acc[0] = (acc[0] * 7 + 1) % F.P
+        drawn.append(acc[0])
+        return acc[0]
+    live = H.LiveTranscript(draw, on_write)
+    res = H.gkr_msm_prove_tr(d_pts, d_bits, lp, lb, live)
+    ref = H.gkr_msm_prove(d_pts, d_bits, lp, lb, drawn)
+    assert [v for m in live.writes for v in m] == ref["msgs"]
+    assert (res["output"], res["point"], res["evs"]) == (ref["output"], ref["point"], ref["evs"])
+    assert res["n_challenges"] == len(drawn) == ref["tape_used"]

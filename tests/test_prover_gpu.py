@@ -46,3 +46,47 @@ def test_prove_image_part_matches_oracle(x_log, d_log, nbits):
     # Pattern A: the final claims are evaluations of the image polynomials (x, y, z)
     for i in range(3):
         assert PL.evaluate_poly(image[i].to_dense(), res["point"]) == res["evs"][i]
+
+
+def test_live_transcript_matches_tape():
+    """gm_pip_prove_image_part_tr: the callbacks see exactly the tape run's messages, in order, and a challenge that
+    depends on everything written so far (a hash chain, as a real Fiat-Shamir transcript) is honoured round by round."""
+    import hashlib
+    x_log, d_log, nbits = 6, 3, 18
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = PL.log2_exact(y_size)
+    n = 1 << x_log
+    pts = F.random_points(n, 21)
+    sc = F.random_scalars(n, nbits, 22)
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    d_sc = H.to_dev(codec.ints_to_limbs(sc))
+    plan = H.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, d_sc)
+    w = H.PipWitness(plan, d_pts, y_log)
+    outs, _ = w.outputs()
+    rng = F.SplitMix64(5)
+    r = [rng.next_fr() for _ in range(y_log)]
+    claims = G.pippenger_claims(outs, r)
+    state = hashlib.sha256(b"live")
+    drawn = []
+
+    def on_write(vals):
+        for v in vals:
+            state.update(v.to_bytes(32, "little"))
+
+    def draw():
+        c = int.from_bytes(state.digest()[:16], "little")
+        state.update(b"c")
+        drawn.append(c)
+        return c
+    live = H.LiveTranscript(draw, on_write)
+    res = H.prove_image_part_tr(w, claims[0], claims[1], live)
+    assert res["n_challenges"] == len(drawn) == live.n_challenges
+    # replay the drawn challenges as a tape: same messages, same final claim
+    ref = w.prove_image_part(claims[0], claims[1], drawn)
+    assert [v for m in live.writes for v in m] == ref["msgs"]
+    assert (res["point"], res["evs"], res["rounds"]) == (ref["point"], ref["evs"], ref["rounds"])
+    # a failing callback aborts with an error code instead of a wrong proof
+    bad = H.LiveTranscript(lambda: None)
+    with pytest.raises(Exception):
+        H.prove_image_part_tr(w, claims[0], claims[1], bad)
