@@ -40,3 +40,63 @@ def points_to_mont(points):
         flat.append(x)
         flat.append(y)
     return to_mont_limbs(flat).reshape(-1, 8)
+
+
+# ---- BLS12-381 Fq / G1 wire forms (include/gkrmsm.h, G1 section)
+Q = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+QR = (1 << 384) % Q
+QR_INV = pow(QR, -1, Q)
+
+
+def fq_to_mont_limbs(vals):
+    """canonical ints mod Q -> (n, 6) uint64 Montgomery limbs"""
+    out = np.empty((len(vals), 6), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        m = (v % Q) * QR % Q
+        for k in range(6):
+            out[i, k] = (m >> (64 * k)) & _M64
+    return out
+
+
+def fq_from_mont_limbs(arr):
+    arr = np.asarray(arr, dtype=np.uint64).reshape(-1, 6)
+    return [sum(int(r[k]) << (64 * k) for k in range(6)) * QR_INV % Q for r in arr]
+
+
+def g1_aff_to_limbs(points):
+    """[(x, y) or None, ...] -> (n, 12) uint64; infinity = (0, 0)"""
+    flat = []
+    for p in points:
+        flat.extend((0, 0) if p is None else p)
+    return fq_to_mont_limbs(flat).reshape(-1, 12)
+
+
+def g1_aff_from_limbs(arr):
+    v = fq_from_mont_limbs(np.asarray(arr, dtype=np.uint64).reshape(-1, 6))
+    return [None if (v[2 * i] == 0 and v[2 * i + 1] == 0) else (v[2 * i], v[2 * i + 1]) for i in range(len(v) // 2)]
+
+
+def g1_jac_to_limbs(points, zs=None):
+    """affine points (or None) -> (n, 18) uint64 Jacobian (x z^2, y z^3, z) with the given z values (default 1)"""
+    flat = []
+    for i, p in enumerate(points):
+        z = 1 if zs is None else zs[i] % Q
+        if p is None:
+            flat.extend((0, 1, 0))
+        else:
+            flat.extend((p[0] * z * z % Q, p[1] * z * z * z % Q, z))
+    return fq_to_mont_limbs(flat).reshape(-1, 18)
+
+
+def g1_jac_from_limbs(arr):
+    """(n, 18) uint64 Jacobian -> affine points (or None)"""
+    v = fq_from_mont_limbs(np.asarray(arr, dtype=np.uint64).reshape(-1, 6))
+    out = []
+    for i in range(len(v) // 3):
+        x, y, z = v[3 * i:3 * i + 3]
+        if z == 0:
+            out.append(None)
+        else:
+            zi = pow(z, -1, Q)
+            out.append((x * zi * zi % Q, y * zi * zi * zi % Q))
+    return out

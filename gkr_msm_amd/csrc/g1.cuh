@@ -1,0 +1,146 @@
+// BLS12-381 G1 (y^2 = x^3 + 4 over Fq) point arithmetic, host + device.
+//
+// The reference reaches G1 only through ark-ec 0.4.2 (`Projective<g1::Config>` = Jacobian (X, Y, Z), x = X/Z^2,
+// y = Y/Z^3; `Affine{x, y, infinity}`); that crate is not vendored (Cargo.lock:135-136).  `Projective` equality there is
+// equality of the represented group element, so the G1 outputs of this library are specified -- and tested -- as group
+// elements (affine coordinates), not as a particular (X, Y, Z) triple.  Formulas: the standard a = 0 Jacobian ones
+// (EFD dbl-2009-l, add-2007-bl, madd-2007-bl, mmadd-2007-bl), complete via explicit special cases.
+//
+// Wire forms at the C ABI (the Rust shim marshals; ark's struct layouts are not repr(C)):
+//   affine:   x, y  Montgomery 6 x u64 each = 96 bytes; the point at infinity is (0, 0) (not on the curve)
+//   jacobian: X, Y, Z = 144 bytes; infinity is Z = 0
+#pragma once
+#include "fq.cuh"
+
+namespace gm {
+
+struct G1Aff {
+    Fq x, y;
+};
+struct G1Jac {
+    Fq x, y, z;
+};
+
+GM_HD bool g1_aff_is_inf(const G1Aff& p) { return fq_is_zero(p.x) && fq_is_zero(p.y); }
+GM_HD bool g1_is_inf(const G1Jac& p) { return fq_is_zero(p.z); }
+
+GM_HD G1Jac g1_inf() {
+    G1Jac r;
+    r.x = fq_zero(); r.y = fq_one(); r.z = fq_zero();
+    return r;
+}
+
+GM_HD G1Jac g1_from_aff(const G1Aff& p) {
+    if (g1_aff_is_inf(p)) return g1_inf();
+    G1Jac r;
+    r.x = p.x; r.y = p.y; r.z = fq_one();
+    return r;
+}
+
+GM_HD G1Aff g1_aff_neg(const G1Aff& p) {
+    G1Aff r;
+    r.x = p.x; r.y = fq_neg(p.y);
+    return r;
+}
+
+GM_HD G1Jac g1_neg(const G1Jac& p) {
+    G1Jac r = p;
+    r.y = fq_neg(p.y);
+    return r;
+}
+
+// dbl-2009-l (a = 0): 2M + 5S
+GM_HD G1Jac g1_dbl(const G1Jac& p) {
+    if (g1_is_inf(p)) return p;
+    const Fq A = fq_sqr(p.x), B = fq_sqr(p.y), C = fq_sqr(B);
+    const Fq D = fq_dbl(fq_sub(fq_sub(fq_sqr(fq_add(p.x, B)), A), C));
+    const Fq E = fq_add(fq_dbl(A), A), F = fq_sqr(E);
+    G1Jac r;
+    r.x = fq_sub(F, fq_dbl(D));
+    const Fq C8 = fq_dbl(fq_dbl(fq_dbl(C)));
+    r.z = fq_dbl(fq_mul(p.y, p.z));
+    r.y = fq_sub(fq_mul(E, fq_sub(D, r.x)), C8);
+    return r;
+}
+
+// shared tail of the three addition formulas: H = U2 - U1, rr = 2 (S2 - S1) given; X1' = U1, Y1' = S1, Zmul = the factor
+// Z3 gets besides H (2 Z1 Z2, computed by the caller)
+GM_HD G1Jac g1_add_tail(const Fq& U1, const Fq& S1, const Fq& H, const Fq& rr, const Fq& zfac) {
+    const Fq I = fq_sqr(fq_dbl(H)), J = fq_mul(H, I), V = fq_mul(U1, I);
+    G1Jac r;
+    r.x = fq_sub(fq_sub(fq_sqr(rr), J), fq_dbl(V));
+    r.y = fq_sub(fq_mul(rr, fq_sub(V, r.x)), fq_dbl(fq_mul(S1, J)));
+    r.z = fq_mul(zfac, H);
+    return r;
+}
+
+// add-2007-bl: 11M + 5S
+GM_HD G1Jac g1_add(const G1Jac& p, const G1Jac& q) {
+    if (g1_is_inf(p)) return q;
+    if (g1_is_inf(q)) return p;
+    const Fq Z1Z1 = fq_sqr(p.z), Z2Z2 = fq_sqr(q.z);
+    const Fq U1 = fq_mul(p.x, Z2Z2), U2 = fq_mul(q.x, Z1Z1);
+    const Fq S1 = fq_mul(fq_mul(p.y, q.z), Z2Z2), S2 = fq_mul(fq_mul(q.y, p.z), Z1Z1);
+    const Fq H = fq_sub(U2, U1), d = fq_sub(S2, S1);
+    if (fq_is_zero(H)) return fq_is_zero(d) ? g1_dbl(p) : g1_inf();
+    const Fq zfac = fq_sub(fq_sub(fq_sqr(fq_add(p.z, q.z)), Z1Z1), Z2Z2);  // 2 Z1 Z2
+    return g1_add_tail(U1, S1, H, fq_dbl(d), zfac);
+}
+
+// madd-2007-bl (Z2 = 1): 7M + 4S
+GM_HD G1Jac g1_add_mixed(const G1Jac& p, const G1Aff& q) {
+    if (g1_aff_is_inf(q)) return p;
+    if (g1_is_inf(p)) return g1_from_aff(q);
+    const Fq Z1Z1 = fq_sqr(p.z);
+    const Fq U2 = fq_mul(q.x, Z1Z1), S2 = fq_mul(fq_mul(q.y, p.z), Z1Z1);
+    const Fq H = fq_sub(U2, p.x), d = fq_sub(S2, p.y);
+    if (fq_is_zero(H)) return fq_is_zero(d) ? g1_dbl(p) : g1_inf();
+    return g1_add_tail(p.x, p.y, H, fq_dbl(d), fq_dbl(p.z));
+}
+
+// mmadd-2007-bl (Z1 = Z2 = 1): 4M + 2S
+GM_HD G1Jac g1_add_aff(const G1Aff& p, const G1Aff& q) {
+    if (g1_aff_is_inf(p)) return g1_from_aff(q);
+    if (g1_aff_is_inf(q)) return g1_from_aff(p);
+    const Fq H = fq_sub(q.x, p.x), d = fq_sub(q.y, p.y);
+    if (fq_is_zero(H)) return fq_is_zero(d) ? g1_dbl(g1_from_aff(p)) : g1_inf();
+    Fq two = fq_dbl(fq_one());
+    return g1_add_tail(p.x, p.y, H, fq_dbl(d), two);
+}
+
+// into_affine: one field inversion
+GM_HD G1Aff g1_to_aff(const G1Jac& p) {
+    G1Aff r;
+    if (g1_is_inf(p)) { r.x = fq_zero(); r.y = fq_zero(); return r; }
+    const Fq zi = fq_inv(p.z), zi2 = fq_sqr(zi);
+    r.x = fq_mul(p.x, zi2);
+    r.y = fq_mul(p.y, fq_mul(zi2, zi));
+    return r;
+}
+
+GM_HD bool g1_aff_on_curve(const G1Aff& p) {
+    if (g1_aff_is_inf(p)) return true;
+    Fq four = fq_dbl(fq_dbl(fq_one()));
+    return fq_eq(fq_sqr(p.y), fq_add(fq_mul(fq_sqr(p.x), p.x), four));
+}
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ G1Aff g1_aff_load(const G1Aff* p) {
+    G1Aff r;
+    r.x = fq_load(&p->x); r.y = fq_load(&p->y);
+    return r;
+}
+__device__ __forceinline__ void g1_aff_store(G1Aff* p, const G1Aff& v) {
+    fq_store(&p->x, v.x); fq_store(&p->y, v.y);
+}
+__device__ __forceinline__ G1Jac g1_load(const G1Jac* p) {
+    G1Jac r;
+    r.x = fq_load(&p->x); r.y = fq_load(&p->y); r.z = fq_load(&p->z);
+    return r;
+}
+__device__ __forceinline__ void g1_store(G1Jac* p, const G1Jac& v) {
+    fq_store(&p->x, v.x); fq_store(&p->y, v.y); fq_store(&p->z, v.z);
+}
+#endif
+
+}  // namespace gm

@@ -1,0 +1,768 @@
+// BLS12-381 G1 side of the hot path on the device.
+//
+// Everything the reference does with G1 on this path is "add up base points grouped by a small integer key", then a
+// weighted sum of the groups:
+//   PushForwardState::new       d_outer[y][digit] += SRS[..], c_outer[y][counter] += SRS[..]   pushforward.rs:395-456
+//                               d_comm / c_comm = sum_i i * bucket_i                            pushforward.rs:504-524
+//   msm_bigint_(wnaf_)nonaff    window buckets, running-sum reduce, window recombination        msm_nonaffine.rs:89-272
+//   KzgProvingKey::commit       <G1 as VariableBaseMSM>::msm                                     commitments/kzg.rs:123-126
+//   binary_msm                  sum of table entries selected by gamma-bit chunks               binary_msm.rs:19-29
+//   Pullback::bucketed_msm      buckets[mapping[i]] += bases[i], then msm_nonaff                pullback.rs:27-59
+// One engine serves all of them: sort (key, point index) pairs by key (rocPRIM radix sort), find the row boundaries,
+// and reduce every row with a flat pairwise tree -- level l adds cells (2i, 2i+1) of every row, the thread -> (row, cell)
+// mapping goes through the per-level row offsets, so the work is perfectly balanced whatever the bucket skew (d_outer
+// has 256 rows of 4096 points per window, an MSM window has 8192 rows of ~128).  Weighted sums sum_i i*B_i use the
+// same engine on the bit decomposition of i:  sum_i i B_i = sum_b 2^b (sum_{i : bit b set} B_i).
+// G1 results are group elements (g1.cuh): the tree order is free, unlike the Bandersnatch bucket sums of msm.hip whose
+// projective coordinates are part of the proof.
+//
+// Bound: integer VALU (a Jacobian addition is 16 Fq multiplications of ~290 v_mad_u64_u32 each); HBM traffic is
+// ~0.4 KB per input point.
+#include <string.h>
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+#include "g1.cuh"
+#include "msm_plan.hpp"
+
+namespace gm {
+
+static constexpr uint32_t G1_NEG_BIT = 0x80000000u;  // task index flag: subtract the point instead of adding it
+
+// ------------------------------------------------------------------------------------------ engine kernels
+// off[k] = first position of the sorted key array holding a key >= k, k = 0..nkeys (off[nkeys] = number of valid tasks)
+__global__ void __launch_bounds__(256) k_g1_lower_bound(const uint32_t* __restrict__ keys, uint64_t ntasks, uint32_t nkeys,
+                                                         uint32_t* __restrict__ off, uint32_t* __restrict__ max_len) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nkeys) return;
+    auto lb = [&](uint32_t key) {
+        uint64_t lo = 0, hi = ntasks;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return (uint32_t)lo;
+    };
+    const uint32_t o = lb(k);
+    off[k] = o;
+    if (k < nkeys) {
+        const uint32_t len = lb(k + 1) - o;
+        if (len) atomicMax(max_len, len);
+    }
+}
+
+// lens[r] = ceil(len0[r] / 2^shift), lens[nkeys] = 0
+__global__ void __launch_bounds__(256) k_g1_level_lens(const uint32_t* __restrict__ off0, uint32_t nkeys, uint32_t shift,
+                                                        uint32_t* __restrict__ lens) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nkeys) return;
+    uint32_t v = 0;
+    if (r < nkeys) {
+        const uint32_t len = off0[r + 1] - off0[r];
+        v = (len + (1u << shift) - 1) >> shift;
+    }
+    lens[r] = v;
+}
+
+__device__ __forceinline__ uint32_t g1_find_row(const uint32_t* __restrict__ off, uint32_t nrows, uint32_t j) {
+    uint32_t lo = 0, hi = nrows;  // off[lo] <= j < off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// sources of level 0: points addressed through the sorted task indices
+struct G1SrcAff {
+    const G1Aff* pts;
+    const uint32_t* idx;
+    __device__ __forceinline__ G1Aff get(uint32_t cell) const {
+        const uint32_t t = idx[cell];
+        G1Aff p = g1_aff_load(pts + (t & ~G1_NEG_BIT));
+        if (t & G1_NEG_BIT) p = g1_aff_neg(p);
+        return p;
+    }
+};
+struct G1SrcJac {
+    const G1Jac* pts;
+    const uint32_t* idx;  // nullptr: cells are stored in place (levels >= 1)
+    __device__ __forceinline__ G1Jac get(uint32_t cell) const {
+        if (!idx) return g1_load(pts + cell);
+        const uint32_t t = idx[cell];
+        G1Jac p = g1_load(pts + (t & ~G1_NEG_BIT));
+        if (t & G1_NEG_BIT) p = g1_neg(p);
+        return p;
+    }
+};
+
+__device__ __forceinline__ G1Jac g1_pair(const G1SrcAff& s, uint32_t c0, bool two) {
+    const G1Aff a = s.get(c0);
+    return two ? g1_add_aff(a, s.get(c0 + 1)) : g1_from_aff(a);
+}
+__device__ __forceinline__ G1Jac g1_pair(const G1SrcJac& s, uint32_t c0, bool two) {
+    const G1Jac a = s.get(c0);
+    return two ? g1_add(a, s.get(c0 + 1)) : a;
+}
+
+// one tree level: out cell j of row r = in cell 2p (+ in cell 2p+1 when the row has it), p = j - off_out[r]
+template <class Src>
+__global__ void __launch_bounds__(128) k_g1_level(Src src, const uint32_t* __restrict__ off_in,
+                                                   const uint32_t* __restrict__ off_out, uint32_t nrows,
+                                                   G1Jac* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= off_out[nrows]) return;
+    const uint32_t r = g1_find_row(off_out, nrows, j);
+    const uint32_t p = j - off_out[r];
+    const uint32_t in0 = off_in[r], len = off_in[r + 1] - in0;
+    g1_store(out + j, g1_pair(src, in0 + 2 * p, 2 * p + 1 < len));
+}
+
+// rows of at most one cell -> dense output (empty rows = infinity)
+template <class Src>
+__global__ void __launch_bounds__(128) k_g1_rows_out(Src src, const uint32_t* __restrict__ off, uint32_t nrows,
+                                                      G1Jac* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t o = off[r];
+    g1_store(out + r, (off[r + 1] > o) ? g1_pair(src, o, false) : g1_inf());
+}
+
+// ------------------------------------------------------------------------------------------ task builders
+// MSM windows: task t = w * n + i -> key (w << c | digit) (digit 0: no task), point i
+__global__ void __launch_bounds__(256) k_g1_msm_tasks(const uint32_t* __restrict__ scalars, uint64_t n, uint32_t c,
+                                                       uint32_t nwin, int mont, uint32_t sentinel,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = fr_load(reinterpret_cast<const Fr*>(scalars) + i);
+    if (mont) s = fr_from_mont(s);  // `into_bigint()` of msm_nonaffine.rs:21-23
+    for (uint32_t w = 0; w < nwin; w++) {
+        const uint32_t bit = w * c;
+        uint32_t d = 0;
+        if (bit < 256) {
+            const uint32_t li = bit >> 5, sh = bit & 31;
+            uint64_t v = s.l[li];
+            if (li + 1 < 8) v |= (uint64_t)s.l[li + 1] << 32;
+            d = (uint32_t)(v >> sh) & ((1u << c) - 1);
+        }
+        const uint64_t t = (uint64_t)w * n + i;
+        keys[t] = d ? ((w << c) | d) : sentinel;
+        idx[t] = (uint32_t)i;
+    }
+}
+
+// weighted sum sum_i i * B[g][i] over groups g of `glen` buckets by bit decomposition: task (g, i, b) -> key g * nbits + b
+__global__ void __launch_bounds__(256) k_g1_bit_tasks(uint32_t ngroups, uint32_t glen, uint32_t nbits, uint32_t sentinel,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)ngroups * glen * nbits;
+    if (t >= total) return;
+    const uint32_t b = (uint32_t)(t % nbits);
+    const uint64_t gi = t / nbits;
+    const uint32_t i = (uint32_t)(gi % glen), g = (uint32_t)(gi / glen);
+    keys[t] = ((i >> b) & 1u) ? g * nbits + b : sentinel;
+    idx[t] = (uint32_t)gi;
+}
+
+// binary_msm: chunk t with coefficient byte c != 0 selects table entry t * (2^gamma - 1) + c - 1   (binary_msm.rs:22)
+__global__ void __launch_bounds__(256) k_g1_binary_tasks(const uint8_t* __restrict__ coefs, uint64_t nchunks, uint32_t tab_len,
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const uint32_t c = coefs[t];
+    keys[t] = c ? 0u : 1u;
+    idx[t] = (uint32_t)(t * tab_len + (c ? c - 1 : 0));
+}
+
+// prepare_chunk (binary_msm.rs:32-42): entry i-1 of chunk k = sum over set bits idx of i of chunk[len-1-idx]
+__global__ void __launch_bounds__(128) k_g1_prepare_tables(const G1Aff* __restrict__ bases, uint64_t n, uint32_t gamma,
+                                                            G1Aff* __restrict__ tables) {
+    const uint32_t tab_len = (1u << gamma) - 1;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nchunks = (n + gamma - 1) / gamma;
+    if (t >= nchunks * tab_len) return;
+    const uint64_t k = t / tab_len;
+    const uint32_t i = (uint32_t)(t % tab_len) + 1;
+    const uint64_t first = k * gamma;
+    const uint32_t clen = (uint32_t)((n - first < gamma) ? n - first : gamma);
+    G1Jac acc = g1_inf();
+    for (uint32_t b = 0; b < clen; b++)
+        if ((i >> b) & 1u) acc = g1_add_mixed(acc, g1_aff_load(bases + first + (clen - 1 - b)));
+    g1_aff_store(tables + t, g1_to_aff(acc));  // G::normalize_batch (binary_msm.rs:41)
+}
+
+// pushforward outer buckets: task (y, x) adds basis[x + N * (y mod comm_mul)] to row (y / comm_mul) * stride + v[y][x]
+__global__ void __launch_bounds__(256) k_g1_outer_tasks_u16(const uint16_t* __restrict__ v, uint64_t N, uint32_t y0, uint32_t ny,
+                                                             uint32_t clm, uint32_t stride, uint32_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ idx) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * ny) return;
+    const uint32_t yl = (uint32_t)(t / N), y = y0 + yl;
+    const uint64_t x = t % N;
+    keys[t] = (y >> clm) * stride + v[t];
+    idx[t] = (uint32_t)(x + N * (y & ((1u << clm) - 1)));
+}
+__global__ void __launch_bounds__(256) k_g1_outer_tasks_u32(const uint32_t* __restrict__ v, uint64_t N, uint32_t y0, uint32_t ny,
+                                                             uint32_t clm, uint32_t stride, uint32_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ idx) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * ny) return;
+    const uint32_t yl = (uint32_t)(t / N), y = y0 + yl;
+    const uint64_t x = t % N;
+    keys[t] = (y >> clm) * stride + v[t];
+    idx[t] = (uint32_t)(x + N * (y & ((1u << clm) - 1)));
+}
+
+// plain keyed tasks: key = mapping[i] (Pullback::bucketed_msm, pullback.rs:44-46), point i
+__global__ void __launch_bounds__(256) k_g1_map_tasks(const uint32_t* __restrict__ mapping, uint64_t n, uint32_t nkeys,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                       uint32_t* __restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = mapping[i];
+    if (m >= nkeys) atomicAdd(bad, 1u);
+    keys[i] = m < nkeys ? m : nkeys;
+    idx[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(128) k_g1_to_affine(const G1Jac* __restrict__ in, uint64_t n, G1Aff* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g1_aff_store(out + i, g1_to_aff(g1_load(in + i)));
+}
+
+__global__ void __launch_bounds__(128) k_g1_from_affine(const G1Aff* __restrict__ in, uint64_t n, G1Jac* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g1_store(out + i, g1_from_aff(g1_aff_load(in + i)));
+}
+
+// k_i * G for the synthetic SRS of bench / tests: double-and-add over a 64-bit seeded scalar per point
+__global__ void __launch_bounds__(128) k_g1_gen_points(G1Aff gen, uint64_t n, uint64_t seed, G1Aff* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (i + 1);  // SplitMix64 of the index
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    z |= 1;
+    G1Jac acc = g1_inf();
+    for (int b = 63; b >= 0; b--) {
+        acc = g1_dbl(acc);
+        if ((z >> b) & 1) acc = g1_add_mixed(acc, gen);
+    }
+    g1_aff_store(out + i, g1_to_aff(acc));
+}
+
+// ------------------------------------------------------------------------------------------ engine (host)
+// grow-only device scratch shared by the G1 calls of this process (one call at a time: guarded by a mutex)
+struct G1Scratch {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    std::mutex mu;
+    int32_t reserve(size_t bytes) {
+        if (bytes <= cap) return GM_OK;
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc((void**)&base, bytes);
+        if (e != hipSuccess) return set_err(GM_ERR_HIP, "hipMalloc(G1 scratch %zu): %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return GM_OK;
+    }
+    void* carve(size_t b) {
+        const size_t a = (used + 255) & ~(size_t)255;
+        used = a + b;
+        return base + a;
+    }
+    void release() {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = used = 0;
+    }
+};
+static G1Scratch& g1_scratch() {
+    static G1Scratch s;
+    return s;
+}
+
+static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct G1Layout {
+    size_t sort_tmp = 0, scan_tmp = 0, total = 0;
+};
+
+static uint32_t bit_len(uint32_t v) {
+    uint32_t b = 0;
+    while (v) { b++; v >>= 1; }
+    return b;
+}
+
+// bytes of scratch the engine needs for ntasks tasks over nkeys rows (besides the caller's task arrays)
+static int32_t g1_engine_layout(uint64_t ntasks, uint32_t nkeys, G1Layout* L) {
+    size_t st = 0, sc = 0;
+    uint32_t* np = nullptr;
+    GM_HIP(rocprim::radix_sort_pairs(nullptr, st, np, np, np, np, ntasks, 0, bit_len(nkeys)));
+    GM_HIP(rocprim::exclusive_scan(nullptr, sc, np, np, 0u, (size_t)nkeys + 1));
+    L->sort_tmp = st;
+    L->scan_tmp = sc;
+    L->total = al(st) + al(sc) + 2 * al(ntasks * 4) + 35 * al(((size_t)nkeys + 1) * 4) + al(64) +
+               al((ntasks / 2 + nkeys + 1) * sizeof(G1Jac)) + al((ntasks / 4 + nkeys + 1) * sizeof(G1Jac)) + 4096;
+    return GM_OK;
+}
+
+// Sums the points of every key.  keys/idx: ntasks unsorted tasks (device, clobbered); tasks with key == nkeys are
+// dropped.  src_aff / src_jac: exactly one non-null.  out: nkeys Jacobian points.  Synchronises the stream once.
+static int32_t g1_sum_by_key(G1Scratch& ws, const G1Aff* src_aff, const G1Jac* src_jac, uint32_t* keys, uint32_t* idx,
+                             uint64_t ntasks, uint32_t nkeys, G1Jac* out, hipStream_t s) {
+    GM_REQUIRE(ntasks < (1ull << 31), "too many G1 tasks (%llu)", (unsigned long long)ntasks);
+    GM_REQUIRE(nkeys >= 1 && nkeys < (1u << 30), "bad key count %u", nkeys);
+    G1Layout L;
+    int32_t rc = g1_engine_layout(ntasks ? ntasks : 1, nkeys, &L);
+    if (rc) return rc;
+    void* sort_tmp = ws.carve(L.sort_tmp);
+    void* scan_tmp = ws.carve(L.scan_tmp);
+    uint32_t* keys_s = (uint32_t*)ws.carve((ntasks + 1) * 4);
+    uint32_t* idx_s = (uint32_t*)ws.carve((ntasks + 1) * 4);
+    const size_t orow = (size_t)nkeys + 1;
+    uint32_t* off_all = (uint32_t*)ws.carve(33 * al(orow * 4));  // level l at off_all + l * ostride
+    const size_t ostride = al(orow * 4) / 4;
+    uint32_t* lens = (uint32_t*)ws.carve(orow * 4);
+    uint32_t* d_max = (uint32_t*)ws.carve(64);
+    G1Jac* bufA = (G1Jac*)ws.carve((ntasks / 2 + nkeys + 1) * sizeof(G1Jac));
+    G1Jac* bufB = (G1Jac*)ws.carve((ntasks / 4 + nkeys + 1) * sizeof(G1Jac));
+    if (ws.used > ws.cap) return set_err(GM_ERR_STATE, "G1 scratch under-reserved (%zu > %zu)", ws.used, ws.cap);
+
+    GM_HIP(hipMemsetAsync(d_max, 0, 4, s));
+    if (ntasks) {
+        size_t st = L.sort_tmp;
+        GM_HIP(rocprim::radix_sort_pairs(sort_tmp, st, keys, keys_s, idx, idx_s, ntasks, 0, bit_len(nkeys), s));
+    }
+    hipLaunchKernelGGL(k_g1_lower_bound, dim3(ceil_div(orow, 256)), dim3(256), 0, s, keys_s, ntasks, nkeys, off_all, d_max);
+    GM_LAUNCH_CHECK();
+    uint32_t max_len = 0;
+    GM_HIP(hipMemcpyAsync(&max_len, d_max, 4, hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    uint32_t nlev = 0;
+    while ((1u << nlev) < max_len) nlev++;
+    GM_REQUIRE(nlev <= 32, "row too long");
+    for (uint32_t l = 1; l <= nlev; l++) {
+        hipLaunchKernelGGL(k_g1_level_lens, dim3(ceil_div(orow, 256)), dim3(256), 0, s, off_all, nkeys, l, lens);
+        GM_LAUNCH_CHECK();
+        size_t sc = L.scan_tmp;
+        GM_HIP(rocprim::exclusive_scan(scan_tmp, sc, lens, off_all + l * ostride, 0u, orow, rocprim::plus<uint32_t>(), s));
+    }
+    const G1SrcAff sa{src_aff, idx_s};
+    const G1SrcJac sj{src_jac, idx_s};
+    if (nlev == 0) {
+        if (src_aff) hipLaunchKernelGGL((k_g1_rows_out<G1SrcAff>), dim3(ceil_div(nkeys, 128)), dim3(128), 0, s, sa, off_all, nkeys, out);
+        else hipLaunchKernelGGL((k_g1_rows_out<G1SrcJac>), dim3(ceil_div(nkeys, 128)), dim3(128), 0, s, sj, off_all, nkeys, out);
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
+    // level 1 from the sources; cells of level l never exceed ntasks / 2^l + nkeys
+    uint64_t bound = ntasks / 2 + nkeys;
+    if (src_aff) hipLaunchKernelGGL((k_g1_level<G1SrcAff>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sa, off_all, off_all + ostride, nkeys, bufA);
+    else hipLaunchKernelGGL((k_g1_level<G1SrcJac>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sj, off_all, off_all + ostride, nkeys, bufA);
+    GM_LAUNCH_CHECK();
+    G1Jac *cur = bufA, *nxt = bufB;
+    for (uint32_t l = 2; l <= nlev; l++) {
+        bound = bound / 2 + nkeys;
+        const G1SrcJac sl{cur, nullptr};
+        hipLaunchKernelGGL((k_g1_level<G1SrcJac>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sl, off_all + (l - 1) * ostride,
+                           off_all + l * ostride, nkeys, nxt);
+        GM_LAUNCH_CHECK();
+        G1Jac* t = cur; cur = nxt; nxt = t;
+    }
+    const G1SrcJac sl{cur, nullptr};
+    hipLaunchKernelGGL((k_g1_rows_out<G1SrcJac>), dim3(ceil_div(nkeys, 128)), dim3(128), 0, s, sl, off_all + nlev * ostride, nkeys, out);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+// bufB must hold level-2 cells: bound_2 = (ntasks/2 + nkeys)/2 + nkeys <= ntasks/4 + 1.5 nkeys: widen the reservation
+static size_t g1_engine_bytes(uint64_t ntasks, uint32_t nkeys) {
+    G1Layout L;
+    if (g1_engine_layout(ntasks ? ntasks : 1, nkeys, &L)) return 0;
+    return L.total + al((size_t)nkeys * sizeof(G1Jac));
+}
+
+// acc = sum_pos 2^pos S[pos] on the host (Horner from the top bit)
+static G1Jac g1_horner_bits(const std::vector<G1Jac>& S) {
+    G1Jac acc = g1_inf();
+    for (size_t pos = S.size(); pos-- > 0;) {
+        acc = g1_dbl(acc);
+        acc = g1_add(acc, S[pos]);
+    }
+    return acc;
+}
+
+// sum_i i * B[g][i] for ngroups groups of glen buckets (device, Jacobian) -> host points
+static int32_t g1_weighted_sums(G1Scratch& ws, const G1Jac* d_buckets, uint32_t ngroups, uint32_t glen, std::vector<G1Jac>* out,
+                                hipStream_t s) {
+    const uint32_t nbits = bit_len(glen - 1) ? bit_len(glen - 1) : 1;
+    const uint64_t ntasks = (uint64_t)ngroups * glen * nbits;
+    const uint32_t nkeys = ngroups * nbits;
+    uint32_t* keys = (uint32_t*)ws.carve(ntasks * 4);
+    uint32_t* idx = (uint32_t*)ws.carve(ntasks * 4);
+    G1Jac* d_S = (G1Jac*)ws.carve((size_t)nkeys * sizeof(G1Jac));
+    if (ws.used > ws.cap) return set_err(GM_ERR_STATE, "G1 scratch under-reserved");
+    hipLaunchKernelGGL(k_g1_bit_tasks, dim3(ceil_div(ntasks, 256)), dim3(256), 0, s, ngroups, glen, nbits, nkeys, keys, idx);
+    GM_LAUNCH_CHECK();
+    int32_t rc = g1_sum_by_key(ws, nullptr, d_buckets, keys, idx, ntasks, nkeys, d_S, s);
+    if (rc) return rc;
+    std::vector<G1Jac> S(nkeys);
+    GM_HIP(hipMemcpyAsync(S.data(), d_S, (size_t)nkeys * sizeof(G1Jac), hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    out->resize(ngroups);
+    for (uint32_t g = 0; g < ngroups; g++)
+        (*out)[g] = g1_horner_bits(std::vector<G1Jac>(S.begin() + (size_t)g * nbits, S.begin() + (size_t)(g + 1) * nbits));
+    return GM_OK;
+}
+static size_t g1_weighted_bytes(uint32_t ngroups, uint32_t glen) {
+    const uint32_t nbits = bit_len(glen - 1) ? bit_len(glen - 1) : 1;
+    const uint64_t ntasks = (uint64_t)ngroups * glen * nbits;
+    return 2 * al(ntasks * 4) + al((size_t)ngroups * nbits * sizeof(G1Jac)) + g1_engine_bytes(ntasks, ngroups * nbits) + 4096;
+}
+
+static uint32_t g1_msm_window(uint64_t n) {
+    uint32_t lg = 0;
+    while ((1ull << lg) < n) lg++;
+    int c = (int)lg - 7;
+    if (c < 2) c = 2;
+    if (c > 14) c = 14;
+    return (uint32_t)c;
+}
+
+// sum_i scalar_i * base_i; exactly one of aff / jac.  Result on the host (Jacobian).
+static int32_t g1_msm_core(const G1Aff* aff, const G1Jac* jac, const uint64_t* d_scalars, uint64_t n, int scalars_mont,
+                           uint32_t nbits, G1Jac* h_out, hipStream_t s) {
+    if (n == 0) { *h_out = g1_inf(); return GM_OK; }
+    GM_REQUIRE(nbits >= 1 && nbits <= 256, "bad scalar width %u", nbits);
+    const uint32_t c = g1_msm_window(n);
+    const uint32_t nwin = (nbits + c - 1) / c;
+    const uint64_t ntasks = (uint64_t)nwin * n;
+    const uint32_t nkeys = nwin << c;
+    GM_REQUIRE(ntasks < (1ull << 31), "MSM too large for one call: %llu tasks", (unsigned long long)ntasks);
+    G1Scratch& ws = g1_scratch();
+    std::lock_guard<std::mutex> lock(ws.mu);
+    const size_t need = 2 * al(ntasks * 4) + al((size_t)nkeys * sizeof(G1Jac)) + g1_engine_bytes(ntasks, nkeys) +
+                        g1_weighted_bytes(nwin, 1u << c) + 8192;
+    int32_t rc = ws.reserve(need);
+    if (rc) return rc;
+    ws.used = 0;
+    uint32_t* keys = (uint32_t*)ws.carve(ntasks * 4);
+    uint32_t* idx = (uint32_t*)ws.carve(ntasks * 4);
+    G1Jac* buckets = (G1Jac*)ws.carve((size_t)nkeys * sizeof(G1Jac));
+    hipLaunchKernelGGL(k_g1_msm_tasks, dim3(ceil_div(n, 256)), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(d_scalars), n, c,
+                       nwin, scalars_mont, nkeys, keys, idx);
+    GM_LAUNCH_CHECK();
+    const size_t mark = ws.used;
+    rc = g1_sum_by_key(ws, aff, jac, keys, idx, ntasks, nkeys, buckets, s);
+    if (rc) return rc;
+    ws.used = mark;  // the engine's scratch is free again; the bucket array stays
+    // window w contributes 2^(c w) * sum_d d * B[w][d]: all windows at once as one weighted sum over bit positions
+    std::vector<G1Jac> wsum;
+    rc = g1_weighted_sums(ws, buckets, nwin, 1u << c, &wsum, s);
+    if (rc) return rc;
+    G1Jac acc = g1_inf();
+    for (uint32_t w = nwin; w-- > 0;) {
+        for (uint32_t k = 0; k < c; k++) acc = g1_dbl(acc);
+        acc = g1_add(acc, wsum[w]);
+    }
+    *h_out = acc;
+    return GM_OK;
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+// ============================================================================================ C ABI
+static void put_aff(uint64_t* h, const G1Jac& p) {
+    const G1Aff a = g1_to_aff(p);
+    memcpy(h, &a, sizeof(G1Aff));
+}
+
+extern "C" int32_t gm_g1_release_scratch(void) {
+    G1Scratch& ws = g1_scratch();
+    std::lock_guard<std::mutex> lock(ws.mu);
+    ws.release();
+    return GM_OK;
+}
+
+// host-side point arithmetic (same source as the device code): op 0 add (jac, jac) -> jac, 1 double, 2 mixed add
+// (jac, aff) -> jac, 3 into_affine (jac -> aff), 4 affine + affine -> jac, 5 on-curve check of an affine point
+// (out: one u64 per point), 6 Fq mul (a, b: 6 x u64), 7 Fq mul through the 32-bit-limb device formulation
+extern "C" int32_t gm_g1_host(int32_t op, const uint64_t* h_a, const uint64_t* h_b, uint64_t* h_out, uint64_t n) {
+    GM_REQUIRE(op >= 0 && op <= 7 && h_a && h_out, "bad argument");
+    GM_REQUIRE(!(op == 0 || op == 2 || op == 4 || op == 6 || op == 7) || h_b, "second operand missing");
+    for (uint64_t i = 0; i < n; i++) {
+        G1Jac ja, jb, jr;
+        G1Aff aa, ab, ar;
+        switch (op) {
+            case 0: memcpy(&ja, h_a + 18 * i, 144); memcpy(&jb, h_b + 18 * i, 144); jr = g1_add(ja, jb); memcpy(h_out + 18 * i, &jr, 144); break;
+            case 1: memcpy(&ja, h_a + 18 * i, 144); jr = g1_dbl(ja); memcpy(h_out + 18 * i, &jr, 144); break;
+            case 2: memcpy(&ja, h_a + 18 * i, 144); memcpy(&ab, h_b + 12 * i, 96); jr = g1_add_mixed(ja, ab); memcpy(h_out + 18 * i, &jr, 144); break;
+            case 3: memcpy(&ja, h_a + 18 * i, 144); ar = g1_to_aff(ja); memcpy(h_out + 12 * i, &ar, 96); break;
+            case 4: memcpy(&aa, h_a + 12 * i, 96); memcpy(&ab, h_b + 12 * i, 96); jr = g1_add_aff(aa, ab); memcpy(h_out + 18 * i, &jr, 144); break;
+            case 5: memcpy(&aa, h_a + 12 * i, 96); h_out[i] = g1_aff_on_curve(aa) ? 1 : 0; break;
+            default: {
+                Fq x, y;
+                memcpy(&x, h_a + 6 * i, 48); memcpy(&y, h_b + 6 * i, 48);
+                const Fq z = op == 6 ? fq_mul(x, y) : fq_mul_c(x, y);
+                memcpy(h_out + 6 * i, &z, 48);
+            }
+        }
+    }
+    return GM_OK;
+}
+
+// elementwise device point ops (tests of the device formulas): same op codes 0..4 as gm_g1_host
+namespace gm {
+__global__ void __launch_bounds__(128) k_g1_batch(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
+                                                   uint64_t* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Jac* ja = reinterpret_cast<const G1Jac*>(a);
+    const G1Jac* jb = reinterpret_cast<const G1Jac*>(b);
+    const G1Aff* aa = reinterpret_cast<const G1Aff*>(a);
+    const G1Aff* ab = reinterpret_cast<const G1Aff*>(b);
+    G1Jac* jo = reinterpret_cast<G1Jac*>(out);
+    switch (op) {
+        case 0: g1_store(jo + i, g1_add(g1_load(ja + i), g1_load(jb + i))); break;
+        case 1: g1_store(jo + i, g1_dbl(g1_load(ja + i))); break;
+        case 2: g1_store(jo + i, g1_add_mixed(g1_load(ja + i), g1_aff_load(ab + i))); break;
+        case 3: g1_aff_store(reinterpret_cast<G1Aff*>(out) + i, g1_to_aff(g1_load(ja + i))); break;
+        default: g1_store(jo + i, g1_add_aff(g1_aff_load(aa + i), g1_aff_load(ab + i))); break;
+    }
+}
+}  // namespace gm
+
+extern "C" int32_t gm_g1_batch(int32_t op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n, void* stream) {
+    GM_REQUIRE(op >= 0 && op <= 4 && d_a && d_out, "bad argument");
+    GM_REQUIRE(!(op == 0 || op == 2 || op == 4) || d_b, "second operand missing");
+    if (n == 0) return GM_OK;
+    hipLaunchKernelGGL(k_g1_batch, dim3(ceil_div(n, 128)), dim3(128), 0, as_stream(stream), op, d_a, d_b, d_out, n);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_gen_points(uint64_t* d_points_aff, uint64_t n, uint64_t seed, void* stream) {
+    GM_REQUIRE(d_points_aff, "null argument");
+    if (n == 0) return GM_OK;
+    // the standard generator (ark-bls12-381 G1_GENERATOR_X / _Y), canonical -> Montgomery on the host
+    static const uint32_t GX[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+                                    0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
+    static const uint32_t GY[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
+                                    0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+    G1Aff g;
+    memcpy(&g.x, GX, 48);
+    memcpy(&g.y, GY, 48);
+    g.x = fq_to_mont(g.x);
+    g.y = fq_to_mont(g.y);
+    GM_REQUIRE(g1_aff_on_curve(g), "generator constant is off the curve");
+    hipLaunchKernelGGL(k_g1_gen_points, dim3(ceil_div(n, 128)), dim3(128), 0, as_stream(stream), g, n, seed,
+                       reinterpret_cast<G1Aff*>(d_points_aff));
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_msm(const uint64_t* d_bases_aff, const uint64_t* d_scalars, uint64_t n, int32_t scalars_mont,
+                             uint32_t nbits, uint64_t* h_out_aff, void* stream) {
+    GM_REQUIRE((d_bases_aff && d_scalars) || n == 0, "null argument");
+    GM_REQUIRE(h_out_aff, "null output");
+    G1Jac r;
+    int32_t rc = g1_msm_core(reinterpret_cast<const G1Aff*>(d_bases_aff), nullptr, d_scalars, n, scalars_mont, nbits, &r,
+                             as_stream(stream));
+    if (rc) return rc;
+    put_aff(h_out_aff, r);
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_msm_nonaff(const uint64_t* d_bases_jac, const uint64_t* d_scalars, uint64_t n, int32_t scalars_mont,
+                                    uint32_t nbits, uint64_t* h_out_aff, void* stream) {
+    GM_REQUIRE((d_bases_jac && d_scalars) || n == 0, "null argument");
+    GM_REQUIRE(h_out_aff, "null output");
+    G1Jac r;
+    int32_t rc = g1_msm_core(nullptr, reinterpret_cast<const G1Jac*>(d_bases_jac), d_scalars, n, scalars_mont, nbits, &r,
+                             as_stream(stream));
+    if (rc) return rc;
+    put_aff(h_out_aff, r);
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_bucket_sums(const uint64_t* d_bases_aff, const uint32_t* d_mapping, uint64_t n, uint32_t n_buckets,
+                                     uint64_t* d_out_jac, void* stream) {
+    GM_REQUIRE(d_bases_aff && d_mapping && d_out_jac && n_buckets >= 1, "bad argument");
+    hipStream_t s = as_stream(stream);
+    G1Scratch& ws = g1_scratch();
+    std::lock_guard<std::mutex> lock(ws.mu);
+    int32_t rc = ws.reserve(2 * al(n * 4 + 4) + al(64) + g1_engine_bytes(n, n_buckets) + 8192);
+    if (rc) return rc;
+    ws.used = 0;
+    uint32_t* keys = (uint32_t*)ws.carve(n * 4 + 4);
+    uint32_t* idx = (uint32_t*)ws.carve(n * 4 + 4);
+    uint32_t* bad = (uint32_t*)ws.carve(64);
+    GM_HIP(hipMemsetAsync(bad, 0, 4, s));
+    if (n) {
+        hipLaunchKernelGGL(k_g1_map_tasks, dim3(ceil_div(n, 256)), dim3(256), 0, s, d_mapping, n, n_buckets, keys, idx, bad);
+        GM_LAUNCH_CHECK();
+    }
+    rc = g1_sum_by_key(ws, reinterpret_cast<const G1Aff*>(d_bases_aff), nullptr, keys, idx, n, n_buckets,
+                       reinterpret_cast<G1Jac*>(d_out_jac), s);
+    if (rc) return rc;
+    uint32_t nbad = 0;
+    GM_HIP(hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    GM_REQUIRE(nbad == 0, "%u mapping entries out of range (index out of bounds panic in pullback.rs:45)", nbad);
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_pullback_msm(const uint64_t* d_bases_aff, const uint32_t* d_mapping, uint64_t n,
+                                      const uint64_t* d_image, uint32_t image_len, uint64_t* h_out_aff, void* stream) {
+    GM_REQUIRE(d_bases_aff && d_mapping && d_image && h_out_aff && image_len >= 1, "bad argument");
+    G1Jac* d_b = nullptr;
+    GM_HIP(hipMalloc((void**)&d_b, (size_t)image_len * sizeof(G1Jac)));
+    int32_t rc = gm_g1_bucket_sums(d_bases_aff, d_mapping, n, image_len, reinterpret_cast<uint64_t*>(d_b), stream);
+    if (!rc) rc = gm_g1_msm_nonaff(reinterpret_cast<const uint64_t*>(d_b), d_image, image_len, 1, 255, h_out_aff, stream);
+    (void)hipFree(d_b);
+    return rc;
+}
+
+extern "C" int32_t gm_g1_weighted_sum(const uint64_t* d_buckets_jac, uint32_t n_groups, uint32_t group_len, uint64_t* h_out_aff,
+                                      void* stream) {
+    GM_REQUIRE(d_buckets_jac && h_out_aff && n_groups >= 1 && group_len >= 1, "bad argument");
+    G1Scratch& ws = g1_scratch();
+    std::lock_guard<std::mutex> lock(ws.mu);
+    int32_t rc = ws.reserve(g1_weighted_bytes(n_groups, group_len));
+    if (rc) return rc;
+    ws.used = 0;
+    std::vector<G1Jac> r;
+    rc = g1_weighted_sums(ws, reinterpret_cast<const G1Jac*>(d_buckets_jac), n_groups, group_len, &r, as_stream(stream));
+    if (rc) return rc;
+    for (uint32_t g = 0; g < n_groups; g++) put_aff(h_out_aff + 12 * (size_t)g, r[g]);
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_prepare_bases(const uint64_t* d_bases_aff, uint64_t n, uint32_t gamma, uint64_t* d_tables_aff,
+                                       void* stream) {
+    GM_REQUIRE(d_bases_aff && d_tables_aff && gamma >= 1 && gamma <= 8, "bad argument (1 <= gamma <= 8: coefficients are u8)");
+    if (n == 0) return GM_OK;
+    const uint64_t total = ((n + gamma - 1) / gamma) * ((1u << gamma) - 1);
+    hipLaunchKernelGGL(k_g1_prepare_tables, dim3(ceil_div(total, 128)), dim3(128), 0, as_stream(stream),
+                       reinterpret_cast<const G1Aff*>(d_bases_aff), n, gamma, reinterpret_cast<G1Aff*>(d_tables_aff));
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_binary_msm(const uint8_t* d_coefs, const uint64_t* d_tables_aff, uint64_t n_chunks, uint32_t gamma,
+                                    uint64_t* h_out_aff, void* stream) {
+    GM_REQUIRE(h_out_aff && gamma >= 1 && gamma <= 8, "bad argument");
+    GM_REQUIRE((d_coefs && d_tables_aff) || n_chunks == 0, "null argument");
+    hipStream_t s = as_stream(stream);
+    if (n_chunks == 0) { put_aff(h_out_aff, g1_inf()); return GM_OK; }
+    GM_REQUIRE(n_chunks * ((1ull << gamma) - 1) < (1ull << 31), "table too large");
+    G1Scratch& ws = g1_scratch();
+    std::lock_guard<std::mutex> lock(ws.mu);
+    int32_t rc = ws.reserve(2 * al(n_chunks * 4 + 4) + al(sizeof(G1Jac)) + g1_engine_bytes(n_chunks, 1) + 8192);
+    if (rc) return rc;
+    ws.used = 0;
+    uint32_t* keys = (uint32_t*)ws.carve(n_chunks * 4 + 4);
+    uint32_t* idx = (uint32_t*)ws.carve(n_chunks * 4 + 4);
+    G1Jac* d_r = (G1Jac*)ws.carve(sizeof(G1Jac));
+    hipLaunchKernelGGL(k_g1_binary_tasks, dim3(ceil_div(n_chunks, 256)), dim3(256), 0, s, d_coefs, n_chunks, (1u << gamma) - 1, keys,
+                       idx);
+    GM_LAUNCH_CHECK();
+    rc = g1_sum_by_key(ws, reinterpret_cast<const G1Aff*>(d_tables_aff), nullptr, keys, idx, n_chunks, 1, d_r, s);
+    if (rc) return rc;
+    G1Jac r;
+    GM_HIP(hipMemcpyAsync(&r, d_r, sizeof(G1Jac), hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    put_aff(h_out_aff, r);
+    return GM_OK;
+}
+
+// PushForwardState::new, G1 part (pushforward.rs:395-456, 504-524) from the digits / counter of the plan's last run.
+//   d_basis_aff: kzg_basis(), >= 2^(x_logsize + clm) affine points
+//   d_d_outer:  n_mat * 2^d_logsize Jacobian points, d_c_outer: n_mat * c_stride (c_stride = longest bucket row of the run,
+//               returned in *c_stride; the reference's c_outer_buckets[m] is the prefix of length c_upper_bound[m] <= c_stride,
+//               the remaining entries are the point at infinity); h_d_comm / h_c_comm: n_mat affine points.
+extern "C" int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_basis_aff, uint32_t clm, uint64_t* d_d_outer,
+                                   uint64_t* d_c_outer, uint64_t c_outer_cap, uint32_t* c_stride, uint64_t* h_d_comm,
+                                   uint64_t* h_c_comm, void* stream) {
+    GM_REQUIRE(plan && d_basis_aff && d_d_outer && d_c_outer && c_stride, "null argument");
+    GM_REQUIRE(plan->y0 == 0 && plan->nwin == plan->y_size, "the outer buckets need a plan over all windows");
+    GM_REQUIRE(clm <= 8 && plan->x_log + clm < 31, "bad commitment_log_multiplicity");
+    hipStream_t s = as_stream(stream);
+    const uint64_t N = plan->N;
+    const uint32_t ny = plan->nwin, nd = 1u << plan->d_log;
+    const uint32_t n_mat = (ny + (1u << clm) - 1) >> clm;
+    const uint64_t ntasks = N * ny;
+    // longest bucket row = max counter + 1
+    std::vector<uint32_t> rl(plan->nrows);
+    GM_HIP(hipMemcpyAsync(rl.data(), plan->row_len, (size_t)plan->nrows * 4, hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    uint32_t cmax = 1;
+    for (uint32_t v : rl) if (v > cmax) cmax = v;
+    *c_stride = cmax;
+    GM_REQUIRE((uint64_t)n_mat * cmax <= c_outer_cap, "c_outer buffer too small: need %llu points", (unsigned long long)n_mat * cmax);
+    G1Scratch& ws = g1_scratch();
+    std::lock_guard<std::mutex> lock(ws.mu);
+    const uint32_t kmax = n_mat * (cmax > nd ? cmax : nd);
+    size_t need = 2 * al(ntasks * 4) + g1_engine_bytes(ntasks, kmax) + 8192;
+    const size_t wneed = g1_weighted_bytes(n_mat, cmax > nd ? cmax : nd);
+    if (wneed > need) need = wneed;
+    int32_t rc = ws.reserve(need);
+    if (rc) return rc;
+    const G1Aff* basis = reinterpret_cast<const G1Aff*>(d_basis_aff);
+    for (int which = 0; which < 2; which++) {
+        ws.used = 0;
+        uint32_t* keys = (uint32_t*)ws.carve(ntasks * 4);
+        uint32_t* idx = (uint32_t*)ws.carve(ntasks * 4);
+        const uint32_t stride = which ? cmax : nd;
+        if (which == 0)
+            hipLaunchKernelGGL(k_g1_outer_tasks_u16, dim3(ceil_div(ntasks, 256)), dim3(256), 0, s, plan->digits, N, 0u, ny, clm, stride,
+                               keys, idx);
+        else
+            hipLaunchKernelGGL(k_g1_outer_tasks_u32, dim3(ceil_div(ntasks, 256)), dim3(256), 0, s, plan->counter, N, 0u, ny, clm, stride,
+                               keys, idx);
+        GM_LAUNCH_CHECK();
+        G1Jac* outp = reinterpret_cast<G1Jac*>(which ? d_c_outer : d_d_outer);
+        rc = g1_sum_by_key(ws, basis, nullptr, keys, idx, ntasks, n_mat * stride, outp, s);
+        if (rc) return rc;
+        uint64_t* h_comm = which ? h_c_comm : h_d_comm;
+        if (h_comm) {
+            ws.used = 0;
+            std::vector<G1Jac> r;
+            rc = g1_weighted_sums(ws, outp, n_mat, stride, &r, s);
+            if (rc) return rc;
+            for (uint32_t m = 0; m < n_mat; m++) put_aff(h_comm + 12 * (size_t)m, r[m]);
+        }
+    }
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_to_affine(const uint64_t* d_in_jac, uint64_t n, uint64_t* d_out_aff, void* stream) {
+    GM_REQUIRE(d_in_jac && d_out_aff, "null argument");
+    if (n == 0) return GM_OK;
+    hipLaunchKernelGGL(k_g1_to_affine, dim3(ceil_div(n, 128)), dim3(128), 0, as_stream(stream),
+                       reinterpret_cast<const G1Jac*>(d_in_jac), n, reinterpret_cast<G1Aff*>(d_out_aff));
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_from_affine(const uint64_t* d_in_aff, uint64_t n, uint64_t* d_out_jac, void* stream) {
+    GM_REQUIRE(d_in_aff && d_out_jac, "null argument");
+    if (n == 0) return GM_OK;
+    hipLaunchKernelGGL(k_g1_from_affine, dim3(ceil_div(n, 128)), dim3(128), 0, as_stream(stream),
+                       reinterpret_cast<const G1Aff*>(d_in_aff), n, reinterpret_cast<G1Jac*>(d_out_jac));
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}

@@ -281,8 +281,16 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs c
         if (VECVEC) {
             const uint32_t cell0 = (uint32_t)(2 * i);
             const uint64_t last_pair = (base + SC_THREADS - 1 < npairs) ? base + SC_THREADS - 1 : npairs - 1;
-            const uint32_t r = find_row_span(vv.off, vv.nrows, cell0, valid, (uint32_t)(2 * base), (uint32_t)(2 * last_pair));
-            if (!valid) continue;
+            // small (split) launches are latency bound: bracket the block's rows once instead of log2(nrows) dependent
+            // loads per thread; large launches hide that latency behind other waves and must not pay the barriers
+            uint32_t r;
+            if (SPLIT) {
+                r = find_row_span(vv.off, vv.nrows, cell0, valid, (uint32_t)(2 * base), (uint32_t)(2 * last_pair));
+                if (!valid) continue;
+            } else {
+                if (!valid) continue;
+                r = find_row(vv.off, vv.nrows, cell0);
+            }
             w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
         } else {
             if (!valid) continue;

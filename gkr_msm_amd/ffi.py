@@ -110,6 +110,20 @@ _SIGS = {
     "gm_msm_profile_read": (C.c_int32, [vp, C.POINTER(C.c_float), C.c_int32]),
     "gm_msm_combine_host": (C.c_int32, [vp, C.c_uint32, C.c_uint32, vp]),
     "gm_msm_te": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
+    "gm_g1_msm": (C.c_int32, [vp, vp, C.c_uint64, C.c_int32, C.c_uint32, vp, vp]),
+    "gm_g1_msm_nonaff": (C.c_int32, [vp, vp, C.c_uint64, C.c_int32, C.c_uint32, vp, vp]),
+    "gm_g1_bucket_sums": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "gm_g1_pullback_msm": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp]),
+    "gm_g1_weighted_sum": (C.c_int32, [vp, C.c_uint32, C.c_uint32, vp, vp]),
+    "gm_g1_prepare_bases": (C.c_int32, [vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "gm_g1_binary_msm": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "gm_msm_g1_outer": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, C.c_uint64, u32p, vp, vp, vp]),
+    "gm_g1_to_affine": (C.c_int32, [vp, C.c_uint64, vp, vp]),
+    "gm_g1_from_affine": (C.c_int32, [vp, C.c_uint64, vp, vp]),
+    "gm_g1_host": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64]),
+    "gm_g1_batch": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64, vp]),
+    "gm_g1_gen_points": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp]),
+    "gm_g1_release_scratch": (C.c_int32, []),
     "gm_bs_scalars_into_bigint": (C.c_int32, [vp, vp, C.c_uint64, vp]),
     "gm_gen_points": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp]),
 }

@@ -439,3 +439,106 @@ def gkr_msm_prove(d_points, d_bits_u8, log_num_points, log_num_scalar_bits, tape
                                                                         for c in range(3)],
                 point=codec.from_mont_limbs(fpt[: npt.value]), evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value,
                 rounds=rounds.value, witness_ms=wms.value)
+
+
+# ------------------------------------------------------------------ BLS12-381 G1 (include/gkrmsm.h, G1 section)
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def g1_aff_dev(points):
+    return to_dev(codec.g1_aff_to_limbs(points))
+
+
+def g1_jac_dev(points, zs=None):
+    return to_dev(codec.g1_jac_to_limbs(points, zs))
+
+
+def g1_read_jac(t):
+    return codec.g1_jac_from_limbs(to_host(t))
+
+
+def g1_read_aff(t):
+    return codec.g1_aff_from_limbs(to_host(t))
+
+
+def _one_aff(buf):
+    return codec.g1_aff_from_limbs(buf)[0]
+
+
+def g1_msm(d_bases_aff, d_scalars, n, mont=False, nbits=255):
+    out = np.zeros(12, dtype=np.uint64)
+    ffi.check(ffi.lib().gm_g1_msm(_p(d_bases_aff), _p(d_scalars), n, 1 if mont else 0, nbits, out.ctypes.data, cur_stream()))
+    return _one_aff(out)
+
+
+def g1_msm_nonaff(d_bases_jac, d_scalars, n, mont=False, nbits=255):
+    out = np.zeros(12, dtype=np.uint64)
+    ffi.check(ffi.lib().gm_g1_msm_nonaff(_p(d_bases_jac), _p(d_scalars), n, 1 if mont else 0, nbits, out.ctypes.data,
+                                         cur_stream()))
+    return _one_aff(out)
+
+
+def g1_bucket_sums(d_bases_aff, mapping, n_buckets):
+    torch = torch_mod()
+    d_map = torch.from_numpy(np.asarray(mapping, dtype=np.uint32).view(np.int32)).cuda()
+    out = dev_empty(18 * n_buckets)
+    ffi.check(ffi.lib().gm_g1_bucket_sums(_p(d_bases_aff), _p(d_map), len(mapping), n_buckets, _p(out), cur_stream()))
+    return out
+
+
+def g1_pullback_msm(d_bases_aff, mapping, image):
+    torch = torch_mod()
+    d_map = torch.from_numpy(np.asarray(mapping, dtype=np.uint32).view(np.int32)).cuda()
+    d_img = to_dev(codec.to_mont_limbs(image))
+    out = np.zeros(12, dtype=np.uint64)
+    ffi.check(ffi.lib().gm_g1_pullback_msm(_p(d_bases_aff), _p(d_map), len(mapping), _p(d_img), len(image), out.ctypes.data,
+                                           cur_stream()))
+    return _one_aff(out)
+
+
+def g1_weighted_sum(d_buckets_jac, n_groups, group_len):
+    out = np.zeros((n_groups, 12), dtype=np.uint64)
+    ffi.check(ffi.lib().gm_g1_weighted_sum(_p(d_buckets_jac), n_groups, group_len, out.ctypes.data, cur_stream()))
+    return codec.g1_aff_from_limbs(out)
+
+
+def g1_prepare_bases(d_bases_aff, n, gamma):
+    nchunks = (n + gamma - 1) // gamma
+    out = dev_empty(12 * nchunks * ((1 << gamma) - 1))
+    ffi.check(ffi.lib().gm_g1_prepare_bases(_p(d_bases_aff), n, gamma, _p(out), cur_stream()))
+    return out
+
+
+def g1_binary_msm(coefs_u8, d_tables, gamma):
+    torch = torch_mod()
+    d_c = torch.from_numpy(np.asarray(coefs_u8, dtype=np.uint8)).cuda()
+    out = np.zeros(12, dtype=np.uint64)
+    ffi.check(ffi.lib().gm_g1_binary_msm(_p(d_c), _p(d_tables), len(coefs_u8), gamma, out.ctypes.data, cur_stream()))
+    return _one_aff(out)
+
+
+def g1_batch(op, d_a, d_b, n, out_words):
+    out = dev_empty(out_words * n)
+    ffi.check(ffi.lib().gm_g1_batch(op, _p(d_a), _p(d_b), _p(out), n, cur_stream()))
+    return out
+
+
+def g1_gen_points(n, seed):
+    out = dev_empty(12 * n)
+    ffi.check(ffi.lib().gm_g1_gen_points(_p(out), n, seed, cur_stream()))
+    return out
+
+
+def msm_g1_outer(plan, d_basis_aff, clm, c_cap_per_mat):
+    """(d_outer tensor, c_outer tensor, c_stride, d_comm, c_comm) of PushForwardState::new's G1 part"""
+    n_mat = (plan.nwin + (1 << clm) - 1) >> clm
+    nd = 1 << plan.d_logsize
+    d_d = dev_empty(18 * n_mat * nd)
+    d_c = dev_empty(18 * n_mat * c_cap_per_mat)
+    stride = C.c_uint32()
+    hd = np.zeros((n_mat, 12), dtype=np.uint64)
+    hc = np.zeros((n_mat, 12), dtype=np.uint64)
+    ffi.check(ffi.lib().gm_msm_g1_outer(plan.h, _p(d_basis_aff), clm, _p(d_d), _p(d_c), n_mat * c_cap_per_mat, C.byref(stride),
+                                        hd.ctypes.data, hc.ctypes.data, cur_stream()))
+    return d_d, d_c, stride.value, codec.g1_aff_from_limbs(hd), codec.g1_aff_from_limbs(hc)

@@ -276,6 +276,55 @@ int32_t gm_gkr_msm_prove_tr(const uint64_t* d_points_xy, const uint8_t* d_scalar
                             uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* n_challenges,
                             uint64_t* rounds, void* stream);
 
+/* ---------------------------------------------------------------- BLS12-381 G1 (a12 G1 part, a13, a14, a15, a17)
+ * The reference reaches G1 through ark-ec 0.4.2 (un-vendored).  Wire forms here (the Rust shim marshals, ark's structs are
+ * not repr(C)):  Fq = Montgomery (R = 2^384) 6 x u64 LE;  affine point = x, y (12 x u64, 96 bytes), the point at infinity is
+ * (0, 0);  Jacobian point = X, Y, Z (18 x u64, 144 bytes), infinity is Z = 0 (`Projective<g1::Config>`: x = X/Z^2, y = Y/Z^3).
+ * `Projective` equality in ark-ec is equality of the group element: single results come back in affine form (`into_affine`),
+ * bucket arrays as Jacobian points whose coordinates are NOT specified beyond the element they represent.
+ * Scalars: canonical bigints (4 x u64) or, with scalars_mont = 1, Fr elements in Montgomery form (`into_bigint()` is applied
+ * on the device, msm_nonaffine.rs:21-23).  nbits: scalar width to process (255 for full Fr; smaller when the caller knows a
+ * bound, the analogue of the max_num_bits early exit msm_nonaffine.rs:93-104).  Each call synchronises `stream`.
+ *
+ *   gm_g1_msm            <G1 as VariableBaseMSM>::msm(&[G1Affine], &[Fr])             KzgProvingKey::commit kzg.rs:123-126,
+ *                                                                                  CommitmentKey::commit_vec gkr_msm_simple.rs:59-62
+ *   gm_g1_msm_nonaff     VariableBaseMsmNonaffine::msm_nonaff / msm_bigint_nonaff   msm_nonaffine.rs:34-50 (bases: &[G1Projective])
+ *   gm_g1_bucket_sums    buckets[mapping[i]] += bases[i]                            pullback.rs:41-57
+ *   gm_g1_pullback_msm   Pullback::bucketed_msm (image: Fr Montgomery)              pullback.rs:27-59
+ *   gm_g1_weighted_sum   acc = sum_i i * bucket[g][i] for n_groups bucket arrays     pushforward.rs:504-524 (running-sum loop)
+ *   gm_g1_prepare_bases  prepare_bases: ceil(n/gamma) tables of 2^gamma - 1 affine   binary_msm.rs:32-48
+ *   gm_g1_binary_msm     binary_msm(coefs, tables)  (coefs = prepare_coefs bytes)   binary_msm.rs:19-29
+ *   gm_msm_g1_outer      d_outer_buckets, c_outer_buckets, d_comm, c_comm of PushForwardState::new from the digits / counter of
+ *                        the plan's last gm_msm_run                                 pushforward.rs:395-456, 504-524
+ *                        (phase 2, pushforward.rs:596-605 = gm_g1_msm_nonaff over these bucket arrays with the eq tables)
+ *   gm_g1_host / gm_g1_batch  elementwise point arithmetic on host / device memory: op 0 add (jac, jac), 1 double (jac),
+ *                        2 mixed add (jac, aff), 3 into_affine (jac -> aff), 4 affine + affine -> jac; host only: 5 on-curve
+ *                        check (one u64 per point), 6 Fq multiplication, 7 Fq multiplication, device formulation */
+int32_t gm_g1_msm(const uint64_t* d_bases_aff, const uint64_t* d_scalars, uint64_t n, int32_t scalars_mont, uint32_t nbits,
+                  uint64_t* h_out_aff, void* stream);
+int32_t gm_g1_msm_nonaff(const uint64_t* d_bases_jac, const uint64_t* d_scalars, uint64_t n, int32_t scalars_mont,
+                         uint32_t nbits, uint64_t* h_out_aff, void* stream);
+int32_t gm_g1_bucket_sums(const uint64_t* d_bases_aff, const uint32_t* d_mapping, uint64_t n, uint32_t n_buckets,
+                          uint64_t* d_out_jac, void* stream);
+int32_t gm_g1_pullback_msm(const uint64_t* d_bases_aff, const uint32_t* d_mapping, uint64_t n, const uint64_t* d_image,
+                           uint32_t image_len, uint64_t* h_out_aff, void* stream);
+int32_t gm_g1_weighted_sum(const uint64_t* d_buckets_jac, uint32_t n_groups, uint32_t group_len, uint64_t* h_out_aff,
+                           void* stream);
+int32_t gm_g1_prepare_bases(const uint64_t* d_bases_aff, uint64_t n, uint32_t gamma, uint64_t* d_tables_aff, void* stream);
+int32_t gm_g1_binary_msm(const uint8_t* d_coefs, const uint64_t* d_tables_aff, uint64_t n_chunks, uint32_t gamma,
+                         uint64_t* h_out_aff, void* stream);
+int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_basis_aff, uint32_t commitment_log_multiplicity,
+                        uint64_t* d_d_outer_jac, uint64_t* d_c_outer_jac, uint64_t c_outer_cap, uint32_t* c_stride,
+                        uint64_t* h_d_comm_aff, uint64_t* h_c_comm_aff, void* stream);
+int32_t gm_g1_to_affine(const uint64_t* d_in_jac, uint64_t n, uint64_t* d_out_aff, void* stream);
+int32_t gm_g1_from_affine(const uint64_t* d_in_aff, uint64_t n, uint64_t* d_out_jac, void* stream);
+int32_t gm_g1_host(int32_t op, const uint64_t* h_a, const uint64_t* h_b, uint64_t* h_out, uint64_t n);
+int32_t gm_g1_batch(int32_t op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n, void* stream);
+/* synthetic SRS for bench / tests: n points k_i * G (G = the standard G1 generator), affine */
+int32_t gm_g1_gen_points(uint64_t* d_points_aff, uint64_t n, uint64_t seed, void* stream);
+/* frees the grow-only device scratch the G1 calls share */
+int32_t gm_g1_release_scratch(void);
+
 /* Bandersnatch ScalarField (Montgomery, as stored by ark `Fr` of ark-ed-on-bls12-381-bandersnatch)
  * -> canonical bigint: the `into_bigint()` of pushforward.rs:352 / msm_nonaffine.rs:21-23. */
 int32_t gm_bs_scalars_into_bigint(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream);
