@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--cpu-sumcheck-xlog", type=int, default=17)
     ap.add_argument("--gen1-log-points", type=int, default=18, help="gen-1 gkr_msm_prove size (0 = skip; 20 needs ~210 GiB)")
     ap.add_argument("--cpu-gen1-log-points", type=int, default=12)
+    ap.add_argument("--g1-log-points", type=int, default=20, help="BLS12-381 G1 MSM size (KZG commit shape; 0 = skip)")
+    ap.add_argument("--cpu-g1-log-points", type=int, default=15)
+    ap.add_argument("--cpu-g1-outer-xlog", type=int, default=13)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -229,6 +232,83 @@ def main():
                        "rounds_per_sec": round(g1["rounds"] / max(g_dt - g1["witness_ms"] * 1e-3, 1e-9), 1),
                        "points_per_sec": round((1 << lp) / g_dt, 1)}
         del d_bits
+
+    # ---- BLS12-381 G1 side: KZG-commit-shaped MSM and the outer buckets of PushForwardState::new
+    if world == 1 and args.g1_log_points > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        ng = 1 << args.g1_log_points
+        d_srs = harness.g1_gen_points(ng, 0x53525331)
+        g_sc = np.random.default_rng(21).integers(0, 2 ** 64, size=(ng, 4), dtype=np.uint64)
+        g_sc[:, 3] &= np.uint64((1 << 62) - 1)            # < 2^254 < r: canonical Fr bigints
+        d_gsc = harness.to_dev(g_sc)
+        harness.g1_msm(d_srs, d_gsc, ng)                   # warmup (scratch allocation)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            g_res = harness.g1_msm(d_srs, d_gsc, ng)
+        g_dt = (time.perf_counter() - t1) / reps
+        out["g1"] = {"msm": {"workload": "G1 MSM (KzgProvingKey::commit shape) 2^%d affine bases x 255-bit scalars" % args.g1_log_points,
+                             "ms": round(g_dt * 1e3, 3), "points_per_sec": round(ng / g_dt, 1)}}
+        if not args.no_sumcheck:
+            # outer buckets of the bench shape: re-run the bucketing (the plan was closed by the gen-1 leg)
+            plan_o = harness.MsmPlan(x_log, d_log, y_size)
+            plan_o.run(d_pts, d_sc)
+            cap = max(n >> 3, 64)
+            harness.msm_g1_outer(plan_o, d_srs[: 12 * n], 0, cap)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            o_res = harness.msm_g1_outer(plan_o, d_srs[: 12 * n], 0, cap)
+            o_dt = time.perf_counter() - t1
+            out["g1"]["outer_buckets"] = {
+                "workload": "d_outer + c_outer accumulation + c/d commitments, x_logsize=%d d_logsize=%d y_size=%d clm=0" % (
+                    x_log, d_log, y_size), "ms": round(o_dt * 1e3, 2), "g1_adds": 2 * n * y_size,
+                "g1_adds_per_sec": round(2 * n * y_size / o_dt, 1)}
+            del o_res
+            plan_o.close()
+        if not args.no_cpu_baseline:
+            import oracle_ffi as O
+            threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+            lg2 = min(args.cpu_g1_log_points, args.g1_log_points)
+            n2 = 1 << lg2
+            srs_h = harness.to_host(d_srs[: 12 * n2]).reshape(n2, 12)
+            t1 = time.perf_counter()
+            c_res = O.g1_msm_affine(srs_h, g_sc[:n2], threads)
+            c_dt = time.perf_counter() - t1
+            g_same = harness.g1_msm(d_srs, d_gsc, n2)
+            t1 = time.perf_counter()
+            g_same = harness.g1_msm(d_srs, d_gsc, n2)
+            gs_dt = time.perf_counter() - t1
+            assert codec.g1_aff_from_limbs(c_res)[0] == g_same, "GPU G1 MSM differs from the CPU oracle"
+            out["g1"]["msm"]["cpu_baseline"] = {
+                "value": round(n2 / c_dt, 1), "unit": "points/s", "cores": threads, "kind": "port",
+                "sample": "msm_bigint_wnaf_nonaff, first 2^%d bases, %.2f s" % (lg2, c_dt),
+                "gpu_same_sample_points_per_sec": round(n2 / gs_dt, 1), "parity": "same group element"}
+            if "outer_buckets" in out["g1"]:
+                xo = min(args.cpu_g1_outer_xlog, x_log)
+                no = 1 << xo
+                plan_s = harness.MsmPlan(xo, d_log, y_size)
+                plan_s.run(harness.to_dev(harness.to_host(d_pts).reshape(n, 8)[:no]), harness.to_dev(sc[:no]))
+                dg, ct, _ = plan_s.digits_counter_rowlen()
+                t1 = time.perf_counter()
+                c_o = O.g1_pushforward_outer(dg, ct, srs_h[:no] if no <= n2 else harness.to_host(d_srs[: 12 * no]).reshape(no, 12),
+                                             xo, d_log, y_size, 0, threads)
+                co_dt = time.perf_counter() - t1
+                harness.msm_g1_outer(plan_s, d_srs[: 12 * no], 0, no)
+                t1 = time.perf_counter()
+                g_o = harness.msm_g1_outer(plan_s, d_srs[: 12 * no], 0, no)
+                go_dt = time.perf_counter() - t1
+                same = (g_o[3] == codec.g1_aff_from_limbs(c_o["d_comm"]) and g_o[4] == codec.g1_aff_from_limbs(c_o["c_comm"])
+                        and harness.g1_read_jac(g_o[0]) == codec.g1_jac_from_limbs(c_o["d_outer"]))
+                assert same, "GPU outer buckets differ from the CPU oracle"
+                out["g1"]["outer_buckets"]["cpu_baseline"] = {
+                    "value": round(2 * no * y_size / co_dt, 1), "unit": "g1_adds/s", "cores": threads, "kind": "port",
+                    "sample": "same accumulation at x_logsize=%d: %.2f s" % (xo, co_dt),
+                    "gpu_same_sample_g1_adds_per_sec": round(2 * no * y_size / go_dt, 1),
+                    "parity": "same group elements (d_outer buckets, c_comm, d_comm)"}
+                plan_s.close()
+        del d_srs, d_gsc
+        ffi.check(L.gm_g1_release_scratch())
 
     # ---- CPU baseline + in-run parity (rank 0, N = 1)
     if world == 1 and not args.no_cpu_baseline:

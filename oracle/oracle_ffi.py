@@ -167,3 +167,67 @@ def gkr_msm_prove(points_mont, bits_u8, lp, lb, tape_limbs, threads=1, msgs_cap=
         raise ValueError("or_gkr_msm_prove failed (rc=%d)" % rc)
     return dict(msgs=msgs[: nm.value], output=outp, point=fpt[: npt.value], evs=fev, tape_used=used.value,
                 rounds=rounds.value)
+
+
+# ------------------------------------------------------------------ G1 side (gkrmsm_oracle_g1.c)
+def g1_msm_wnaf_nonaff(bases_jac_limbs, scalars_limbs, threads=1):
+    """msm_bigint_wnaf_nonaff over (n, 18) uint64 Jacobian bases and (n, 4) canonical scalars -> (12,) affine limbs"""
+    L = lib()
+    b = np.ascontiguousarray(bases_jac_limbs, dtype=np.uint64)
+    s = np.ascontiguousarray(scalars_limbs, dtype=np.uint64)
+    out = np.zeros(12, dtype=np.uint64)
+    rc = L.or_g1_msm_wnaf_nonaff(C.c_void_p(b.ctypes.data), C.c_void_p(s.ctypes.data), C.c_uint64(len(s)), C.c_int(threads),
+                                 C.c_void_p(out.ctypes.data))
+    assert rc == 0
+    return out
+
+
+def g1_msm_affine(bases_aff_limbs, scalars_limbs, threads=1):
+    L = lib()
+    b = np.ascontiguousarray(bases_aff_limbs, dtype=np.uint64)
+    s = np.ascontiguousarray(scalars_limbs, dtype=np.uint64)
+    out = np.zeros(12, dtype=np.uint64)
+    rc = L.or_g1_msm_affine(C.c_void_p(b.ctypes.data), C.c_void_p(s.ctypes.data), C.c_uint64(len(s)), C.c_int(threads),
+                            C.c_void_p(out.ctypes.data))
+    assert rc == 0
+    return out
+
+
+def g1_binary_msm(coefs_u8, tables_aff_limbs, gamma):
+    L = lib()
+    c = np.ascontiguousarray(coefs_u8, dtype=np.uint8)
+    t = np.ascontiguousarray(tables_aff_limbs, dtype=np.uint64)
+    out = np.zeros(12, dtype=np.uint64)
+    rc = L.or_g1_binary_msm(C.c_void_p(c.ctypes.data), C.c_void_p(t.ctypes.data), C.c_uint64(len(c)), C.c_uint(gamma),
+                            C.c_void_p(out.ctypes.data))
+    assert rc == 0
+    return out
+
+
+def g1_pushforward_outer(digits_u16, counter_u32, basis_aff_limbs, x_log, d_log, y_size, clm, threads=1):
+    """-> dict(d_outer (n_mat*2^d, 18), c_outer (n_mat*c_stride, 18), c_stride, d_comm (n_mat, 12), c_comm (n_mat, 12))"""
+    L = lib()
+    dg = np.ascontiguousarray(digits_u16, dtype=np.uint16)
+    ct = np.ascontiguousarray(counter_u32, dtype=np.uint32)
+    bs = np.ascontiguousarray(basis_aff_limbs, dtype=np.uint64)
+    n_mat = (y_size + (1 << clm) - 1) >> clm
+    cmax = int(ct.max()) + 1
+    d_outer = np.zeros((n_mat << d_log, 18), dtype=np.uint64)
+    c_outer = np.zeros((n_mat * cmax, 18), dtype=np.uint64)
+    d_comm = np.zeros((n_mat, 12), dtype=np.uint64)
+    c_comm = np.zeros((n_mat, 12), dtype=np.uint64)
+    stride = C.c_uint32()
+    rc = L.or_g1_pushforward_outer(C.c_void_p(dg.ctypes.data), C.c_void_p(ct.ctypes.data), C.c_void_p(bs.ctypes.data),
+                                   C.c_uint(x_log), C.c_uint(d_log), C.c_uint(y_size), C.c_uint(clm), C.c_int(threads),
+                                   C.c_void_p(d_outer.ctypes.data), C.c_void_p(c_outer.ctypes.data), C.c_uint64(n_mat * cmax),
+                                   C.byref(stride), C.c_void_p(d_comm.ctypes.data), C.c_void_p(c_comm.ctypes.data))
+    assert rc == 0 and stride.value == cmax
+    return dict(d_outer=d_outer, c_outer=c_outer, c_stride=cmax, d_comm=d_comm, c_comm=c_comm)
+
+
+def g1_to_affine(jac_limbs):
+    L = lib()
+    j = np.ascontiguousarray(jac_limbs, dtype=np.uint64).reshape(-1, 18)
+    out = np.zeros((len(j), 12), dtype=np.uint64)
+    L.or_g1_to_affine(C.c_void_p(j.ctypes.data), C.c_uint64(len(j)), C.c_void_p(out.ctypes.data))
+    return out

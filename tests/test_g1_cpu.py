@@ -116,3 +116,50 @@ def test_host_fq_and_point_ops_vs_oracle():
     bad = codec.g1_aff_to_limbs([(3, 5)])
     ffi.check(L.gm_g1_host(5, bad.ctypes.data, None, oc.ctypes.data, 1))
     assert oc[0] == 0
+
+
+def test_c_oracle_g1_vs_python_oracle():
+    """the C restatement (CPU baseline of bench.py) against the Python big-int one"""
+    import oracle_ffi as O
+    n = 45
+    rng = F.SplitMix64(51)
+    bases = G.random_points(n, 52)
+    bases[4] = None
+    bases[6] = bases[5]
+    sc = [rng.next_fr() for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, 1, F.P - 1
+    zs = [rng.next_fr() | 1 for _ in range(n)]
+    want = G.msm_bigint_wnaf_nonaff(bases, sc)
+    got = O.g1_msm_wnaf_nonaff(codec.g1_jac_to_limbs(bases, zs), codec.ints_to_limbs(sc), threads=2)
+    assert codec.g1_aff_from_limbs(got)[0] == want
+    got = O.g1_msm_affine(codec.g1_aff_to_limbs(bases), codec.ints_to_limbs(sc))
+    assert codec.g1_aff_from_limbs(got)[0] == want
+    small = [rng.next() & 0xFFFF for _ in range(n)]    # the <= 60-bit early exit
+    got = O.g1_msm_affine(codec.g1_aff_to_limbs(bases), codec.ints_to_limbs(small))
+    assert codec.g1_aff_from_limbs(got)[0] == G.msm_bigint_wnaf_nonaff(bases, small)
+    # binary_msm
+    bits = [bool(rng.next() & 1) for _ in range(n)]
+    tabs = G.prepare_bases(bases, 4)
+    flat = [e for t in tabs for e in (t + [None] * (15 - len(t)))]
+    got = O.g1_binary_msm(G.prepare_coefs(bits, 4), codec.g1_aff_to_limbs(flat), 4)
+    assert codec.g1_aff_from_limbs(got)[0] == G.binary_msm(G.prepare_coefs(bits, 4), tabs)
+    # pushforward outer buckets: synthetic digits / counters consistent with a bucketing
+    x_log, d_log, y_size, clm = 4, 2, 3, 1
+    N = 1 << x_log
+    digits = [[rng.next() % (1 << d_log) for _ in range(N)] for _ in range(y_size)]
+    counter = []
+    for y in range(y_size):
+        seen, row = {}, []
+        for x in range(N):
+            row.append(seen.get(digits[y][x], 0))
+            seen[digits[y][x]] = row[-1] + 1
+        counter.append(row)
+    basis = G.random_points(N << clm, 53)
+    d_out, c_out, d_comm, c_comm = G.pushforward_outer(digits, counter, basis, x_log, d_log, clm)
+    r = O.g1_pushforward_outer(np.array(digits), np.array(counter), codec.g1_aff_to_limbs(basis), x_log, d_log, y_size, clm, 2)
+    gd, gc = codec.g1_jac_from_limbs(r["d_outer"]), codec.g1_jac_from_limbs(r["c_outer"])
+    for m in range(len(d_out)):
+        assert gd[m << d_log:(m + 1) << d_log] == d_out[m]
+        row = gc[m * r["c_stride"]:(m + 1) * r["c_stride"]]
+        assert row[:len(c_out[m])] == c_out[m] and all(p is None for p in row[len(c_out[m]):])
+    assert codec.g1_aff_from_limbs(r["d_comm"]) == d_comm and codec.g1_aff_from_limbs(r["c_comm"]) == c_comm
