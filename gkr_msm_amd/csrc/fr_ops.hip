@@ -156,6 +156,7 @@ extern "C" int32_t gm_set_device(int32_t device) { GM_HIP(hipSetDevice(device));
 extern "C" int32_t gm_stream_sync(void* stream) { GM_HIP(hipStreamSynchronize(as_stream(stream))); return GM_OK; }
 extern "C" int32_t gm_malloc(void** out, size_t bytes) { GM_REQUIRE(out, "null out"); GM_HIP(hipMalloc(out, bytes ? bytes : 16)); return GM_OK; }
 extern "C" int32_t gm_free(void* p) { GM_HIP(hipFree(p)); return GM_OK; }
+extern "C" int32_t gm_release_cached_memory(void) { gm::dev_pool().release(); return GM_OK; }
 extern "C" int32_t gm_memcpy_h2d(void* d, const void* h, size_t bytes, void* stream) {
     GM_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, as_stream(stream)));
     GM_HIP(hipStreamSynchronize(as_stream(stream)));

@@ -268,10 +268,10 @@ struct G1Scratch {
     std::mutex mu;
     int32_t reserve(size_t bytes) {
         if (bytes <= cap) return GM_OK;
-        if (base) (void)hipFree(base);
+        if (base) dev_free(base);
         base = nullptr;
         cap = 0;
-        hipError_t e = hipMalloc((void**)&base, bytes);
+        hipError_t e = dev_alloc((void**)&base, bytes);
         if (e != hipSuccess) return set_err(GM_ERR_HIP, "hipMalloc(G1 scratch %zu): %s", bytes, hipGetErrorString(e));
         cap = bytes;
         return GM_OK;
@@ -282,7 +282,7 @@ struct G1Scratch {
         return base + a;
     }
     void release() {
-        if (base) (void)hipFree(base);
+        if (base) dev_free(base);
         base = nullptr;
         cap = used = 0;
     }
@@ -629,10 +629,10 @@ extern "C" int32_t gm_g1_pullback_msm(const uint64_t* d_bases_aff, const uint32_
                                       const uint64_t* d_image, uint32_t image_len, uint64_t* h_out_aff, void* stream) {
     GM_REQUIRE(d_bases_aff && d_mapping && d_image && h_out_aff && image_len >= 1, "bad argument");
     G1Jac* d_b = nullptr;
-    GM_HIP(hipMalloc((void**)&d_b, (size_t)image_len * sizeof(G1Jac)));
+    GM_HIP(dev_alloc((void**)&d_b, (size_t)image_len * sizeof(G1Jac)));
     int32_t rc = gm_g1_bucket_sums(d_bases_aff, d_mapping, n, image_len, reinterpret_cast<uint64_t*>(d_b), stream);
     if (!rc) rc = gm_g1_msm_nonaff(reinterpret_cast<const uint64_t*>(d_b), d_image, image_len, 1, 255, h_out_aff, stream);
-    (void)hipFree(d_b);
+    dev_free(d_b);
     return rc;
 }
 

@@ -34,7 +34,7 @@ struct Arena {
     char* base = nullptr;
     size_t cap = 0, used = 0, high = 0;
     int32_t init(size_t bytes) {
-        hipError_t e = hipMalloc((void**)&base, bytes);
+        hipError_t e = dev_alloc((void**)&base, bytes);
         if (e != hipSuccess) return set_err(GM_ERR_HIP, "hipMalloc(arena %zu): %s", bytes, hipGetErrorString(e));
         cap = bytes;
         return GM_OK;
@@ -47,7 +47,7 @@ struct Arena {
         return base + a;
     }
     void reset() { used = 0; }
-    ~Arena() { if (base) (void)hipFree(base); }
+    ~Arena() { if (base) dev_free(base); }
 };
 inline Arena*& current_arena() {
     static thread_local Arena* a = nullptr;
@@ -78,14 +78,14 @@ struct DevBuf {
             bytes = b;
             return GM_OK;
         }
-        hipError_t e = hipMalloc(&p, b);
+        hipError_t e = dev_alloc(&p, b);
         if (e != hipSuccess) return set_err(GM_ERR_HIP, "hipMalloc(%zu): %s", b, hipGetErrorString(e));
         owned = true;
         bytes = b;
         return GM_OK;
     }
     void free() {
-        if (p && owned) (void)hipFree(p);
+        if (p && owned) dev_free(p);
         p = nullptr;
         bytes = 0;
     }

@@ -520,7 +520,7 @@ template <typename T>
 static int32_t plan_alloc(gm_msm_plan* p, T** ptr, uint64_t count) {
     size_t b = (size_t)count * sizeof(T);
     if (b == 0) b = 16;
-    GM_HIP(hipMalloc((void**)ptr, b));
+    GM_HIP(dev_alloc((void**)ptr, b));
     p->bytes += b;
     return GM_OK;
 }
@@ -568,11 +568,11 @@ extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, ui
 
 extern "C" int32_t gm_msm_plan_destroy(gm_msm_plan* p) {
     if (!p) return GM_OK;
-    (void)hipFree(p->digits); (void)hipFree(p->counter); (void)hipFree(p->hist); (void)hipFree(p->row_len);
-    (void)hipFree(p->off[0]); (void)hipFree(p->off[1]); (void)hipFree(p->off[2]); (void)hipFree(p->cells);
-    for (int c = 0; c < 3; c++) { (void)hipFree(p->lvl[0][c]); (void)hipFree(p->lvl[1][c]); (void)hipFree(p->bsum[c]); }
-    (void)hipFree(p->win_pts);
-    (void)hipFree(p->tri_scratch);
+    dev_free(p->digits); dev_free(p->counter); dev_free(p->hist); dev_free(p->row_len);
+    dev_free(p->off[0]); dev_free(p->off[1]); dev_free(p->off[2]); dev_free(p->cells);
+    for (int c = 0; c < 3; c++) { dev_free(p->lvl[0][c]); dev_free(p->lvl[1][c]); dev_free(p->bsum[c]); }
+    dev_free(p->win_pts);
+    dev_free(p->tri_scratch);
     for (int i = 0; i <= GM_MSM_NSTAGE; i++) if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
     delete p;
     return GM_OK;
@@ -776,7 +776,7 @@ extern "C" int32_t gm_msm_phase1_polys(const gm_msm_plan* p, uint64_t* d_c, uint
     GM_LAUNCH_CHECK();
     uint32_t* cnt = nullptr;
     const uint64_t nc = p->N + p->nd;
-    GM_HIP(hipMalloc((void**)&cnt, nc * 4));
+    GM_HIP(dev_alloc((void**)&cnt, nc * 4));
     GM_HIP(hipMemsetAsync(cnt, 0, nc * 4, s));
     hipLaunchKernelGGL(k_access_counts, dim3(ceil_div(n, 256)), dim3(256), 0, s, p->digits, p->counter, n, cnt + p->N, cnt);
     GM_LAUNCH_CHECK();
@@ -786,7 +786,7 @@ extern "C" int32_t gm_msm_phase1_polys(const gm_msm_plan* p, uint64_t* d_c, uint
                        reinterpret_cast<Fr*>(d_ac_d));
     GM_LAUNCH_CHECK();
     GM_HIP(hipStreamSynchronize(s));
-    GM_HIP(hipFree(cnt));
+    dev_free(cnt);
     return GM_OK;
 }
 
@@ -800,7 +800,7 @@ extern "C" int32_t gm_msm_second_phase(const gm_msm_plan* p, const uint64_t* h_r
     memcpy(r.data(), h_r, r.size() * sizeof(Fr));
     Fr* buf = nullptr;
     const uint64_t tot = (2ull << xl) + (2ull << dl);
-    GM_HIP(hipMalloc((void**)&buf, tot * sizeof(Fr)));
+    GM_HIP(dev_alloc((void**)&buf, tot * sizeof(Fr)));
     Fr* eq_c = buf;                       // 2^xl, scratch 2^xl after it
     Fr* eq_d = buf + (2ull << xl);        // 2^dl, scratch after it
     std::vector<Fr*> lv(xl + 1);
@@ -820,6 +820,6 @@ extern "C" int32_t gm_msm_second_phase(const gm_msm_plan* p, const uint64_t* h_r
         if (hipGetLastError() != hipSuccess) rc = set_err(GM_ERR_HIP, "k_pull launch failed");
     }
     (void)hipStreamSynchronize(s);
-    (void)hipFree(buf);
+    dev_free(buf);
     return rc;
 }

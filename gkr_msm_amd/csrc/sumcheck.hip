@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs c
             // small (split) launches are latency bound: bracket the block's rows once instead of log2(nrows) dependent
             // loads per thread; large launches hide that latency behind other waves and must not pay the barriers
             uint32_t r;
-            if (SPLIT) {
+            if (SPLIT && (uint64_t)gridDim.x * SC_THREADS >= npairs) {  // single pass (block-uniform condition)
                 r = find_row_span(vv.off, vv.nrows, cell0, valid, (uint32_t)(2 * base), (uint32_t)(2 * last_pair));
                 if (!valid) continue;
             } else {
@@ -312,6 +312,132 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs c
         }
     }
     block_reduce_finish<NACC>(acc, fc);
+}
+
+// ------------------------------------------------------------------------------------------ lean large-round kernels
+// The generic kernels above keep every segment's inputs, outputs and both evaluation points live at once (256 VGPRs plus
+// AGPR spills: one wave per SIMD, ~45 G mul/s).  Large rounds of single-primitive layers -- every bintree layer and every
+// gen-1 layer -- go through these instead: the primitive is a template parameter, each output is folded into the gamma
+// combination as soon as it exists, and the evaluation points are walked by a rolled loop that reloads the pair (an L2
+// hit), so the live state is one set of inputs.  Field sums are exact: same round polynomials, bit for bit.
+#define LEAN_AFF_L1_BC 11  // StackedAlgFn(affine_l1, RepeatedAlgFn(BitCheckFn, 2)): the first bintree layer (bintree_add.rs:258-285)
+
+__device__ __forceinline__ constexpr int lean_n_in(int prim) {
+    return prim == FN_AFF_L1 ? 4 : prim == FN_AFF_L2 ? 3 : prim == FN_AFF_L3 ? 3 : prim == FN_PROJ_L1 ? 6 : prim == FN_PROJ_L2 ? 4
+         : prim == FN_PROJ_L3 ? 4 : prim == FN_PT_BIT_CHOICE ? 3 : prim == LEAN_AFF_L1_BC ? 6 : 0;
+}
+
+// sum_o gamma^o f_o(v) for the whole (single-primitive) layer function; g[o] = gamma^o on the device
+template <int PRIM>
+__device__ __forceinline__ Fr lean_gamma_eval(const Fr* v, const Fr* __restrict__ g) {
+    if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
+        Fr A = fr_mul(v[0], v[3]);
+        A = fr_add(A, fr_mul(fr_load(g + 1), fr_mul(v[2], v[1])));
+        const Fr t = fr_sub(fr_mul(v[1], v[3]), fr_mul_by_a(fr_mul(v[0], v[2])));
+        A = fr_add(A, fr_mul(fr_load(g + 2), t));
+        if (PRIM == LEAN_AFF_L1_BC) {
+            A = fr_add(A, fr_mul(fr_load(g + 3), fr_sub(fr_sqr(v[4]), v[4])));
+            A = fr_add(A, fr_mul(fr_load(g + 4), fr_sub(fr_sqr(v[5]), v[5])));
+        }
+        return A;
+    } else if (PRIM == FN_AFF_L2) {
+        Fr A = fr_add(v[0], v[1]);
+        A = fr_add(A, fr_mul(fr_load(g + 1), v[2]));
+        return fr_add(A, fr_mul(fr_load(g + 2), fr_mul(v[0], v[1])));
+    } else if (PRIM == FN_AFF_L3 || PRIM == FN_PROJ_L3) {
+        const Fr dxy = fr_mul_by_d(v[PRIM == FN_AFF_L3 ? 2 : 3]);
+        const Fr base = PRIM == FN_AFF_L3 ? fr_one() : v[2];
+        const Fr m = fr_sub(base, dxy), q = fr_add(base, dxy);
+        Fr A = fr_mul(m, v[0]);
+        A = fr_add(A, fr_mul(fr_load(g + 1), fr_mul(q, v[1])));
+        return fr_add(A, fr_mul(fr_load(g + 2), fr_mul(m, q)));
+    } else if (PRIM == FN_PROJ_L1) {
+        Fr A = fr_mul(v[0], v[4]);
+        A = fr_add(A, fr_mul(fr_load(g + 1), fr_mul(v[3], v[1])));
+        const Fr t = fr_sub(fr_mul(v[1], v[4]), fr_mul_by_a(fr_mul(v[0], v[3])));
+        A = fr_add(A, fr_mul(fr_load(g + 2), t));
+        return fr_add(A, fr_mul(fr_load(g + 3), fr_mul(v[2], v[5])));
+    } else if (PRIM == FN_PROJ_L2) {
+        Fr A = fr_mul(fr_add(v[0], v[1]), v[3]);
+        A = fr_add(A, fr_mul(fr_load(g + 1), fr_mul(v[2], v[3])));
+        A = fr_add(A, fr_mul(fr_load(g + 2), fr_sqr(v[3])));
+        return fr_add(A, fr_mul(fr_load(g + 3), fr_mul(v[0], v[1])));
+    } else {  // FN_PT_BIT_CHOICE: (b, x, y) -> (b x, b (y - 1) + 1)
+        Fr A = fr_mul(v[0], v[1]);
+        const Fr by = fr_add(fr_mul(v[0], fr_sub(v[2], fr_one())), fr_one());
+        return fr_add(A, fr_mul(fr_load(g + 1), by));
+    }
+}
+
+struct LeanCols {
+    const Fr* p[7];  // inputs of the primitive in order (+ the eq column for the generic object)
+};
+
+// deg-2 round sums with eq factored out (same contract as k_round_deg2<VECVEC, false>)
+template <int PRIM, bool VECVEC>
+__global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, const Fr* __restrict__ eq, const Fr* __restrict__ gp,
+                                                                 uint64_t npairs_dense, VVArgs vv, FinishCtx fc) {
+    constexpr int NACC = VECVEC ? 3 : 2;
+    constexpr int NI = lean_n_in(PRIM);
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    if (VECVEC) {
+        for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
+            const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+        }
+    }
+    const uint64_t npairs = VECVEC ? (uint64_t)(vv.off[vv.nrows] >> 1) : npairs_dense;
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+        Fr w;
+        if (VECVEC) {
+            const uint32_t cell0 = (uint32_t)(2 * i);
+            const uint32_t r = find_row(vv.off, vv.nrows, cell0);
+            w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
+        } else {
+            w = fr_load(eq + i);
+        }
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            Fr v[NI];
+#pragma unroll
+            for (int q = 0; q < NI; q++) {
+                const Fr p1 = fr_load(cols.p[q] + 2 * i + 1);
+                v[q] = h ? fr_sub(fr_dbl(p1), fr_load(cols.p[q] + 2 * i)) : p1;
+            }
+            const Fr t = fr_mul(lean_gamma_eval<PRIM>(v, gp), w);
+            if (h == 0) acc[0] = fr_add(acc[0], t); else acc[1] = fr_add(acc[1], t);
+        }
+    }
+    block_reduce_finish<NACC>(acc, fc);
+}
+
+// generic degree-3 round of F = eq * GammaWrapper(f) (same contract as k_round_generic<3, false>, kind 0); cols.p[NI] = eq
+template <int PRIM>
+__global__ void __launch_bounds__(SC_THREADS) k_round_generic3_lean(LeanCols cols, const Fr* __restrict__ gp, uint64_t npairs,
+                                                                     FinishCtx fc) {
+    constexpr int NI = lean_n_in(PRIM);
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+#pragma unroll 1
+        for (int s = 0; s < 3; s++) {
+            // argument at evaluation point s + 1:  p1 + s (p1 - p0)
+            Fr v[NI + 1];
+#pragma unroll
+            for (int q = 0; q <= NI; q++) {
+                const Fr p1 = fr_load(cols.p[q] + 2 * i + 1);
+                if (s == 0) v[q] = p1;
+                else {
+                    const Fr d = fr_sub(p1, fr_load(cols.p[q] + 2 * i));
+                    v[q] = fr_add(p1, s == 1 ? d : fr_dbl(d));
+                }
+            }
+            const Fr t = fr_mul(lean_gamma_eval<PRIM>(v, gp), v[NI]);
+            if (s == 0) acc[0] = fr_add(acc[0], t);
+            else if (s == 1) acc[1] = fr_add(acc[1], t);
+            else acc[2] = fr_add(acc[2], t);
+        }
+    }
+    block_reduce_finish<3>(acc, fc);
 }
 
 // inclusive->exclusive prefix sums of a (short) eq level: prefix[0] = 0, prefix[k] = sum_{i<k} v[i]; single block
@@ -550,7 +676,14 @@ struct RoundScratch {
 };
 
 // grid for a round: x over pairs (grid-stride beyond the cap), y = sub-units in split mode
-static constexpr uint64_t SC_SPLIT_MAX_PAIRS = 1ull << 14;
+static uint64_t sc_split_max_pairs() {
+    static const uint64_t v = [] {
+        const char* e = getenv("GM_SC_SPLIT_MAX_LOG");  // tuning knob (development): log2 of the largest split-mode round
+        return e ? (1ull << atoi(e)) : (1ull << 14);
+    }();
+    return v;
+}
+#define SC_SPLIT_MAX_PAIRS sc_split_max_pairs()
 static dim3 round_grid(uint64_t npairs, int ny) {
     uint64_t bx = (npairs + SC_THREADS - 1) / SC_THREADS;
     if (bx < 1) bx = 1;
@@ -558,6 +691,52 @@ static dim3 round_grid(uint64_t npairs, int ny) {
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     return dim3((unsigned)bx, (unsigned)ny);
+}
+
+// lean-kernel dispatch (large rounds of single-primitive layers)
+static int lean_prim_of(const SegPlan& sp) {
+    if (sp.nseg == 1 && sp.seg[0].out0 == 0) {
+        switch (sp.seg[0].prim) {
+            case FN_AFF_L1: case FN_AFF_L2: case FN_AFF_L3: case FN_PROJ_L1: case FN_PROJ_L2: case FN_PROJ_L3:
+            case FN_PT_BIT_CHOICE:
+                for (int q = 0; q < sp.seg[0].n_in; q++) if (sp.seg[0].in[q] != q) return 0;
+                return sp.seg[0].prim;
+            default: return 0;
+        }
+    }
+    if (sp.nseg == 3 && sp.seg[0].prim == FN_AFF_L1 && sp.seg[1].prim == FN_BITCHECK && sp.seg[2].prim == FN_BITCHECK &&
+        sp.seg[0].out0 == 0 && sp.seg[1].in[0] == 4 && sp.seg[2].in[0] == 5 && sp.seg[1].out0 == 3 && sp.seg[2].out0 == 4)
+        return LEAN_AFF_L1_BC;
+    return 0;
+}
+
+template <bool VECVEC>
+static int32_t launch_deg2_lean(int prim, dim3 grid, hipStream_t s, const LeanCols& lc, const Fr* eq, const Fr* gp, uint64_t npairs,
+                                const VVArgs& va, const FinishCtx& fc) {
+#define GM_LEAN_CASE(P)                                                                                                  \
+    case P: hipLaunchKernelGGL((k_round_deg2_lean<P, VECVEC>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, npairs, va, fc); break;
+    switch (prim) {
+        GM_LEAN_CASE(FN_AFF_L1) GM_LEAN_CASE(FN_AFF_L2) GM_LEAN_CASE(FN_AFF_L3) GM_LEAN_CASE(FN_PROJ_L1)
+        GM_LEAN_CASE(FN_PROJ_L2) GM_LEAN_CASE(FN_PROJ_L3) GM_LEAN_CASE(FN_PT_BIT_CHOICE) GM_LEAN_CASE(LEAN_AFF_L1_BC)
+        default: return set_err(GM_ERR_STATE, "no lean kernel for primitive %d", prim);
+    }
+#undef GM_LEAN_CASE
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+static int32_t launch_generic3_lean(int prim, dim3 grid, hipStream_t s, const LeanCols& lc, const Fr* gp, uint64_t npairs,
+                                    const FinishCtx& fc) {
+#define GM_LEAN_CASE(P)                                                                                                  \
+    case P: hipLaunchKernelGGL((k_round_generic3_lean<P>), grid, dim3(SC_THREADS), 0, s, lc, gp, npairs, fc); break;
+    switch (prim) {
+        GM_LEAN_CASE(FN_AFF_L1) GM_LEAN_CASE(FN_AFF_L2) GM_LEAN_CASE(FN_AFF_L3) GM_LEAN_CASE(FN_PROJ_L1)
+        GM_LEAN_CASE(FN_PROJ_L2) GM_LEAN_CASE(FN_PROJ_L3) GM_LEAN_CASE(FN_PT_BIT_CHOICE)
+        default: return set_err(GM_ERR_STATE, "no lean kernel for primitive %d", prim);
+    }
+#undef GM_LEAN_CASE
+    GM_LAUNCH_CHECK();
+    return GM_OK;
 }
 
 // ---- columns with ping-pong fold buffers --------------------------------------------------------
@@ -642,7 +821,13 @@ struct ScDense : gm_sc {
             const int ny = split ? D * (kind == 1 ? 1 : sp.nseg) : 1;
             const dim3 grid = round_grid(npairs, ny);
             const FinishCtx fc = rs.ctx();
-            if (D == 3 && split)
+            const int lean = (kind == 0 && D == 3 && !split && cols.k <= 7) ? lean_prim_of(sp) : 0;
+            if (lean && lean != LEAN_AFF_L1_BC) {
+                LeanCols lc;
+                for (int i = 0; i < cols.k; i++) lc.p[i] = cols.cur[i];
+                int32_t rc = launch_generic3_lean(lean, grid, stream, lc, d_gamma.fr(), npairs, fc);
+                if (rc) return rc;
+            } else if (D == 3 && split)
                 hipLaunchKernelGGL((k_round_generic<3, true>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
                                    d_gamma.fr(), npairs, fc);
             else if (D == 3)
@@ -718,7 +903,14 @@ struct ScDenseDeg2 : gm_sc {
         const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
         const dim3 grid = round_grid(npairs, split ? 2 * sp.nseg : 1);
         const VVArgs none{nullptr, 0, nullptr, nullptr};
-        if (split)
+        const int lean = (!split && cols.k <= 6) ? lean_prim_of(sp) : 0;
+        if (lean) {
+            LeanCols lc;
+            for (int i = 0; i < cols.k; i++) lc.p[i] = cols.cur[i];
+            int32_t rc = launch_deg2_lean<false>(lean, grid, stream, lc, eq_level(num_vars - 1 - round_idx), d_gamma.fr(), npairs, none,
+                                                 rs.ctx());
+            if (rc) return rc;
+        } else if (split)
             hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp,
                                eq_level(num_vars - 1 - round_idx), d_gamma.fr(), npairs, none, rs.ctx());
         else
@@ -805,7 +997,13 @@ struct ScVecVecDeg2 : gm_sc {
         const uint64_t gx = bound_pairs > nrows ? bound_pairs : nrows;  // the tail-weight loop runs over rows
         const dim3 grid = round_grid(gx, split ? 2 * sp.nseg : 1);
         const VVArgs va{off_cur, nrows, d_row_coef.fr(), eq_pre};
-        if (split)
+        const int lean = (!split && k <= 6) ? lean_prim_of(sp) : 0;
+        if (lean) {
+            LeanCols lc;
+            for (int i = 0; i < k; i++) lc.p[i] = cur[i];
+            int32_t rc = launch_deg2_lean<true>(lean, grid, stream, lc, eq_row, d_gamma.fr(), (uint64_t)0, va, rs.ctx());
+            if (rc) return rc;
+        } else if (split)
             hipLaunchKernelGGL((k_round_deg2<true, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
                                (uint64_t)0, va, rs.ctx());
         else

@@ -39,6 +39,9 @@ int32_t gm_stream_sync(void* stream);
 /* plain device memory helpers for non-torch callers (the Rust shim) */
 int32_t gm_malloc(void** out_d_ptr, size_t bytes);
 int32_t gm_free(void* d_ptr);
+/* Handles and workspaces keep the large device blocks they free on an idle list (re-allocating freshly freed HBM is slow
+ * and hipFree synchronises); this returns the idle blocks to the driver. */
+int32_t gm_release_cached_memory(void);
 int32_t gm_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
 int32_t gm_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 int32_t gm_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream); /* asynchronous */
