@@ -119,20 +119,33 @@ __global__ void k_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict
     for (uint32_t i = lane; i < nd; i += 64) out[i] = cnt[i];
 }
 
-// exclusive scan over chunks for every (window, digit); totals -> row_len
-__global__ void k_scan_chunks(uint32_t* __restrict__ hist, uint32_t* __restrict__ row_len, uint32_t nd,
-                              uint32_t nchunks, uint32_t nrows) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;  // r = w * nd + digit
-    if (r >= nrows) return;
-    uint32_t w = r / nd, dg = r % nd;
+// exclusive scan over chunks for every (window, digit); totals -> row_len.
+// hist[w][chunk][digit]: one 1024-thread block owns G = min(nd, 64) consecutive digits of one window; lane d walks digit
+// d (coalesced across the G lanes) over 1 / PARTS of the chunks, the PARTS partial sums are combined through LDS, and a
+// second walk writes the exclusive prefixes.  (A single thread per (window, digit) walking all chunks took 0.24 ms.)
+__global__ void __launch_bounds__(1024) k_scan_chunks(uint32_t* __restrict__ hist, uint32_t* __restrict__ row_len, uint32_t nd,
+                                                       uint32_t nchunks, uint32_t nrows) {
+    __shared__ uint32_t part_sum[1024];
+    const uint32_t G = nd < 64 ? nd : 64, parts = 1024 / G;
+    const uint32_t groups_per_win = nd / G;
+    const uint32_t w = blockIdx.x / groups_per_win, g = blockIdx.x % groups_per_win;
+    const uint32_t d = threadIdx.x % G, part = threadIdx.x / G;
+    const uint32_t dg = g * G + d;
+    const uint32_t per = (nchunks + parts - 1) / parts;
+    const uint32_t c0 = part * per, c1 = (c0 + per < nchunks) ? c0 + per : nchunks;
     uint32_t* p = hist + (uint64_t)w * nchunks * nd + dg;
+    uint32_t sum = 0;
+    for (uint32_t c = c0; c < c1; c++) sum += p[(uint64_t)c * nd];
+    part_sum[threadIdx.x] = sum;
+    __syncthreads();
     uint32_t acc = 0;
-    for (uint32_t c = 0; c < nchunks; c++) {
-        uint32_t v = p[(uint64_t)c * nd];
+    for (uint32_t q = 0; q < part; q++) acc += part_sum[q * G + d];
+    for (uint32_t c = c0; c < c1; c++) {
+        const uint32_t v = p[(uint64_t)c * nd];
         p[(uint64_t)c * nd] = acc;
         acc += v;
     }
-    row_len[r] = acc;
+    if (part == parts - 1) row_len[w * nd + dg] = acc;
 }
 
 // Exclusive scan of per-row lengths into row offsets, one 1024-thread block: every thread sums a contiguous
@@ -262,7 +275,7 @@ __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* _
 }
 
 // bintree level >= 1
-__global__ void k_add_level(const Fr* __restrict__ ix, const Fr* __restrict__ iy, const Fr* __restrict__ iz,
+__global__ void __launch_bounds__(128) k_add_level(const Fr* __restrict__ ix, const Fr* __restrict__ iy, const Fr* __restrict__ iz,
                             const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
                             uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -630,7 +643,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
                        p->digits, p->hist, N, nd, p->nchunks, p->chunk, ntasks);
     GM_LAUNCH_CHECK();
     STAGE_MARK(2);
-    hipLaunchKernelGGL(k_scan_chunks, dim3(ceil_div(nrows, 256)), dim3(256), 0, s, p->hist, p->row_len, nd,
+    hipLaunchKernelGGL(k_scan_chunks, dim3(p->nwin * (nd / (nd < 64 ? nd : 64))), dim3(1024), 0, s, p->hist, p->row_len, nd,
                        p->nchunks, nrows);
     GM_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_offsets_all_levels<false>), dim3(1), dim3(1024), 0, s, p->row_len, p->off[0], nrows, p->x_log);
