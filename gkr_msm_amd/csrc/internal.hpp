@@ -26,6 +26,43 @@ std::vector<Fr> from12(const Fr& p1, const Fr& p2, const Fr& eq1, const Fr& prev
 Fr eq_bind_factor(const Fr& q, const Fr& t);                                    // 1 - q - t + 2qt
 Fr eq_sum_host(const Fr* pt, uint32_t n, uint64_t k);                           // utils.rs:265-291
 
+// ---- sharding context: which slice of the bucket rows this process owns and how to reach the other ranks.
+// Sumcheck objects capture the current one at creation (the drivers set it around the sharded layers).
+struct Shard {
+    const gm_comm* comm = nullptr;  // nullptr: unsharded
+    uint32_t rank = 0, world = 1, lg = 0;
+};
+inline Shard& current_shard() {
+    static thread_local Shard s;
+    return s;
+}
+struct ShardScope {
+    Shard prev;
+    explicit ShardScope(const Shard& s) : prev(current_shard()) { current_shard() = s; }
+    ~ShardScope() { current_shard() = prev; }
+};
+// all ranks' copies of `bytes` bytes, rank-major
+inline int32_t shard_all_gather(const Shard& sh, const void* mine, size_t bytes, std::vector<char>* all) {
+    all->assign((size_t)sh.world * bytes, 0);
+    memcpy(all->data() + (size_t)sh.rank * bytes, mine, bytes);
+    const int32_t rc = sh.comm->all_gather(sh.comm->ctx, all->data(), bytes);
+    if (rc) return set_err(GM_ERR_STATE, "gm_comm all_gather failed with %d", rc);
+    return GM_OK;
+}
+// vals[i] <- sum over ranks of vals[i]   (field addition is exact: the order of the ranks does not matter)
+inline int32_t shard_sum_fr(const Shard& sh, Fr* vals, int n) {
+    std::vector<char> all;
+    const int32_t rc = shard_all_gather(sh, vals, (size_t)n * sizeof(Fr), &all);
+    if (rc) return rc;
+    const Fr* a = reinterpret_cast<const Fr*>(all.data());
+    for (int i = 0; i < n; i++) {
+        Fr s = fr_zero();
+        for (uint32_t r = 0; r < sh.world; r++) s = fr_add(s, a[(size_t)r * n + i]);
+        vals[i] = s;
+    }
+    return GM_OK;
+}
+
 // Bump allocator over one device allocation.  The image-part prover creates ~65 short-lived sumcheck objects;
 // hipMalloc/hipFree per buffer (hipFree synchronises the device) dominated the per-round cost, so the driver opens
 // an ArenaScope around each layer and resets the arena afterwards.  DevBuf::alloc carves from the current arena

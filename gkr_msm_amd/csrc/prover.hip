@@ -140,7 +140,7 @@ int32_t adv_map_split_lo0(const gm_fn& f, const Advice& in, uint32_t layer_idx, 
     SegPlan sp = plan_of(f);
     if (layer_idx + 2 == row_logsize) {
         out->kind = Advice::DENSE;
-        out->len = 1ull << in.vv->v->col_logsize;
+        out->len = in.vv->v->sharded ? in.vv->v->nrows : (1ull << in.vv->v->col_logsize);
         TRY(dense_alloc(2 * sp.n_outs, out->len, &out->cols));
         std::vector<Fr*> co;
         for (auto& c : out->cols) co.push_back(c->fr());
@@ -307,6 +307,7 @@ int32_t simple_gkr_prove(Tape* tr, const std::vector<Layer>& layers, const std::
 struct gm_pip_witness {
     uint32_t x_log, y_log, d_log;
     hipStream_t stream;
+    Shard sh;               // sharded witness: this rank's windows only
     Arena arena;            // per-layer workspace of the sumcheck objects (reset after every layer)
     Fr* pinned = nullptr;   // host staging for the per-round results
     ~gm_pip_witness() { if (pinned) (void)hipHostFree(pinned); }
@@ -410,18 +411,43 @@ static std::vector<Layer> triangle_layers(uint32_t num_vars, uint32_t hi_idx) {
 }
 
 // ------------------------------------------------------------------------------------------- C ABI
-// PippengerWG::new without the G1 commitments (pippenger.rs:37-70): image -> GlueSplit::witness -> PippengerEndingWG::new
-extern "C" int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
-                                         gm_pip_witness** out, void* stream) {
+// PippengerWG::new without the G1 commitments (pippenger.rs:37-70): image -> GlueSplit::witness -> PippengerEndingWG::new.
+// comm != nullptr: the plan covers this rank's windows; everything up to the bucket sums is local to its bucket rows,
+// the bucket sums are exchanged once and the bucket-reduction (triangle) witness is built replicated.
+static int32_t pip_witness_create(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize, const gm_comm* comm,
+                                  gm_pip_witness** out, void* stream) {
     GM_REQUIRE(plan && d_points_xy && out, "null argument");
     GM_REQUIRE(plan->x_log >= plan->d_log, "x_logsize >= d_logsize required (pippenger.rs:93)");
     GM_REQUIRE(plan->x_log >= 2, "x_logsize >= 2 required");
     hipStream_t s = as_stream(stream);
     std::unique_ptr<gm_pip_witness> w(new gm_pip_witness());
     w->x_log = plan->x_log; w->y_log = y_logsize; w->d_log = plan->d_log; w->stream = s;
+    if (comm && comm->world > 1) {
+        GM_REQUIRE(comm->all_gather && comm->rank < comm->world && (comm->world & (comm->world - 1)) == 0, "bad gm_comm");
+        GM_REQUIRE(plan->y_size == (1u << y_logsize), "the sharded prover needs y_size = 2^y_logsize");
+        GM_REQUIRE(plan->y_size % comm->world == 0 && plan->nwin == plan->y_size / comm->world &&
+                       plan->y0 == comm->rank * plan->nwin,
+                   "rank %u of %u must own windows [%u, %u)", comm->rank, comm->world, comm->rank * (plan->y_size / comm->world),
+                   (comm->rank + 1) * (plan->y_size / comm->world));
+        w->sh.comm = comm; w->sh.rank = comm->rank; w->sh.world = comm->world;
+        while ((1u << w->sh.lg) < comm->world) w->sh.lg++;
+    } else {
+        GM_REQUIRE(plan->y0 == 0 && plan->y1 == plan->y_size, "the image needs a plan over all windows");
+    }
+    const bool sharded = w->sh.comm != nullptr;
     gm_vv* image = nullptr;
-    TRY(gm_vv_from_msm(plan, d_points_xy, y_logsize, &image, stream));
+    TRY(vv_from_msm(plan, d_points_xy, y_logsize, sharded, &image, stream));
     VVHolder img(image);
+    if (sharded) {  // EQPolyData::new looks at the longest row of the whole polynomial (vecvec.rs:86)
+        std::vector<char> all;
+        const uint32_t mine = image->max_row_len;
+        TRY(shard_all_gather(w->sh, &mine, sizeof(uint32_t), &all));
+        for (uint32_t r = 0; r < w->sh.world; r++) {
+            uint32_t v;
+            memcpy(&v, all.data() + 4 * (size_t)r, 4);
+            if (v > image->max_row_len) image->max_row_len = v;
+        }
+    }
     // GlueSplit::witness (splits.rs:172-176)
     gm_vv *xy = nullptr, *z = nullptr, *xy_s = nullptr, *z_s = nullptr, *glued = nullptr;
     TRY(gm_vv_slice(image, 0, 2, &xy));
@@ -440,9 +466,33 @@ extern "C" int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t
     const uint32_t horizontal = plan->x_log, multirow = y_logsize, bucket = plan->d_log;
     TRY(bintree_witness_build(in, horizontal, horizontal, true, &w->bintree_advices, s));
     // last_step (bintree_add.rs:128-135)
-    TRY(adv_map(mkfn(horizontal - 1 == 0 ? GM_FN_AFF_L3 : GM_FN_PROJ_L3, 1), w->bintree_advices.back(), &w->bucket_sums, s));
-    GM_REQUIRE(w->bucket_sums.kind == Advice::DENSE, "bucket sums are not dense");
+    Advice local_sums;
+    TRY(adv_map(mkfn(horizontal - 1 == 0 ? GM_FN_AFF_L3 : GM_FN_PROJ_L3, 1), w->bintree_advices.back(), &local_sums, s));
+    GM_REQUIRE(local_sums.kind == Advice::DENSE, "bucket sums are not dense");
     const uint32_t nv = multirow + bucket;
+    if (sharded) {
+        // every rank gets all bucket sums: 3 columns of 2^(y_log + d) elements (0.75 MiB at config B)
+        const uint64_t L = local_sums.len, full = (uint64_t)1 << nv;
+        GM_REQUIRE(L * w->sh.world == full, "bucket sum slices do not tile the rows");
+        std::vector<Fr> mine(3 * L);
+        for (int c = 0; c < 3; c++)
+            GM_HIP(hipMemcpyAsync(mine.data() + c * L, local_sums.cols[c]->p, L * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        GM_HIP(hipStreamSynchronize(s));
+        std::vector<char> all;
+        TRY(shard_all_gather(w->sh, mine.data(), 3 * L * sizeof(Fr), &all));
+        const Fr* a = reinterpret_cast<const Fr*>(all.data());
+        w->bucket_sums.kind = Advice::DENSE;
+        w->bucket_sums.len = full;
+        TRY(dense_alloc(3, full, &w->bucket_sums.cols));
+        std::vector<Fr> col(full);
+        for (int c = 0; c < 3; c++) {
+            for (uint32_t r = 0; r < w->sh.world; r++) memcpy(col.data() + r * L, a + ((size_t)r * 3 + c) * L, L * sizeof(Fr));
+            GM_HIP(hipMemcpyAsync(w->bucket_sums.cols[c]->p, col.data(), full * sizeof(Fr), hipMemcpyHostToDevice, s));
+            GM_HIP(hipStreamSynchronize(s));  // col is reused
+        }
+    } else {
+        w->bucket_sums = local_sums;
+    }
     Advice s1, s2;
     TRY(dense_map_split_adv(mkfn(GM_FN_ID, 3), w->bucket_sums, nv - 1 - multirow, 3, &s1, s));
     TRY(dense_map_split_adv(mkfn(GM_FN_ID, 6), s1, (nv - 1) - 1 - multirow, 3, &s2, s));
@@ -453,7 +503,7 @@ extern "C" int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t
     // fold buffers of 1/2 and 1/4 of the cells per polynomial + tables
     {
         const uint64_t T = glued->total, nr = glued->nrows;
-        const size_t bytes = (size_t)6 * 32 * (T / 2 + T / 4 + 4 * nr + 64) + ((size_t)48 << 20);
+        const size_t bytes = (size_t)6 * 32 * (T / 2 + T / 4 + 4 * nr + 64) + ((size_t)48 << 20) + ((size_t)96 << nv);
         TRY(w->arena.init(bytes));
         GM_HIP(hipHostMalloc((void**)&w->pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
         memset(w->pinned, 0, 16 * sizeof(Fr));
@@ -461,6 +511,24 @@ extern "C" int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t
     GM_HIP(hipStreamSynchronize(s));
     *out = w.release();
     return GM_OK;
+}
+
+extern "C" int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                         gm_pip_witness** out, void* stream) {
+    return pip_witness_create(plan, d_points_xy, y_logsize, nullptr, out, stream);
+}
+
+extern "C" int32_t gm_pip_witness_create_sharded(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                                 const gm_comm* comm, gm_pip_witness** out, void* stream) {
+    GM_REQUIRE(comm, "null gm_comm");
+    return pip_witness_create(plan, d_points_xy, y_logsize, comm, out, stream);
+}
+
+extern "C" int32_t gm_comm_sum_fr(const gm_comm* comm, uint64_t* h_vals, uint32_t n) {
+    GM_REQUIRE(comm && comm->all_gather && h_vals && comm->rank < comm->world, "bad argument");
+    Shard sh;
+    sh.comm = comm; sh.rank = comm->rank; sh.world = comm->world;
+    return shard_sum_fr(sh, reinterpret_cast<Fr*>(h_vals), (int)n);
 }
 
 extern "C" int32_t gm_pip_witness_destroy(gm_pip_witness* w) {
@@ -520,8 +588,11 @@ static int32_t prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim
     TRY(simple_gkr_prove(&tr, triangle_layers(multirow + bucket - 2, multirow), w->triangle_advices, &c, &wm->arena, s));
     TRY(split_at_prove(&tr, &c, true, multirow, 3));
     TRY(split_at_prove(&tr, &c, true, multirow, 3));
-    TRY(simple_gkr_prove(&tr, bintree_layers(multirow + bucket + horizontal, horizontal, horizontal, true),
-                         w->bintree_advices, &c, &wm->arena, s));
+    {   // the bucket-sum tree runs over this rank's rows only when the witness is sharded
+        ShardScope scope(w->sh);
+        TRY(simple_gkr_prove(&tr, bintree_layers(multirow + bucket + horizontal, horizontal, horizontal, true),
+                             w->bintree_advices, &c, &wm->arena, s));
+    }
     // GlueSplit::prove (splits.rs:185-197)
     {
         Fr r;

@@ -808,13 +808,49 @@ struct ScDense : gm_sc {
     std::vector<Fr> cached;
     bool has_cached = false;
     std::vector<std::unique_ptr<DevBuf>> owned;  // columns built by a handover
+    // sharded: the columns are this rank's contiguous slice of 2^loc_vars elements; rounds add up the ranks'
+    // partial sums; when the slice is down to one element the ranks exchange it and finish the last lg rounds replicated
+    Shard sh;
+    uint32_t loc_vars = 0;
 
     Fr claim() const override { return claim_; }
+
+    int32_t gather_cols() {
+        const int k = cols.k;
+        std::vector<Fr> mine(k);
+        for (int i = 0; i < k; i++) GM_HIP(hipMemcpyAsync(&mine[i], cols.cur[i], sizeof(Fr), hipMemcpyDeviceToHost, stream));
+        GM_HIP(hipStreamSynchronize(stream));
+        std::vector<char> all;
+        int32_t rc = shard_all_gather(sh, mine.data(), (size_t)k * sizeof(Fr), &all);
+        if (rc) return rc;
+        const Fr* a = reinterpret_cast<const Fr*>(all.data());
+        std::vector<const Fr*> ptrs;
+        for (int i = 0; i < k; i++) {
+            std::vector<Fr> col(sh.world);
+            for (uint32_t r = 0; r < sh.world; r++) col[r] = a[(size_t)r * k + i];
+            owned.emplace_back(new DevBuf());
+            rc = owned.back()->alloc((size_t)sh.world * sizeof(Fr));
+            if (rc) return rc;
+            rc = upload_small(col.data(), col.size(), owned.back()->fr(), stream);
+            if (rc) return rc;
+            ptrs.push_back(owned.back()->fr());
+        }
+        cols = FoldCols();
+        rc = cols.init(k, ptrs.data(), sh.world);
+        if (rc) return rc;
+        loc_vars = sh.lg;
+        sh = Shard();
+        return GM_OK;
+    }
 
     int32_t unipoly(std::vector<Fr>* coeffs) override {
         if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended (sumcheck.rs:279)");
         if (!has_cached) {
-            const uint64_t npairs = 1ull << (num_vars - round_idx - 1);
+            if (sh.comm && loc_vars == 0) {
+                int32_t rc = gather_cols();
+                if (rc) return rc;
+            }
+            const uint64_t npairs = 1ull << (loc_vars - 1);
             ColPtrs cp;
             for (int i = 0; i < cols.k; i++) cp.p[i] = cols.cur[i];
             const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
@@ -845,6 +881,10 @@ struct ScDense : gm_sc {
             Fr acc[4];
             int32_t rc = rs.finish(D, stream, acc);
             if (rc) return rc;
+            if (sh.comm) {
+                rc = shard_sum_fr(sh, acc, D);
+                if (rc) return rc;
+            }
             std::vector<Fr> total(D + 1);
             for (int s = 0; s < D; s++) total[s + 1] = acc[s];
             total[0] = fr_sub(claim_, total[1]);  // sumcheck.rs:325
@@ -860,11 +900,12 @@ struct ScDense : gm_sc {
         if (!has_cached) return set_err(GM_ERR_STATE, "should evaluate unipoly before binding (sumcheck.rs:271)");
         std::vector<Fr*> dst;
         cols.next(&dst);
-        const uint64_t n_out = 1ull << (num_vars - round_idx - 1);
+        const uint64_t n_out = 1ull << (loc_vars - 1);
         int32_t rc = launch_dense_fold(cols.cur.data(), dst.data(), cols.k, n_out, t, stream);
         if (rc) return rc;
         cols.commit(dst);
         round_idx++;
+        loc_vars--;
         claim_ = evaluate_univar(cached, t);
         has_cached = false;
         return GM_OK;
@@ -872,6 +913,7 @@ struct ScDense : gm_sc {
 
     int32_t final_evals(std::vector<Fr>* out) override {
         if (round_idx != num_vars) return set_err(GM_ERR_STATE, "can only call final evals after the last round (sumcheck.rs:338)");
+        if (sh.comm) return set_err(GM_ERR_STATE, "sharded columns were never exchanged");
         out->resize(cols.k);
         for (int i = 0; i < cols.k; i++) GM_HIP(hipMemcpyAsync(&(*out)[i], cols.cur[i], sizeof(Fr), hipMemcpyDeviceToHost, stream));
         GM_HIP(hipStreamSynchronize(stream));
@@ -890,14 +932,52 @@ struct ScDenseDeg2 : gm_sc {
     Fr claim_, multiplier;
     std::vector<Fr> cached, inv_eq0;
     bool has_cached = false;
+    Shard sh;                 // see ScDense
+    uint32_t loc_vars = 0;
+    uint64_t glob_off = 0;    // global index of the slice's first element at the current round
+    std::vector<std::unique_ptr<DevBuf>> owned;
 
     Fr claim() const override { return claim_; }
     const Fr* eq_level(uint32_t i) const { return d_eq.fr() + ((1ull << i) - 1); }
 
+    int32_t gather_cols() {
+        const int k = cols.k;
+        std::vector<Fr> mine(k);
+        for (int i = 0; i < k; i++) GM_HIP(hipMemcpyAsync(&mine[i], cols.cur[i], sizeof(Fr), hipMemcpyDeviceToHost, stream));
+        GM_HIP(hipStreamSynchronize(stream));
+        std::vector<char> all;
+        int32_t rc = shard_all_gather(sh, mine.data(), (size_t)k * sizeof(Fr), &all);
+        if (rc) return rc;
+        const Fr* a = reinterpret_cast<const Fr*>(all.data());
+        std::vector<const Fr*> ptrs;
+        for (int i = 0; i < k; i++) {
+            std::vector<Fr> col(sh.world);
+            for (uint32_t r = 0; r < sh.world; r++) col[r] = a[(size_t)r * k + i];
+            owned.emplace_back(new DevBuf());
+            rc = owned.back()->alloc((size_t)sh.world * sizeof(Fr));
+            if (rc) return rc;
+            rc = upload_small(col.data(), col.size(), owned.back()->fr(), stream);
+            if (rc) return rc;
+            ptrs.push_back(owned.back()->fr());
+        }
+        cols = FoldCols();
+        rc = cols.init(k, ptrs.data(), sh.world);
+        if (rc) return rc;
+        loc_vars = sh.lg;
+        glob_off = 0;
+        sh = Shard();
+        return GM_OK;
+    }
+
     int32_t unipoly(std::vector<Fr>* coeffs) override {
         if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (dense_eq.rs:109-111)");
         if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended");
-        const uint64_t npairs = 1ull << (num_vars - round_idx - 1);
+        if (sh.comm && loc_vars == 0) {
+            int32_t rc = gather_cols();
+            if (rc) return rc;
+        }
+        const uint64_t npairs = 1ull << (loc_vars - 1);
+        const Fr* eq_cur = eq_level(num_vars - 1 - round_idx) + (glob_off >> 1);
         ColPtrs cp;
         for (int i = 0; i < cols.k; i++) cp.p[i] = cols.cur[i];
         const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
@@ -907,19 +987,23 @@ struct ScDenseDeg2 : gm_sc {
         if (lean) {
             LeanCols lc;
             for (int i = 0; i < cols.k; i++) lc.p[i] = cols.cur[i];
-            int32_t rc = launch_deg2_lean<false>(lean, grid, stream, lc, eq_level(num_vars - 1 - round_idx), d_gamma.fr(), npairs, none,
+            int32_t rc = launch_deg2_lean<false>(lean, grid, stream, lc, eq_cur, d_gamma.fr(), npairs, none,
                                                  rs.ctx());
             if (rc) return rc;
         } else if (split)
             hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp,
-                               eq_level(num_vars - 1 - round_idx), d_gamma.fr(), npairs, none, rs.ctx());
+                               eq_cur, d_gamma.fr(), npairs, none, rs.ctx());
         else
             hipLaunchKernelGGL((k_round_deg2<false, false>), grid, dim3(SC_THREADS), 0, stream, sp, cp,
-                               eq_level(num_vars - 1 - round_idx), d_gamma.fr(), npairs, none, rs.ctx());
+                               eq_cur, d_gamma.fr(), npairs, none, rs.ctx());
         GM_LAUNCH_CHECK();
         Fr acc[4];
         int32_t rc = rs.finish(2, stream, acc);
         if (rc) return rc;
+        if (sh.comm) {
+            rc = shard_sum_fr(sh, acc, 2);
+            if (rc) return rc;
+        }
         // full-length dense columns: sum of eq = 1, the trailing pad term (dense_eq.rs:141-146) vanishes
         const Fr total1 = fr_mul(acc[0], multiplier), total2 = fr_mul(acc[1], multiplier);
         if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);  // first round: point is still complete
@@ -934,12 +1018,14 @@ struct ScDenseDeg2 : gm_sc {
         multiplier = fr_mul(multiplier, eq_bind_factor(point.back(), t));
         std::vector<Fr*> dst;
         cols.next(&dst);
-        const uint64_t n_out = 1ull << (num_vars - round_idx - 1);
+        const uint64_t n_out = 1ull << (loc_vars - 1);
         int32_t rc = launch_dense_fold(cols.cur.data(), dst.data(), cols.k, n_out, t, stream);
         if (rc) return rc;
         cols.commit(dst);
         point.pop_back();
         round_idx++;
+        loc_vars--;
+        glob_off >>= 1;
         claim_ = evaluate_univar(cached, t);
         has_cached = false;
         return GM_OK;
@@ -979,6 +1065,8 @@ struct ScVecVecDeg2 : gm_sc {
     std::vector<Fr> cached, inv_eq0;
     bool has_cached = false;
     std::unique_ptr<ScDense> dense;
+    Shard sh;                // sharded: this object holds the rows row_base .. row_base + nrows of the global polynomials
+    uint32_t row_base = 0;
 
     Fr claim() const override { return dense ? dense->claim() : claim_; }
 
@@ -996,7 +1084,7 @@ struct ScVecVecDeg2 : gm_sc {
         const bool split = bound_pairs <= SC_SPLIT_MAX_PAIRS;
         const uint64_t gx = bound_pairs > nrows ? bound_pairs : nrows;  // the tail-weight loop runs over rows
         const dim3 grid = round_grid(gx, split ? 2 * sp.nseg : 1);
-        const VVArgs va{off_cur, nrows, d_row_coef.fr(), eq_pre};
+        const VVArgs va{off_cur, nrows, d_row_coef.fr() + row_base, eq_pre};
         const int lean = (!split && k <= 6) ? lean_prim_of(sp) : 0;
         if (lean) {
             LeanCols lc;
@@ -1013,6 +1101,10 @@ struct ScVecVecDeg2 : gm_sc {
         Fr acc[4];
         int32_t rc = rs.finish(3, stream, acc);
         if (rc) return rc;
+        if (sh.comm) {
+            rc = shard_sum_fr(sh, acc, 3);
+            if (rc) return rc;
+        }
         const Fr* w = acc + 2;
         // pads: f(row_pad..) weighted by W, f(col_pad..) by the coefficient tail (vecvec_eq.rs:309-315, 345-371)
         Fr in[GM_MAX_COLS], pr[GM_MAX_COLS], pc[GM_MAX_COLS];
@@ -1026,7 +1118,7 @@ struct ScVecVecDeg2 : gm_sc {
             colsum = fr_add(colsum, o == 0 ? pc[o] : fr_mul(pc[o], gamma_pows[o]));
         }
         Fr extra = fr_mul(padsum, w[0]);
-        if (nrows < (1u << col_logsize)) extra = fr_add(extra, fr_mul(colsum, row_coef_tail[nrows]));
+        if (!sh.comm && nrows < (1u << col_logsize)) extra = fr_add(extra, fr_mul(colsum, row_coef_tail[nrows]));
         const Fr total1 = fr_mul(fr_add(acc[0], extra), multiplier);
         const Fr total2 = fr_mul(fr_add(acc[1], extra), multiplier);
         if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);
@@ -1084,7 +1176,10 @@ struct ScVecVecDeg2 : gm_sc {
         d->sp = sp;
         d->D = 3;
         d->num_vars = col_logsize;
-        const uint32_t nd = 1u << col_logsize;
+        d->sh = sh;
+        d->loc_vars = col_logsize - sh.lg;
+        const uint32_t nd_glob = 1u << col_logsize;
+        const uint32_t nd = sh.comm ? nrows : nd_glob;  // sharded: the dense columns are this rank's slice of the rows
         std::vector<const Fr*> cptr;
         ColPtrs ci;
         ColPtrsMut co;
@@ -1105,14 +1200,14 @@ struct ScVecVecDeg2 : gm_sc {
         // eq over the vertical variables, scaled by the multiplier after this bind (vecvec_eq.rs:177-180)
         const Fr mult = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));
         d->owned.emplace_back(new DevBuf());
-        int32_t rc = d->owned.back()->alloc((size_t)2 * nd * sizeof(Fr));
+        int32_t rc = d->owned.back()->alloc((size_t)2 * nd_glob * sizeof(Fr));
         if (rc) return rc;
         Fr* base = d->owned.back()->fr();
         std::vector<Fr*> lv(col_logsize + 1);
         for (uint32_t i = 0; i <= col_logsize; i++) lv[i] = base + ((1ull << i) - 1);
         rc = launch_eq_sequence(mult, point.data(), col_logsize, lv.data(), stream);
         if (rc) return rc;
-        cptr.push_back(lv[col_logsize]);
+        cptr.push_back(lv[col_logsize] + row_base);
         rc = d->cols.init(k + 1, cptr.data(), nd);
         if (rc) return rc;
         // GammaWrapper::new(func, gamma_pows[1])  (vecvec_eq.rs:185-187): same powers gamma^o
@@ -1165,6 +1260,10 @@ extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, co
     GM_REQUIRE(so->sp.deg == 2, "DenseDeg2Sumcheck needs a degree-2 function (dense_eq.rs:200)");
     so->stream = as_stream(stream);
     so->num_vars = num_vars;
+    so->sh = current_shard();
+    GM_REQUIRE(so->sh.lg <= num_vars, "more ranks than elements");
+    so->loc_vars = num_vars - so->sh.lg;
+    so->glob_off = (uint64_t)so->sh.rank << so->loc_vars;
     Fr gamma;
     memcpy(&gamma, h_gamma, 32);
     so->gamma_pows = make_gamma_pows(gamma, so->sp.n_outs);
@@ -1172,7 +1271,7 @@ extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, co
     so->point.resize(num_vars);
     memcpy(so->point.data(), h_point, 32 * (size_t)num_vars);
     so->multiplier = fr_one();
-    rc = so->cols.init(so->sp.n_ins, reinterpret_cast<const Fr* const*>(d_cols), 1ull << num_vars);
+    rc = so->cols.init(so->sp.n_ins, reinterpret_cast<const Fr* const*>(d_cols), 1ull << so->loc_vars);
     if (rc) return rc;
     rc = upload_gamma(so->gamma_pows, &so->d_gamma, so->stream);
     if (rc) return rc;
@@ -1211,6 +1310,15 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
     so->row_pad = polys->row_pad;
     so->col_pad = polys->col_pad;
     so->cells_bound = polys->total;
+    so->sh = current_shard();
+    so->row_base = polys->row_base;
+    if (so->sh.comm) {
+        GM_REQUIRE(((uint64_t)polys->nrows << so->sh.lg) == (1ull << polys->col_logsize) &&
+                       polys->row_base == so->sh.rank * polys->nrows,
+                   "sharded VecVec sumcheck: every rank must hold 2^col_logsize / world rows, in rank order");
+    } else {
+        GM_REQUIRE(polys->row_base == 0, "a partial VecVec needs a sharding context");
+    }
     const uint32_t nvars = polys->row_logsize + polys->col_logsize;
     Fr gamma;
     memcpy(&gamma, h_gamma, 32);
@@ -1332,7 +1440,10 @@ extern "C" int32_t gm_sc_dense_create(int32_t kind, const gm_fn* f, uint32_t num
     }
     GM_REQUIRE(so->D == 2 || so->D == 3, "unsupported degree %d", so->D);
     memcpy(&so->claim_, h_claim, 32);
-    int32_t rc = so->cols.init(ncols, reinterpret_cast<const Fr* const*>(d_cols), 1ull << num_vars);
+    so->sh = current_shard();
+    GM_REQUIRE(so->sh.lg <= num_vars, "more ranks than elements");
+    so->loc_vars = num_vars - so->sh.lg;
+    int32_t rc = so->cols.init(ncols, reinterpret_cast<const Fr* const*>(d_cols), 1ull << so->loc_vars);
     if (rc) return rc;
     rc = upload_gamma(gp, &so->d_gamma, so->stream);
     if (rc) return rc;

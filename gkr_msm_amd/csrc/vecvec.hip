@@ -199,6 +199,7 @@ int32_t vv_map(const SegPlan& sp, const gm_vv* in, gm_vv** out, hipStream_t s) {
     std::unique_ptr<gm_vv> o(new gm_vv());
     o->nrows = in->nrows; o->row_logsize = in->row_logsize; o->col_logsize = in->col_logsize;
     o->max_row_len = in->max_row_len;
+    o->row_base = in->row_base; o->sharded = in->sharded;
     o->off = in->off;  // shared shape
     int32_t rc = o->alloc_cols(sp.n_outs, in->total);
     if (rc) return rc;
@@ -224,6 +225,7 @@ int32_t vv_map_split(const SegPlan& sp, const gm_vv* in, uint32_t bundle, gm_vv*
     std::unique_ptr<gm_vv> o(new gm_vv());
     o->nrows = in->nrows; o->row_logsize = in->row_logsize - 1; o->col_logsize = in->col_logsize;
     o->max_row_len = pad2(in->max_row_len / 2);
+    o->row_base = in->row_base; o->sharded = in->sharded;
     o->off.reset(new DevBuf());
     int32_t rc = o->off->alloc((size_t)(in->nrows + 1) * 4);
     if (rc) return rc;
@@ -273,7 +275,7 @@ int32_t vv_map_split_to_dense(const SegPlan& sp, const gm_vv* in, uint32_t bundl
     ColPtrsMut co;
     for (int i = 0; i < sp.n_ins; i++) ci.p[i] = in->cols[i]->fr();
     for (int i = 0; i < 2 * sp.n_outs; i++) co.p[i] = d_out[i];
-    const uint32_t nd = 1u << in->col_logsize;
+    const uint32_t nd = in->sharded ? in->nrows : (1u << in->col_logsize);  // sharded: this rank's rows only
     hipLaunchKernelGGL(k_vv_map_split_to_dense, dim3(ceil_div(nd, 256)), dim3(256), 0, s, sp, ci, co,
                        reinterpret_cast<const uint32_t*>(in->off->p), in->nrows, nd, bundle, prow, pcol);
     GM_LAUNCH_CHECK();
@@ -347,15 +349,25 @@ extern "C" int32_t gm_vv_from_host(uint32_t k, uint32_t nrows, const uint32_t* h
     return GM_OK;
 }
 
-// The bucket image of the last gm_msm_run as 3 VecVec polynomials (x, y, z); plan must cover all windows.
+// The bucket image of the last gm_msm_run as 3 VecVec polynomials (x, y, z).  partial = false: the plan must cover all
+// windows.  partial = true (sharded prover): the handle holds the rows of the plan's windows, row_base = y0 << d_logsize.
+namespace gm {
+int32_t vv_from_msm(const gm_msm_plan* p, const uint64_t* d_points_xy, uint32_t y_logsize, bool partial, gm_vv** out, void* stream);
+}
 extern "C" int32_t gm_vv_from_msm(const gm_msm_plan* p, const uint64_t* d_points_xy, uint32_t y_logsize, gm_vv** out,
                                   void* stream) {
+    return gm::vv_from_msm(p, d_points_xy, y_logsize, false, out, stream);
+}
+int32_t gm::vv_from_msm(const gm_msm_plan* p, const uint64_t* d_points_xy, uint32_t y_logsize, bool partial, gm_vv** out,
+                        void* stream) {
     GM_REQUIRE(p && d_points_xy && out, "null argument");
-    GM_REQUIRE(p->y0 == 0 && p->y1 == p->y_size, "the image needs a plan over all windows");
+    GM_REQUIRE(partial || (p->y0 == 0 && p->y1 == p->y_size), "the image needs a plan over all windows");
     GM_REQUIRE((1u << y_logsize) >= p->y_size, "y_logsize too small");
     hipStream_t s = as_stream(stream);
     std::unique_ptr<gm_vv> v(new gm_vv());
     v->nrows = p->nrows; v->row_logsize = p->x_log; v->col_logsize = y_logsize + p->d_log;
+    v->row_base = p->y0 << p->d_log;
+    v->sharded = partial;
     v->off.reset(new DevBuf());
     int32_t rc = v->off->alloc((size_t)(p->nrows + 1) * 4);
     if (rc) return rc;
@@ -418,7 +430,7 @@ extern "C" int32_t gm_vv_slice(const gm_vv* in, uint32_t first, uint32_t count, 
     GM_REQUIRE(in && out && count >= 1 && first + count <= in->k, "bad slice");
     gm_vv* v = new gm_vv();
     v->k = count; v->nrows = in->nrows; v->total = in->total; v->row_logsize = in->row_logsize;
-    v->col_logsize = in->col_logsize; v->max_row_len = in->max_row_len; v->off = in->off;
+    v->col_logsize = in->col_logsize; v->max_row_len = in->max_row_len; v->off = in->off; v->row_base = in->row_base; v->sharded = in->sharded;
     for (uint32_t i = 0; i < count; i++) {
         v->cols.push_back(in->cols[first + i]);
         v->row_pad.push_back(in->row_pad[first + i]);

@@ -5,13 +5,16 @@
 
 #include "internal.hpp"
 
+struct gm_msm_plan;
 struct gm_vv {
     uint32_t k = 0;
     uint32_t nrows = 0;        // stored rows (data.len() in the reference); rows past it are col_pad
     uint64_t total = 0;        // cells = sum of (even) stored row lengths
     uint32_t row_logsize = 0;  // low variables: index inside a row; the ones a sumcheck runs over
     uint32_t col_logsize = 0;  // high variables: row index
-    uint32_t max_row_len = 0;  // EQPolyData::new needs it (vecvec.rs:86)
+    uint32_t max_row_len = 0;  // EQPolyData::new needs it (vecvec.rs:86); the GLOBAL maximum when sharded
+    bool sharded = false;      // this handle is one rank's slice of the rows (dense conversions then produce the slice only)
+    uint32_t row_base = 0;     // sharded: global index of stored row 0 (this handle holds rows row_base .. row_base + nrows)
     std::shared_ptr<gm::DevBuf> off;                // u32[nrows + 1]
     std::vector<std::shared_ptr<gm::DevBuf>> cols;  // k arrays of `total` elements
     std::vector<gm::Fr> row_pad, col_pad;
@@ -19,6 +22,7 @@ struct gm_vv {
 };
 
 namespace gm {
+int32_t vv_from_msm(const gm_msm_plan* p, const uint64_t* d_points_xy, uint32_t y_logsize, bool partial, gm_vv** out, void* stream);
 int32_t vv_map(const SegPlan& sp, const gm_vv* in, gm_vv** out, hipStream_t s);
 int32_t vv_map_split(const SegPlan& sp, const gm_vv* in, uint32_t bundle, gm_vv** out, hipStream_t s);
 int32_t vv_map_split_to_dense(const SegPlan& sp, const gm_vv* in, uint32_t bundle, Fr* const* d_out, hipStream_t s);

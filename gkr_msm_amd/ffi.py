@@ -48,6 +48,14 @@ class GmTranscript(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("write_scalars", WRITE_SCALARS_CB), ("challenge", CHALLENGE_CB)]
 
 
+ALL_GATHER_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)
+
+
+class GmComm(C.Structure):
+    """gm_comm: rank / world and one host-buffer all-gather"""
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", ALL_GATHER_CB)]
+
+
 _SIGS = {
     "gm_last_error": (C.c_char_p, []),
     "gm_version": (C.c_char_p, []),
@@ -89,6 +97,8 @@ _SIGS = {
     "gm_sc_claim": (C.c_int32, [vp, vp]),
     "gm_sc_destroy": (C.c_int32, [vp]),
     "gm_pip_witness_create": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(vp), vp]),
+    "gm_pip_witness_create_sharded": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(GmComm), C.POINTER(vp), vp]),
+    "gm_comm_sum_fr": (C.c_int32, [C.POINTER(GmComm), vp, C.c_uint32]),
     "gm_pip_witness_destroy": (C.c_int32, [vp]),
     "gm_pip_witness_outputs": (C.c_int32, [vp, vp, u32p, u64p, vp]),
     "gm_pip_witness_bytes": (C.c_uint64, [vp]),

@@ -323,12 +323,16 @@ class Sumcheckable:
 class PipWitness:
     """gm_pip_witness: the witness of the image part (bintree + triangle traces) on the device"""
 
-    def __init__(self, plan, d_points, y_logsize):
+    def __init__(self, plan, d_points, y_logsize, comm=None):
         self.L = ffi.lib()
-        self.plan, self.y_logsize = plan, y_logsize
+        self.plan, self.y_logsize, self.comm = plan, y_logsize, comm
         self.h = C.c_void_p()
-        ffi.check(self.L.gm_pip_witness_create(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, C.byref(self.h),
-                                               cur_stream()))
+        if comm is None:
+            ffi.check(self.L.gm_pip_witness_create(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, C.byref(self.h),
+                                                   cur_stream()))
+        else:  # sharded: plan covers this rank's windows (gkr_msm_amd.dist.Comm)
+            ffi.check(self.L.gm_pip_witness_create_sharded(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize,
+                                                           C.byref(comm.c), C.byref(self.h), cur_stream()))
 
     def close(self):
         if self.h:

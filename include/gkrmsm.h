@@ -234,6 +234,25 @@ typedef struct gm_transcript {
     int32_t (*challenge)(void* ctx, uint64_t* out);
 } gm_transcript;
 
+/* ---------------------------------------------------------------- multi-GPU seam
+ * One process per GPU.  The path shards by MSM window: rank g owns windows [g*y_size/G, (g+1)*y_size/G), i.e. the bucket
+ * rows (y << d_logsize | digit) of its windows -- MSM, witness build, round sums and folds of the bintree GKR are all local to
+ * those rows.  The exchange steps are tiny and go through ONE caller-provided collective on host buffers (the harness
+ * backs it with torch.distributed: RCCL on GPUs, gloo in the CPU tests; the Rust shim can back it with anything):
+ *   - per sumcheck round: all-gather of the 2-3 partial round sums (<= 96 bytes per rank), added mod p by every rank;
+ *   - once per proof: all-gather of the bucket sums (3 * 2^(y_logsize + d_logsize) field elements in total), after which the
+ *     bucket-reduction (triangle) GKR runs replicated, and of one element per column when a dense layer's local
+ *     slice is exhausted (the last log2(G) rounds of that layer run replicated).
+ * all_gather: `h_buf` holds world * bytes_per_rank bytes; the caller has filled slot `rank`; on return every slot is filled.
+ * Every rank must run the same sequence of calls (the provers are deterministic given the same challenges). */
+typedef struct gm_comm {
+    void* ctx;
+    uint32_t rank, world;   /* world: a power of two dividing y_size */
+    int32_t (*all_gather)(void* ctx, void* h_buf, uint64_t bytes_per_rank);
+} gm_comm;
+/* host-only self-test of a gm_comm (no GPU): sums the field elements h_vals[0..n) of all ranks in place (Montgomery) */
+int32_t gm_comm_sum_fr(const gm_comm* comm, uint64_t* h_vals, uint32_t n);
+
 /* ---------------------------------------------------------------- "prove image part" (a10, a11)
  * Host-side driver over the kernels, mirroring PippengerWG::new (pippenger.rs:37-70, without the BLS12-381 G1
  * commitments: SURVEY 8f-1) and Pippenger::prove's "prove image part" span (pippenger.rs:138-141):
@@ -246,6 +265,11 @@ typedef struct gm_transcript {
 typedef struct gm_pip_witness gm_pip_witness;
 int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
                               gm_pip_witness** out, void* stream);
+/* Sharded form: `plan` covers this rank's windows only (gm_msm_plan_create(.., y_begin, y_end)), y_size = the global window
+ * count; requires y_size = 2^y_logsize and comm->world | y_size.  The prove calls below then run the sharded protocol on
+ * every rank (same messages and final claims on all ranks, bit-identical to the unsharded run).  `comm` must outlive w. */
+int32_t gm_pip_witness_create_sharded(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                      const gm_comm* comm, gm_pip_witness** out, void* stream);
 int32_t gm_pip_witness_destroy(gm_pip_witness* w);
 int32_t gm_pip_witness_outputs(const gm_pip_witness* w, const uint64_t** d_output_cols, uint32_t* n_output_cols,
                                uint64_t* output_len, const uint64_t** d_bucket_sum_cols);

@@ -80,3 +80,45 @@ def test_window_range_partition():
     assert [gd.window_range(r, 8, 32) for r in range(8)] == [(4 * r, 4 * r + 4) for r in range(8)]
     with pytest.raises(ValueError):
         gd.window_range(0, 3, 32)
+
+
+def _comm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
+    from gkr_msm_amd import codec, dist as gd, ffi
+    from pyref import field as F
+    comm = gd.Comm(dist, rank, world)
+    rng = F.SplitMix64(100 + rank)
+    vals = [rng.next_fr() for _ in range(3)]
+    buf = codec.to_mont_limbs(vals)
+    ffi.check(ffi.lib().gm_comm_sum_fr(C.byref(comm.c), buf.ctypes.data, 3))
+    q.put((rank, vals, codec.from_mont_limbs(buf), comm.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_field_sum_world2_gloo():
+    """the per-round exchange of the sharded prover: partial round sums of all ranks added mod p through the
+    gm_comm all-gather callback -- host only, world_size 2, gloo"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pyref import field as F
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    res.sort()
+    want = [(a + b) % F.P for a, b in zip(res[0][1], res[1][1])]
+    assert res[0][2] == want and res[1][2] == want
+    assert res[0][3] == 1 and res[1][3] == 1

@@ -1,0 +1,86 @@
+"""GPU test of the sharded "prove image part" (SURVEY 8e): world_size-2 (and 4) processes share the one GPU of the box and
+exchange through gloo; every rank owns half (a quarter) of the MSM windows = bucket rows.  The sharded run must give the
+same prover messages and final claims as the unsharded run, bit for bit, on every rank."""
+import os
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, x_log, d_log, nbits, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from gkr_msm_amd import codec, dist as gd, harness as H
+        from pyref import field as F
+        y_size = (nbits + d_log - 1) // d_log
+        y_log = (y_size - 1).bit_length()
+        n = 1 << x_log
+        d_pts = H.to_dev(codec.points_to_mont(F.random_points(n, 5)))
+        sc = F.random_scalars(n, nbits, 6)
+        sc[0] = 0
+        d_sc = H.to_dev(codec.ints_to_limbs(sc))
+        rng = F.SplitMix64(9)
+        r = [rng.next_fr() for _ in range(y_log)]
+        tape = [rng.next_bits(128) for _ in range(4000)]
+        # unsharded reference (every rank computes it: small)
+        plan = H.MsmPlan(x_log, d_log, y_size)
+        plan.run(d_pts, d_sc)
+        w = H.PipWitness(plan, d_pts, y_log)
+        outs, bs = w.outputs()
+        P = codec.P
+
+        def ev(poly):
+            cur = list(poly)
+            for f in reversed(r):
+                cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
+            return cur[0]
+        evs = [ev(o) for o in outs]
+        ref = w.prove_image_part(r, evs, tape)
+        # sharded: this rank's windows only
+        y0, y1 = gd.window_range(rank, world, y_size)
+        comm = gd.Comm(dist, rank, world)
+        plan_s = H.MsmPlan(x_log, d_log, y_size, y0, y1)
+        plan_s.run(d_pts, d_sc)
+        ws = H.PipWitness(plan_s, d_pts, y_log, comm=comm)
+        outs_s, bs_s = ws.outputs()
+        got = ws.prove_image_part(r, evs, tape)
+        ok = (outs_s == outs and bs_s == bs and got["msgs"] == ref["msgs"] and got["point"] == ref["point"] and
+              got["evs"] == ref["evs"] and got["rounds"] == ref["rounds"] and got["tape_used"] == ref["tape_used"])
+        q.put((rank, ok, comm.calls, got["rounds"]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # report instead of hanging the parent
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc(), 0))
+
+
+@pytest.mark.parametrize("world,x_log,d_log,nbits", [(2, 5, 3, 12), (2, 7, 4, 32), (4, 6, 2, 16), (2, 4, 2, 4)])
+def test_sharded_prove_image_part_matches_unsharded(world, x_log, d_log, nbits):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, x_log, d_log, nbits, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=240))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert len(res) == world
+    for rank, ok, calls, rounds in sorted(res):
+        assert ok is True, "rank %d: %s" % (rank, calls)
+        assert calls > rounds // 2      # the round sums really went through the collective
