@@ -233,19 +233,32 @@ static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_
         // folded claim: sum_i ev_i gamma^i (make_folded_claim, sumcheck.rs:659-673)
         Fr claim = fr_zero(), gp = fr_one();
         for (size_t i = 0; i < evs.size(); i++) { claim = fr_add(claim, fr_mul(evs[i], gp)); gp = fr_mul(gp, c0); }
-        // EqPoly(point) on the full shape = the eq table; it becomes the last column
-        DevBuf eqbuf;
-        TRY(eqbuf.alloc(((size_t)2 << nv) * sizeof(Fr)));
-        std::vector<Fr*> lv(nv + 1);
-        for (uint32_t i = 0; i < nv; i++) lv[i] = eqbuf.fr() + ((size_t)1 << nv) + (((size_t)1 << i) - 1);
-        lv[nv] = eqbuf.fr();
-        TRY(launch_eq_sequence(fr_one(), point.data(), nv, lv.data(), s));
+        // Round polynomial of sum_x eq(point, x) sum_i gamma^i f_i(p(x))  (FragmentedLincomb::unipoly, sumcheck.rs:99-151).
+        // The reference evaluates it at deg + 2 points with the eq table as one more factor; the polynomial itself is what
+        // goes on the transcript, so it is computed here with eq factored out (two evaluations of f per pair and no eq
+        // column to fold -- the DenseDeg2 object, dense_eq.rs:98-173 + from12): the same coefficients, exactly.  from12
+        // divides by 1 - point_j; if a coordinate equals 1 (probability 2^-255) the generic object is used instead.
+        bool coord_is_one = false;
+        for (const Fr& c : point) coord_is_one = coord_is_one || fr_eq(c, fr_one());
         std::vector<const uint64_t*> cols;
         for (int i = 0; i < sp.n_ins; i++) cols.push_back(reinterpret_cast<const uint64_t*>(trace[li].c[i]->p));
-        cols.push_back(reinterpret_cast<const uint64_t*>(eqbuf.p));
         ScHolder h;
-        TRY(gm_sc_dense_create(0, &L.f, nv, cols.data(), reinterpret_cast<const uint64_t*>(&c0),
-                               reinterpret_cast<const uint64_t*>(&claim), &h.so, stream));
+        DevBuf eqbuf;
+        if (!coord_is_one && sp.deg == 2) {
+            TRY(gm_sc_dense_deg2_create(&L.f, nv, cols.data(), reinterpret_cast<const uint64_t*>(point.data()),
+                                        reinterpret_cast<const uint64_t*>(&c0), reinterpret_cast<const uint64_t*>(evs.data()),
+                                        &h.so, stream));
+        } else {
+            // EqPoly(point) on the full shape = the eq table; it becomes the last column
+            TRY(eqbuf.alloc(((size_t)2 << nv) * sizeof(Fr)));
+            std::vector<Fr*> lv(nv + 1);
+            for (uint32_t i = 0; i < nv; i++) lv[i] = eqbuf.fr() + ((size_t)1 << nv) + (((size_t)1 << i) - 1);
+            lv[nv] = eqbuf.fr();
+            TRY(launch_eq_sequence(fr_one(), point.data(), nv, lv.data(), s));
+            cols.push_back(reinterpret_cast<const uint64_t*>(eqbuf.p));
+            TRY(gm_sc_dense_create(0, &L.f, nv, cols.data(), reinterpret_cast<const uint64_t*>(&c0),
+                                   reinterpret_cast<const uint64_t*>(&claim), &h.so, stream));
+        }
         std::vector<Fr> rs;
         for (uint32_t rd = 0; rd < nv; rd++) {
             Fr co[8];
