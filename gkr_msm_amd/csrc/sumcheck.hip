@@ -1065,12 +1065,15 @@ struct ScVecVecDeg2 : gm_sc {
     std::vector<Fr> cached, inv_eq0;
     bool has_cached = false;
     std::unique_ptr<ScDense> dense;
+    std::unique_ptr<gm_sc> dense2;  // the dense stage through the eq-factored object (see bind_into_dense)
+    Fr dense2_eq_final() const;
     Shard sh;                // sharded: this object holds the rows row_base .. row_base + nrows of the global polynomials
     uint32_t row_base = 0;
 
-    Fr claim() const override { return dense ? dense->claim() : claim_; }
+    Fr claim() const override { return dense2 ? dense2->claim() : dense ? dense->claim() : claim_; }
 
     int32_t unipoly(std::vector<Fr>* coeffs) override {
+        if (dense2) return dense2->unipoly(coeffs);
         if (dense) return dense->unipoly(coeffs);
         if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (vecvec_eq.rs:305-307)");
         // current eq level: row_eq_poly_seq[len - 1 - already_bound]  (vecvec.rs:129-135) and its prefix sums
@@ -1132,6 +1135,7 @@ struct ScVecVecDeg2 : gm_sc {
     uint32_t n_off_tables = 0;
 
     int32_t bind(const Fr& t) override {
+        if (dense2) return dense2->bind(t);
         if (dense) return dense->bind(t);
         if (!has_cached) return set_err(GM_ERR_STATE, "bind before unipoly (vecvec_eq.rs:299 unwrap)");
         if ((uint32_t)binding_var_idx > col_logsize) {
@@ -1169,7 +1173,15 @@ struct ScVecVecDeg2 : gm_sc {
     }
 
     // vecvec_eq.rs:157-190
+    // The reference hands over to a generic DenseSumcheckObjectSO whose function is eq * GammaWrapper(f) with the eq table as
+    // one more column (vecvec_eq.rs:177-189).  The round polynomials of that object are those of the eq-factored one
+    // (DenseDeg2: two evaluations of f per pair instead of three, no eq column to fold), so the latter is used; its running
+    // multiplier is the eq column's final evaluation.  from12 divides by 1 - point_j: with a coordinate equal to 1 the
+    // generic object is kept.
     int32_t bind_into_dense(const Fr& t) {
+        bool coord_is_one = col_logsize == 0;
+        for (uint32_t i = 0; i < col_logsize; i++) coord_is_one = coord_is_one || fr_eq(point[i], fr_one());
+        if (!coord_is_one) return bind_into_dense_deg2(t);
         std::unique_ptr<ScDense> d(new ScDense());
         d->stream = stream;
         d->kind = 0;
@@ -1221,11 +1233,68 @@ struct ScVecVecDeg2 : gm_sc {
         return GM_OK;
     }
 
+    int32_t bind_into_dense_deg2(const Fr& t);
+
     int32_t final_evals(std::vector<Fr>* out) override {
+        if (dense2) {
+            int32_t rc = dense2->final_evals(out);
+            if (rc) return rc;
+            out->push_back(dense2_eq_final());  // the eq column of the reference's dense stage (vecvec_eq.rs:451 drops it again)
+            return GM_OK;
+        }
         if (!dense) return set_err(GM_ERR_STATE, "final_evals in the sparse stage (vecvec_eq.rs:391 unreachable!)");
         return dense->final_evals(out);
     }
 };
+
+Fr ScVecVecDeg2::dense2_eq_final() const { return static_cast<const ScDenseDeg2*>(dense2.get())->multiplier; }
+
+int32_t ScVecVecDeg2::bind_into_dense_deg2(const Fr& t) {
+    std::unique_ptr<ScDenseDeg2> d(new ScDenseDeg2());
+    d->stream = stream;
+    d->sp = sp;
+    d->num_vars = col_logsize;
+    d->sh = sh;
+    d->loc_vars = col_logsize - sh.lg;
+    d->glob_off = row_base;
+    d->gamma_pows = gamma_pows;
+    d->point.assign(point.begin(), point.begin() + col_logsize);
+    d->multiplier = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));  // vecvec_eq.rs:177-180
+    d->claim_ = evaluate_univar(cached, t);
+    const uint32_t nd = sh.comm ? nrows : (1u << col_logsize);  // sharded: this rank's slice of the rows
+    std::vector<const Fr*> cptr;
+    ColPtrs ci;
+    ColPtrsMut co;
+    PadCols rp, cpad;
+    for (int i = 0; i < k; i++) {
+        d->owned.emplace_back(new DevBuf());
+        int32_t rc = d->owned.back()->alloc((size_t)nd * sizeof(Fr));
+        if (rc) return rc;
+        ci.p[i] = cur[i];
+        co.p[i] = d->owned.back()->fr();
+        rp.v[i] = row_pad[i];
+        cpad.v[i] = col_pad[i];
+        cptr.push_back(d->owned.back()->fr());
+    }
+    hipLaunchKernelGGL(k_vv_fold_to_dense, dim3(ceil_div(nd, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co, off_cur, nrows,
+                       nd, t, rp, cpad);
+    GM_LAUNCH_CHECK();
+    int32_t rc = d->cols.init(k, cptr.data(), nd);
+    if (rc) return rc;
+    rc = upload_gamma(gamma_pows, &d->d_gamma, stream);
+    if (rc) return rc;
+    rc = d->d_eq.alloc(((size_t)1 << col_logsize) * sizeof(Fr));
+    if (rc) return rc;
+    std::vector<Fr*> lv(col_logsize);
+    for (uint32_t i = 0; i < col_logsize; i++) lv[i] = d->d_eq.fr() + ((1ull << i) - 1);
+    rc = launch_eq_sequence(fr_one(), d->point.data(), col_logsize - 1, lv.data(), stream);
+    if (rc) return rc;
+    rc = d->rs.init(stream);
+    if (rc) return rc;
+    has_cached = false;
+    dense2 = std::move(d);
+    return GM_OK;
+}
 
 }  // namespace
 
