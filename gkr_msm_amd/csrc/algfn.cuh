@@ -22,6 +22,8 @@ enum : int {
     FN_ID = 8,       // IdAlgFn(1)                      1 -> 1
     FN_BITCHECK = 9, // BitCheckFn                      1 -> 1
     FN_PT_BIT_CHOICE = 10,  // gen-1 pt_bit_choice      3 -> 2
+    FN_ADD_INVERSES = 11,   // AddInversesFn (pushforward.rs:255-281)      (a, b) -> (a + b, a b)
+    FN_LOGUP_LAYER = 12,    // LogupLayerFn (logup_mainphase.rs:30-61)     (a, b, c, d) -> (a d + b c, b d)
 };
 
 GM_HD int prim_n_ins(int id) {
@@ -29,7 +31,7 @@ GM_HD int prim_n_ins(int id) {
         case FN_AFF_L1: return 4; case FN_AFF_L2: return 3; case FN_AFF_L3: return 3;
         case FN_PROJ_L1: return 6; case FN_PROJ_L2: return 4; case FN_PROJ_L3: return 4;
         case FN_TRI_L1: return 12; case FN_ID: return 1; case FN_BITCHECK: return 1;
-        case FN_PT_BIT_CHOICE: return 3; default: return 0;
+        case FN_PT_BIT_CHOICE: return 3; case FN_ADD_INVERSES: return 2; case FN_LOGUP_LAYER: return 4; default: return 0;
     }
 }
 GM_HD int prim_n_outs(int id) {
@@ -37,7 +39,7 @@ GM_HD int prim_n_outs(int id) {
         case FN_AFF_L1: return 3; case FN_AFF_L2: return 3; case FN_AFF_L3: return 3;
         case FN_PROJ_L1: return 4; case FN_PROJ_L2: return 4; case FN_PROJ_L3: return 3;
         case FN_TRI_L1: return 12; case FN_ID: return 1; case FN_BITCHECK: return 1;
-        case FN_PT_BIT_CHOICE: return 2; default: return 0;
+        case FN_PT_BIT_CHOICE: return 2; case FN_ADD_INVERSES: return 2; case FN_LOGUP_LAYER: return 2; default: return 0;
     }
 }
 GM_HD int prim_deg(int id) { return (id == FN_ID) ? 1 : 2; }
@@ -110,6 +112,16 @@ GM_HD void prim_exec(int id, const Fr* a, Fr* o) {
             Fr bx = fr_mul(a[0], a[1]);
             Fr by = fr_add(fr_mul(a[0], fr_sub(a[2], fr_one())), fr_one());
             o[0] = bx; o[1] = by;
+        } break;
+        case FN_ADD_INVERSES: {
+            Fr s0 = fr_add(a[0], a[1]);
+            Fr p0 = fr_mul(a[0], a[1]);
+            o[0] = s0; o[1] = p0;
+        } break;
+        case FN_LOGUP_LAYER: {
+            Fr n0 = fr_add(fr_mul(a[0], a[3]), fr_mul(a[1], a[2]));
+            Fr d0 = fr_mul(a[1], a[3]);
+            o[0] = n0; o[1] = d0;
         } break;
         default: break;
     }

@@ -89,7 +89,7 @@ int32_t to_gmfn(const gm_fn* f, GmFn* g) {
     if (!f || f->nseg < 1 || f->nseg > GM_FN_MAX_SEG) return set_err(GM_ERR_INVALID, "bad gm_fn");
     g->nseg = f->nseg;
     for (int s = 0; s < f->nseg; s++) {
-        if (f->prim[s] < 1 || f->prim[s] > 10 || f->count[s] < 0) return set_err(GM_ERR_INVALID, "bad gm_fn segment %d", s);
+        if (f->prim[s] < 1 || f->prim[s] > 12 || f->count[s] < 0) return set_err(GM_ERR_INVALID, "bad gm_fn segment %d", s);
         g->prim[s] = f->prim[s];
         g->count[s] = f->count[s];
     }

@@ -638,3 +638,403 @@ extern "C" int32_t gm_pip_prove_image_part_tr(const gm_pip_witness* w, const uin
     return prove_image_part(w, h_claim_point, h_claim_evs, nullptr, 0, tr, nullptr, 0, nullptr, h_final_point, n_final_point,
                             h_final_evs, n_challenges, rounds);
 }
+
+// =================================================================================================================
+// "prove pushforward" (pippenger.rs:147-160): PushforwardProtocol::prove (pushforward/pushforward.rs:640-846) with the
+// logup main phase (pushforward/logup_mainphase.rs:83-208).  The Fr columns come from the plan's last gm_msm_run
+// (gm_msm_phase1_polys, gm_msm_second_phase); the G1 commitments of those columns are gm_msm_g1_outer / gm_g1_msm.
+// Every sumcheck here is the eq-factored degree-2 object (the round polynomials of DenseEqSumcheckObject, sumcheck.rs:378-417)
+// or the generic object with Prod3Fn; the layer maps are dense maps, `map_split_hi` (utils/algfn.rs:82-89) is a map followed
+// by taking the two contiguous halves.
+namespace gm {
+
+// c_adj[i] = c_pull[i] + psi c[i] - tau   for i < n_active, the suppression term beyond (pushforward.rs:699-702)
+__global__ void __launch_bounds__(256) k_pf_adj(const Fr* __restrict__ pull, const Fr* __restrict__ v, Fr psi, Fr tau, Fr supp,
+                                                 uint64_t n_active, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(out + i, i < n_active ? fr_sub(fr_add(fr_load(pull + i), fr_mul(psi, fr_load(v + i))), tau) : supp);
+}
+
+// table[i] = eq[i] + psi * i - tau   (pushforward.rs:727-728)
+__global__ void __launch_bounds__(256) k_pf_table(const Fr* __restrict__ eq, Fr psi, Fr tau, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(out + i, fr_sub(fr_add(fr_load(eq + i), fr_mul(psi, fr_from_u64(i))), tau));
+}
+
+// p_selector_prod[i] = eq_sel_y[i_y] * (p0[i_x] + gamma (p1[i_x] - 1) + gamma^2)   (pushforward.rs:751-759); points_xy = (x, y) pairs
+__global__ void __launch_bounds__(256) k_pf_psel(const Fr* __restrict__ points_xy, const Fr* __restrict__ eq_sel_y, Fr g1, Fr g2,
+                                                  uint32_t x_log, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t iy = i >> x_log, ix = i & ((1ull << x_log) - 1);
+    const Fr p0 = fr_load(points_xy + 2 * ix), p1 = fr_load(points_xy + 2 * ix + 1);
+    const Fr pf = fr_add(fr_add(p0, fr_mul(g1, fr_sub(p1, fr_one()))), g2);
+    fr_store(out + i, fr_mul(fr_load(eq_sel_y + iy), pf));
+}
+
+}  // namespace gm
+
+extern "C" {
+int32_t gm_msm_phase1_polys(const gm_msm_plan* p, uint64_t* d_c, uint64_t* d_d, uint64_t* d_ac_c, uint64_t* d_ac_d, void* stream);
+int32_t gm_msm_second_phase(const gm_msm_plan* p, const uint64_t* h_r, uint32_t y_logsize, uint64_t* d_c_pull, uint64_t* d_d_pull,
+                            void* stream);
+int32_t gm_sc_dense_create(int32_t kind, const gm_fn* f, uint32_t num_vars, const uint64_t* const* d_cols, const uint64_t* h_gamma,
+                           const uint64_t* h_claim, gm_sc** out, void* stream);
+}
+
+namespace {
+
+// EqTruncPoly::evaluate (verifier_polys.rs:108-147)
+Fr eq_trunc_evaluate(uint32_t nv, uint64_t k, const Fr* r, const Fr* pt) {
+    std::vector<Fr> partial(nv + 1);
+    partial[0] = fr_one();
+    for (uint32_t i = 0; i < nv; i++) {
+        const uint32_t j = nv - i - 1;
+        partial[i + 1] = fr_mul(partial[i], eq_bind_factor(r[j], pt[j]));
+    }
+    if (k >= (1ull << nv)) return partial[nv];
+    Fr mult = fr_one(), acc = fr_zero();
+    for (uint32_t i = 0; i < nv; i++) {
+        const uint64_t left = k >> (nv - i - 1);
+        const Fr prev = mult;
+        if (left == 1) {
+            mult = fr_mul(fr_mul(mult, pt[i]), r[i]);
+            acc = fr_add(acc, fr_mul(fr_mul(fr_mul(prev, fr_sub(fr_one(), pt[i])), fr_sub(fr_one(), r[i])), partial[nv - i - 1]));
+        } else {
+            mult = fr_mul(fr_mul(mult, fr_sub(fr_one(), pt[i])), fr_sub(fr_one(), r[i]));
+        }
+        k -= left << (nv - i - 1);
+    }
+    return acc;
+}
+
+struct Frac {  // one (numerator, denominator) pair of the logup tree; the arrays may be halves of a parent's buffers
+    const Fr* num = nullptr;
+    const Fr* den = nullptr;
+    uint64_t len = 0;
+    std::shared_ptr<DevBuf> keep_n, keep_d;
+};
+
+int32_t read_fr(const Fr* d, Fr* h, hipStream_t s) {
+    GM_HIP(hipMemcpyAsync(h, d, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    return GM_OK;
+}
+
+int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_log, const uint64_t* h_claim_point,
+                          const uint64_t* h_claim_evs, Tape* tr, Fr* out_gamma, Claims* out_matrix, Claims* out_ac_c,
+                          Claims* out_ac_d, hipStream_t s) {
+    GM_REQUIRE(plan->y0 == 0 && plan->y1 == plan->y_size, "the pushforward argument needs a plan over all windows");
+    const uint32_t x_log = plan->x_log, d_log = plan->d_log, y_size = plan->y_size;
+    GM_REQUIRE((1u << y_log) >= y_size, "y_logsize too small");
+    const uint32_t mlog = x_log + y_log;
+    GM_REQUIRE(mlog >= 1 && mlog <= 30, "matrix too large");
+    const uint64_t M = 1ull << mlog, msize = (uint64_t)y_size << x_log, X = 1ull << x_log, D = 1ull << d_log;
+    void* stream = reinterpret_cast<void*>(s);
+    std::vector<Fr> r(y_log + d_log + x_log), evs(3);
+    memcpy(r.data(), h_claim_point, r.size() * sizeof(Fr));
+    memcpy(evs.data(), h_claim_evs, 3 * sizeof(Fr));
+    evs[1] = fr_sub(evs[1], fr_one());  // claims.evs[1] -= 1 (pushforward.rs:641)
+
+    // phase-1 / phase-2 columns, padded with zeros to 2^mlog (pushforward.rs:706-709)
+    auto mk = [&](uint64_t n, std::shared_ptr<DevBuf>* b) -> int32_t {
+        b->reset(new DevBuf());
+        return (*b)->alloc(n * sizeof(Fr));
+    };
+    std::shared_ptr<DevBuf> c, d, ac_c, ac_d, c_pull, d_pull, c_adj, d_adj, num, den, table_c, table_d, p_sel, eqs;
+    TRY(mk(M, &c)); TRY(mk(M, &d)); TRY(mk(X, &ac_c)); TRY(mk(D, &ac_d)); TRY(mk(M, &c_pull)); TRY(mk(M, &d_pull));
+    if (M > msize) {
+        for (auto* b : {&c, &d, &c_pull, &d_pull}) GM_HIP(hipMemsetAsync((*b)->fr() + msize, 0, (M - msize) * sizeof(Fr), s));
+    }
+    TRY(gm_msm_phase1_polys(plan, (uint64_t*)c->p, (uint64_t*)d->p, (uint64_t*)ac_c->p, (uint64_t*)ac_d->p, stream));
+    TRY(gm_msm_second_phase(plan, h_claim_point, y_log, (uint64_t*)c_pull->p, (uint64_t*)d_pull->p, stream));
+
+    // challenges (pushforward.rs:684-685)
+    Fr psi, tau_c, tau_d, tau_s, gamma;
+    TRY(tr->challenge(&psi)); TRY(tr->challenge(&tau_c)); TRY(tr->challenge(&tau_d)); TRY(tr->challenge(&tau_s));
+    TRY(tr->challenge(&gamma));
+    GM_REQUIRE(!fr_is_zero(tau_s) && !fr_is_zero(psi), "zero challenge (inverse().unwrap() in the reference)");
+
+    TRY(mk(M, &c_adj)); TRY(mk(M, &d_adj)); TRY(mk(M, &num)); TRY(mk(M, &den));
+    hipLaunchKernelGGL(k_pf_adj, dim3(ceil_div(M, 256)), dim3(256), 0, s, c_pull->fr(), c->fr(), psi, tau_c, tau_s, msize, M, c_adj->fr());
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pf_adj, dim3(ceil_div(M, 256)), dim3(256), 0, s, d_pull->fr(), d->fr(), psi, tau_d, tau_s, msize, M, d_adj->fr());
+    GM_LAUNCH_CHECK();
+    {   // [left, right] = f_addinv.map_split_hi(&[&c_adj, &d_adj]) (pushforward.rs:719)
+        const Fr* in[2] = {c_adj->fr(), d_adj->fr()};
+        Fr* outp[2] = {num->fr(), den->fr()};
+        TRY(launch_dense_map(plan_of(mkfn(GM_FN_ADD_INVERSES, 1)), in, outp, M, s));
+    }
+    // tables (pushforward.rs:725-728): eq_c / eq_d with all their levels in scratch
+    TRY(mk(2 * X + 2 * D, &eqs)); TRY(mk(X, &table_c)); TRY(mk(D, &table_d));
+    {
+        Fr* eq_c = eqs->fr();
+        Fr* eq_d = eqs->fr() + 2 * X;
+        std::vector<Fr*> lv(x_log + 1);
+        for (uint32_t i = 0; i < x_log; i++) lv[i] = eq_c + X + ((1ull << i) - 1);
+        lv[x_log] = eq_c;
+        TRY(launch_eq_sequence(fr_one(), r.data() + y_log + d_log, x_log, lv.data(), s));
+        lv.assign(d_log + 1, nullptr);
+        for (uint32_t i = 0; i < d_log; i++) lv[i] = eq_d + D + ((1ull << i) - 1);
+        lv[d_log] = eq_d;
+        TRY(launch_eq_sequence(fr_one(), r.data() + y_log, d_log, lv.data(), s));
+        hipLaunchKernelGGL(k_pf_table, dim3(ceil_div(X, 256)), dim3(256), 0, s, eq_c, psi, tau_c, X, table_c->fr());
+        GM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pf_table, dim3(ceil_div(D, 256)), dim3(256), 0, s, eq_d, psi, tau_d, D, table_d->fr());
+        GM_LAUNCH_CHECK();
+    }
+    // suppression_term_total = 2 (2^mlog - matrix_size) / tau_suppression_term (pushforward.rs:730)
+    const Fr supp_total = fr_mul(fr_from_u64(2 * (M - msize)), fr_inv(tau_s));
+
+    // ---- LogupMainphaseProtocol::make_witness (logup_mainphase.rs:83-143) over logsizes [mlog-1, mlog-1, x_log, d_log]
+    std::vector<Frac> inputs(4), layers;
+    inputs[0].num = num->fr(); inputs[0].den = den->fr(); inputs[0].len = M / 2; inputs[0].keep_n = num; inputs[0].keep_d = den;
+    inputs[1].num = num->fr() + M / 2; inputs[1].den = den->fr() + M / 2; inputs[1].len = M / 2; inputs[1].keep_n = num; inputs[1].keep_d = den;
+    inputs[2].num = ac_c->fr(); inputs[2].den = table_c->fr(); inputs[2].len = X; inputs[2].keep_n = ac_c; inputs[2].keep_d = table_c;
+    inputs[3].num = ac_d->fr(); inputs[3].den = table_d->fr(); inputs[3].len = D; inputs[3].keep_n = ac_d; inputs[3].keep_d = table_d;
+    std::vector<uint32_t> logsizes = {mlog - 1, mlog - 1, x_log, d_log};
+    GM_REQUIRE(mlog - 1 >= x_log && x_log >= d_log, "logsizes must be non-increasing (logup_mainphase.rs:75-77)");
+    size_t next_in = 2;
+    layers.push_back(inputs[0]);
+    layers.push_back(inputs[1]);
+    const SegPlan logup = plan_of(mkfn(GM_FN_LOGUP_LAYER, 1));
+    for (size_t i = 0;; i += 2) {
+        const uint64_t next_size = next_in < inputs.size() ? inputs[next_in].len : 1;
+        const uint64_t curr = layers[i].len;
+        Frac o;
+        o.len = curr;
+        TRY(mk(curr, &o.keep_n)); TRY(mk(curr, &o.keep_d));
+        o.num = o.keep_n->fr(); o.den = o.keep_d->fr();
+        const Fr* in[4] = {layers[i].num, layers[i].den, layers[i + 1].num, layers[i + 1].den};
+        Fr* outp[2] = {o.keep_n->fr(), o.keep_d->fr()};
+        TRY(launch_dense_map(logup, in, outp, curr, s));
+        if (curr == next_size) {
+            layers.push_back(o);
+            if (next_in < inputs.size()) layers.push_back(inputs[next_in++]);
+            else break;
+        } else {
+            GM_REQUIRE(curr > next_size, "logup witness: unreachable size order");
+            Frac lo = o, hi = o;
+            lo.len = hi.len = curr / 2;
+            hi.num = o.num + curr / 2; hi.den = o.den + curr / 2;
+            layers.push_back(lo);
+            layers.push_back(hi);
+        }
+    }
+    Frac top = layers.back();
+    layers.pop_back();
+    GM_REQUIRE(top.len == 1, "logup witness does not end in a single fraction");
+    Fr nd[2];
+    TRY(read_fr(top.num, &nd[0], s));
+    TRY(read_fr(top.den, &nd[1], s));
+    GM_REQUIRE(!fr_is_zero(nd[1]), "logup denominator is zero (logup_mainphase.rs:161)");
+    GM_REQUIRE(fr_eq(nd[0], fr_mul(nd[1], supp_total)), "logup total does not match the suppression term (logup_mainphase.rs:162)");
+    tr->write_scalars({nd[0], nd[1]});
+
+    // workspace of the sumcheck objects: fold buffers of the widest layer + eq levels
+    Arena arena;
+    TRY(arena.init((size_t)32 * (5 * (M / 2 + M / 4) + 2 * M) + ((size_t)64 << 20)));
+    Fr* pinned = nullptr;
+    GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(pinned, 0, 16 * sizeof(Fr));
+    shared_pinned() = pinned;
+    struct Cleanup { Fr* p; ~Cleanup() { shared_pinned() = nullptr; (void)hipHostFree(p); } } cleanup{pinned};
+
+    // ---- LogupMainphaseProtocol::prove (logup_mainphase.rs:156-208)
+    uint32_t curr_log = 0;
+    Claims running;
+    running.evs = {nd[0], nd[1]};
+    std::vector<Claims> accumulated;
+    Claims last;
+    const gm_fn f_logup = mkfn(GM_FN_LOGUP_LAYER, 1);
+    for (;;) {
+        const uint32_t incoming = logsizes.back();
+        GM_REQUIRE(layers.size() >= 2, "logup witness exhausted");
+        const Frac rr = layers.back(); layers.pop_back();
+        const Frac ll = layers.back(); layers.pop_back();
+        GM_REQUIRE(ll.len == (1ull << curr_log) && rr.len == ll.len, "logup layer size mismatch");
+        Claims c4 = running;
+        if (curr_log == 0) {
+            // DenseEqSumcheck over zero variables (sumcheck.rs:844-872): gamma is drawn, no rounds, the four values are sent
+            Fr g0;
+            TRY(tr->challenge(&g0));
+            std::vector<Fr> v(4);
+            TRY(read_fr(ll.num, &v[0], s)); TRY(read_fr(ll.den, &v[1], s)); TRY(read_fr(rr.num, &v[2], s)); TRY(read_fr(rr.den, &v[3], s));
+            tr->write_scalars(v);
+            c4.point.clear();
+            c4.evs = v;
+        } else {
+            arena.reset();
+            ArenaScope scope(&arena);
+            Advice adv;
+            adv.kind = Advice::DENSE;
+            adv.len = ll.len;
+            for (const Fr* ptr : {ll.num, ll.den, rr.num, rr.den}) {
+                adv.cols.emplace_back(new DevBuf());
+                adv.cols.back()->p = const_cast<Fr*>(ptr);   // borrowed view
+                adv.cols.back()->owned = false;
+                adv.cols.back()->bytes = ll.len * sizeof(Fr);
+            }
+            TRY(dense_deg2_prove(tr, f_logup, curr_log, &c4, adv, s));
+        }
+        if (incoming == curr_log) {
+            if (logsizes.size() == 2) { last = c4; break; }
+            running.point = c4.point;
+            running.evs = {c4.evs[0], c4.evs[1]};
+            Claims a;
+            a.point = c4.point;
+            a.evs = {c4.evs[2], c4.evs[3]};
+            accumulated.push_back(a);
+            logsizes.pop_back();
+        } else {
+            running = c4;
+            TRY(split_at_prove(tr, &running, true, 0, 2));
+            curr_log++;
+        }
+    }
+    accumulated.push_back(last);
+    std::reverse(accumulated.begin(), accumulated.end());
+    GM_REQUIRE(accumulated.size() == 3, "logup main phase must end with 3 claims");
+    Claims cd = accumulated[0];
+    *out_ac_c = accumulated[1];
+    *out_ac_d = accumulated[2];
+    TRY(split_at_prove(tr, &cd, true, 0, 2));   // SplitAt(HI(0), 2) (pushforward.rs:744-746)
+    GM_REQUIRE(cd.evs.size() == 2 && cd.point.size() == mlog, "cd claims have the wrong shape");
+
+    // ---- combined sumcheck (pushforward.rs:748-801)
+    const Fr g1 = gamma, g2 = fr_mul(gamma, gamma);
+    TRY(mk(M, &p_sel));
+    {
+        // EqTruncPoly(y_log, y_size, r_y).evals() (verifier_polys.rs:98-106): tiny, built on the host
+        std::vector<Fr> e(1ull << y_log, fr_zero());
+        e[0] = fr_one();
+        for (uint32_t i = 0; i < y_log; i++)
+            for (uint64_t j = (1ull << i); j-- > 0;) {
+                const Fr w = e[j], m = fr_mul(r[i], w);
+                e[2 * j] = fr_sub(w, m);
+                e[2 * j + 1] = m;
+            }
+        for (uint64_t i = y_size; i < (1ull << y_log); i++) e[i] = fr_zero();
+        std::shared_ptr<DevBuf> d_e;
+        TRY(mk(e.size(), &d_e));
+        GM_HIP(hipMemcpyAsync(d_e->p, e.data(), e.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pf_psel, dim3(ceil_div(M, 256)), dim3(256), 0, s, reinterpret_cast<const Fr*>(d_points_xy), d_e->fr(), g1,
+                           g2, x_log, M, p_sel->fr());
+        GM_LAUNCH_CHECK();
+        GM_HIP(hipStreamSynchronize(s));  // e / d_e go out of scope
+    }
+    const Fr ev_folded = fr_add(fr_add(evs[0], fr_mul(g1, evs[1])), fr_mul(g2, evs[2]));
+    Fr claim = fr_add(fr_add(cd.evs[0], fr_mul(g1, cd.evs[1])), fr_mul(g2, ev_folded));
+    arena.reset();
+    ArenaScope scope(&arena);
+    ScHolder prod3, frac;
+    {
+        const uint64_t* pc[3] = {(const uint64_t*)p_sel->p, (const uint64_t*)c_pull->p, (const uint64_t*)d_pull->p};
+        TRY(gm_sc_dense_create(1, nullptr, mlog, pc, nullptr, reinterpret_cast<const uint64_t*>(&ev_folded), &prod3.so, stream));
+        const uint64_t* fc[2] = {(const uint64_t*)c_adj->p, (const uint64_t*)d_adj->p};
+        const gm_fn f_inv = mkfn(GM_FN_ADD_INVERSES, 1);
+        TRY(gm_sc_dense_deg2_create(&f_inv, mlog, fc, reinterpret_cast<const uint64_t*>(cd.point.data()),
+                                    reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(cd.evs.data()),
+                                    &frac.so, stream));
+    }
+    std::vector<Fr> out_pt;
+    for (uint32_t i = 0; i < mlog; i++) {
+        Fr pr[8], fq[8];
+        uint32_t n1 = 0, n2 = 0;
+        TRY(gm_sc_unipoly(prod3.so, reinterpret_cast<uint64_t*>(pr), &n1));
+        TRY(gm_sc_unipoly(frac.so, reinterpret_cast<uint64_t*>(fq), &n2));
+        GM_REQUIRE(n1 == 4 && n2 == 4, "combined sumcheck: responses must have 4 coefficients");
+        std::vector<Fr> comb(4);
+        for (int k = 0; k < 4; k++) comb[k] = fr_add(fq[k], fr_mul(g2, pr[k]));
+        const Fr chk = fr_add(fr_add(fr_dbl(comb[0]), comb[1]), fr_add(comb[2], comb[3]));
+        GM_REQUIRE(fr_eq(chk, claim), "combined sumcheck: round %u does not sum to the claim (pushforward.rs:789)", i);
+        tr->write_scalars({comb[0], comb[2], comb[3]});   // compress_coefficients
+        Fr t;
+        TRY(tr->challenge(&t));
+        claim = evaluate_univar(comb, t);
+        out_pt.push_back(t);
+        TRY(gm_sc_bind(prod3.so, reinterpret_cast<const uint64_t*>(&t)));
+        TRY(gm_sc_bind(frac.so, reinterpret_cast<const uint64_t*>(&t)));
+        tr->rounds++;
+    }
+    std::reverse(out_pt.begin(), out_pt.end());
+    Fr pe[GM_MAX_COLS + 1], fe[GM_MAX_COLS + 1];
+    uint32_t ne = 0;
+    TRY(gm_sc_final_evals(prod3.so, reinterpret_cast<uint64_t*>(pe), &ne));
+    GM_REQUIRE(ne == 3, "prod3 final evaluations");
+    TRY(gm_sc_final_evals(frac.so, reinterpret_cast<uint64_t*>(fe), &ne));
+    GM_REQUIRE(ne == 2, "frac final evaluations");
+    const Fr p_sel_ev = pe[0], c_pull_ev = pe[1], d_pull_ev = pe[2], c_adj_ev = fe[0], d_adj_ev = fe[1];
+    const Fr eqy = eq_trunc_evaluate(y_log, y_size, r.data(), out_pt.data());
+    GM_REQUIRE(!fr_is_zero(eqy), "eq_sel_y evaluates to zero (inverse().unwrap(), pushforward.rs:808)");
+    const Fr p_folded_ev = fr_add(fr_mul(p_sel_ev, fr_inv(eqy)), gamma);
+    const Fr sel_ev = eq_sum_host(out_pt.data(), y_log, y_size);
+    const Fr tmp = fr_mul(tau_s, fr_sub(fr_one(), sel_ev));
+    const Fr psi_inv = fr_inv(psi);
+    const Fr c_ev = fr_mul(psi_inv, fr_sub(fr_add(fr_sub(c_adj_ev, c_pull_ev), fr_mul(tau_c, sel_ev)), tmp));
+    const Fr d_ev = fr_mul(psi_inv, fr_sub(fr_add(fr_sub(d_adj_ev, d_pull_ev), fr_mul(tau_d, sel_ev)), tmp));
+    out_matrix->point = out_pt;
+    out_matrix->evs = {p_folded_ev, c_pull_ev, d_pull_ev, c_ev, d_ev};
+    tr->write_scalars(out_matrix->evs);
+    *out_gamma = gamma;
+    return GM_OK;
+}
+
+int32_t put_claims(const Claims& c, uint64_t* h_point, uint64_t* h_evs) {
+    if (h_point) memcpy(h_point, c.point.data(), c.point.size() * sizeof(Fr));
+    if (h_evs) memcpy(h_evs, c.evs.data(), c.evs.size() * sizeof(Fr));
+    return GM_OK;
+}
+
+int32_t pushforward_entry(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize, const uint64_t* h_claim_point,
+                          const uint64_t* h_claim_evs, const uint64_t* h_tape, uint64_t n_tape, const gm_transcript* cb,
+                          uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_gamma, uint64_t* h_matrix_point,
+                          uint64_t* h_matrix_evs, uint64_t* h_ac_c_point, uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point,
+                          uint64_t* h_ac_d_evs, uint64_t* tape_used, uint64_t* rounds, void* stream) {
+    GM_REQUIRE(plan && d_points_xy && h_claim_point && h_claim_evs, "null argument");
+    std::vector<Fr> msgs;
+    Tape tr{h_tape, n_tape, 0, &msgs, 0, cb, 0};
+    Fr gamma;
+    Claims mx, acc, acd;
+    TRY(pushforward_prove(plan, d_points_xy, y_logsize, h_claim_point, h_claim_evs, &tr, &gamma, &mx, &acc, &acd, as_stream(stream)));
+    if (tr.cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", tr.cb_rc);
+    if (n_msgs) *n_msgs = msgs.size();
+    if (h_msgs) {
+        GM_REQUIRE(msgs.size() <= msgs_cap, "message buffer too small: %zu > %llu", msgs.size(), (unsigned long long)msgs_cap);
+        memcpy(h_msgs, msgs.data(), msgs.size() * sizeof(Fr));
+    }
+    if (h_gamma) memcpy(h_gamma, &gamma, sizeof(Fr));
+    put_claims(mx, h_matrix_point, h_matrix_evs);
+    put_claims(acc, h_ac_c_point, h_ac_c_evs);
+    put_claims(acd, h_ac_d_point, h_ac_d_evs);
+    if (tape_used) *tape_used = tr.pos;
+    if (rounds) *rounds = tr.rounds;
+    return GM_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t gm_pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                        const uint64_t* h_claim_point, const uint64_t* h_claim_evs, const uint64_t* h_tape,
+                                        uint64_t n_tape, uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_gamma,
+                                        uint64_t* h_matrix_point, uint64_t* h_matrix_evs, uint64_t* h_ac_c_point,
+                                        uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point, uint64_t* h_ac_d_evs, uint64_t* tape_used,
+                                        uint64_t* rounds, void* stream) {
+    GM_REQUIRE(h_tape, "null tape");
+    return pushforward_entry(plan, d_points_xy, y_logsize, h_claim_point, h_claim_evs, h_tape, n_tape, nullptr, h_msgs, msgs_cap,
+                             n_msgs, h_gamma, h_matrix_point, h_matrix_evs, h_ac_c_point, h_ac_c_evs, h_ac_d_point, h_ac_d_evs,
+                             tape_used, rounds, stream);
+}
+
+extern "C" int32_t gm_pushforward_prove_tr(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                           const uint64_t* h_claim_point, const uint64_t* h_claim_evs, const gm_transcript* tr,
+                                           uint64_t* h_gamma, uint64_t* h_matrix_point, uint64_t* h_matrix_evs,
+                                           uint64_t* h_ac_c_point, uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point,
+                                           uint64_t* h_ac_d_evs, uint64_t* n_challenges, uint64_t* rounds, void* stream) {
+    GM_REQUIRE(tr && tr->challenge, "null transcript");
+    return pushforward_entry(plan, d_points_xy, y_logsize, h_claim_point, h_claim_evs, nullptr, 0, tr, nullptr, 0, nullptr, h_gamma,
+                             h_matrix_point, h_matrix_evs, h_ac_c_point, h_ac_c_evs, h_ac_d_point, h_ac_d_evs, n_challenges, rounds,
+                             stream);
+}

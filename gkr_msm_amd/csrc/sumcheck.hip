@@ -320,11 +320,12 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs c
 // gen-1 layer -- go through these instead: the primitive is a template parameter, each output is folded into the gamma
 // combination as soon as it exists, and the evaluation points are walked by a rolled loop that reloads the pair (an L2
 // hit), so the live state is one set of inputs.  Field sums are exact: same round polynomials, bit for bit.
-#define LEAN_AFF_L1_BC 11  // StackedAlgFn(affine_l1, RepeatedAlgFn(BitCheckFn, 2)): the first bintree layer (bintree_add.rs:258-285)
+#define LEAN_AFF_L1_BC 100  // StackedAlgFn(affine_l1, RepeatedAlgFn(BitCheckFn, 2)): the first bintree layer (bintree_add.rs:258-285)
 
 __device__ __forceinline__ constexpr int lean_n_in(int prim) {
     return prim == FN_AFF_L1 ? 4 : prim == FN_AFF_L2 ? 3 : prim == FN_AFF_L3 ? 3 : prim == FN_PROJ_L1 ? 6 : prim == FN_PROJ_L2 ? 4
-         : prim == FN_PROJ_L3 ? 4 : prim == FN_PT_BIT_CHOICE ? 3 : prim == LEAN_AFF_L1_BC ? 6 : 0;
+         : prim == FN_PROJ_L3 ? 4 : prim == FN_PT_BIT_CHOICE ? 3 : prim == LEAN_AFF_L1_BC ? 6 : prim == FN_ADD_INVERSES ? 2
+         : prim == FN_LOGUP_LAYER ? 4 : 0;
 }
 
 // sum_o gamma^o f_o(v) for the whole (single-primitive) layer function; g[o] = gamma^o on the device
@@ -362,6 +363,11 @@ __device__ __forceinline__ Fr lean_gamma_eval(const Fr* v, const Fr* __restrict_
         A = fr_add(A, fr_mul(fr_load(g + 1), fr_mul(v[2], v[3])));
         A = fr_add(A, fr_mul(fr_load(g + 2), fr_sqr(v[3])));
         return fr_add(A, fr_mul(fr_load(g + 3), fr_mul(v[0], v[1])));
+    } else if (PRIM == FN_ADD_INVERSES) {
+        return fr_add(fr_add(v[0], v[1]), fr_mul(fr_load(g + 1), fr_mul(v[0], v[1])));
+    } else if (PRIM == FN_LOGUP_LAYER) {
+        const Fr n = fr_add(fr_mul(v[0], v[3]), fr_mul(v[1], v[2]));
+        return fr_add(n, fr_mul(fr_load(g + 1), fr_mul(v[1], v[3])));
     } else {  // FN_PT_BIT_CHOICE: (b, x, y) -> (b x, b (y - 1) + 1)
         Fr A = fr_mul(v[0], v[1]);
         const Fr by = fr_add(fr_mul(v[0], fr_sub(v[2], fr_one())), fr_one());
@@ -698,7 +704,7 @@ static int lean_prim_of(const SegPlan& sp) {
     if (sp.nseg == 1 && sp.seg[0].out0 == 0) {
         switch (sp.seg[0].prim) {
             case FN_AFF_L1: case FN_AFF_L2: case FN_AFF_L3: case FN_PROJ_L1: case FN_PROJ_L2: case FN_PROJ_L3:
-            case FN_PT_BIT_CHOICE:
+            case FN_PT_BIT_CHOICE: case FN_ADD_INVERSES: case FN_LOGUP_LAYER:
                 for (int q = 0; q < sp.seg[0].n_in; q++) if (sp.seg[0].in[q] != q) return 0;
                 return sp.seg[0].prim;
             default: return 0;
@@ -718,6 +724,7 @@ static int32_t launch_deg2_lean(int prim, dim3 grid, hipStream_t s, const LeanCo
     switch (prim) {
         GM_LEAN_CASE(FN_AFF_L1) GM_LEAN_CASE(FN_AFF_L2) GM_LEAN_CASE(FN_AFF_L3) GM_LEAN_CASE(FN_PROJ_L1)
         GM_LEAN_CASE(FN_PROJ_L2) GM_LEAN_CASE(FN_PROJ_L3) GM_LEAN_CASE(FN_PT_BIT_CHOICE) GM_LEAN_CASE(LEAN_AFF_L1_BC)
+        GM_LEAN_CASE(FN_ADD_INVERSES) GM_LEAN_CASE(FN_LOGUP_LAYER)
         default: return set_err(GM_ERR_STATE, "no lean kernel for primitive %d", prim);
     }
 #undef GM_LEAN_CASE
@@ -732,6 +739,7 @@ static int32_t launch_generic3_lean(int prim, dim3 grid, hipStream_t s, const Le
     switch (prim) {
         GM_LEAN_CASE(FN_AFF_L1) GM_LEAN_CASE(FN_AFF_L2) GM_LEAN_CASE(FN_AFF_L3) GM_LEAN_CASE(FN_PROJ_L1)
         GM_LEAN_CASE(FN_PROJ_L2) GM_LEAN_CASE(FN_PROJ_L3) GM_LEAN_CASE(FN_PT_BIT_CHOICE)
+        GM_LEAN_CASE(FN_ADD_INVERSES) GM_LEAN_CASE(FN_LOGUP_LAYER)
         default: return set_err(GM_ERR_STATE, "no lean kernel for primitive %d", prim);
     }
 #undef GM_LEAN_CASE

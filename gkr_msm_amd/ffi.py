@@ -19,7 +19,7 @@ class GmFn(C.Structure):
 
 
 FN_AFF_L1, FN_AFF_L2, FN_AFF_L3, FN_PROJ_L1, FN_PROJ_L2, FN_PROJ_L3 = 1, 2, 3, 4, 5, 6
-FN_TRI_L1, FN_ID, FN_BITCHECK, FN_PT_BIT_CHOICE = 7, 8, 9, 10
+FN_TRI_L1, FN_ID, FN_BITCHECK, FN_PT_BIT_CHOICE, FN_ADD_INVERSES, FN_LOGUP_LAYER = 7, 8, 9, 10, 11, 12
 
 
 def make_fn(*segs):
@@ -106,6 +106,10 @@ _SIGS = {
     "gm_pip_prove_image_part_tr": (C.c_int32, [vp, vp, vp, C.POINTER(GmTranscript), vp, u32p, vp, u64p, u64p]),
     "gm_gkr_msm_prove_tr": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(GmTranscript), vp, vp, u32p, vp, u64p, u64p,
                                         vp]),
+    "gm_pushforward_prove": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, vp, vp, vp, vp, vp,
+                                         u64p, u64p, vp]),
+    "gm_pushforward_prove_tr": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, C.POINTER(GmTranscript), vp, vp, vp, vp, vp, vp, vp, u64p,
+                                            u64p, vp]),
     "gm_gkr_msm_prove": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u32p, vp,
                                      u64p, u64p, C.POINTER(C.c_double), vp]),
     "gm_msm_plan_create": (C.c_int32, [C.c_uint32] * 5 + [C.POINTER(vp)]),

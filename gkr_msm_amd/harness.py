@@ -372,6 +372,27 @@ class PipWitness:
                     evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value, rounds=rounds.value)
 
 
+def pushforward_prove(plan, d_points, y_logsize, claim_point, claim_evs, tape, msgs_cap=1 << 16):
+    """gm_pushforward_prove -> dict(msgs, gamma, matrix=(point, evs), ac_c=(point, evs), ac_d=(point, evs), tape_used, rounds)"""
+    L = ffi.lib()
+    x, d = plan.x_logsize, plan.d_logsize
+    cp, ce = fr_arg(claim_point), fr_arg(claim_evs)
+    tp = codec.ints_to_limbs(tape)
+    msgs = np.zeros((msgs_cap, 4), dtype=np.uint64)
+    g = np.zeros((1, 4), dtype=np.uint64)
+    mp, me = np.zeros((x + y_logsize, 4), dtype=np.uint64), np.zeros((5, 4), dtype=np.uint64)
+    cpt, cev = np.zeros((max(x, 1), 4), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64)
+    dpt, dev = np.zeros((max(d, 1), 4), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64)
+    nm, used, rounds = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    ffi.check(L.gm_pushforward_prove(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, cp.ctypes.data, ce.ctypes.data,
+                                     tp.ctypes.data, len(tape), msgs.ctypes.data, msgs_cap, C.byref(nm), g.ctypes.data,
+                                     mp.ctypes.data, me.ctypes.data, cpt.ctypes.data, cev.ctypes.data, dpt.ctypes.data,
+                                     dev.ctypes.data, C.byref(used), C.byref(rounds), cur_stream()))
+    f = codec.from_mont_limbs
+    return dict(msgs=f(msgs[: nm.value]), gamma=f(g)[0], matrix=(f(mp), f(me)), ac_c=(f(cpt[:x]), f(cev)), ac_d=(f(dpt[:d]), f(dev)),
+                tape_used=used.value, rounds=rounds.value)
+
+
 class LiveTranscript:
     """A gm_transcript whose callbacks run Python code: `on_write(list of canonical ints)` and `draw() -> int`.
     Stands in for the Rust shim's wrappers over ProofTranscript2 (tests drive it from a tape or a hash)."""

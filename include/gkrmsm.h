@@ -61,6 +61,8 @@ int32_t gm_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream
 #define GM_FN_ID 8       /* IdAlgFn::new(1); use count=n for IdAlgFn::new(n) */
 #define GM_FN_BITCHECK 9 /* BitCheckFn */
 #define GM_FN_PT_BIT_CHOICE 10 /* gkr_msm_simple.rs:82-84 */
+#define GM_FN_ADD_INVERSES 11  /* AddInversesFn  pushforward/pushforward.rs:255-281  (deg 2, 2 -> 2) */
+#define GM_FN_LOGUP_LAYER 12   /* LogupLayerFn   pushforward/logup_mainphase.rs:30-61 (deg 2, 4 -> 2) */
 #define GM_FN_MAX_SEG 4
 
 typedef struct gm_fn {
@@ -282,6 +284,27 @@ int32_t gm_pip_prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim
 int32_t gm_pip_prove_image_part_tr(const gm_pip_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
                                    const gm_transcript* tr, uint64_t* h_final_point, uint32_t* n_final_point,
                                    uint64_t* h_final_evs, uint64_t* n_challenges, uint64_t* rounds);
+
+/* ---------------------------------------------------------------- "prove pushforward" (a7, a10, a12, a13)
+ * PushforwardProtocol::prove (pushforward/pushforward.rs:640-846) with LogupMainphaseProtocol (pushforward/logup_mainphase.rs:83-208)
+ * on the Fr columns of the plan's last gm_msm_run: c / d / ac_c / ac_d (PushForwardState::new :489-510), c_pull / d_pull
+ * (second_phase :572-596, point = the image part's final point [r_y | r_d | r_c]), p_0 / p_1 = the points' coordinates.
+ *   h_claim_point / h_claim_evs: the final claims of gm_pip_prove_image_part (y_logsize + d_logsize + x_logsize coordinates, 3 evs)
+ *   challenges: 4 of 512 bits (canonical field elements on the tape), then `challenge(128)` values, in draw order
+ *   outputs = PushforwardFinalClaims (:626-631): gamma; claims_about_matrix: point (x_logsize + y_logsize coordinates) and
+ *   [p_folded, c_pull, d_pull, c, d] evaluations; claims_ac_c: point (x_logsize) + [ac_c, table_c] evaluations; claims_ac_d:
+ *   point (d_logsize) + [ac_d, table_d] evaluations.  (The G1 commitments written to the transcript around this call,
+ *   pippenger.rs:126-133, 152-153, are gm_msm_g1_outer / gm_g1_msm / gm_g1_msm_nonaff results.) */
+int32_t gm_pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                             const uint64_t* h_claim_point, const uint64_t* h_claim_evs, const uint64_t* h_tape, uint64_t n_tape,
+                             uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_gamma, uint64_t* h_matrix_point,
+                             uint64_t* h_matrix_evs, uint64_t* h_ac_c_point, uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point,
+                             uint64_t* h_ac_d_evs, uint64_t* tape_used, uint64_t* rounds, void* stream);
+int32_t gm_pushforward_prove_tr(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                const uint64_t* h_claim_point, const uint64_t* h_claim_evs, const gm_transcript* tr,
+                                uint64_t* h_gamma, uint64_t* h_matrix_point, uint64_t* h_matrix_evs, uint64_t* h_ac_c_point,
+                                uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point, uint64_t* h_ac_d_evs, uint64_t* n_challenges,
+                                uint64_t* rounds, void* stream);
 
 /* ---------------------------------------------------------------- gen-1 prover (a6, a16)
  * gkr_msm_prove (src/gkr_msm_simple.rs:86-338) without the BLS12-381 G1 column commitments: base polys

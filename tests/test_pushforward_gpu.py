@@ -1,0 +1,50 @@
+"""GPU parity of "prove pushforward" (PushforwardProtocol::prove + the logup main phase) through the C ABI vs the Python
+oracle with the same challenge tape: every prover message, gamma, and the three final claims; chained after the image part
+exactly as Pippenger::prove does (pippenger.rs:138-160)."""
+import pytest
+
+from gkr_msm_amd import codec, harness as H
+from pyref import field as F
+from pyref import gkr as G
+from pyref import polys as PL
+from pyref import pushforward as PF
+from pyref.sumcheck import TapeTranscript
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("x_log,d_log,nbits", [(3, 2, 8), (4, 2, 6), (3, 3, 15), (5, 2, 4), (6, 3, 24), (5, 4, 16)])
+def test_pushforward_matches_oracle(x_log, d_log, nbits):
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = (y_size - 1).bit_length()
+    n = 1 << x_log
+    pts = F.random_points(n, 11 + x_log)
+    sc = F.random_scalars(n, nbits, 12 + d_log)
+    sc[0] = 0
+    image, digits, counter = G.bucketing_image(pts, sc, y_size, y_log, d_log, x_log)
+    rng = F.SplitMix64(31)
+    r = [rng.next_fr() for _ in range(y_log + d_log + x_log)]
+    evs = [PL.evaluate_poly(p.to_dense(), r) for p in image]
+    tape = [rng.next_bits(512) % F.P for _ in range(3000)]
+    tr = TapeTranscript(tape)
+    p1 = PF.phase1_data(pts, digits, counter, x_log, d_log)
+    p2 = PF.phase2_data(digits, counter, r, y_log, d_log, x_log)
+    want = PF.pushforward_prove(tr, x_log, y_log, y_size, d_log, (r, evs), p1, p2)
+
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    plan = H.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, H.to_dev(codec.ints_to_limbs(sc)))
+    # the device draws challenge(128) as the low 128 bits too: feed canonical values, masked where the oracle masks
+    got = H.pushforward_prove(plan, d_pts, y_log, r, evs, _device_tape(tape, tr))
+    assert got["tape_used"] == tr.pos
+    assert got["msgs"] == [v for m in tr.msgs for v in m]
+    assert got["gamma"] == want["gamma"]
+    assert (list(got["matrix"][0]), list(got["matrix"][1])) == (want["matrix"][0], want["matrix"][1])
+    assert (list(got["ac_c"][0]), list(got["ac_c"][1])) == (list(want["ac_c"][0]), list(want["ac_c"][1]))
+    assert (list(got["ac_d"][0]), list(got["ac_d"][1])) == (list(want["ac_d"][0]), list(want["ac_d"][1]))
+    assert got["rounds"] == sum(range(x_log + y_log)) + x_log + d_log + x_log + y_log
+
+
+def _device_tape(tape, tr):
+    """the challenges as the oracle consumed them (4 x 512-bit reduced mod p, then 128-bit truncations)"""
+    return [t % F.P if i < 4 else t & ((1 << 128) - 1) for i, t in enumerate(tape[: tr.pos])] + [0] * 8
