@@ -224,6 +224,21 @@ def main():
                            "witness_trace_GiB": round(L.gm_pip_witness_bytes(w.h) / 2 ** 30, 2),
                            "workload": "prove image part (triangle + bintree GKR) x_logsize=%d d_logsize=%d nbits=%d" % (
                                x_log, d_log, nbits)}
+        # "prove pushforward" chained on the image part's final claims (pippenger.rs:147-160): logup main phase + combined sumcheck
+        pr = np.random.default_rng(9)
+        pf_tape = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(4)] + [int.from_bytes(pr.bytes(16), "little")
+                                                                                     for _ in range(1200)]
+        harness.pushforward_prove(plan, d_pts, y_log, res["point"], res["evs"], pf_tape)     # warmup (pool growth)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pf = harness.pushforward_prove(plan, d_pts, y_log, res["point"], res["evs"], pf_tape)
+        pf_dt = time.perf_counter() - t1
+        out["sumcheck"]["pushforward"] = {"workload": "prove pushforward (columns + logup main phase + combined sumcheck)",
+                                          "ms": round(pf_dt * 1e3, 2), "rounds": pf["rounds"],
+                                          "rounds_per_sec": round(pf["rounds"] / pf_dt, 1)}
+        out["sumcheck"]["gen2_fr_prover_total"] = {"rounds": res["rounds"] + pf["rounds"],
+                                                   "ms": round(prove_dt * 1e3 + pf_dt * 1e3, 2),
+                                                   "rounds_per_sec": round((res["rounds"] + pf["rounds"]) / (prove_dt + pf_dt), 1)}
         w.close()
         del w
 

@@ -787,12 +787,29 @@ extern "C" int32_t gm_msm_phase1_polys(const gm_msm_plan* p, uint64_t* d_c, uint
     hipLaunchKernelGGL(k_u_to_fr, dim3(ceil_div(n, 256)), dim3(256), 0, s, p->digits, p->counter, n,
                        reinterpret_cast<Fr*>(d_d), reinterpret_cast<Fr*>(d_c));
     GM_LAUNCH_CHECK();
+    // access counts (pushforward.rs:496-508) from the bucket populations instead of 2^25 contended atomics:
+    //   ac_d[digit] = sum over windows of the population of bucket (window, digit)
+    //   ac_c[k]     = number of buckets with more than k points (counter value k occurs once in each of them)
     uint32_t* cnt = nullptr;
     const uint64_t nc = p->N + p->nd;
     GM_HIP(dev_alloc((void**)&cnt, nc * 4));
-    GM_HIP(hipMemsetAsync(cnt, 0, nc * 4, s));
-    hipLaunchKernelGGL(k_access_counts, dim3(ceil_div(n, 256)), dim3(256), 0, s, p->digits, p->counter, n, cnt + p->N, cnt);
-    GM_LAUNCH_CHECK();
+    {
+        std::vector<uint32_t> rl(p->nrows), h(nc, 0);
+        GM_HIP(hipMemcpyAsync(rl.data(), p->row_len, (size_t)p->nrows * 4, hipMemcpyDeviceToHost, s));
+        GM_HIP(hipStreamSynchronize(s));
+        std::vector<uint32_t> by_len(p->N + 2, 0);
+        for (uint32_t r = 0; r < p->nrows; r++) {
+            h[p->N + (r % p->nd)] += rl[r];
+            by_len[rl[r]]++;
+        }
+        uint32_t longer = 0;  // buckets with population > k, walking k down from N
+        for (uint64_t k = p->N; k-- > 0;) {
+            longer += by_len[k + 1];
+            h[k] = longer;
+        }
+        GM_HIP(hipMemcpyAsync(cnt, h.data(), nc * 4, hipMemcpyHostToDevice, s));
+        GM_HIP(hipStreamSynchronize(s));
+    }
     hipLaunchKernelGGL(k_neg_count_to_fr, dim3(ceil_div(p->N, 256)), dim3(256), 0, s, cnt, p->N, reinterpret_cast<Fr*>(d_ac_c));
     GM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_neg_count_to_fr, dim3(ceil_div(p->nd, 256)), dim3(256), 0, s, cnt + p->N, (uint64_t)p->nd,

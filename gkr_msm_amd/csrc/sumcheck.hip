@@ -446,6 +446,31 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic3_lean(LeanCols col
     block_reduce_finish<3>(acc, fc);
 }
 
+// Prod3Fn rounds (pushforward.rs:27-49; the combined sumcheck of the pushforward argument): acc[s] += a b c at p1 + s (p1 - p0)
+__global__ void __launch_bounds__(SC_THREADS) k_round_prod3_lean(LeanCols cols, uint64_t npairs, FinishCtx fc) {
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+#pragma unroll 1
+        for (int s = 0; s < 3; s++) {
+            Fr v[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const Fr p1 = fr_load(cols.p[q] + 2 * i + 1);
+                if (s == 0) v[q] = p1;
+                else {
+                    const Fr d = fr_sub(p1, fr_load(cols.p[q] + 2 * i));
+                    v[q] = fr_add(p1, s == 1 ? d : fr_dbl(d));
+                }
+            }
+            const Fr t = fr_mul(fr_mul(v[0], v[1]), v[2]);
+            if (s == 0) acc[0] = fr_add(acc[0], t);
+            else if (s == 1) acc[1] = fr_add(acc[1], t);
+            else acc[2] = fr_add(acc[2], t);
+        }
+    }
+    block_reduce_finish<3>(acc, fc);
+}
+
 // inclusive->exclusive prefix sums of a (short) eq level: prefix[0] = 0, prefix[k] = sum_{i<k} v[i]; single block
 __global__ void __launch_bounds__(SC_THREADS) k_prefix_sums(const Fr* __restrict__ v, uint32_t n, Fr* __restrict__ prefix) {
     __shared__ Fr part[SC_THREADS];
@@ -866,7 +891,11 @@ struct ScDense : gm_sc {
             const dim3 grid = round_grid(npairs, ny);
             const FinishCtx fc = rs.ctx();
             const int lean = (kind == 0 && D == 3 && !split && cols.k <= 7) ? lean_prim_of(sp) : 0;
-            if (lean && lean != LEAN_AFF_L1_BC) {
+            if (kind == 1 && D == 3 && !split) {
+                LeanCols lc;
+                for (int i = 0; i < 3; i++) lc.p[i] = cols.cur[i];
+                hipLaunchKernelGGL(k_round_prod3_lean, grid, dim3(SC_THREADS), 0, stream, lc, npairs, fc);
+            } else if (lean && lean != LEAN_AFF_L1_BC) {
                 LeanCols lc;
                 for (int i = 0; i < cols.k; i++) lc.p[i] = cols.cur[i];
                 int32_t rc = launch_generic3_lean(lean, grid, stream, lc, d_gamma.fr(), npairs, fc);
