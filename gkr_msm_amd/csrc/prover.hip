@@ -1038,3 +1038,83 @@ extern "C" int32_t gm_pushforward_prove_tr(const gm_msm_plan* plan, const uint64
                              h_matrix_point, h_matrix_evs, h_ac_c_point, h_ac_c_evs, h_ac_d_point, h_ac_d_evs, n_challenges, rounds,
                              stream);
 }
+
+// =================================================================================================================
+// MultiOpenReduction::prove (cleanup/protocols/multiopen_reduction.rs:65-93): nargs polynomials of nvars variables with one
+// evaluation claim each (at different points) are reduced to claims at one common point by the sumcheck of
+// sum_i gamma^i p_i(x) eq(point_i, x).  d_polys: nargs device columns of 2^nvars elements (the caller zero-pads, pippenger.rs:233);
+// h_points: nargs x nvars coordinates; h_evs: nargs evaluations.
+namespace {
+int32_t multiopen_entry(uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
+                        const uint64_t* h_evs, const uint64_t* h_tape, uint64_t n_tape, const gm_transcript* cb, uint64_t* h_msgs,
+                        uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_out_point, uint64_t* h_out_evs, uint64_t* tape_used,
+                        uint64_t* rounds, void* stream) {
+    GM_REQUIRE(d_polys && h_points && h_evs && nvars >= 1 && nvars <= 28 && nargs >= 1 && nargs <= 8, "bad argument");
+    hipStream_t s = as_stream(stream);
+    std::vector<Fr> msgs;
+    Tape tr{h_tape, n_tape, 0, &msgs, 0, cb, 0};
+    Fr gamma;
+    TRY(tr.challenge(&gamma));
+    // folded_claim = gamma_rlc(gamma, evs) (sumcheck.rs:591-602)
+    std::vector<Fr> evs(nargs);
+    memcpy(evs.data(), h_evs, nargs * sizeof(Fr));
+    Fr claim = evs[nargs - 1];
+    for (uint32_t i = 1; i < nargs; i++) claim = fr_add(fr_mul(claim, gamma), evs[nargs - 1 - i]);
+    // advice.extend(EqPoly(point_i).evals())
+    const uint64_t n = 1ull << nvars;
+    std::vector<std::shared_ptr<DevBuf>> eqs(nargs);
+    std::vector<const uint64_t*> cols(d_polys, d_polys + nargs);
+    for (uint32_t i = 0; i < nargs; i++) {
+        eqs[i].reset(new DevBuf());
+        TRY(eqs[i]->alloc(2 * n * sizeof(Fr)));
+        std::vector<Fr> pt(nvars);
+        memcpy(pt.data(), h_points + 4 * (size_t)i * nvars, nvars * sizeof(Fr));
+        std::vector<Fr*> lv(nvars + 1);
+        for (uint32_t l = 0; l < nvars; l++) lv[l] = eqs[i]->fr() + n + ((1ull << l) - 1);
+        lv[nvars] = eqs[i]->fr();
+        TRY(launch_eq_sequence(fr_one(), pt.data(), nvars, lv.data(), s));
+        cols.push_back(reinterpret_cast<const uint64_t*>(eqs[i]->p));
+    }
+    Fr* pinned = nullptr;
+    GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(pinned, 0, 16 * sizeof(Fr));
+    shared_pinned() = pinned;
+    struct Cleanup { Fr* p; ~Cleanup() { shared_pinned() = nullptr; (void)hipHostFree(p); } } cleanup{pinned};
+    ScHolder h;
+    gm_fn f = mkfn(GM_FN_ID, (int)nargs);
+    TRY(gm_sc_dense_create(2, &f, nvars, cols.data(), reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(&claim),
+                           &h.so, stream));
+    std::vector<Fr> pt, fin;
+    TRY(generic_sumcheck_prove(&tr, h.so, nvars, 2, &pt, &fin));
+    fin.resize(nargs);   // poly_evs[..nargs] (multiopen_reduction.rs:84)
+    tr.write_scalars(fin);
+    if (tr.cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", tr.cb_rc);
+    if (n_msgs) *n_msgs = msgs.size();
+    if (h_msgs) {
+        GM_REQUIRE(msgs.size() <= msgs_cap, "message buffer too small");
+        memcpy(h_msgs, msgs.data(), msgs.size() * sizeof(Fr));
+    }
+    if (h_out_point) memcpy(h_out_point, pt.data(), pt.size() * sizeof(Fr));
+    if (h_out_evs) memcpy(h_out_evs, fin.data(), fin.size() * sizeof(Fr));
+    if (tape_used) *tape_used = tr.pos;
+    if (rounds) *rounds = tr.rounds;
+    return GM_OK;
+}
+}  // namespace
+
+extern "C" int32_t gm_multiopen_prove(uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
+                                      const uint64_t* h_evs, const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_msgs,
+                                      uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_out_point, uint64_t* h_out_evs,
+                                      uint64_t* tape_used, uint64_t* rounds, void* stream) {
+    GM_REQUIRE(h_tape, "null tape");
+    return multiopen_entry(nvars, nargs, d_polys, h_points, h_evs, h_tape, n_tape, nullptr, h_msgs, msgs_cap, n_msgs, h_out_point,
+                           h_out_evs, tape_used, rounds, stream);
+}
+
+extern "C" int32_t gm_multiopen_prove_tr(uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
+                                         const uint64_t* h_evs, const gm_transcript* tr, uint64_t* h_out_point, uint64_t* h_out_evs,
+                                         uint64_t* n_challenges, uint64_t* rounds, void* stream) {
+    GM_REQUIRE(tr && tr->challenge, "null transcript");
+    return multiopen_entry(nvars, nargs, d_polys, h_points, h_evs, nullptr, 0, tr, nullptr, 0, nullptr, h_out_point, h_out_evs,
+                           n_challenges, rounds, stream);
+}

@@ -471,6 +471,33 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_prod3_lean(LeanCols cols, 
     block_reduce_finish<3>(acc, fc);
 }
 
+// FoldedProdAlgFn rounds (multiopen_reduction.rs:13-42): F = sum_i gamma^i a_i e_i over nargs (polynomial, eq table) pairs,
+// degree 2: acc[s] += F(p1 + s (p1 - p0)), s = 0, 1.  cols.p[i] = a_i, cols.p[nargs + i] = e_i.
+struct FoldedCols {
+    const Fr* p[16];
+};
+__global__ void __launch_bounds__(SC_THREADS) k_round_folded_prod(FoldedCols cols, int nargs, const Fr* __restrict__ gp, uint64_t npairs,
+                                                                   FinishCtx fc) {
+    Fr acc[2] = {fr_zero(), fr_zero()};
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+#pragma unroll 1
+        for (int q = 0; q < nargs; q++) {
+            const Fr a0 = fr_load(cols.p[q] + 2 * i), a1 = fr_load(cols.p[q] + 2 * i + 1);
+            const Fr e0 = fr_load(cols.p[nargs + q] + 2 * i), e1 = fr_load(cols.p[nargs + q] + 2 * i + 1);
+            Fr t0 = fr_mul(a1, e1);
+            Fr t1 = fr_mul(fr_sub(fr_dbl(a1), a0), fr_sub(fr_dbl(e1), e0));
+            if (q) {
+                const Fr g = fr_load(gp + q);
+                t0 = fr_mul(t0, g);
+                t1 = fr_mul(t1, g);
+            }
+            acc[0] = fr_add(acc[0], t0);
+            acc[1] = fr_add(acc[1], t1);
+        }
+    }
+    block_reduce_finish<2>(acc, fc);
+}
+
 // inclusive->exclusive prefix sums of a (short) eq level: prefix[0] = 0, prefix[k] = sum_{i<k} v[i]; single block
 __global__ void __launch_bounds__(SC_THREADS) k_prefix_sums(const Fr* __restrict__ v, uint32_t n, Fr* __restrict__ prefix) {
     __shared__ Fr part[SC_THREADS];
@@ -891,7 +918,12 @@ struct ScDense : gm_sc {
             const dim3 grid = round_grid(npairs, ny);
             const FinishCtx fc = rs.ctx();
             const int lean = (kind == 0 && D == 3 && !split && cols.k <= 7) ? lean_prim_of(sp) : 0;
-            if (kind == 1 && D == 3 && !split) {
+            if (kind == 2) {
+                FoldedCols fcols;
+                for (int i = 0; i < cols.k; i++) fcols.p[i] = cols.cur[i];
+                hipLaunchKernelGGL(k_round_folded_prod, round_grid(npairs, 1), dim3(SC_THREADS), 0, stream, fcols, cols.k / 2,
+                                   d_gamma.fr(), npairs, fc);
+            } else if (kind == 1 && D == 3 && !split) {
                 LeanCols lc;
                 for (int i = 0; i < 3; i++) lc.p[i] = cols.cur[i];
                 hipLaunchKernelGGL(k_round_prod3_lean, grid, dim3(SC_THREADS), 0, stream, lc, npairs, fc);
@@ -1523,7 +1555,7 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
 // or Prod3Fn (kind 1: 3 columns, f ignored); claim_hint as in sumcheck.rs:250.
 extern "C" int32_t gm_sc_dense_create(int32_t kind, const gm_fn* f, uint32_t num_vars, const uint64_t* const* d_cols,
                                       const uint64_t* h_gamma, const uint64_t* h_claim, gm_sc** out, void* stream) {
-    GM_REQUIRE(out && d_cols && h_claim && num_vars >= 1 && num_vars <= 30 && (kind == 0 || kind == 1), "bad argument");
+    GM_REQUIRE(out && d_cols && h_claim && num_vars >= 1 && num_vars <= 30 && kind >= 0 && kind <= 2, "bad argument");
     std::unique_ptr<ScDense> so(new ScDense());
     so->stream = as_stream(stream);
     so->kind = kind;
@@ -1541,6 +1573,15 @@ extern "C" int32_t gm_sc_dense_create(int32_t kind, const gm_fn* f, uint32_t num
         Fr gamma;
         memcpy(&gamma, h_gamma, 32);
         gp = make_gamma_pows(gamma, so->sp.n_outs);
+    } else if (kind == 2) {
+        // FoldedProdAlgFn(gamma, nargs) (multiopen_reduction.rs:13-42): f = IdAlgFn(nargs) only carries nargs
+        GM_REQUIRE(h_gamma && f && f->nseg == 1 && f->count[0] >= 1 && f->count[0] <= 8, "kind 2 needs gamma and f = {GM_FN_ID x nargs}, nargs <= 8");
+        const int nargs = f->count[0];
+        so->D = 2;
+        ncols = 2 * nargs;
+        Fr gamma;
+        memcpy(&gamma, h_gamma, 32);
+        gp = make_gamma_pows(gamma, nargs > 1 ? nargs : 2);
     } else {
         so->D = 3;
     }

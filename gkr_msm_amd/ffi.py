@@ -110,6 +110,8 @@ _SIGS = {
                                          u64p, u64p, vp]),
     "gm_pushforward_prove_tr": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, C.POINTER(GmTranscript), vp, vp, vp, vp, vp, vp, vp, u64p,
                                             u64p, vp]),
+    "gm_multiopen_prove": (C.c_int32, [C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u64p, u64p, vp]),
+    "gm_multiopen_prove_tr": (C.c_int32, [C.c_uint32, C.c_uint32, vp, vp, vp, C.POINTER(GmTranscript), vp, vp, u64p, u64p, vp]),
     "gm_gkr_msm_prove": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u32p, vp,
                                      u64p, u64p, C.POINTER(C.c_double), vp]),
     "gm_msm_plan_create": (C.c_int32, [C.c_uint32] * 5 + [C.POINTER(vp)]),

@@ -393,6 +393,23 @@ def pushforward_prove(plan, d_points, y_logsize, claim_point, claim_evs, tape, m
                 tape_used=used.value, rounds=rounds.value)
 
 
+def multiopen_prove(cols, nvars, points, evs, tape, msgs_cap=4096):
+    """gm_multiopen_prove over device columns (list of tensors)"""
+    L = ffi.lib()
+    nargs = len(cols)
+    pts = fr_arg([c for p in points for c in p])
+    ev = fr_arg(evs)
+    tp = codec.ints_to_limbs(tape)
+    msgs = np.zeros((msgs_cap, 4), dtype=np.uint64)
+    op, oe = np.zeros((nvars, 4), dtype=np.uint64), np.zeros((nargs, 4), dtype=np.uint64)
+    nm, used, rounds = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    ffi.check(L.gm_multiopen_prove(nvars, nargs, ptr_array(cols), pts.ctypes.data, ev.ctypes.data, tp.ctypes.data, len(tape),
+                                   msgs.ctypes.data, msgs_cap, C.byref(nm), op.ctypes.data, oe.ctypes.data, C.byref(used),
+                                   C.byref(rounds), cur_stream()))
+    f = codec.from_mont_limbs
+    return dict(msgs=f(msgs[: nm.value]), point=f(op), evs=f(oe), tape_used=used.value, rounds=rounds.value)
+
+
 class LiveTranscript:
     """A gm_transcript whose callbacks run Python code: `on_write(list of canonical ints)` and `draw() -> int`.
     Stands in for the Rust shim's wrappers over ProofTranscript2 (tests drive it from a tape or a hash)."""

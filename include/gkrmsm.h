@@ -140,7 +140,8 @@ int32_t gm_vv_destroy(gm_vv* v);
  *                             (sparse rounds, then bind_into_dense :157-190 and the dense rounds)
  *   gm_sc_dense_create        DenseSumcheckObjectSO::new                  sumcheck.rs:248-257; kind 0: F = EqWrapper(
  *                             GammaWrapper(f, gamma)) over f.n_ins columns + the eq column (:706-829), kind 1: Prod3Fn
- *                             (pushforward.rs:27-49)
+ *                             (pushforward.rs:27-49), kind 2: FoldedProdAlgFn(gamma, nargs) (multiopen_reduction.rs:13-42)
+ *                             over nargs polynomials followed by nargs eq tables, f = {GM_FN_ID, count nargs}
  * h_claims: n_outs evaluation claims (folded with gamma as in rlc); h_point: num_vars elements, point[0] = MSB.
  * Input columns are read, never written.  gm_sc_unipoly returns the deg+1 coefficients (low to high) of the
  * round polynomial, i.e. `unipoly().as_vec()`; the caller drops the linear one (compress_coefficients :27-31). */
@@ -305,6 +306,17 @@ int32_t gm_pushforward_prove_tr(const gm_msm_plan* plan, const uint64_t* d_point
                                 uint64_t* h_gamma, uint64_t* h_matrix_point, uint64_t* h_matrix_evs, uint64_t* h_ac_c_point,
                                 uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point, uint64_t* h_ac_d_evs, uint64_t* n_challenges,
                                 uint64_t* rounds, void* stream);
+
+/* MultiOpenReduction::prove (cleanup/protocols/multiopen_reduction.rs:65-93; the first step of the "open" span, pippenger.rs:222-258):
+ * nargs (<= 8) device columns of 2^nvars elements with one claim each -- h_points: nargs x nvars coordinates, h_evs: nargs
+ * evaluations -- are reduced to nargs claims at one common point (h_out_point: nvars coordinates, h_out_evs: nargs evaluations). */
+int32_t gm_multiopen_prove(uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
+                           const uint64_t* h_evs, const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_msgs, uint64_t msgs_cap,
+                           uint64_t* n_msgs, uint64_t* h_out_point, uint64_t* h_out_evs, uint64_t* tape_used, uint64_t* rounds,
+                           void* stream);
+int32_t gm_multiopen_prove_tr(uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
+                              const uint64_t* h_evs, const gm_transcript* tr, uint64_t* h_out_point, uint64_t* h_out_evs,
+                              uint64_t* n_challenges, uint64_t* rounds, void* stream);
 
 /* ---------------------------------------------------------------- gen-1 prover (a6, a16)
  * gkr_msm_prove (src/gkr_msm_simple.rs:86-338) without the BLS12-381 G1 column commitments: base polys

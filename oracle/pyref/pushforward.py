@@ -240,3 +240,31 @@ def pushforward_prove(tr, x_logsize, y_logsize, y_size, d_logsize, claims, p1, p
     out_evs = [p_folded_ev, c_pull_ev, d_pull_ev, c_ev, d_ev]
     tr.write_scalars(out_evs)
     return dict(gamma=gamma, matrix=(out_pt, out_evs), ac_c=ac_c_claims, ac_d=ac_d_claims)
+
+
+# ------------------------------------------------------------------ MultiOpenReduction (multiopen_reduction.rs)
+class FoldedProdAlgFn:
+    """multiopen_reduction.rs:13-42"""
+    deg = 2
+
+    def __init__(self, gamma, nargs):
+        self.gammas, self.nargs, self.n_ins = make_gamma_pows(gamma, max(nargs, 2))[:nargs], nargs, 2 * nargs
+
+    def exec(self, a):
+        return sum(a[i] * a[i + self.nargs] % P * self.gammas[i] for i in range(self.nargs)) % P
+
+
+def multiopen_prove(tr, nvars, claims, advice):
+    """multiopen_reduction.rs:65-93; claims = [(point, ev), ...]; returns (point, evs)"""
+    from .polys import zip_with_gamma
+    from .sumcheck import generic_sumcheck_prove
+    nargs = len(claims)
+    gamma = tr.challenge(128)
+    fun = FoldedProdAlgFn(gamma, nargs)
+    folded = zip_with_gamma(gamma, [ev for _, ev in claims])
+    polys = [list(a) for a in advice] + [eq_poly_sequence_last(pt) for pt, _ in claims]
+    so = DenseSumcheckObjectSO(polys, fun, nvars, folded)
+    (_, pt), poly_evs = generic_sumcheck_prove(tr, [2] * nvars, so.claim, so)
+    evs = poly_evs[:nargs]
+    tr.write_scalars(evs)
+    return (pt, evs)

@@ -48,3 +48,23 @@ def test_pushforward_matches_oracle(x_log, d_log, nbits):
 def _device_tape(tape, tr):
     """the challenges as the oracle consumed them (4 x 512-bit reduced mod p, then 128-bit truncations)"""
     return [t % F.P if i < 4 else t & ((1 << 128) - 1) for i, t in enumerate(tape[: tr.pos])] + [0] * 8
+
+
+@pytest.mark.parametrize("nvars,nargs", [(1, 1), (3, 4), (6, 4), (5, 8), (9, 2)])
+def test_multiopen_reduction_matches_oracle(nvars, nargs):
+    """MultiOpenReduction::prove (multiopen_reduction.rs:65-93) vs the oracle; Pattern A on the output claims"""
+    rng = F.SplitMix64(50 + nvars)
+    n = 1 << nvars
+    polys = [[rng.next_fr() for _ in range(n)] for _ in range(nargs)]
+    polys[0][n // 2:] = [0] * (n - n // 2)            # zero-padded tail, as the caller's witness has (pippenger.rs:233)
+    points = [[rng.next_fr() for _ in range(nvars)] for _ in range(nargs)]
+    claims = [(pt, PL.evaluate_poly(p, pt)) for p, pt in zip(polys, points)]
+    tape = [rng.next_bits(128) for _ in range(200)]
+    tr = TapeTranscript(tape)
+    want_pt, want_evs = PF.multiopen_prove(tr, nvars, claims, polys)
+    cols = [H.to_dev(codec.to_mont_limbs(p)).reshape(-1) for p in polys]
+    got = H.multiopen_prove(cols, nvars, points, [ev for _, ev in claims], tape)
+    assert got["msgs"] == [v for m in tr.msgs for v in m]
+    assert got["point"] == want_pt and got["evs"] == want_evs
+    assert got["tape_used"] == tr.pos and got["rounds"] == nvars
+    assert got["evs"] == [PL.evaluate_poly(p, got["point"]) for p in polys]
