@@ -45,7 +45,8 @@ CHALLENGE_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64))
 
 class GmTranscript(C.Structure):
     """gm_transcript: the caller's live Fiat-Shamir transcript as two callbacks"""
-    _fields_ = [("ctx", C.c_void_p), ("write_scalars", WRITE_SCALARS_CB), ("challenge", CHALLENGE_CB)]
+    _fields_ = [("ctx", C.c_void_p), ("write_scalars", WRITE_SCALARS_CB), ("challenge", CHALLENGE_CB),
+                ("write_points", WRITE_SCALARS_CB)]
 
 
 ALL_GATHER_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -112,6 +113,9 @@ _SIGS = {
                                             u64p, vp]),
     "gm_multiopen_prove": (C.c_int32, [C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u64p, u64p, vp]),
     "gm_multiopen_prove_tr": (C.c_int32, [C.c_uint32, C.c_uint32, vp, vp, vp, C.POINTER(GmTranscript), vp, vp, u64p, u64p, vp]),
+    "gm_knuckles_setup": (C.c_int32, [vp, C.c_uint32, vp, vp]),
+    "gm_knuckles_open": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]),
+    "gm_knuckles_open_tr": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, C.POINTER(GmTranscript), vp, vp, vp]),
     "gm_gkr_msm_prove": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u32p, vp,
                                      u64p, u64p, C.POINTER(C.c_double), vp]),
     "gm_msm_plan_create": (C.c_int32, [C.c_uint32] * 5 + [C.POINTER(vp)]),

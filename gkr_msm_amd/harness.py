@@ -410,6 +410,28 @@ def multiopen_prove(cols, nvars, points, evs, tape, msgs_cap=4096):
     return dict(msgs=f(msgs[: nm.value]), point=f(op), evs=f(oe), tape_used=used.value, rounds=rounds.value)
 
 
+def knuckles_setup(k, num_vars):
+    d_inv = dev_empty(4 * ((2 << num_vars) - 1))
+    ffi.check(ffi.lib().gm_knuckles_setup(fr_arg([k]).ctypes.data, num_vars, _p(d_inv), cur_stream()))
+    return d_inv
+
+
+def knuckles_open(d_basis_aff, d_inverses, k, num_vars, d_poly, poly_len, point, claimed_ev, commitment, tape):
+    """-> (proof dict, (A, B)) with G1 points as affine int pairs"""
+    kk, pt, ev = fr_arg([k]), fr_arg(point), fr_arg([claimed_ev])
+    cm = codec.g1_aff_to_limbs([commitment])
+    tp = codec.ints_to_limbs(tape)
+    proof = np.zeros(48, dtype=np.uint64)
+    pair = np.zeros(24, dtype=np.uint64)
+    ffi.check(ffi.lib().gm_knuckles_open(_p(d_basis_aff), _p(d_inverses), kk.ctypes.data, num_vars, _p(d_poly), poly_len, pt.ctypes.data,
+                                         ev.ctypes.data, cm.ctypes.data, tp.ctypes.data, len(tape), proof.ctypes.data, pair.ctypes.data,
+                                         cur_stream()))
+    f, g = codec.from_mont_limbs, codec.g1_aff_from_limbs
+    pr = dict(t_comm=g(proof[0:12])[0], t_x=f(proof[12:16])[0], p_x=f(proof[16:20])[0], p_lt_x_proof=g(proof[20:32])[0],
+              t_kx=f(proof[32:36])[0], t_kx_proof=g(proof[36:48])[0])
+    return pr, tuple(g(pair))
+
+
 class LiveTranscript:
     """A gm_transcript whose callbacks run Python code: `on_write(list of canonical ints)` and `draw() -> int`.
     Stands in for the Rust shim's wrappers over ProofTranscript2 (tests drive it from a tape or a hash)."""
@@ -433,8 +455,14 @@ class LiveTranscript:
             for i in range(4):
                 out[i] = (v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
             return 0
-        self._w, self._c = ffi.WRITE_SCALARS_CB(_w), ffi.CHALLENGE_CB(_c)   # keep the thunks alive
-        self.c = ffi.GmTranscript(None, self._w, self._c)
+        self.points = []
+
+        def _pts(ctx, ptr, n):
+            arr = np.ctypeslib.as_array(ptr, shape=(n * 12,)).reshape(n, 12).copy()
+            self.points.extend(codec.g1_aff_from_limbs(arr))
+            return 0
+        self._w, self._c, self._pt = ffi.WRITE_SCALARS_CB(_w), ffi.CHALLENGE_CB(_c), ffi.WRITE_SCALARS_CB(_pts)  # keep alive
+        self.c = ffi.GmTranscript(None, self._w, self._c, self._pt)
 
 
 def prove_image_part_tr(w, claim_point, claim_evs, transcript):

@@ -230,11 +230,14 @@ int32_t gm_msm_te(const uint64_t* d_points_xy, const uint64_t* d_scalars, uint32
  * pre-drawn challenges and returns the messages (tests, benches, replay).
  *   write_scalars: n field elements in the reference's in-memory form (Montgomery, 4 x u64), in write order; may be NULL
  *   challenge:     one field element, canonical 4 x u64 LE (gen-2: < 2^128; gen-1: 64 bytes reduced mod p)
- * A non-zero return from either aborts the prover with GM_ERR_STATE. */
+ *   write_points:  n G1 points in the affine wire form (12 x u64 each), `write_points::<G1>` (proof_transcript.rs:59-69); only
+ *                  the Knuckles opening uses it; may be NULL
+ * A non-zero return from any of them aborts the prover with GM_ERR_STATE. */
 typedef struct gm_transcript {
     void* ctx;
     int32_t (*write_scalars)(void* ctx, const uint64_t* elems, uint64_t n);
     int32_t (*challenge)(void* ctx, uint64_t* out);
+    int32_t (*write_points)(void* ctx, const uint64_t* aff_points, uint64_t n);
 } gm_transcript;
 
 /* ---------------------------------------------------------------- multi-GPU seam
@@ -317,6 +320,25 @@ int32_t gm_multiopen_prove(uint32_t nvars, uint32_t nargs, const uint64_t* const
 int32_t gm_multiopen_prove_tr(uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
                               const uint64_t* h_evs, const gm_transcript* tr, uint64_t* h_out_point, uint64_t* h_out_evs,
                               uint64_t* n_challenges, uint64_t* rounds, void* stream);
+
+/* Knuckles opening: KnucklesOpeningProtocol::prove (cleanup/protocols/opening.rs:39-98) = compute_t
+ * (commitments/knuckles.rs:111-154), three KZG commitments / openings (kzg.rs:73-81, 123-132) and the deferred pairing pair.
+ *   gm_knuckles_setup   the `inverses` table of KnucklesProvingKey::new (knuckles.rs:64-82): 2^(num_vars+1) - 1 elements
+ *   gm_knuckles_open    d_basis_aff: kzg_pk.ptau_1 (>= 2^(num_vars+1) - 1 affine points); d_poly: poly_len <= 2^num_vars
+ *                       coefficients; h_point: num_vars coordinates; h_claimed_ev; h_commitment_aff: the claim's commitment.
+ *                       Transcript order: point T, challenge x, scalars [T(x), P(x)], challenge lambda, point, scalar T(kx),
+ *                       point, challenge fin (3 challenges on the tape).
+ *                       h_proof (48 x u64): t_comm (12) | t_x (4) | p_x (4) | p_lt_x_proof (12) | t_kx (4) | t_kx_proof (12);
+ *                       h_pair (24 x u64): the deferred pair (A, B) with <A, H0> = <B, H1>. */
+int32_t gm_knuckles_setup(const uint64_t* h_k, uint32_t num_vars, uint64_t* d_inverses, void* stream);
+int32_t gm_knuckles_open(const uint64_t* d_basis_aff, const uint64_t* d_inverses, const uint64_t* h_k, uint32_t num_vars,
+                         const uint64_t* d_poly, uint64_t poly_len, const uint64_t* h_point, const uint64_t* h_claimed_ev,
+                         const uint64_t* h_commitment_aff, const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_proof,
+                         uint64_t* h_pair, void* stream);
+int32_t gm_knuckles_open_tr(const uint64_t* d_basis_aff, const uint64_t* d_inverses, const uint64_t* h_k, uint32_t num_vars,
+                            const uint64_t* d_poly, uint64_t poly_len, const uint64_t* h_point, const uint64_t* h_claimed_ev,
+                            const uint64_t* h_commitment_aff, const gm_transcript* tr, uint64_t* h_proof, uint64_t* h_pair,
+                            void* stream);
 
 /* ---------------------------------------------------------------- gen-1 prover (a6, a16)
  * gkr_msm_prove (src/gkr_msm_simple.rs:86-338) without the BLS12-381 G1 column commitments: base polys
