@@ -166,6 +166,13 @@ struct Tape {
     int32_t cb_rc = 0;
     int32_t challenge(Fr* out) {
         Fr c;
+        const int32_t rc0 = challenge_raw(&c);
+        if (rc0) return rc0;
+        *out = fr_to_mont(c);
+        return GM_OK;
+    }
+    int32_t challenge_raw(Fr* out) {  // canonical limbs, as drawn
+        Fr c;
         if (cb) {
             if (cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", cb_rc);
             const int32_t rc = cb->challenge(cb->ctx, reinterpret_cast<uint64_t*>(&c));
@@ -175,13 +182,18 @@ struct Tape {
             memcpy(&c, tape + 4 * pos, 32);  // canonical value < 2^128 (transcript.challenge(128), proof_transcript.rs:37-39)
         }
         pos++;
-        *out = fr_to_mont(c);
+        *out = c;
         return GM_OK;
     }
     void write_scalars(const std::vector<Fr>& v) {
         msgs->insert(msgs->end(), v.begin(), v.end());
         if (cb && cb->write_scalars && !cb_rc && !v.empty())
             cb_rc = cb->write_scalars(cb->ctx, reinterpret_cast<const uint64_t*>(v.data()), v.size());
+    }
+    std::vector<uint64_t>* points = nullptr;  // G1 points written (affine wire form, 12 x u64 each), when the driver has any
+    void write_points(const uint64_t* aff, uint64_t n) {
+        if (points) points->insert(points->end(), aff, aff + 12 * n);
+        if (cb && cb->write_points && !cb_rc && n) cb_rc = cb->write_points(cb->ctx, aff, n);
     }
 };
 
@@ -568,18 +580,11 @@ extern "C" uint64_t gm_pip_witness_bytes(const gm_pip_witness* w) {
 //   h_tape: n_tape challenges, canonical 4 x u64 (values < 2^128)
 //   outputs: prover messages in order (h_msgs, capacity msgs_cap elements), final claims (point of
 //   y_log + d + x_log elements, 3 evaluations: x, y, z of the image), challenges consumed, sumcheck rounds run.
-static int32_t prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
-                                const uint64_t* h_tape, uint64_t n_tape, const gm_transcript* cb, uint64_t* h_msgs,
-                                uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_final_point, uint32_t* n_final_point,
-                                uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds) {
+// PippengerBucketed::prove + GlueSplit::prove on an open transcript; c: claims in (r_y, dense-output evs) -> out (point, x/y/z evs)
+static int32_t image_part_core(const gm_pip_witness* w, Tape* trp, Claims* cp) {
+    Tape& tr = *trp;
+    Claims& c = *cp;
     const uint32_t multirow = w->y_log, bucket = w->d_log, horizontal = w->x_log;
-    std::vector<Fr> msgs;
-    Tape tr{h_tape, n_tape, 0, &msgs, 0, cb, 0};
-    Claims c;
-    c.point.resize(multirow);
-    memcpy(c.point.data(), h_claim_point, 32 * (size_t)multirow);
-    c.evs.resize(3 * (bucket + 1));
-    memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
     hipStream_t s = w->stream;
     // PippengerBucketed::prove (pippenger_ending.rs:142-149)
     gm_pip_witness* wm = const_cast<gm_pip_witness*>(w);
@@ -604,6 +609,22 @@ static int32_t prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim
         c.point.push_back(r);
         c.evs = nw;
     }
+    return GM_OK;
+}
+
+static int32_t prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                const uint64_t* h_tape, uint64_t n_tape, const gm_transcript* cb, uint64_t* h_msgs,
+                                uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_final_point, uint32_t* n_final_point,
+                                uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds) {
+    const uint32_t multirow = w->y_log, bucket = w->d_log;
+    std::vector<Fr> msgs;
+    Tape tr{h_tape, n_tape, 0, &msgs, 0, cb, 0};
+    Claims c;
+    c.point.resize(multirow);
+    memcpy(c.point.data(), h_claim_point, 32 * (size_t)multirow);
+    c.evs.resize(3 * (bucket + 1));
+    memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
+    TRY(image_part_core(w, &tr, &c));
     if (n_msgs) *n_msgs = msgs.size();
     if (h_msgs) {
         GM_REQUIRE(msgs.size() <= msgs_cap, "message buffer too small: %zu > %llu", msgs.size(), (unsigned long long)msgs_cap);
@@ -723,9 +744,13 @@ int32_t read_fr(const Fr* d, Fr* h, hipStream_t s) {
     return GM_OK;
 }
 
+struct PfCols {  // the Fr columns of the argument, handed to the opening phase
+    std::shared_ptr<DevBuf> c, d, c_pull, d_pull, ac_c, ac_d;
+};
+
 int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_log, const uint64_t* h_claim_point,
                           const uint64_t* h_claim_evs, Tape* tr, Fr* out_gamma, Claims* out_matrix, Claims* out_ac_c,
-                          Claims* out_ac_d, hipStream_t s) {
+                          Claims* out_ac_d, hipStream_t s, PfCols* keep = nullptr) {
     GM_REQUIRE(plan->y0 == 0 && plan->y1 == plan->y_size, "the pushforward argument needs a plan over all windows");
     const uint32_t x_log = plan->x_log, d_log = plan->d_log, y_size = plan->y_size;
     GM_REQUIRE((1u << y_log) >= y_size, "y_logsize too small");
@@ -979,6 +1004,7 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     out_matrix->evs = {p_folded_ev, c_pull_ev, d_pull_ev, c_ev, d_ev};
     tr->write_scalars(out_matrix->evs);
     *out_gamma = gamma;
+    if (keep) { keep->c = c; keep->d = d; keep->c_pull = c_pull; keep->d_pull = d_pull; keep->ac_c = ac_c; keep->ac_d = ac_d; }
     return GM_OK;
 }
 
@@ -1045,14 +1071,10 @@ extern "C" int32_t gm_pushforward_prove_tr(const gm_msm_plan* plan, const uint64
 // sum_i gamma^i p_i(x) eq(point_i, x).  d_polys: nargs device columns of 2^nvars elements (the caller zero-pads, pippenger.rs:233);
 // h_points: nargs x nvars coordinates; h_evs: nargs evaluations.
 namespace {
-int32_t multiopen_entry(uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
-                        const uint64_t* h_evs, const uint64_t* h_tape, uint64_t n_tape, const gm_transcript* cb, uint64_t* h_msgs,
-                        uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_out_point, uint64_t* h_out_evs, uint64_t* tape_used,
-                        uint64_t* rounds, void* stream) {
-    GM_REQUIRE(d_polys && h_points && h_evs && nvars >= 1 && nvars <= 28 && nargs >= 1 && nargs <= 8, "bad argument");
-    hipStream_t s = as_stream(stream);
-    std::vector<Fr> msgs;
-    Tape tr{h_tape, n_tape, 0, &msgs, 0, cb, 0};
+int32_t multiopen_core(Tape* trp, uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
+                       const uint64_t* h_evs, std::vector<Fr>* out_pt, std::vector<Fr>* out_evs, hipStream_t s) {
+    Tape& tr = *trp;
+    void* stream = reinterpret_cast<void*>(s);
     Fr gamma;
     TRY(tr.challenge(&gamma));
     // folded_claim = gamma_rlc(gamma, evs) (sumcheck.rs:591-602)
@@ -1084,10 +1106,23 @@ int32_t multiopen_entry(uint32_t nvars, uint32_t nargs, const uint64_t* const* d
     gm_fn f = mkfn(GM_FN_ID, (int)nargs);
     TRY(gm_sc_dense_create(2, &f, nvars, cols.data(), reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(&claim),
                            &h.so, stream));
-    std::vector<Fr> pt, fin;
-    TRY(generic_sumcheck_prove(&tr, h.so, nvars, 2, &pt, &fin));
+    std::vector<Fr> fin;
+    TRY(generic_sumcheck_prove(&tr, h.so, nvars, 2, out_pt, &fin));
     fin.resize(nargs);   // poly_evs[..nargs] (multiopen_reduction.rs:84)
     tr.write_scalars(fin);
+    *out_evs = fin;
+    return GM_OK;
+}
+
+int32_t multiopen_entry(uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
+                        const uint64_t* h_evs, const uint64_t* h_tape, uint64_t n_tape, const gm_transcript* cb, uint64_t* h_msgs,
+                        uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_out_point, uint64_t* h_out_evs, uint64_t* tape_used,
+                        uint64_t* rounds, void* stream) {
+    GM_REQUIRE(d_polys && h_points && h_evs && nvars >= 1 && nvars <= 28 && nargs >= 1 && nargs <= 8, "bad argument");
+    std::vector<Fr> msgs;
+    Tape tr{h_tape, n_tape, 0, &msgs, 0, cb, 0};
+    std::vector<Fr> pt, fin;
+    TRY(multiopen_core(&tr, nvars, nargs, d_polys, h_points, h_evs, &pt, &fin, as_stream(stream)));
     if (tr.cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", tr.cb_rc);
     if (n_msgs) *n_msgs = msgs.size();
     if (h_msgs) {
@@ -1117,4 +1152,363 @@ extern "C" int32_t gm_multiopen_prove_tr(uint32_t nvars, uint32_t nargs, const u
     GM_REQUIRE(tr && tr->challenge, "null transcript");
     return multiopen_entry(nvars, nargs, d_polys, h_points, h_evs, nullptr, 0, tr, nullptr, 0, nullptr, h_out_point, h_out_evs,
                            n_challenges, rounds, stream);
+}
+
+// =================================================================================================================
+// The whole gen-2 prover: PippengerWG::new (pippenger.rs:37-70) and Pippenger::prove (pippenger.rs:118-290) behind two calls.
+// Everything below is orchestration of entry points that exist on their own (and are tested on their own): bucketing
+// (gm_msm_run, done by the caller), phase-1 commitments (gm_msm_g1_outer, gm_g1_msm), the image part, second_phase and its
+// commitments (gm_g1_msm_nonaff over the outer buckets), the pushforward argument, MultiOpenReduction and the Knuckles
+// opening; plus the host-side scalar / G1 glue of the "open" span.
+#include "g1.cuh"
+
+extern "C" {
+int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_basis_aff, uint32_t clm, uint64_t* d_d_outer, uint64_t* d_c_outer,
+                        uint64_t c_outer_cap, uint32_t* c_stride, uint64_t* h_d_comm, uint64_t* h_c_comm, void* stream);
+int32_t gm_g1_msm(const uint64_t* d_bases_aff, const uint64_t* d_scalars, uint64_t n, int32_t scalars_mont, uint32_t nbits,
+                  uint64_t* h_out_aff, void* stream);
+int32_t gm_g1_msm_nonaff(const uint64_t* d_bases_jac, const uint64_t* d_scalars, uint64_t n, int32_t scalars_mont, uint32_t nbits,
+                         uint64_t* h_out_aff, void* stream);
+int32_t gm_knuckles_open_tr(const uint64_t* d_basis_aff, const uint64_t* d_inverses, const uint64_t* h_k, uint32_t num_vars,
+                            const uint64_t* d_poly, uint64_t poly_len, const uint64_t* h_point, const uint64_t* h_claimed_ev,
+                            const uint64_t* h_commitment_aff, const gm_transcript* tr, uint64_t* h_proof, uint64_t* h_pair,
+                            void* stream);
+}
+
+namespace gm {
+
+__global__ void __launch_bounds__(256) k_pp_split_xy(const Fr* __restrict__ pts, uint64_t n, Fr* __restrict__ p0, Fr* __restrict__ p1) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(p0 + i, fr_load(pts + 2 * i));
+    fr_store(p1 + i, fr_load(pts + 2 * i + 1));
+}
+
+// out[i] = a[i] + g * b[i]
+__global__ void __launch_bounds__(256) k_pp_axpy(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr g, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(out + i, fr_add(fr_load(a + i), fr_mul(g, fr_load(b + i))));
+}
+
+// combined_witness (pippenger.rs:208-222): out[i] = sum_{y : y % cm == i >> x_log} multirow[y / cm] *
+//   (c[idx] + d[idx] u + c_pull[idx] u^2 + d_pull[idx] u^3),  idx = (i mod 2^x_log) + 2^x_log * y
+struct Us { Fr u[4]; };
+__global__ void __launch_bounds__(256) k_pp_combined(const Fr* __restrict__ c, const Fr* __restrict__ d, const Fr* __restrict__ cp,
+                                                      const Fr* __restrict__ dp, const Fr* __restrict__ multirow, Us us,
+                                                      uint32_t x_log, uint32_t y_size, uint32_t clm, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t x = i & ((1ull << x_log) - 1);
+    const uint32_t y_rem = (uint32_t)(i >> x_log), cm = 1u << clm;
+    Fr acc = fr_zero();
+    for (uint32_t y = y_rem; y < y_size; y += cm) {
+        const uint64_t idx = x + ((uint64_t)y << x_log);
+        Fr v = fr_load(c + idx);
+        v = fr_add(v, fr_mul(fr_load(d + idx), us.u[1]));
+        v = fr_add(v, fr_mul(fr_load(cp + idx), us.u[2]));
+        v = fr_add(v, fr_mul(fr_load(dp + idx), us.u[3]));
+        acc = fr_add(acc, fr_mul(fr_load(multirow + (y >> clm)), v));
+    }
+    fr_store(out + i, acc);
+}
+
+// out[i] = sum_j q[j] w_j[i]  (the folded opening witness, pippenger.rs:269-275)
+struct Cols4 { const Fr* p[4]; };
+__global__ void __launch_bounds__(256) k_pp_fold4(Cols4 w, Us q, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = fr_mul(fr_load(w.p[0] + i), q.u[0]);
+#pragma unroll
+    for (int j = 1; j < 4; j++) acc = fr_add(acc, fr_mul(fr_load(w.p[j] + i), q.u[j]));
+    fr_store(out + i, acc);
+}
+
+}  // namespace gm
+
+struct gm_pippenger_wg {
+    const gm_msm_plan* plan = nullptr;
+    const uint64_t* d_points_xy = nullptr;
+    const uint64_t* d_basis = nullptr;
+    uint32_t y_log = 0, clm = 0, n_mat = 0, c_stride = 0;
+    gm_pip_witness* w = nullptr;
+    std::shared_ptr<DevBuf> d_outer, c_outer, p0, p1;
+    std::vector<uint64_t> comm_c, comm_d;          // n_mat affine points each
+    uint64_t comm_p0[12], comm_p1[12], comm_ac_c[12], comm_ac_d[12];
+    hipStream_t stream = nullptr;
+    ~gm_pippenger_wg() { delete w; }
+};
+
+namespace {
+
+G1Jac pp_aff_in(const uint64_t* h) {
+    G1Aff a;
+    memcpy(&a, h, sizeof(G1Aff));
+    return g1_from_aff(a);
+}
+void pp_aff_out(uint64_t* h, const G1Jac& p) {
+    const G1Aff a = g1_to_aff(p);
+    memcpy(h, &a, sizeof(G1Aff));
+}
+G1Jac pp_mul(const G1Jac& p, const Fr& k_mont) {
+    const Fr k = fr_from_mont(k_mont);
+    G1Jac acc = g1_inf();
+    for (int i = 7; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+            acc = g1_dbl(acc);
+            if ((k.l[i] >> b) & 1) acc = g1_add(acc, p);
+        }
+    return acc;
+}
+
+// gm_transcript adapter over the driver's Tape (the Knuckles opening is driven through its public entry point)
+int32_t tape_ws(void* ctx, const uint64_t* e, uint64_t n) {
+    Tape* t = static_cast<Tape*>(ctx);
+    t->write_scalars(std::vector<Fr>(reinterpret_cast<const Fr*>(e), reinterpret_cast<const Fr*>(e) + n));
+    return t->cb_rc;
+}
+int32_t tape_ch(void* ctx, uint64_t* out) {
+    Tape* t = static_cast<Tape*>(ctx);
+    return t->challenge_raw(reinterpret_cast<Fr*>(out));
+}
+int32_t tape_wp(void* ctx, const uint64_t* aff, uint64_t n) {
+    Tape* t = static_cast<Tape*>(ctx);
+    t->write_points(aff, n);
+    return t->cb_rc;
+}
+
+int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                        const uint64_t* d_kn_inverses, const uint64_t* h_k, Tape* tr, uint64_t* h_pair) {
+    const gm_msm_plan* plan = st->plan;
+    const uint32_t x_log = plan->x_log, d_log = plan->d_log, y_log = st->y_log, y_size = plan->y_size, clm = st->clm;
+    const uint32_t n_mat = st->n_mat, cm = 1u << clm;
+    hipStream_t s = st->stream;
+    void* stream = reinterpret_cast<void*>(s);
+    GM_REQUIRE(y_log >= clm, "commitment_log_multiplicity exceeds y_logsize");
+    // phase-1 commitments onto the transcript (pippenger.rs:126-133; ac_c is written twice there)
+    tr->write_points(st->comm_c.data(), n_mat);
+    tr->write_points(st->comm_d.data(), n_mat);
+    tr->write_points(st->comm_p0, 1);
+    tr->write_points(st->comm_p1, 1);
+    tr->write_points(st->comm_ac_c, 1);
+    tr->write_points(st->comm_ac_c, 1);
+    tr->write_points(st->comm_ac_d, 1);
+    // prove image part
+    Claims c;
+    c.point.resize(y_log);
+    memcpy(c.point.data(), h_claim_point, 32 * (size_t)y_log);
+    c.evs.resize(3 * (d_log + 1));
+    memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
+    TRY(image_part_core(st->w, tr, &c));
+    // commit phase 2 (second_phase, pushforward.rs:596-605): msm_nonaff of the outer buckets with the eq tables
+    std::vector<uint64_t> comm_cp(12 * (size_t)n_mat), comm_dp(12 * (size_t)n_mat);
+    {
+        const uint64_t X = 1ull << x_log, D = 1ull << d_log;
+        DevBuf eqs;
+        TRY(eqs.alloc((2 * X + 2 * D) * sizeof(Fr)));
+        Fr* eq_c = eqs.fr();
+        Fr* eq_d = eqs.fr() + 2 * X;
+        std::vector<Fr*> lv(x_log + 1);
+        for (uint32_t i = 0; i < x_log; i++) lv[i] = eq_c + X + ((1ull << i) - 1);
+        lv[x_log] = eq_c;
+        TRY(launch_eq_sequence(fr_one(), c.point.data() + y_log + d_log, x_log, lv.data(), s));
+        lv.assign(d_log + 1, nullptr);
+        for (uint32_t i = 0; i < d_log; i++) lv[i] = eq_d + D + ((1ull << i) - 1);
+        lv[d_log] = eq_d;
+        TRY(launch_eq_sequence(fr_one(), c.point.data() + y_log, d_log, lv.data(), s));
+        const G1Jac* dob = reinterpret_cast<const G1Jac*>(st->d_outer->p);
+        const G1Jac* cob = reinterpret_cast<const G1Jac*>(st->c_outer->p);
+        for (uint32_t m = 0; m < n_mat; m++) {
+            TRY(gm_g1_msm_nonaff(reinterpret_cast<const uint64_t*>(dob + (size_t)m * D), reinterpret_cast<const uint64_t*>(eq_d), D, 1,
+                                 255, comm_dp.data() + 12 * (size_t)m, stream));
+            // entries of c_outer past the row's c_upper_bound are the point at infinity: the prefix product is unchanged
+            TRY(gm_g1_msm_nonaff(reinterpret_cast<const uint64_t*>(cob + (size_t)m * st->c_stride), reinterpret_cast<const uint64_t*>(eq_c),
+                                 st->c_stride, 1, 255, comm_cp.data() + 12 * (size_t)m, stream));
+        }
+    }
+    tr->write_points(comm_cp.data(), n_mat);
+    tr->write_points(comm_dp.data(), n_mat);
+    // prove pushforward
+    Fr gamma;
+    Claims mx, acc, acd;
+    PfCols cols;
+    TRY(pushforward_prove(plan, st->d_points_xy, y_log, reinterpret_cast<const uint64_t*>(c.point.data()),
+                          reinterpret_cast<const uint64_t*>(c.evs.data()), tr, &gamma, &mx, &acc, &acd, s, &cols));
+    // ---- open (pippenger.rs:162-286)
+    const Fr p_folded_ev = mx.evs[0], c_pull_ev = mx.evs[1], d_pull_ev = mx.evs[2], c_ev = mx.evs[3], d_ev = mx.evs[4];
+    const uint32_t nv = x_log + clm;
+    const uint64_t n = 1ull << nv, X = 1ull << x_log;
+    std::vector<Fr> pts(4 * (size_t)nv, fr_zero());   // the four claim points, nv coordinates each
+    for (uint32_t i = 0; i < x_log; i++) pts[0 * nv + clm + i] = mx.point[y_log + i];            // p_folded_point
+    for (uint32_t i = 0; i < x_log; i++) pts[1 * nv + clm + i] = acc.point[i];                    // ac_c_point
+    for (uint32_t i = 0; i < d_log; i++) pts[2 * nv + (nv - d_log) + i] = acd.point[i];           // ac_d_point
+    for (uint32_t i = 0; i < nv; i++) pts[3 * nv + i] = mx.point[y_log - clm + i];                // combined_opening_point
+    // multirow_evs = EqPoly(y_log - clm, matrix_pt[..y_log - clm]).evals()
+    std::vector<Fr> multirow(1ull << (y_log - clm), fr_zero());
+    multirow[0] = fr_one();
+    for (uint32_t i = 0; i < y_log - clm; i++)
+        for (uint64_t j = (1ull << i); j-- > 0;) {
+            const Fr w = multirow[j], m = fr_mul(mx.point[i], w);
+            multirow[2 * j] = fr_sub(w, m);
+            multirow[2 * j + 1] = m;
+        }
+    auto comb = [&](const uint64_t* cs) {
+        G1Jac a = g1_inf();
+        for (uint32_t m = 0; m < n_mat && m < multirow.size(); m++) a = g1_add(a, pp_mul(pp_aff_in(cs + 12 * (size_t)m), multirow[m]));
+        return a;
+    };
+    const G1Jac c_comb = comb(st->comm_c.data()), d_comb = comb(st->comm_d.data()), cp_comb = comb(comm_cp.data()),
+                dp_comb = comb(comm_dp.data());
+    Fr u;
+    TRY(tr->challenge(&u));   // challenge(512)
+    Us us;
+    us.u[0] = fr_one(); us.u[1] = u; us.u[2] = fr_mul(u, u); us.u[3] = fr_mul(us.u[2], u);
+    const G1Jac combined_comm = g1_add(g1_add(c_comb, pp_mul(d_comb, us.u[1])), g1_add(pp_mul(cp_comb, us.u[2]), pp_mul(dp_comb, us.u[3])));
+    const Fr combined_ev = fr_add(fr_add(c_ev, fr_mul(d_ev, us.u[1])), fr_add(fr_mul(c_pull_ev, us.u[2]), fr_mul(d_pull_ev, us.u[3])));
+    // the four opening witnesses, zero-padded to 2^nv
+    DevBuf w0, w1, w2, w3, d_multirow, folded;
+    TRY(w0.alloc(n * sizeof(Fr))); TRY(w1.alloc(n * sizeof(Fr))); TRY(w2.alloc(n * sizeof(Fr))); TRY(w3.alloc(n * sizeof(Fr)));
+    TRY(folded.alloc(n * sizeof(Fr)));
+    for (DevBuf* b : {&w0, &w1, &w2}) GM_HIP(hipMemsetAsync(b->p, 0, n * sizeof(Fr), s));
+    hipLaunchKernelGGL(k_pp_axpy, dim3(ceil_div(X, 256)), dim3(256), 0, s, st->p0->fr(), st->p1->fr(), gamma, X, w0.fr());
+    GM_LAUNCH_CHECK();
+    GM_HIP(hipMemcpyAsync(w1.p, cols.ac_c->p, X * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+    GM_HIP(hipMemcpyAsync(w2.p, cols.ac_d->p, ((size_t)1 << d_log) * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+    TRY(d_multirow.alloc(multirow.size() * sizeof(Fr)));
+    GM_HIP(hipMemcpyAsync(d_multirow.p, multirow.data(), multirow.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pp_combined, dim3(ceil_div(n, 256)), dim3(256), 0, s, cols.c->fr(), cols.d->fr(), cols.c_pull->fr(),
+                       cols.d_pull->fr(), d_multirow.fr(), us, x_log, y_size, clm, n, w3.fr());
+    GM_LAUNCH_CHECK();
+    GM_HIP(hipStreamSynchronize(s));  // multirow (host) is consumed
+    // MultiOpenReduction (pippenger.rs:224-258)
+    std::vector<Fr> mo_evs = {fr_sub(p_folded_ev, fr_mul(gamma, gamma)), acc.evs[0], acd.evs[0], combined_ev};
+    const uint64_t* wcols[4] = {(const uint64_t*)w0.p, (const uint64_t*)w1.p, (const uint64_t*)w2.p, (const uint64_t*)w3.p};
+    std::vector<Fr> mo_pt, mo_out;
+    TRY(multiopen_core(tr, nv, 4, wcols, reinterpret_cast<const uint64_t*>(pts.data()), reinterpret_cast<const uint64_t*>(mo_evs.data()),
+                       &mo_pt, &mo_out, s));
+    Fr q;
+    TRY(tr->challenge(&q));
+    Us qs;
+    qs.u[0] = fr_one(); qs.u[1] = q; qs.u[2] = fr_mul(q, q); qs.u[3] = fr_mul(qs.u[2], q);
+    const G1Jac parts[4] = {g1_add(pp_aff_in(st->comm_p0), pp_mul(pp_aff_in(st->comm_p1), gamma)), pp_aff_in(st->comm_ac_c),
+                            pp_aff_in(st->comm_ac_d), combined_comm};
+    G1Jac folded_comm = g1_inf();
+    for (int j = 0; j < 4; j++) folded_comm = g1_add(folded_comm, pp_mul(parts[j], qs.u[j]));
+    Cols4 c4;
+    c4.p[0] = w0.fr(); c4.p[1] = w1.fr(); c4.p[2] = w2.fr(); c4.p[3] = w3.fr();
+    hipLaunchKernelGGL(k_pp_fold4, dim3(ceil_div(n, 256)), dim3(256), 0, s, c4, qs, n, folded.fr());
+    GM_LAUNCH_CHECK();
+    // ev = gamma_rlc(q, multiopen_claims.evs)
+    Fr open_ev = mo_out[3];
+    for (int j = 2; j >= 0; j--) open_ev = fr_add(fr_mul(open_ev, q), mo_out[j]);
+    uint64_t fc_aff[12], proof[48];
+    pp_aff_out(fc_aff, folded_comm);
+    gm_transcript adapter{tr, tape_ws, tape_ch, tape_wp};
+    TRY(gm_knuckles_open_tr(st->d_basis, d_kn_inverses, h_k, nv, reinterpret_cast<const uint64_t*>(folded.p), n,
+                            reinterpret_cast<const uint64_t*>(mo_pt.data()), reinterpret_cast<const uint64_t*>(&open_ev), fc_aff,
+                            &adapter, proof, h_pair, stream));
+    if (tr->cb_rc) return set_err(GM_ERR_STATE, "transcript callback failed with %d", tr->cb_rc);
+    return GM_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                          uint32_t commitment_log_multiplicity, const uint64_t* d_kzg_basis_aff,
+                                          gm_pippenger_wg** out, void* stream) {
+    GM_REQUIRE(plan && d_points_xy && d_kzg_basis_aff && out, "null argument");
+    GM_REQUIRE(commitment_log_multiplicity <= y_logsize, "commitment_log_multiplicity exceeds y_logsize");
+    hipStream_t s = as_stream(stream);
+    std::unique_ptr<gm_pippenger_wg> st(new gm_pippenger_wg());
+    st->plan = plan; st->d_points_xy = d_points_xy; st->d_basis = d_kzg_basis_aff; st->y_log = y_logsize;
+    st->clm = commitment_log_multiplicity; st->stream = s;
+    const uint32_t cm = 1u << st->clm;
+    st->n_mat = (plan->y_size + cm - 1) / cm;
+    TRY(pip_witness_create(plan, d_points_xy, y_logsize, nullptr, &st->w, stream));
+    // outer buckets + c / d commitments
+    {
+        std::vector<uint32_t> rl(plan->nrows);
+        GM_HIP(hipMemcpyAsync(rl.data(), plan->row_len, (size_t)plan->nrows * 4, hipMemcpyDeviceToHost, s));
+        GM_HIP(hipStreamSynchronize(s));
+        uint32_t cmax = 1;
+        for (uint32_t v : rl) cmax = v > cmax ? v : cmax;
+        st->d_outer.reset(new DevBuf());
+        st->c_outer.reset(new DevBuf());
+        TRY(st->d_outer->alloc(((size_t)st->n_mat << plan->d_log) * sizeof(G1Jac)));
+        TRY(st->c_outer->alloc((size_t)st->n_mat * cmax * sizeof(G1Jac)));
+        st->comm_c.assign(12 * (size_t)st->n_mat, 0);
+        st->comm_d.assign(12 * (size_t)st->n_mat, 0);
+        TRY(gm_msm_g1_outer(plan, d_kzg_basis_aff, st->clm, (uint64_t*)st->d_outer->p, (uint64_t*)st->c_outer->p,
+                            (uint64_t)st->n_mat * cmax, &st->c_stride, st->comm_d.data(), st->comm_c.data(), stream));
+    }
+    // p_0, p_1, ac_c, ac_d commitments (pushforward.rs:533-536)
+    const uint64_t X = plan->N, D = 1ull << plan->d_log;
+    st->p0.reset(new DevBuf());
+    st->p1.reset(new DevBuf());
+    TRY(st->p0->alloc(X * sizeof(Fr)));
+    TRY(st->p1->alloc(X * sizeof(Fr)));
+    hipLaunchKernelGGL(k_pp_split_xy, dim3(ceil_div(X, 256)), dim3(256), 0, s, reinterpret_cast<const Fr*>(d_points_xy), X, st->p0->fr(),
+                       st->p1->fr());
+    GM_LAUNCH_CHECK();
+    {
+        DevBuf c, d, ac_c, ac_d;
+        const uint64_t msize = (uint64_t)plan->y_size * X;
+        TRY(c.alloc(msize * sizeof(Fr))); TRY(d.alloc(msize * sizeof(Fr))); TRY(ac_c.alloc(X * sizeof(Fr))); TRY(ac_d.alloc(D * sizeof(Fr)));
+        TRY(gm_msm_phase1_polys(plan, (uint64_t*)c.p, (uint64_t*)d.p, (uint64_t*)ac_c.p, (uint64_t*)ac_d.p, stream));
+        TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)st->p0->p, X, 1, 255, st->comm_p0, stream));
+        TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)st->p1->p, X, 1, 255, st->comm_p1, stream));
+        TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)ac_c.p, X, 1, 255, st->comm_ac_c, stream));
+        TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)ac_d.p, D, 1, 255, st->comm_ac_d, stream));
+    }
+    *out = st.release();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_pippenger_wg_destroy(gm_pippenger_wg* st) {
+    delete st;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_pippenger_wg_witness(const gm_pippenger_wg* st, const gm_pip_witness** w) {
+    GM_REQUIRE(st && w, "null argument");
+    *w = st->w;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                      const uint64_t* d_knuckles_inverses, const uint64_t* h_k, const uint64_t* h_tape,
+                                      uint64_t n_tape, uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_points,
+                                      uint64_t points_cap, uint64_t* n_points, uint64_t* h_pair, uint64_t* tape_used,
+                                      uint64_t* rounds) {
+    GM_REQUIRE(st && h_claim_point && h_claim_evs && d_knuckles_inverses && h_k && h_tape && h_pair, "null argument");
+    std::vector<Fr> msgs;
+    std::vector<uint64_t> points;
+    Tape tr{h_tape, n_tape, 0, &msgs, 0, nullptr, 0};
+    tr.points = &points;
+    TRY(pippenger_prove(st, h_claim_point, h_claim_evs, d_knuckles_inverses, h_k, &tr, h_pair));
+    if (n_msgs) *n_msgs = msgs.size();
+    if (h_msgs) {
+        GM_REQUIRE(msgs.size() <= msgs_cap, "message buffer too small: %zu > %llu", msgs.size(), (unsigned long long)msgs_cap);
+        memcpy(h_msgs, msgs.data(), msgs.size() * sizeof(Fr));
+    }
+    if (n_points) *n_points = points.size() / 12;
+    if (h_points) {
+        GM_REQUIRE(points.size() / 12 <= points_cap, "point buffer too small");
+        memcpy(h_points, points.data(), points.size() * 8);
+    }
+    if (tape_used) *tape_used = tr.pos;
+    if (rounds) *rounds = tr.rounds;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_pippenger_prove_tr(const gm_pippenger_wg* st, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                         const uint64_t* d_knuckles_inverses, const uint64_t* h_k, const gm_transcript* tr,
+                                         uint64_t* h_pair, uint64_t* n_challenges, uint64_t* rounds) {
+    GM_REQUIRE(st && h_claim_point && h_claim_evs && d_knuckles_inverses && h_k && tr && tr->challenge && h_pair, "null argument");
+    std::vector<Fr> msgs;
+    Tape t{nullptr, 0, 0, &msgs, 0, tr, 0};
+    TRY(pippenger_prove(st, h_claim_point, h_claim_evs, d_knuckles_inverses, h_k, &t, h_pair));
+    if (n_challenges) *n_challenges = t.pos;
+    if (rounds) *rounds = t.rounds;
+    return GM_OK;
 }

@@ -432,6 +432,51 @@ def knuckles_open(d_basis_aff, d_inverses, k, num_vars, d_poly, poly_len, point,
     return pr, tuple(g(pair))
 
 
+class PippengerWG:
+    """gm_pippenger_wg: PippengerWG::new on the device (witness + phase-1 commitments)"""
+
+    def __init__(self, plan, d_points, y_logsize, clm, d_basis_aff):
+        self.L = ffi.lib()
+        self.plan, self.y_logsize, self.clm = plan, y_logsize, clm
+        self.keep = (d_points, d_basis_aff)
+        self.h = C.c_void_p()
+        ffi.check(self.L.gm_pippenger_wg_create(plan.h, _p(d_points), y_logsize, clm, _p(d_basis_aff), C.byref(self.h), cur_stream()))
+
+    def close(self):
+        if self.h:
+            self.L.gm_pippenger_wg_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dense_output(self):
+        w = C.c_void_p()
+        ffi.check(self.L.gm_pippenger_wg_witness(self.h, C.byref(w)))
+        d = self.plan.d_logsize
+        ncol = 3 * (d + 1)
+        out_ptrs = (C.c_void_p * ncol)()
+        n, ln = C.c_uint32(), C.c_uint64()
+        ffi.check(self.L.gm_pip_witness_outputs(w, out_ptrs, C.byref(n), C.byref(ln), None))
+        return [codec.from_mont_limbs(read_dev(out_ptrs[i], ln.value * 32)) for i in range(n.value)]
+
+    def prove(self, claim_point, claim_evs, d_kn_inverses, k, tape, msgs_cap=1 << 16, points_cap=256):
+        cp, ce, kk = fr_arg(claim_point), fr_arg(claim_evs), fr_arg([k])
+        tp = codec.ints_to_limbs(tape)
+        msgs = np.zeros((msgs_cap, 4), dtype=np.uint64)
+        pts = np.zeros((points_cap, 12), dtype=np.uint64)
+        pair = np.zeros(24, dtype=np.uint64)
+        nm, npnt, used, rounds = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ffi.check(self.L.gm_pippenger_prove(self.h, cp.ctypes.data, ce.ctypes.data, _p(d_kn_inverses), kk.ctypes.data, tp.ctypes.data,
+                                            len(tape), msgs.ctypes.data, msgs_cap, C.byref(nm), pts.ctypes.data, points_cap,
+                                            C.byref(npnt), pair.ctypes.data, C.byref(used), C.byref(rounds)))
+        return dict(msgs=codec.from_mont_limbs(msgs[: nm.value]), points=codec.g1_aff_from_limbs(pts[: npnt.value]),
+                    pair=tuple(codec.g1_aff_from_limbs(pair)), tape_used=used.value, rounds=rounds.value)
+
+
 class LiveTranscript:
     """A gm_transcript whose callbacks run Python code: `on_write(list of canonical ints)` and `draw() -> int`.
     Stands in for the Rust shim's wrappers over ProofTranscript2 (tests drive it from a tape or a hash)."""

@@ -340,6 +340,31 @@ int32_t gm_knuckles_open_tr(const uint64_t* d_basis_aff, const uint64_t* d_inver
                             const uint64_t* h_commitment_aff, const gm_transcript* tr, uint64_t* h_proof, uint64_t* h_pair,
                             void* stream);
 
+/* ---------------------------------------------------------------- the whole gen-2 prover
+ * PippengerWG::new (cleanup/protocols/pippenger.rs:37-70) and Pippenger::prove (pippenger.rs:118-290) behind two calls; pure
+ * orchestration of the entry points above (phase-1 commitments, image part, second phase + its commitments, pushforward
+ * argument, MultiOpenReduction, Knuckles opening) with the scalar / G1 glue of the "open" span on the host.
+ *   gm_pippenger_wg_create  after gm_msm_run(plan, ...): witness of the image part, outer buckets, commitments c[], d[] (one per
+ *                           2^clm windows), p_0, p_1, ac_c, ac_d.  d_kzg_basis_aff: >= 2^(x_logsize + clm + 1) - 1 affine points.
+ *   gm_pippenger_wg_witness the gm_pip_witness inside (gm_pip_witness_outputs gives the dense output the claims are about)
+ *   gm_pippenger_prove      claims = (r_y, the 3 (d_logsize + 1) evaluations of the dense output at r_y).  Scalars written go to
+ *                           h_msgs, G1 points (12 x u64 affine each) to h_points, both in write order; h_pair = the deferred
+ *                           pairing pair (A, B), <A, H0> = <B, H1>.  d_knuckles_inverses / h_k: gm_knuckles_setup for
+ *                           num_vars = x_logsize + clm.  The `_tr` form drives the caller's live transcript instead. */
+typedef struct gm_pippenger_wg gm_pippenger_wg;
+int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                               uint32_t commitment_log_multiplicity, const uint64_t* d_kzg_basis_aff, gm_pippenger_wg** out,
+                               void* stream);
+int32_t gm_pippenger_wg_destroy(gm_pippenger_wg* wg);
+int32_t gm_pippenger_wg_witness(const gm_pippenger_wg* wg, const gm_pip_witness** w);
+int32_t gm_pippenger_prove(const gm_pippenger_wg* wg, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                           const uint64_t* d_knuckles_inverses, const uint64_t* h_k, const uint64_t* h_tape, uint64_t n_tape,
+                           uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_points, uint64_t points_cap,
+                           uint64_t* n_points, uint64_t* h_pair, uint64_t* tape_used, uint64_t* rounds);
+int32_t gm_pippenger_prove_tr(const gm_pippenger_wg* wg, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                              const uint64_t* d_knuckles_inverses, const uint64_t* h_k, const gm_transcript* tr, uint64_t* h_pair,
+                              uint64_t* n_challenges, uint64_t* rounds);
+
 /* ---------------------------------------------------------------- gen-1 prover (a6, a16)
  * gkr_msm_prove (src/gkr_msm_simple.rs:86-338) without the BLS12-381 G1 column commitments: base polys
  * (bit, px, py) over index point*2^lb + bit, BintreeProtocol::witness (protocol/bintree.rs:168-184) over the layer list of

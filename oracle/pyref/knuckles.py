@@ -82,8 +82,12 @@ def knuckles_open(tr, points_out, basis, inverses, k, num_vars, commitment, poin
     Returns ((A, B), proof dict)."""
     t, opening = compute_t(poly, point, num_vars, inverses)
     assert opening == claimed_ev
+    def wp(pt_):   # write_points::<G1> in transcript order when the transcript records points
+        points_out.append(pt_)
+        if hasattr(tr, "write_points"):
+            tr.write_points([pt_])
     t_comm = kzg_commit(basis, t)
-    points_out.append(t_comm)
+    wp(t_comm)
     x = tr.challenge(128)
     kx = x * k % P
     t_x, p_x = ev(t, x), ev(poly, x)
@@ -92,10 +96,10 @@ def knuckles_open(tr, points_out, basis, inverses, k, num_vars, commitment, poin
     padded = list(poly) + [0] * (len(t) - len(poly))
     p_lt = [(lam * b + a) % P for a, b in zip(padded, t)]
     p_lt_x_proof, _ = kzg_open(basis, p_lt, x)
-    points_out.append(p_lt_x_proof)
+    wp(p_lt_x_proof)
     t_kx_proof, t_kx = kzg_open(basis, t, kx)
     tr.write_scalars([t_kx])
-    points_out.append(t_kx_proof)
+    wp(t_kx_proof)
     fin = tr.challenge(128)
     p_lt_comm = G.add(G.mul(t_comm, lam), commitment)
     p_lt_open = (t_x * lam + p_x) % P

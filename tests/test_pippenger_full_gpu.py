@@ -1,0 +1,63 @@
+"""GPU test of the whole gen-2 prover, gm_pippenger_wg_create + gm_pippenger_prove = PippengerWG::new + Pippenger::prove
+(pippenger.rs:37-70, 118-290), against the Python oracle's orchestration of the same protocol with the same challenge tape:
+every scalar and every G1 point written to the transcript, in order, and the deferred pairing pair.  The SRS is built from a
+known tau, so the final pairing equation <A, H0> = <B, H1> is checked in the exponent (A = tau * B): the proof verifies."""
+import pytest
+
+from gkr_msm_amd import codec, harness as H
+from pyref import field as F
+from pyref import g1 as G
+from pyref import gkr as GK
+from pyref import knuckles as KN
+from pyref import pippenger as PP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("x_log,d_log,nbits,clm", [(3, 2, 8, 0), (3, 2, 8, 1), (4, 2, 6, 0), (4, 3, 12, 2)])
+def test_full_prover_matches_oracle_and_verifies(x_log, d_log, nbits, clm):
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = (y_size - 1).bit_length()
+    n = 1 << x_log
+    rng = F.SplitMix64(90 + x_log + clm)
+    pts = F.random_points(n, 2)
+    sc = F.random_scalars(n, nbits, 3)
+    sc[0] = 0
+    nv = x_log + clm
+    N = 1 << nv
+    tau, k = rng.next_fr(), 2
+    basis, cur = [], G.GEN
+    for _ in range(2 * N - 1):
+        basis.append(cur)
+        cur = G.mul(cur, tau)
+    st = PP.pippenger_wg(pts, sc, y_size, y_log, d_log, x_log, clm, basis)
+    out = GK.pippenger_dense_output(st["wg"], y_log, d_log)
+    r = [rng.next_fr() for _ in range(y_log)]
+    claims = GK.pippenger_claims(out, r)
+    tape = [rng.next_bits(512) for _ in range(4000)]
+    tr = PP.Transcript(tape)
+    inv = KN.setup_inverses(k, nv)
+    want_pair = PP.pippenger_prove(tr, st, claims, y_size, y_log, d_log, x_log, clm, basis, inv, k)
+    assert want_pair[0] == G.mul(want_pair[1], tau)
+
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    plan = H.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, H.to_dev(codec.ints_to_limbs(sc)))
+    d_basis = H.g1_aff_dev(basis)
+    wg = H.PippengerWG(plan, d_pts, y_log, clm, d_basis)
+    assert wg.dense_output() == out
+    d_inv = H.knuckles_setup(k, nv)
+    # the tape as the oracle consumed it: 512-bit draws reduced mod p, 128-bit draws truncated (the oracle records which is which)
+    dev_tape = _consumed(tape, tr)
+    got = wg.prove(claims[0], claims[1], d_inv, k, dev_tape)
+    assert got["tape_used"] == tr.pos
+    assert got["points"] == tr.points
+    assert got["msgs"] == [v for m in tr.msgs for v in m]
+    assert got["pair"] == want_pair
+    assert got["pair"][0] == G.mul(got["pair"][1], tau)          # the proof verifies
+
+
+def _consumed(tape, tr):
+    """replay which draws were 512-bit: psi, tau_c, tau_d, tau_suppression (the first 4 draws of the pushforward) and u"""
+    wide = getattr(tr, "wide", None)
+    return [t % F.P if (wide and i in wide) else t & ((1 << 128) - 1) for i, t in enumerate(tape[: tr.pos])] + [0] * 8
