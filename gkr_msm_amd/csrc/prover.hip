@@ -1234,6 +1234,7 @@ struct gm_pippenger_wg {
     gm_pip_witness* w = nullptr;
     std::shared_ptr<DevBuf> d_outer, c_outer, p0, p1;
     std::vector<uint64_t> comm_c, comm_d;          // n_mat affine points each
+    std::vector<uint32_t> c_upper;                 // c_upper_bound of every matrix (pushforward.rs:431): its longest bucket row
     uint64_t comm_p0[12], comm_p1[12], comm_ac_c[12], comm_ac_d[12];
     hipStream_t stream = nullptr;
     ~gm_pippenger_wg() { delete w; }
@@ -1321,9 +1322,9 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
         for (uint32_t m = 0; m < n_mat; m++) {
             TRY(gm_g1_msm_nonaff(reinterpret_cast<const uint64_t*>(dob + (size_t)m * D), reinterpret_cast<const uint64_t*>(eq_d), D, 1,
                                  255, comm_dp.data() + 12 * (size_t)m, stream));
-            // entries of c_outer past the row's c_upper_bound are the point at infinity: the prefix product is unchanged
+            // eq_c[..basis.len()] with basis = c_outer_buckets[m] of length c_upper_bound[m] (pushforward.rs:601-604)
             TRY(gm_g1_msm_nonaff(reinterpret_cast<const uint64_t*>(cob + (size_t)m * st->c_stride), reinterpret_cast<const uint64_t*>(eq_c),
-                                 st->c_stride, 1, 255, comm_cp.data() + 12 * (size_t)m, stream));
+                                 st->c_upper[m], 1, 255, comm_cp.data() + 12 * (size_t)m, stream));
         }
     }
     tr->write_points(comm_cp.data(), n_mat);
@@ -1352,13 +1353,25 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
             multirow[2 * j] = fr_sub(w, m);
             multirow[2 * j + 1] = m;
         }
-    auto comb = [&](const uint64_t* cs) {
-        G1Jac a = g1_inf();
-        for (uint32_t m = 0; m < n_mat && m < multirow.size(); m++) a = g1_add(a, pp_mul(pp_aff_in(cs + 12 * (size_t)m), multirow[m]));
-        return a;
+    // sum_m multirow_evs[m] * commitment[m] (pippenger.rs:191-194): small MSMs on the device
+    const uint32_t n_comb = n_mat < multirow.size() ? n_mat : (uint32_t)multirow.size();
+    DevBuf d_mr, d_cs;
+    TRY(d_mr.alloc(n_comb * sizeof(Fr)));
+    TRY(d_cs.alloc((size_t)n_comb * sizeof(G1Aff)));
+    GM_HIP(hipMemcpyAsync(d_mr.p, multirow.data(), n_comb * sizeof(Fr), hipMemcpyHostToDevice, s));
+    auto comb = [&](const uint64_t* cs, G1Jac* out) -> int32_t {
+        uint64_t r12[12];
+        GM_HIP(hipMemcpyAsync(d_cs.p, cs, (size_t)n_comb * sizeof(G1Aff), hipMemcpyHostToDevice, s));
+        const int32_t rc = gm_g1_msm((const uint64_t*)d_cs.p, (const uint64_t*)d_mr.p, n_comb, 1, 255, r12, stream);
+        if (rc) return rc;
+        *out = pp_aff_in(r12);
+        return GM_OK;
     };
-    const G1Jac c_comb = comb(st->comm_c.data()), d_comb = comb(st->comm_d.data()), cp_comb = comb(comm_cp.data()),
-                dp_comb = comb(comm_dp.data());
+    G1Jac c_comb, d_comb, cp_comb, dp_comb;
+    TRY(comb(st->comm_c.data(), &c_comb));
+    TRY(comb(st->comm_d.data(), &d_comb));
+    TRY(comb(comm_cp.data(), &cp_comb));
+    TRY(comb(comm_dp.data(), &dp_comb));
     Fr u;
     TRY(tr->challenge(&u));   // challenge(512)
     Us us;
@@ -1432,6 +1445,11 @@ extern "C" int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_
         GM_HIP(hipStreamSynchronize(s));
         uint32_t cmax = 1;
         for (uint32_t v : rl) cmax = v > cmax ? v : cmax;
+        st->c_upper.assign(st->n_mat, 1);
+        for (uint32_t r = 0; r < plan->nrows; r++) {
+            const uint32_t m = (r >> plan->d_log) >> st->clm;
+            if (rl[r] > st->c_upper[m]) st->c_upper[m] = rl[r];
+        }
         st->d_outer.reset(new DevBuf());
         st->c_outer.reset(new DevBuf());
         TRY(st->d_outer->alloc(((size_t)st->n_mat << plan->d_log) * sizeof(G1Jac)));
