@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--cpu-sumcheck-xlog", type=int, default=17)
     ap.add_argument("--gen1-log-points", type=int, default=18, help="gen-1 gkr_msm_prove size (0 = skip; 20 needs ~210 GiB)")
     ap.add_argument("--cpu-gen1-log-points", type=int, default=12)
-    ap.add_argument("--g1-log-points", type=int, default=20, help="BLS12-381 G1 MSM size (KZG commit shape; 0 = skip)")
+    ap.add_argument("--g1-log-points", type=int, default=21, help="BLS12-381 G1 MSM size (KZG commit shape; 0 = skip)")
     ap.add_argument("--cpu-g1-log-points", type=int, default=19)
     ap.add_argument("--cpu-g1-outer-xlog", type=int, default=17)
     args = ap.parse_args()
@@ -376,6 +376,46 @@ def main():
                     "gpu_same_sample_g1_adds_per_sec": round(2 * no * y_size / go_dt, 1),
                     "parity": "same group elements (d_outer buckets, c_comm, d_comm)"}
                 plan_s.close()
+        # ---- the whole gen-2 prover at the bench shape: PippengerWG::new + Pippenger::prove (pippenger.rs:37-70, 118-290)
+        if not args.no_sumcheck and args.g1_log_points >= x_log + 1:
+            y_log = (y_size - 1).bit_length()
+            plan_f = harness.MsmPlan(x_log, d_log, y_size)
+            d_inv = harness.knuckles_setup(2, x_log)
+            d_basis = d_srs if ng >= (2 << x_log) - 1 else harness.g1_gen_points((2 << x_log) - 1, 0x53525331)
+            full = None
+            for it in range(2):                               # second pass = warm memory pool
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                plan_f.run(d_pts, d_sc)
+                torch.cuda.synchronize()
+                t_b = time.perf_counter() - t1
+                t1 = time.perf_counter()
+                wgf = harness.PippengerWG(plan_f, d_pts, y_log, 0, d_basis)
+                torch.cuda.synchronize()
+                t_w = time.perf_counter() - t1
+                outs = wgf.dense_output()
+                pr2 = np.random.default_rng(17)
+                r_f = [int.from_bytes(pr2.bytes(64), "little") % P for _ in range(y_log)]
+
+                def ev_f(poly):
+                    cur = list(poly)
+                    for f in reversed(r_f):
+                        cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
+                    return cur[0]
+                evs_f = [ev_f(o) for o in outs]
+                tape_f = [int.from_bytes(pr2.bytes(16), "little") for _ in range(6000)]
+                t1 = time.perf_counter()
+                full = wgf.prove(r_f, evs_f, d_inv, 2, tape_f)
+                t_p = time.perf_counter() - t1
+                wgf.close()
+            out["full_gen2_prover"] = {
+                "workload": "PippengerWG::new + Pippenger::prove, x_logsize=%d d_logsize=%d nbits=%d clm=0 (synthetic SRS of 2^%d - 1 points)" % (
+                    x_log, d_log, nbits, x_log + 1),
+                "bucketing_and_msm_ms": round(t_b * 1e3, 2), "witness_and_commitments_ms": round(t_w * 1e3, 2),
+                "prove_ms": round(t_p * 1e3, 2), "total_ms": round((t_b + t_w + t_p) * 1e3, 2), "sumcheck_rounds": full["rounds"],
+                "transcript_scalars": len(full["msgs"]), "transcript_points": len(full["points"]),
+                "proofs_per_sec": round(1.0 / (t_b + t_w + t_p), 3)}
+            plan_f.close()
         del d_srs, d_gsc
         ffi.check(L.gm_g1_release_scratch())
 
