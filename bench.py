@@ -160,7 +160,7 @@ def main():
     # HBM traffic per k_add_level0 launch from the committed PMC passes (profiles/r01/msm_bench_pmc_hbm.csv, config B,
     # 32 windows on this GPU): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction.
     # Raw (uncorrected) it is 3.68e9; the gather pattern is uncalibrated, the truth lies between the two.
-    pmc_traffic = 5740748531 if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None
+    pmc_traffic = 5741469043 if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None
     roofline = None
     if dom:
         ach = alg_bytes / (dom * 1e-3) / 1e9
