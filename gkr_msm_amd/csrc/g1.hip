@@ -157,6 +157,38 @@ __global__ void __launch_bounds__(256) k_g1_msm_tasks(const uint32_t* __restrict
     }
 }
 
+// grouped MSM (several base arrays against one scalar array: the pull commitments of second_phase, pushforward.rs:596-605):
+// flat base j of group g (pre[g] <= j < pre[g+1], i = j - pre[g]) in window w -> key ((g * nwin + w) << c | digit), point g * stride + i
+__global__ void __launch_bounds__(256) k_g1_msm_tasks_grouped(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ pre,
+                                                               uint32_t ngroups, uint64_t stride, uint64_t total, uint32_t c,
+                                                               uint32_t nwin, int mont, uint32_t sentinel,
+                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    uint32_t lo = 0, hi = ngroups;  // pre[lo] <= j < pre[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pre[mid] <= j) lo = mid; else hi = mid;
+    }
+    const uint32_t g = lo;
+    const uint64_t i = j - pre[g];
+    Fr s = fr_load(reinterpret_cast<const Fr*>(scalars) + i);
+    if (mont) s = fr_from_mont(s);
+    for (uint32_t w = 0; w < nwin; w++) {
+        const uint32_t bit = w * c;
+        uint32_t d = 0;
+        if (bit < 256) {
+            const uint32_t li = bit >> 5, sh = bit & 31;
+            uint64_t v = s.l[li];
+            if (li + 1 < 8) v |= (uint64_t)s.l[li + 1] << 32;
+            d = (uint32_t)(v >> sh) & ((1u << c) - 1);
+        }
+        const uint64_t t = (uint64_t)w * total + j;
+        keys[t] = d ? (((g * nwin + w) << c) | d) : sentinel;
+        idx[t] = (uint32_t)(g * stride + i);
+    }
+}
+
 // weighted sum sum_i i * B[g][i] over groups g of `glen` buckets by bit decomposition: task (g, i, b) -> key g * nbits + b
 __global__ void __launch_bounds__(256) k_g1_bit_tasks(uint32_t ngroups, uint32_t glen, uint32_t nbits, uint32_t sentinel,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
@@ -480,6 +512,65 @@ static int32_t g1_msm_core(const G1Aff* aff, const G1Jac* jac, const uint64_t* d
     return GM_OK;
 }
 
+// ngroups MSMs sharing one scalar array: group g = bases[g * stride .. g * stride + n_g[g]) against scalars[0 .. n_g[g]).
+// One engine call for all groups and windows (the 64 separate calls of the full prover were launch-bound).
+static int32_t g1_msm_grouped_core(const G1Jac* jac, uint64_t stride, const uint32_t* h_n, uint32_t ngroups, const uint64_t* d_scalars,
+                                   int scalars_mont, uint32_t nbits, G1Jac* h_out, hipStream_t s) {
+    GM_REQUIRE(ngroups >= 1 && ngroups <= 65536 && nbits >= 1 && nbits <= 256, "bad argument");
+    std::vector<uint32_t> pre(ngroups + 1, 0);
+    uint32_t nmax = 0;
+    for (uint32_t g = 0; g < ngroups; g++) {
+        GM_REQUIRE(h_n[g] <= stride, "group longer than the stride");
+        pre[g + 1] = pre[g] + h_n[g];
+        nmax = h_n[g] > nmax ? h_n[g] : nmax;
+    }
+    const uint64_t total = pre[ngroups];
+    for (uint32_t g = 0; g < ngroups; g++) h_out[g] = g1_inf();
+    if (total == 0) return GM_OK;
+    // window from the typical group size (buckets are per (group, window)): c = log2(median-ish n) - 4, within [2, 12]
+    uint32_t lg = 0;
+    while ((1ull << lg) < (total / ngroups + 1)) lg++;
+    int ci = (int)lg - 4;
+    if (ci < 2) ci = 2;
+    if (ci > 12) ci = 12;
+    const uint32_t c = (uint32_t)ci, nwin = (nbits + c - 1) / c;
+    const uint64_t ntasks = (uint64_t)nwin * total;
+    const uint64_t nkeys64 = ((uint64_t)ngroups * nwin) << c;
+    GM_REQUIRE(ntasks < (1ull << 31) && nkeys64 < (1ull << 30) && stride * ngroups < (1ull << 31), "grouped MSM too large for one call");
+    const uint32_t nkeys = (uint32_t)nkeys64;
+    G1Scratch& ws = g1_scratch();
+    std::lock_guard<std::mutex> lock(ws.mu);
+    const size_t need = 2 * al(ntasks * 4) + al((size_t)nkeys * sizeof(G1Jac)) + al((ngroups + 1) * 4) + g1_engine_bytes(ntasks, nkeys) +
+                        g1_weighted_bytes(ngroups * nwin, 1u << c) + 8192;
+    int32_t rc = ws.reserve(need);
+    if (rc) return rc;
+    ws.used = 0;
+    uint32_t* keys = (uint32_t*)ws.carve(ntasks * 4);
+    uint32_t* idx = (uint32_t*)ws.carve(ntasks * 4);
+    G1Jac* buckets = (G1Jac*)ws.carve((size_t)nkeys * sizeof(G1Jac));
+    uint32_t* d_pre = (uint32_t*)ws.carve((ngroups + 1) * 4);
+    GM_HIP(hipMemcpyAsync(d_pre, pre.data(), (ngroups + 1) * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_g1_msm_tasks_grouped, dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(d_scalars),
+                       d_pre, ngroups, stride, total, c, nwin, scalars_mont, nkeys, keys, idx);
+    GM_LAUNCH_CHECK();
+    const size_t mark = ws.used;
+    rc = g1_sum_by_key(ws, nullptr, jac, keys, idx, ntasks, nkeys, buckets, s);  // synchronises: `pre` may go
+    if (rc) return rc;
+    ws.used = mark;
+    std::vector<G1Jac> wsum;
+    rc = g1_weighted_sums(ws, buckets, ngroups * nwin, 1u << c, &wsum, s);
+    if (rc) return rc;
+    for (uint32_t g = 0; g < ngroups; g++) {
+        G1Jac acc = g1_inf();
+        for (uint32_t w = nwin; w-- > 0;) {
+            for (uint32_t k = 0; k < c; k++) acc = g1_dbl(acc);
+            acc = g1_add(acc, wsum[(size_t)g * nwin + w]);
+        }
+        h_out[g] = acc;
+    }
+    return GM_OK;
+}
+
 }  // namespace gm
 
 using namespace gm;
@@ -595,6 +686,18 @@ extern "C" int32_t gm_g1_msm_nonaff(const uint64_t* d_bases_jac, const uint64_t*
                              as_stream(stream));
     if (rc) return rc;
     put_aff(h_out_aff, r);
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_msm_nonaff_grouped(const uint64_t* d_bases_jac, uint64_t stride, const uint32_t* h_n, uint32_t n_groups,
+                                            const uint64_t* d_scalars, int32_t scalars_mont, uint32_t nbits, uint64_t* h_out_aff,
+                                            void* stream) {
+    GM_REQUIRE(d_bases_jac && h_n && d_scalars && h_out_aff && n_groups >= 1, "null argument");
+    std::vector<G1Jac> r(n_groups);
+    int32_t rc = g1_msm_grouped_core(reinterpret_cast<const G1Jac*>(d_bases_jac), stride, h_n, n_groups, d_scalars, scalars_mont, nbits,
+                                     r.data(), as_stream(stream));
+    if (rc) return rc;
+    for (uint32_t g = 0; g < n_groups; g++) put_aff(h_out_aff + 12 * (size_t)g, r[g]);
     return GM_OK;
 }
 

@@ -1169,6 +1169,8 @@ int32_t gm_g1_msm(const uint64_t* d_bases_aff, const uint64_t* d_scalars, uint64
                   uint64_t* h_out_aff, void* stream);
 int32_t gm_g1_msm_nonaff(const uint64_t* d_bases_jac, const uint64_t* d_scalars, uint64_t n, int32_t scalars_mont, uint32_t nbits,
                          uint64_t* h_out_aff, void* stream);
+int32_t gm_g1_msm_nonaff_grouped(const uint64_t* d_bases_jac, uint64_t stride, const uint32_t* h_n, uint32_t n_groups,
+                                 const uint64_t* d_scalars, int32_t scalars_mont, uint32_t nbits, uint64_t* h_out_aff, void* stream);
 int32_t gm_knuckles_open_tr(const uint64_t* d_basis_aff, const uint64_t* d_inverses, const uint64_t* h_k, uint32_t num_vars,
                             const uint64_t* d_poly, uint64_t poly_len, const uint64_t* h_point, const uint64_t* h_claimed_ev,
                             const uint64_t* h_commitment_aff, const gm_transcript* tr, uint64_t* h_proof, uint64_t* h_pair,
@@ -1317,15 +1319,13 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
         for (uint32_t i = 0; i < d_log; i++) lv[i] = eq_d + D + ((1ull << i) - 1);
         lv[d_log] = eq_d;
         TRY(launch_eq_sequence(fr_one(), c.point.data() + y_log, d_log, lv.data(), s));
-        const G1Jac* dob = reinterpret_cast<const G1Jac*>(st->d_outer->p);
-        const G1Jac* cob = reinterpret_cast<const G1Jac*>(st->c_outer->p);
-        for (uint32_t m = 0; m < n_mat; m++) {
-            TRY(gm_g1_msm_nonaff(reinterpret_cast<const uint64_t*>(dob + (size_t)m * D), reinterpret_cast<const uint64_t*>(eq_d), D, 1,
-                                 255, comm_dp.data() + 12 * (size_t)m, stream));
-            // eq_c[..basis.len()] with basis = c_outer_buckets[m] of length c_upper_bound[m] (pushforward.rs:601-604)
-            TRY(gm_g1_msm_nonaff(reinterpret_cast<const uint64_t*>(cob + (size_t)m * st->c_stride), reinterpret_cast<const uint64_t*>(eq_c),
-                                 st->c_upper[m], 1, 255, comm_cp.data() + 12 * (size_t)m, stream));
-        }
+        // every outer-bucket array against the same eq table: one grouped MSM per kind
+        std::vector<uint32_t> nd_all(n_mat, (uint32_t)D);
+        TRY(gm_g1_msm_nonaff_grouped(reinterpret_cast<const uint64_t*>(st->d_outer->p), D, nd_all.data(), n_mat,
+                                     reinterpret_cast<const uint64_t*>(eq_d), 1, 255, comm_dp.data(), stream));
+        // eq_c[..basis.len()] with basis = c_outer_buckets[m] of length c_upper_bound[m] (pushforward.rs:601-604)
+        TRY(gm_g1_msm_nonaff_grouped(reinterpret_cast<const uint64_t*>(st->c_outer->p), st->c_stride, st->c_upper.data(), n_mat,
+                                     reinterpret_cast<const uint64_t*>(eq_c), 1, 255, comm_cp.data(), stream));
     }
     tr->write_points(comm_cp.data(), n_mat);
     tr->write_points(comm_dp.data(), n_mat);

@@ -594,6 +594,14 @@ def g1_msm_nonaff(d_bases_jac, d_scalars, n, mont=False, nbits=255):
     return _one_aff(out)
 
 
+def g1_msm_nonaff_grouped(d_bases_jac, stride, ns, d_scalars, mont=False, nbits=255):
+    hn = np.asarray(ns, dtype=np.uint32)
+    out = np.zeros((len(ns), 12), dtype=np.uint64)
+    ffi.check(ffi.lib().gm_g1_msm_nonaff_grouped(_p(d_bases_jac), stride, hn.ctypes.data, len(ns), _p(d_scalars), 1 if mont else 0, nbits,
+                                                 out.ctypes.data, cur_stream()))
+    return codec.g1_aff_from_limbs(out)
+
+
 def g1_bucket_sums(d_bases_aff, mapping, n_buckets):
     torch = torch_mod()
     d_map = torch.from_numpy(np.asarray(mapping, dtype=np.uint32).view(np.int32)).cuda()

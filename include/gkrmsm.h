@@ -413,6 +413,10 @@ int32_t gm_g1_msm(const uint64_t* d_bases_aff, const uint64_t* d_scalars, uint64
                   uint64_t* h_out_aff, void* stream);
 int32_t gm_g1_msm_nonaff(const uint64_t* d_bases_jac, const uint64_t* d_scalars, uint64_t n, int32_t scalars_mont,
                          uint32_t nbits, uint64_t* h_out_aff, void* stream);
+/* n_groups MSMs over projective bases against ONE scalar array: group g = d_bases_jac[g * stride .. + h_n[g]) with scalars[0 .. h_n[g]);
+ * the pull commitments of second_phase (pushforward.rs:596-605: every outer-bucket array against the same eq table) in one call */
+int32_t gm_g1_msm_nonaff_grouped(const uint64_t* d_bases_jac, uint64_t stride, const uint32_t* h_n, uint32_t n_groups,
+                                 const uint64_t* d_scalars, int32_t scalars_mont, uint32_t nbits, uint64_t* h_out_aff, void* stream);
 int32_t gm_g1_bucket_sums(const uint64_t* d_bases_aff, const uint32_t* d_mapping, uint64_t n, uint32_t n_buckets,
                           uint64_t* d_out_jac, void* stream);
 int32_t gm_g1_pullback_msm(const uint64_t* d_bases_aff, const uint32_t* d_mapping, uint64_t n, const uint64_t* d_image,

@@ -188,3 +188,17 @@ def test_pushforward_outer_buckets_and_commitments(x_log, d_log, nbits, clm):
     for m in range(n_mat):
         sub = g_d[m * 18 * (1 << d_log):(m + 1) * 18 * (1 << d_log)]
         assert H.g1_msm_nonaff(sub, d_eq, 1 << d_log, mont=True) == G.msm_nonaff(d_out[m], eq_d)
+
+
+def test_grouped_msm_matches_separate_msms():
+    """gm_g1_msm_nonaff_grouped: several projective base arrays (different lengths, one stride) against one scalar array"""
+    stride, ns = 40, [40, 0, 7, 33, 1]
+    rng = F.SplitMix64(61)
+    sc = [rng.next_fr() for _ in range(stride)]
+    sc[0] = 0
+    groups = [G.random_points(stride, 70 + g) for g in range(len(ns))]
+    groups[3][5] = None
+    zs = [rng.next_fr() | 1 for _ in range(stride * len(ns))]
+    flat = [p for grp in groups for p in grp]
+    got = H.g1_msm_nonaff_grouped(H.g1_jac_dev(flat, zs), stride, ns, H.to_dev(codec.to_mont_limbs(sc)), mont=True)
+    assert got == [G.msm_nonaff(grp[:n], sc[:n]) if n else None for grp, n in zip(groups, ns)]
