@@ -1475,8 +1475,19 @@ extern "C" int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_
         TRY(gm_msm_phase1_polys(plan, (uint64_t*)c.p, (uint64_t*)d.p, (uint64_t*)ac_c.p, (uint64_t*)ac_d.p, stream));
         TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)st->p0->p, X, 1, 255, st->comm_p0, stream));
         TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)st->p1->p, X, 1, 255, st->comm_p1, stream));
-        TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)ac_c.p, X, 1, 255, st->comm_ac_c, stream));
-        TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)ac_d.p, D, 1, 255, st->comm_ac_d, stream));
+        // ac_c / ac_d are negated access counts (pushforward.rs:507-508): commit(-v) = -commit(v) with v < 2^32, so the MSM
+        // runs over 32-bit scalars and the result is negated -- the same group element at a sixth of the work
+        auto commit_negated_counts = [&](DevBuf& col, uint64_t len, uint64_t* out12) -> int32_t {
+            TRY(gm_fr_batch(3, (const uint64_t*)col.p, nullptr, (uint64_t*)col.p, len, stream));   // in place: -(-count) = count
+            TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)col.p, len, 1, 32, out12, stream));
+            G1Aff a;
+            memcpy(&a, out12, sizeof(G1Aff));
+            if (!g1_aff_is_inf(a)) a = g1_aff_neg(a);
+            memcpy(out12, &a, sizeof(G1Aff));
+            return GM_OK;
+        };
+        TRY(commit_negated_counts(ac_c, X, st->comm_ac_c));
+        TRY(commit_negated_counts(ac_d, D, st->comm_ac_d));
     }
     *out = st.release();
     return GM_OK;
