@@ -105,3 +105,21 @@ def test_host_combine_vs_oracle():
     for p, s in zip(pts, sc):
         acc = F.te_add_affine(acc, F.te_mul_affine(p, s))
     assert got == acc
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """argument validation happens before any device work: error codes, not crashes (the reference panics on the same conditions)"""
+    L = ffi.lib()
+    assert L.gm_g1_msm(None, None, 5, 0, 255, None, None) == 1
+    assert L.gm_g1_binary_msm(None, None, 3, 9, None, None) == 1                 # gamma > 8: coefficients are u8
+    assert L.gm_g1_prepare_bases(None, 4, 0, None, None) == 1
+    assert L.gm_pushforward_prove(None, None, 2, None, None, None, 0, None, 0, None, None, None, None, None, None, None, None, None,
+                                  None, None) == 1
+    assert L.gm_multiopen_prove(0, 4, None, None, None, None, 0, None, 0, None, None, None, None, None, None) == 1
+    assert L.gm_knuckles_setup(None, 3, None, None) == 1
+    assert L.gm_knuckles_open(None, None, None, 3, None, 1, None, None, None, None, 0, None, None, None) == 1
+    assert L.gm_pippenger_wg_create(None, None, 2, 0, None, None, None) == 1
+    assert L.gm_pip_witness_create_sharded(None, None, 2, None, None, None) == 1
+    assert L.gm_comm_sum_fr(None, None, 0) == 1
+    assert L.gm_release_cached_memory() == 0 and L.gm_g1_release_scratch() == 0   # nothing cached: no device call
+    assert b"argument" in L.gm_last_error() or b"null" in L.gm_last_error() or len(L.gm_last_error()) > 0

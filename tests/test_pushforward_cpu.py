@@ -29,9 +29,7 @@ def test_pushforward_prover_claims_are_evaluations(x_log, d_log, nbits):
     r = [rng.next_fr() for _ in range(y_log + d_log + x_log)]
     p1 = PF.phase1_data(pts, digits, counter, x_log, d_log)
     p2 = PF.phase2_data(digits, counter, r, y_log, d_log, x_log)
-    # the claims the image part hands over: evaluations of the image polynomials (x, y, z) at r; any consistent triple works
-    # for the argument as long as it equals sum_{(x,y)} eq-pulled values, which is what the image evaluation is
-    image, _, _ = G.bucketing_image(pts, [0] * len(pts), y_size, y_log, d_log, x_log) if False else (None, None, None)
+    # the claims the image part hands over: evaluations of the image polynomials (x, y, z) at r
     img, _, _ = G.bucketing_image(pts, _scalars(digits, d_log), y_size, y_log, d_log, x_log)
     evs = [PL.evaluate_poly(p.to_dense(), r) for p in img]
     tape = [rng.next_bits(512) for _ in range(3000)]
