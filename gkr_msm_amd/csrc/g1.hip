@@ -852,6 +852,71 @@ extern "C" int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_ba
     return GM_OK;
 }
 
+// ---- gen-1 column commitments (gkr_msm_prove, gkr_msm_simple.rs:117-151): bit columns through binary_msm, the point column
+// through a plain MSM.  prepare_coefs (binary_msm.rs:51-53) packs gamma bits MSB-first into one byte per chunk.
+namespace gm {
+__global__ void __launch_bounds__(256) k_g1_pack_coefs(const uint8_t* __restrict__ bits, uint64_t nbits, uint32_t gamma,
+                                                        uint64_t nchunks, uint8_t* __restrict__ coefs) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    uint32_t v = 0;
+    for (uint32_t b = 0; b < gamma; b++) {
+        const uint64_t i = t * gamma + b;
+        if (i < nbits) v = (v << 1) + (bits[i] ? 1u : 0u);   // into_u8: s = (s << 1) + bit, over the (possibly short) chunk
+    }
+    coefs[t] = (uint8_t)v;
+}
+// pts_prep = x coordinates, then y coordinates, then zeros up to col_size (gkr_msm_simple.rs:139-146)
+__global__ void __launch_bounds__(256) k_g1_pts_prep(const Fr* __restrict__ points_xy, uint64_t npts, uint64_t col_size,
+                                                      Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= col_size) return;
+    Fr v = fr_zero();
+    if (i < npts) v = fr_load(points_xy + 2 * i);
+    else if (i < 2 * npts) v = fr_load(points_xy + 2 * (i - npts) + 1);
+    fr_store(out + i, v);
+}
+}  // namespace gm
+
+extern "C" int32_t gm_g1_binary_msm(const uint8_t* d_coefs, const uint64_t* d_tables_aff, uint64_t n_chunks, uint32_t gamma,
+                                    uint64_t* h_out_aff, void* stream);
+
+extern "C" int32_t gm_gkr_msm_commit(const uint64_t* d_points_xy, const uint8_t* d_scalar_bits, uint32_t log_num_points,
+                                     uint32_t log_num_scalar_bits, uint32_t log_num_bit_columns, const uint64_t* d_bases_aff,
+                                     const uint64_t* d_binary_tables_aff, uint32_t gamma, uint64_t* h_bit_comms_aff,
+                                     uint64_t* h_pts_comm_aff, void* stream) {
+    GM_REQUIRE(d_points_xy && d_scalar_bits && d_bases_aff && d_binary_tables_aff && h_bit_comms_aff && h_pts_comm_aff, "null argument");
+    GM_REQUIRE(gamma >= 1 && gamma <= 8, "1 <= gamma <= 8");
+    const uint32_t nv = log_num_points + log_num_scalar_bits;
+    GM_REQUIRE(nv <= 32 && log_num_bit_columns <= nv, "bad sizes");
+    const uint64_t size = 1ull << nv, ncols = 1ull << log_num_bit_columns, col_size = size >> log_num_bit_columns;
+    const uint64_t npts = 1ull << log_num_points;
+    GM_REQUIRE(col_size >= 2 * npts, "Points should fit in a single column. Please reduce the amount of columns. (gkr_msm_simple.rs:134-137)");
+    hipStream_t s = as_stream(stream);
+    const uint64_t nchunks = (col_size + gamma - 1) / gamma;
+    uint8_t* coefs = nullptr;
+    Fr* prep = nullptr;
+    GM_HIP(dev_alloc((void**)&coefs, nchunks + 64));
+    GM_HIP(dev_alloc((void**)&prep, col_size * sizeof(Fr)));
+    int32_t rc = GM_OK;
+    for (uint64_t i = 0; i < ncols && rc == GM_OK; i++) {
+        hipLaunchKernelGGL(k_g1_pack_coefs, dim3(ceil_div(nchunks, 256)), dim3(256), 0, s, d_scalar_bits + col_size * i, col_size, gamma,
+                           nchunks, coefs);
+        if (hipGetLastError() != hipSuccess) { rc = set_err(GM_ERR_HIP, "k_g1_pack_coefs launch failed"); break; }
+        rc = gm_g1_binary_msm(coefs, d_binary_tables_aff, nchunks, gamma, h_bit_comms_aff + 12 * i, stream);
+    }
+    if (rc == GM_OK) {
+        hipLaunchKernelGGL(k_g1_pts_prep, dim3(ceil_div(col_size, 256)), dim3(256), 0, s, reinterpret_cast<const Fr*>(d_points_xy), npts,
+                           col_size, prep);
+        if (hipGetLastError() != hipSuccess) rc = set_err(GM_ERR_HIP, "k_g1_pts_prep launch failed");
+    }
+    if (rc == GM_OK) rc = gm_g1_msm(d_bases_aff, reinterpret_cast<const uint64_t*>(prep), col_size, 1, 255, h_pts_comm_aff, stream);
+    (void)hipStreamSynchronize(s);
+    dev_free(coefs);
+    dev_free(prep);
+    return rc;
+}
+
 extern "C" int32_t gm_g1_to_affine(const uint64_t* d_in_jac, uint64_t n, uint64_t* d_out_aff, void* stream) {
     GM_REQUIRE(d_in_jac && d_out_aff, "null argument");
     if (n == 0) return GM_OK;

@@ -138,6 +138,7 @@ _SIGS = {
     "gm_msm_te": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "gm_g1_msm": (C.c_int32, [vp, vp, C.c_uint64, C.c_int32, C.c_uint32, vp, vp]),
     "gm_g1_msm_nonaff": (C.c_int32, [vp, vp, C.c_uint64, C.c_int32, C.c_uint32, vp, vp]),
+    "gm_gkr_msm_commit": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp]),
     "gm_g1_msm_nonaff_grouped": (C.c_int32, [vp, C.c_uint64, vp, C.c_uint32, vp, C.c_int32, C.c_uint32, vp, vp]),
     "gm_g1_bucket_sums": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "gm_g1_pullback_msm": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp]),

@@ -438,6 +438,15 @@ int32_t gm_g1_gen_points(uint64_t* d_points_aff, uint64_t n, uint64_t seed, void
 /* frees the grow-only device scratch the G1 calls share */
 int32_t gm_g1_release_scratch(void);
 
+/* The G1 column commitments gkr_msm_prove makes before the GKR (gkr_msm_simple.rs:117-151): 2^log_num_bit_columns bit columns
+ * through CommitmentKey::commit_bitvec = binary_msm(prepare_coefs(bits, gamma), binary_extended_bases) and the point column
+ * (x coordinates, y coordinates, zero padding) through commit_vec = G::msm.  d_bases_aff: col_size = 2^(lp + lb - log_cols) affine
+ * bases; d_binary_tables_aff: gm_g1_prepare_bases(d_bases_aff, col_size, gamma).  Outputs: affine points, in transcript order. */
+int32_t gm_gkr_msm_commit(const uint64_t* d_points_xy, const uint8_t* d_scalar_bits, uint32_t log_num_points,
+                          uint32_t log_num_scalar_bits, uint32_t log_num_bit_columns, const uint64_t* d_bases_aff,
+                          const uint64_t* d_binary_tables_aff, uint32_t gamma, uint64_t* h_bit_comms_aff, uint64_t* h_pts_comm_aff,
+                          void* stream);
+
 /* Bandersnatch ScalarField (Montgomery, as stored by ark `Fr` of ark-ed-on-bls12-381-bandersnatch)
  * -> canonical bigint: the `into_bigint()` of pushforward.rs:352 / msm_nonaffine.rs:21-23. */
 int32_t gm_bs_scalars_into_bigint(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream);

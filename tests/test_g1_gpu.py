@@ -202,3 +202,33 @@ def test_grouped_msm_matches_separate_msms():
     flat = [p for grp in groups for p in grp]
     got = H.g1_msm_nonaff_grouped(H.g1_jac_dev(flat, zs), stride, ns, H.to_dev(codec.to_mont_limbs(sc)), mont=True)
     assert got == [G.msm_nonaff(grp[:n], sc[:n]) if n else None for grp, n in zip(groups, ns)]
+
+
+@pytest.mark.parametrize("lp,lb,lcols,gamma", [(2, 2, 1, 3), (3, 3, 2, 5), (2, 4, 0, 8)])
+def test_gen1_column_commitments(lp, lb, lcols, gamma):
+    """gm_gkr_msm_commit = the commitments gkr_msm_prove writes first (gkr_msm_simple.rs:117-151)"""
+    import ctypes as C
+    import torch
+    from gkr_msm_amd import ffi
+    npts, nbits_total = 1 << lp, 1 << (lp + lb)
+    col_size = nbits_total >> lcols
+    pts = F.random_points(npts, 5)
+    rng = F.SplitMix64(7)
+    bits = [rng.next() & 1 for _ in range(nbits_total)]
+    bases = G.random_points(col_size, 9)
+    tables = G.prepare_bases(bases, gamma)
+    want_bits = [G.binary_msm(G.prepare_coefs([bool(b) for b in bits[col_size * i:col_size * (i + 1)]], gamma), tables)
+                 for i in range(1 << lcols)]
+    prep = [p[0] for p in pts] + [p[1] for p in pts] + [0] * (col_size - 2 * npts)
+    want_pts = G.naive_msm(bases, prep)
+    d_bases = H.g1_aff_dev(bases)
+    d_tables = H.g1_prepare_bases(d_bases, col_size, gamma)
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    d_bits = torch.from_numpy(np.array(bits, dtype=np.uint8)).cuda()
+    hb = np.zeros((1 << lcols, 12), dtype=np.uint64)
+    hp = np.zeros(12, dtype=np.uint64)
+    ffi.check(ffi.lib().gm_gkr_msm_commit(C.c_void_p(d_pts.data_ptr()), C.c_void_p(d_bits.data_ptr()), lp, lb, lcols,
+                                          C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_tables.data_ptr()), gamma, hb.ctypes.data,
+                                          hp.ctypes.data, H.cur_stream()))
+    assert codec.g1_aff_from_limbs(hb) == want_bits
+    assert codec.g1_aff_from_limbs(hp)[0] == want_pts
