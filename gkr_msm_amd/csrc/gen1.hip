@@ -177,7 +177,7 @@ static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_
         Fr v;
         if (cb) {
             if (cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", cb_rc);
-            const int32_t rc = cb->challenge(cb->ctx, reinterpret_cast<uint64_t*>(&v));
+            const int32_t rc = cb->challenge(cb->ctx, 1, 512, reinterpret_cast<uint64_t*>(&v));  // challenge_scalar: 64 bytes mod p
             if (rc) return set_err(GM_ERR_STATE, "transcript challenge callback failed with %d", rc);
         } else {
             if (pos >= n_tape) return set_err(GM_ERR_INVALID, "challenge tape exhausted after %llu challenges", (unsigned long long)pos);

@@ -182,7 +182,7 @@ struct KnTape {
     int32_t challenge(Fr* out) {
         Fr c;
         if (cb) {
-            const int32_t rc = cb->challenge(cb->ctx, reinterpret_cast<uint64_t*>(&c));
+            const int32_t rc = cb->challenge(cb->ctx, 1, 128, reinterpret_cast<uint64_t*>(&c));
             if (rc) return set_err(GM_ERR_STATE, "transcript challenge callback failed with %d", rc);
         } else {
             if (pos >= n) return set_err(GM_ERR_INVALID, "challenge tape exhausted after %llu challenges", (unsigned long long)pos);

@@ -164,25 +164,24 @@ struct Tape {
     uint64_t rounds = 0;
     const gm_transcript* cb = nullptr;  // the caller's live transcript; replaces the tape when set
     int32_t cb_rc = 0;
-    int32_t challenge(Fr* out) {
-        Fr c;
-        const int32_t rc0 = challenge_raw(&c);
+    int32_t challenge(Fr* out, uint32_t bits = 128) { return challenge_vec(out, 1, bits); }
+    // challenge_vec(n, bits) (proof_transcript.rs:41-45): one squeeze; tape mode: the next n tape entries
+    int32_t challenge_vec(Fr* out, uint32_t cnt, uint32_t bits) {
+        const int32_t rc0 = challenge_raw(out, cnt, bits);
         if (rc0) return rc0;
-        *out = fr_to_mont(c);
+        for (uint32_t i = 0; i < cnt; i++) out[i] = fr_to_mont(out[i]);
         return GM_OK;
     }
-    int32_t challenge_raw(Fr* out) {  // canonical limbs, as drawn
-        Fr c;
+    int32_t challenge_raw(Fr* out, uint32_t cnt = 1, uint32_t bits = 128) {  // canonical limbs, as drawn
         if (cb) {
             if (cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", cb_rc);
-            const int32_t rc = cb->challenge(cb->ctx, reinterpret_cast<uint64_t*>(&c));
+            const int32_t rc = cb->challenge(cb->ctx, cnt, bits, reinterpret_cast<uint64_t*>(out));
             if (rc) return set_err(GM_ERR_STATE, "transcript challenge callback failed with %d", rc);
         } else {
-            if (pos >= n) return set_err(GM_ERR_INVALID, "challenge tape exhausted after %llu challenges", (unsigned long long)pos);
-            memcpy(&c, tape + 4 * pos, 32);  // canonical value < 2^128 (transcript.challenge(128), proof_transcript.rs:37-39)
+            if (pos + cnt > n) return set_err(GM_ERR_INVALID, "challenge tape exhausted after %llu challenges", (unsigned long long)pos);
+            memcpy(out, tape + 4 * pos, 32 * (size_t)cnt);  // canonical values as the transcript would yield them
         }
-        pos++;
-        *out = c;
+        pos += cnt;
         return GM_OK;
     }
     void write_scalars(const std::vector<Fr>& v) {
@@ -778,7 +777,11 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
 
     // challenges (pushforward.rs:684-685)
     Fr psi, tau_c, tau_d, tau_s, gamma;
-    TRY(tr->challenge(&psi)); TRY(tr->challenge(&tau_c)); TRY(tr->challenge(&tau_d)); TRY(tr->challenge(&tau_s));
+    {
+        Fr four[4];
+        TRY(tr->challenge_vec(four, 4, 512));   // challenge_vec::<F>(4, 512) (pushforward.rs:684)
+        psi = four[0]; tau_c = four[1]; tau_d = four[2]; tau_s = four[3];
+    }
     TRY(tr->challenge(&gamma));
     GM_REQUIRE(!fr_is_zero(tau_s) && !fr_is_zero(psi), "zero challenge (inverse().unwrap() in the reference)");
 
@@ -1270,9 +1273,9 @@ int32_t tape_ws(void* ctx, const uint64_t* e, uint64_t n) {
     t->write_scalars(std::vector<Fr>(reinterpret_cast<const Fr*>(e), reinterpret_cast<const Fr*>(e) + n));
     return t->cb_rc;
 }
-int32_t tape_ch(void* ctx, uint64_t* out) {
+int32_t tape_ch(void* ctx, uint32_t cnt, uint32_t bits, uint64_t* out) {
     Tape* t = static_cast<Tape*>(ctx);
-    return t->challenge_raw(reinterpret_cast<Fr*>(out));
+    return t->challenge_raw(reinterpret_cast<Fr*>(out), cnt, bits);
 }
 int32_t tape_wp(void* ctx, const uint64_t* aff, uint64_t n) {
     Tape* t = static_cast<Tape*>(ctx);
@@ -1373,7 +1376,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     TRY(comb(comm_cp.data(), &cp_comb));
     TRY(comb(comm_dp.data(), &dp_comb));
     Fr u;
-    TRY(tr->challenge(&u));   // challenge(512)
+    TRY(tr->challenge(&u, 512));   // transcript.challenge(512) (pippenger.rs:197)
     Us us;
     us.u[0] = fr_one(); us.u[1] = u; us.u[2] = fr_mul(u, u); us.u[3] = fr_mul(us.u[2], u);
     const G1Jac combined_comm = g1_add(g1_add(c_comb, pp_mul(d_comb, us.u[1])), g1_add(pp_mul(cp_comb, us.u[2]), pp_mul(dp_comb, us.u[3])));

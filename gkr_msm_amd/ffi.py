@@ -40,7 +40,7 @@ u16p = C.POINTER(C.c_uint16)
 vp = C.c_void_p
 
 WRITE_SCALARS_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64)
-CHALLENGE_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64))
+CHALLENGE_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64))
 
 
 class GmTranscript(C.Structure):

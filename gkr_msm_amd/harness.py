@@ -492,13 +492,18 @@ class LiveTranscript:
                 on_write(vals)
             return 0
 
-        def _c(ctx, out):
-            v = draw()
-            if v is None:
-                return 7
-            self.n_challenges += 1
-            for i in range(4):
-                out[i] = (v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+        self.requests = []   # (n, bitsize) of every challenge request, in order
+
+        def _c(ctx, cnt, bits, out):
+            self.requests.append((cnt, bits))
+            for j in range(cnt):
+                v = draw()
+                if v is None:
+                    return 7
+                self.n_challenges += 1
+                v = v % codec.P if bits >= 255 else v & ((1 << bits) - 1)
+                for i in range(4):
+                    out[4 * j + i] = (v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
             return 0
         self.points = []
 

@@ -229,14 +229,17 @@ int32_t gm_msm_te(const uint64_t* d_points_xy, const uint64_t* d_scalars, uint32
  * TranscriptReceiver::append_scalars / TranscriptSender::challenge_scalar, transcript.rs:70-101); the tape form takes
  * pre-drawn challenges and returns the messages (tests, benches, replay).
  *   write_scalars: n field elements in the reference's in-memory form (Montgomery, 4 x u64), in write order; may be NULL
- *   challenge:     one field element, canonical 4 x u64 LE (gen-2: < 2^128; gen-1: 64 bytes reduced mod p)
+ *   challenge:     `challenge_vec(n, bitsize)` (proof_transcript.rs:41-45; n = 1 is `challenge(bitsize)`): ONE squeeze of
+ *                  n * ceil(bitsize / 8) bytes, every chunk `from_le_bytes_mod_order`; out = n canonical elements (4 x u64 LE each).
+ *                  gen-2 draws (1, 128) everywhere except (4, 512) at the start of the pushforward argument and (1, 512) in the
+ *                  opening; gen-1's `challenge_scalar` (64 bytes reduced mod p, transcript.rs:96-101) is requested as (1, 512)
  *   write_points:  n G1 points in the affine wire form (12 x u64 each), `write_points::<G1>` (proof_transcript.rs:59-69); only
  *                  the Knuckles opening uses it; may be NULL
  * A non-zero return from any of them aborts the prover with GM_ERR_STATE. */
 typedef struct gm_transcript {
     void* ctx;
     int32_t (*write_scalars)(void* ctx, const uint64_t* elems, uint64_t n);
-    int32_t (*challenge)(void* ctx, uint64_t* out);
+    int32_t (*challenge)(void* ctx, uint32_t n, uint32_t bitsize, uint64_t* out);
     int32_t (*write_points)(void* ctx, const uint64_t* aff_points, uint64_t n);
 } gm_transcript;
 

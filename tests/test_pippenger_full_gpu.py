@@ -61,3 +61,55 @@ def _consumed(tape, tr):
     """replay which draws were 512-bit: psi, tau_c, tau_d, tau_suppression (the first 4 draws of the pushforward) and u"""
     wide = getattr(tr, "wide", None)
     return [t % F.P if (wide and i in wide) else t & ((1 << 128) - 1) for i, t in enumerate(tape[: tr.pos])] + [0] * 8
+
+
+def test_full_prover_live_transcript_requests():
+    """gm_pippenger_prove_tr: the live transcript sees the same scalars and points as the tape run, and the challenge requests
+    carry the reference's sizes: one challenge_vec(4, 512) (pushforward.rs:684), one challenge(512) (pippenger.rs:197), the
+    rest challenge(128)"""
+    import ctypes as C
+    import numpy as np
+    from gkr_msm_amd import ffi
+    x_log, d_log, nbits, clm = 3, 2, 8, 1
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = (y_size - 1).bit_length()
+    n = 1 << x_log
+    rng = F.SplitMix64(123)
+    pts = F.random_points(n, 2)
+    sc = F.random_scalars(n, nbits, 3)
+    nv = x_log + clm
+    basis = G.random_points((2 << nv) - 1, 4)        # any SRS works for transcript parity
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    plan = H.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, H.to_dev(codec.ints_to_limbs(sc)))
+    wg = H.PippengerWG(plan, d_pts, y_log, clm, H.g1_aff_dev(basis))
+    out = wg.dense_output()
+    r = [rng.next_fr() for _ in range(y_log)]
+    claims = GK.pippenger_claims(out, r)
+    d_inv = H.knuckles_setup(2, nv)
+    drawn = []
+
+    def draw():
+        v = rng.next_bits(512)
+        drawn.append(v)
+        return v
+    live = H.LiveTranscript(draw)
+    cp, ce, kk = H.fr_arg(claims[0]), H.fr_arg(claims[1]), H.fr_arg([2])
+    pair = np.zeros(24, dtype=np.uint64)
+    used, rounds = C.c_uint64(), C.c_uint64()
+    ffi.check(ffi.lib().gm_pippenger_prove_tr(wg.h, cp.ctypes.data, ce.ctypes.data, C.c_void_p(d_inv.data_ptr()), kk.ctypes.data,
+                                              C.byref(live.c), pair.ctypes.data, C.byref(used), C.byref(rounds)))
+    assert live.requests.count((4, 512)) == 1 and live.requests.count((1, 512)) == 1
+    assert all(rq in ((4, 512), (1, 512), (1, 128)) for rq in live.requests)
+    assert sum(c for c, _ in live.requests) == used.value == len(drawn)
+    # replay as a tape: identical transcript and pair
+    it = iter(drawn)
+    tape = []
+    for cnt, bits in live.requests:
+        for _ in range(cnt):
+            v = next(it)
+            tape.append(v % F.P if bits >= 255 else v & ((1 << bits) - 1))
+    ref = wg.prove(claims[0], claims[1], d_inv, 2, tape + [0] * 8)
+    assert [v for m in live.writes for v in m] == ref["msgs"]
+    assert live.points == ref["points"]
+    assert tuple(codec.g1_aff_from_limbs(pair)) == ref["pair"] and rounds.value == ref["rounds"]
