@@ -118,6 +118,13 @@ _SIGS = {
     "gm_pippenger_wg_witness": (C.c_int32, [vp, C.POINTER(vp)]),
     "gm_pippenger_prove": (C.c_int32, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, C.c_uint64, u64p, vp, u64p, u64p]),
     "gm_pippenger_prove_tr": (C.c_int32, [vp, vp, vp, vp, vp, C.POINTER(GmTranscript), vp, u64p, u64p]),
+    "gm_merlin_create": (C.c_int32, [vp, C.c_uint64, C.POINTER(vp)]),
+    "gm_merlin_destroy": (C.c_int32, [vp]),
+    "gm_merlin_transcript": (C.c_int32, [vp, C.POINTER(GmTranscript)]),
+    "gm_merlin_proof": (C.c_int32, [vp, C.POINTER(vp), u64p]),
+    "gm_merlin_append_message": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint64]),
+    "gm_merlin_challenge_bytes": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint64]),
+    "gm_keccak_f1600": (C.c_int32, [vp]),
     "gm_knuckles_setup": (C.c_int32, [vp, C.c_uint32, vp, vp]),
     "gm_knuckles_open": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]),
     "gm_knuckles_open_tr": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, C.POINTER(GmTranscript), vp, vp, vp]),

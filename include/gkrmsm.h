@@ -243,6 +243,20 @@ typedef struct gm_transcript {
     int32_t (*write_points)(void* ctx, const uint64_t* aff_points, uint64_t n);
 } gm_transcript;
 
+/* A host-side ProofTranscript2 (cleanup/proof_transcript.rs:76-136) for callers without a Rust transcript: merlin
+ * v1.0 (STROBE-128 / Keccak-f[1600]) with empty labels, scalars as 32-byte LE canonical elements, G1 points in ark-bls12-381's
+ * 48-byte compressed encoding, challenges = from_le_bytes_mod_order.  gm_merlin_transcript fills a gm_transcript whose callbacks
+ * feed it; gm_merlin_proof returns the proof bytes (every message written, concatenated).  A restatement of the published
+ * formats pinned by public vectors -- not by bytes of the Rust binary.  No GPU work. */
+typedef struct gm_merlin gm_merlin;
+int32_t gm_merlin_create(const uint8_t* pparam, uint64_t len, gm_merlin** out);
+int32_t gm_merlin_destroy(gm_merlin* t);
+int32_t gm_merlin_transcript(gm_merlin* t, gm_transcript* out);
+int32_t gm_merlin_proof(const gm_merlin* t, const uint8_t** bytes, uint64_t* len);
+int32_t gm_merlin_append_message(gm_merlin* t, const uint8_t* label, uint64_t label_len, const uint8_t* msg, uint64_t len);
+int32_t gm_merlin_challenge_bytes(gm_merlin* t, const uint8_t* label, uint64_t label_len, uint8_t* dest, uint64_t len);
+int32_t gm_keccak_f1600(uint8_t* state200);
+
 /* ---------------------------------------------------------------- multi-GPU seam
  * One process per GPU.  The path shards by MSM window: rank g owns windows [g*y_size/G, (g+1)*y_size/G), i.e. the bucket
  * rows (y << d_logsize | digit) of its windows -- MSM, witness build, round sums and folds of the bintree GKR are all local to
