@@ -175,6 +175,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise GmError("libgkrmsm_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(expected at %s)" % LIB_PATH)
+        try:  # load torch's HIP runtime first: a second libamdhip64 loaded before it would not see the devices torch sees
+            import torch  # noqa: F401
+        except Exception:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
