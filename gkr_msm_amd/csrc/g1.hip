@@ -292,6 +292,26 @@ __global__ void __launch_bounds__(128) k_g1_gen_points(G1Aff gen, uint64_t n, ui
     g1_aff_store(out + i, g1_to_aff(acc));
 }
 
+// mock KZG setup (KzgProvingKey::mock_setup, commitments/kzg.rs:84-98): ptau_1[i] = tau^i * g0, for tests and the bench's
+// end-to-end check (a proof against this SRS satisfies the pairing equation, which the known tau lets one check in G1)
+__global__ void __launch_bounds__(128) k_g1_mock_srs(G1Aff g0, Fr tau, uint64_t n, G1Aff* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = fr_one(), b = tau;
+    for (uint64_t e = i; e; e >>= 1) {
+        if (e & 1) acc = fr_mul(acc, b);
+        b = fr_sqr(b);
+    }
+    const Fr k = fr_from_mont(acc);
+    G1Jac r = g1_inf();
+    for (int li = 7; li >= 0; li--)
+        for (int bit = 31; bit >= 0; bit--) {
+            r = g1_dbl(r);
+            if ((k.l[li] >> bit) & 1) r = g1_add_mixed(r, g0);
+        }
+    g1_aff_store(out + i, g1_to_aff(r));
+}
+
 // ------------------------------------------------------------------------------------------ engine (host)
 // grow-only device scratch shared by the G1 calls of this process (one call at a time: guarded by a mutex)
 struct G1Scratch {
@@ -661,6 +681,19 @@ extern "C" int32_t gm_g1_gen_points(uint64_t* d_points_aff, uint64_t n, uint64_t
     GM_REQUIRE(g1_aff_on_curve(g), "generator constant is off the curve");
     hipLaunchKernelGGL(k_g1_gen_points, dim3(ceil_div(n, 128)), dim3(128), 0, as_stream(stream), g, n, seed,
                        reinterpret_cast<G1Aff*>(d_points_aff));
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_g1_mock_srs(const uint64_t* h_tau, const uint64_t* h_g0_aff, uint64_t n, uint64_t* d_out_aff, void* stream) {
+    GM_REQUIRE(h_tau && h_g0_aff && d_out_aff, "null argument");
+    if (n == 0) return GM_OK;
+    Fr tau;
+    G1Aff g0;
+    memcpy(&tau, h_tau, 32);
+    memcpy(&g0, h_g0_aff, sizeof(G1Aff));
+    GM_REQUIRE(g1_aff_on_curve(g0) && !g1_aff_is_inf(g0), "g0 is not a finite point of the curve");
+    hipLaunchKernelGGL(k_g1_mock_srs, dim3(ceil_div(n, 128)), dim3(128), 0, as_stream(stream), g0, tau, n, reinterpret_cast<G1Aff*>(d_out_aff));
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -157,6 +157,7 @@ _SIGS = {
     "gm_g1_from_affine": (C.c_int32, [vp, C.c_uint64, vp, vp]),
     "gm_g1_host": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64]),
     "gm_g1_batch": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64, vp]),
+    "gm_g1_mock_srs": (C.c_int32, [vp, vp, C.c_uint64, vp, vp]),
     "gm_g1_gen_points": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp]),
     "gm_g1_release_scratch": (C.c_int32, []),
     "gm_bs_scalars_into_bigint": (C.c_int32, [vp, vp, C.c_uint64, vp]),

@@ -652,6 +652,14 @@ def g1_batch(op, d_a, d_b, n, out_words):
     return out
 
 
+def g1_mock_srs(tau, n, g0):
+    """tau^i * g0 for i < n (KzgProvingKey::mock_setup) as a device tensor of affine points"""
+    out = dev_empty(12 * n)
+    t, g = fr_arg([tau]), codec.g1_aff_to_limbs([g0])
+    ffi.check(ffi.lib().gm_g1_mock_srs(t.ctypes.data, g.ctypes.data, n, _p(out), cur_stream()))
+    return out
+
+
 def g1_gen_points(n, seed):
     out = dev_empty(12 * n)
     ffi.check(ffi.lib().gm_g1_gen_points(_p(out), n, seed, cur_stream()))

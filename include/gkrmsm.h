@@ -452,6 +452,9 @@ int32_t gm_g1_host(int32_t op, const uint64_t* h_a, const uint64_t* h_b, uint64_
 int32_t gm_g1_batch(int32_t op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n, void* stream);
 /* synthetic SRS for bench / tests: n points k_i * G (G = the standard G1 generator), affine */
 int32_t gm_g1_gen_points(uint64_t* d_points_aff, uint64_t n, uint64_t seed, void* stream);
+/* KzgProvingKey::mock_setup (commitments/kzg.rs:84-98): ptau_1[i] = tau^i * g0, i < n (tau: Fr Montgomery; g0: affine).  For
+ * tests and the bench's end-to-end check: with a known tau the pairing equation <A, H0> = <B, H1> of a proof reads A = tau * B. */
+int32_t gm_g1_mock_srs(const uint64_t* h_tau, const uint64_t* h_g0_aff, uint64_t n, uint64_t* d_out_aff, void* stream);
 /* frees the grow-only device scratch the G1 calls share */
 int32_t gm_g1_release_scratch(void);
 

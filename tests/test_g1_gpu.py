@@ -232,3 +232,13 @@ def test_gen1_column_commitments(lp, lb, lcols, gamma):
                                           hp.ctypes.data, H.cur_stream()))
     assert codec.g1_aff_from_limbs(hb) == want_bits
     assert codec.g1_aff_from_limbs(hp)[0] == want_pts
+
+
+def test_mock_srs_is_powers_of_tau():
+    rng = F.SplitMix64(88)
+    tau = rng.next_fr()
+    got = H.g1_read_aff(H.g1_mock_srs(tau, 9, G.GEN))
+    cur = G.GEN
+    for p in got:
+        assert p == cur
+        cur = G.mul(cur, tau)
