@@ -94,6 +94,18 @@ inline Fr*& shared_pinned() {  // pinned host staging (>= 8 Fr) shared by the ro
     static thread_local Fr* p = nullptr;
     return p;
 }
+// true while at most one sumcheck object at a time uses the shared pinned staging (the drivers' normal case); objects then may
+// pre-enqueue kernels that report through it.  The combined sumcheck of the pushforward argument runs two objects in
+// lock-step on one stream and clears it for that stretch.
+inline bool& pinned_exclusive() {
+    static thread_local bool v = true;
+    return v;
+}
+struct PinnedSharedScope {
+    bool prev;
+    PinnedSharedScope() : prev(pinned_exclusive()) { pinned_exclusive() = false; }
+    ~PinnedSharedScope() { pinned_exclusive() = prev; }
+};
 struct ArenaScope {
     Arena* prev;
     explicit ArenaScope(Arena* a) : prev(current_arena()) { current_arena() = a; }

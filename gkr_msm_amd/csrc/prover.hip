@@ -957,6 +957,7 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     Fr claim = fr_add(fr_add(cd.evs[0], fr_mul(g1, cd.evs[1])), fr_mul(g2, ev_folded));
     arena.reset();
     ArenaScope scope(&arena);
+    PinnedSharedScope two_objects;   // prod3 and frac run in lock-step and share the pinned staging
     ScHolder prod3, frac;
     {
         const uint64_t* pc[3] = {(const uint64_t*)p_sel->p, (const uint64_t*)c_pull->p, (const uint64_t*)d_pull->p};

@@ -15,6 +15,7 @@
 // registers and folds with the plain formula: every round polynomial, folded polynomial and final evaluation
 // is the same canonical field element as in the reference (sums in a field do not depend on their order).
 #include <atomic>
+#include <chrono>
 
 #include "internal.hpp"
 #include "ragged.cuh"
@@ -312,6 +313,54 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs c
         }
     }
     block_reduce_finish<NACC>(acc, fc);
+}
+
+// ------------------------------------------------------------------------------------------ pre-enqueued folds (small rounds)
+// A small round costs ~22 us of kernel time but ~45 us of wall time: after the host has the round sums it still has to
+// launch the fold and the next round kernel, and each launch takes ~5 us of API time plus ~4 us until the GPU starts it.
+// Small rounds therefore enqueue the fold of round r and the round kernel of round r + 1 BEFORE the challenge t_r exists:
+// a gate kernel in front of the fold waits (bounded) for the host to publish t_r in pinned memory.  The launch latency is
+// spent while round r's kernel is still running.  The wait is bounded (2^21 polls, a few seconds); on timeout the fold reports through a
+// status word and exits, so a host that never answers cannot wedge the GPU.
+// One wave (the gate) polls the host's ticket word -- thousands of fold blocks polling over PCIe would queue behind each
+// other's reads -- and copies the challenge into device memory; the fold behind it in the stream is an ordinary kernel.
+__global__ void __launch_bounds__(64) k_fold_gate(const Fr* __restrict__ t_slot, const uint32_t* __restrict__ ticket_word, uint32_t ticket,
+                                                  uint32_t* __restrict__ status, Fr* __restrict__ d_t) {
+    if (threadIdx.x != 0) return;
+    for (int it = 0; it < (1 << 22); it++) {
+        const uint32_t f = __hip_atomic_load(ticket_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(f - ticket) >= 0) {
+            Fr t;
+#pragma unroll
+            for (int l = 0; l < 8; l++) t.l[l] = __hip_atomic_load(&t_slot->l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *d_t = t;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the fold runs on a stale t; the host reports the error
+}
+
+__global__ void __launch_bounds__(256) k_dense_fold_dev(ColPtrs in, ColPtrsMut out, uint64_t n_out, const Fr* __restrict__ d_t) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const Fr t = fr_load(d_t);
+    const Fr* src = in.p[blockIdx.y];
+    const Fr p0 = fr_load(src + 2 * i), p1 = fr_load(src + 2 * i + 1);
+    fr_store(out.p[blockIdx.y] + i, fr_add(p0, fr_mul(t, fr_sub(p1, p0))));
+}
+
+// Final evaluations of a finished sumcheck: element 0 of every column, gathered by one wave straight into pinned host
+// memory, then a sequence number the host polls (k separate 32-byte copies cost ~20 us each).
+__global__ void __launch_bounds__(64) k_gather_finals(ColPtrs cols, int k, Fr* __restrict__ h_out, uint32_t* __restrict__ h_seq, uint32_t seq) {
+    for (int i = threadIdx.x; i < k; i += 64) {
+        const Fr v = fr_load(cols.p[i]);
+#pragma unroll
+        for (int l = 0; l < 8; l++) __hip_atomic_store(&h_out[i].l[l], v.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------ lean large-round kernels
@@ -690,15 +739,15 @@ struct RoundScratch {
     int32_t init(hipStream_t s) {
         int32_t rc = partial.alloc((size_t)SC_MAX_BLOCKS * 3 * sizeof(Fr));
         if (rc) return rc;
-        rc = counter.alloc(64);
+        rc = counter.alloc(128);  // [0] last-block counter, [64..96) the device copy of a pre-enqueued fold's challenge
         if (rc) return rc;
-        GM_HIP(hipMemsetAsync(counter.p, 0, 64, s));
+        GM_HIP(hipMemsetAsync(counter.p, 0, 128, s));
         if (shared_pinned()) {
             h_result = shared_pinned();
             own_pinned = false;
         } else {
-            GM_HIP(hipHostMalloc((void**)&h_result, 8 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
-            memset(h_result, 0, 8 * sizeof(Fr));
+            GM_HIP(hipHostMalloc((void**)&h_result, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
+            memset(h_result, 0, 16 * sizeof(Fr));
             own_pinned = true;
         }
         return GM_OK;
@@ -719,12 +768,38 @@ struct RoundScratch {
     // The launch writes `nacc` results and then the sequence number into the pinned buffer.  Poll the sequence
     // slot (a PCIe write lands in ~2 us; hipStreamSynchronize costs 10-20 us per round); fall back to the stream
     // synchronisation if it has not shown up after a bounded spin.
-    int32_t finish(int nacc, hipStream_t s, Fr* out) {
+    int32_t finish(int nacc, hipStream_t s, Fr* out) { return finish_seq(expect, nacc, s, out); }
+    // pinned layout (16 elements): [0..6] round results, [7] result sequence number, [8..11] challenge slots of pre-enqueued
+    // folds, [12] ticket word the waiting folds watch (l[0]) and their status word (l[1])
+    Fr* t_slot(uint32_t round) const { return h_result + 8 + (round & 3); }
+    uint32_t* ticket_word() const { return reinterpret_cast<uint32_t*>(h_result + 12); }
+    static uint32_t& ticket_counter() {
+        static thread_local uint32_t c = 0;
+        return c;
+    }
+    void publish(uint32_t round, const Fr& t, uint32_t ticket) {
+        *t_slot(round) = t;
+        std::atomic_thread_fence(std::memory_order_release);
+        *reinterpret_cast<volatile uint32_t*>(ticket_word()) = ticket;
+    }
+    // can_sync = false: a pre-enqueued fold is waiting in the stream for a challenge the host has not published yet, so a
+    // stream synchronisation would wait for it; keep polling (bounded by wall time) instead
+    int32_t finish_seq(uint32_t want, int nacc, hipStream_t s, Fr* out, bool can_sync = true) {
         volatile uint32_t* slot = reinterpret_cast<volatile uint32_t*>(h_result + 7);
         bool seen = false;
         for (int spin = 0; spin < 200000; spin++) {
-            if (*slot == expect) { seen = true; break; }
+            if (*slot == want) { seen = true; break; }
             __builtin_ia32_pause();
+        }
+        if (!seen && !can_sync) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!seen && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20)) {
+                for (int spin = 0; spin < 10000 && !seen; spin++) {
+                    if (*slot == want) seen = true;
+                    __builtin_ia32_pause();
+                }
+            }
+            if (!seen) return set_err(GM_ERR_STATE, "round kernel result did not arrive within 20 s");
         }
         if (!seen) GM_HIP(hipStreamSynchronize(s));
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -732,6 +807,38 @@ struct RoundScratch {
         return GM_OK;
     }
 };
+
+// pinned staging of k_gather_finals: one per host thread, kept for the life of the process
+struct FinalsStage {
+    Fr* h = nullptr;
+    uint32_t seq = 0;
+};
+static int32_t gather_finals(const Fr* const* cur, int k, hipStream_t s, std::vector<Fr>* out) {
+    static thread_local FinalsStage st;
+    if (!st.h) {
+        GM_HIP(hipHostMalloc((void**)&st.h, (GM_MAX_COLS + 1) * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
+        memset(st.h, 0, (GM_MAX_COLS + 1) * sizeof(Fr));
+    }
+    GM_REQUIRE(k >= 0 && k <= GM_MAX_COLS, "too many columns");
+    out->resize(k);
+    if (k == 0) return GM_OK;
+    ColPtrs cp;
+    for (int i = 0; i < k; i++) cp.p[i] = cur[i];
+    if (++st.seq == 0) ++st.seq;
+    uint32_t* h_seq = reinterpret_cast<uint32_t*>(st.h + GM_MAX_COLS);
+    hipLaunchKernelGGL(k_gather_finals, dim3(1), dim3(64), 0, s, cp, k, st.h, h_seq, st.seq);
+    GM_LAUNCH_CHECK();
+    volatile uint32_t* slot = h_seq;
+    bool seen = false;
+    for (int spin = 0; spin < 200000; spin++) {
+        if (*slot == st.seq) { seen = true; break; }
+        __builtin_ia32_pause();
+    }
+    if (!seen) GM_HIP(hipStreamSynchronize(s));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int i = 0; i < k; i++) (*out)[i] = st.h[i];
+    return GM_OK;
+}
 
 // grid for a round: x over pairs (grid-stride beyond the cap), y = sub-units in split mode
 static uint64_t sc_split_max_pairs() {
@@ -983,10 +1090,7 @@ struct ScDense : gm_sc {
     int32_t final_evals(std::vector<Fr>* out) override {
         if (round_idx != num_vars) return set_err(GM_ERR_STATE, "can only call final evals after the last round (sumcheck.rs:338)");
         if (sh.comm) return set_err(GM_ERR_STATE, "sharded columns were never exchanged");
-        out->resize(cols.k);
-        for (int i = 0; i < cols.k; i++) GM_HIP(hipMemcpyAsync(&(*out)[i], cols.cur[i], sizeof(Fr), hipMemcpyDeviceToHost, stream));
-        GM_HIP(hipStreamSynchronize(stream));
-        return GM_OK;
+        return gather_finals(cols.cur.data(), cols.k, stream, out);
     }
 };
 
@@ -1053,6 +1157,9 @@ struct ScDenseDeg2 : gm_sc {
         const dim3 grid = round_grid(npairs, split ? 2 * sp.nseg : 1);
         const VVArgs none{nullptr, 0, nullptr, nullptr};
         const int lean = (!split && cols.k <= 6) ? lean_prim_of(sp) : 0;
+        // results of pre-enqueued kernels land in the pinned staging: it must be this object's alone for the duration
+        if (split && !sh.comm && pipeline_enabled() && (rs.own_pinned || pinned_exclusive() || k_enq > round_idx))
+            return unipoly_pipelined(coeffs, npairs, eq_cur, cp);
         if (lean) {
             LeanCols lc;
             for (int i = 0; i < cols.k; i++) lc.p[i] = cols.cur[i];
@@ -1082,9 +1189,85 @@ struct ScDenseDeg2 : gm_sc {
         return GM_OK;
     }
 
+    // ---- pre-enqueued small rounds (see k_fold_gate)
+    uint32_t k_enq = 0;            // round kernels enqueued so far: rounds [0, k_enq)
+    uint32_t k_seq[64] = {};       // result sequence number of the enqueued round kernels
+    bool fold_pending = false;     // the fold of round `round_idx` is enqueued and waits for its challenge
+    uint32_t fold_ticket = 0;
+    std::vector<Fr*> fold_dst;
+    static bool pipeline_enabled() {
+        static const bool v = [] { const char* e = getenv("GM_SC_NO_PIPELINE"); return !(e && e[0] == '1'); }();
+        return v;
+    }
+    int32_t launch_small_round(const ColPtrs& cp, const Fr* eq, uint64_t npairs, uint32_t round) {
+        const dim3 grid = round_grid(npairs, 2 * sp.nseg);
+        const VVArgs none{nullptr, 0, nullptr, nullptr};
+        const FinishCtx fc = rs.ctx();
+        hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq, d_gamma.fr(), npairs, none, fc);
+        GM_LAUNCH_CHECK();
+        k_seq[round & 63] = fc.seq;
+        return GM_OK;
+    }
+    int32_t unipoly_pipelined(std::vector<Fr>* coeffs, uint64_t npairs, const Fr* eq_cur, const ColPtrs& cp) {
+        const uint32_t r = round_idx;
+        if (k_enq <= r) {  // the first small round of this object: nothing was enqueued ahead
+            int32_t rc = launch_small_round(cp, eq_cur, npairs, r);
+            if (rc) return rc;
+            k_enq = r + 1;
+        }
+        if (!fold_pending && r + 1 < num_vars && k_enq == r + 1) {
+            // enqueue fold r (waiting for t_r) and round kernel r + 1 while round r is still running
+            cols.next(&fold_dst);
+            ColPtrs ci;
+            ColPtrsMut co;
+            ColPtrs cn;
+            for (int i = 0; i < cols.k; i++) { ci.p[i] = cols.cur[i]; co.p[i] = fold_dst[i]; cn.p[i] = fold_dst[i]; }
+            fold_ticket = ++RoundScratch::ticket_counter();
+            if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
+            const uint64_t n_out = npairs;
+            Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
+            hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(r), rs.ticket_word(), fold_ticket, rs.ticket_word() + 1, d_t);
+            hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(n_out, 256), cols.k), dim3(256), 0, stream, ci, co, n_out, d_t);
+            GM_LAUNCH_CHECK();
+            fold_pending = true;
+            const Fr* eq_next = eq_level(num_vars - 2 - r) + (glob_off >> 2);
+            int32_t rc = launch_small_round(cn, eq_next, npairs >> 1, r + 1);
+            if (rc) return rc;
+            k_enq = r + 2;
+        }
+        Fr acc[4];
+        int32_t rc = rs.finish_seq(k_seq[r & 63], 2, stream, acc, !fold_pending);
+        if (rc) return rc;
+        if (rs.ticket_word()[1]) return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge");
+        const Fr total1 = fr_mul(acc[0], multiplier), total2 = fr_mul(acc[1], multiplier);
+        if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);
+        cached = from12_inv(total1, total2, point.back(), inv_eq0[point.size() - 1], claim_);
+        has_cached = true;
+        *coeffs = cached;
+        return GM_OK;
+    }
+    ~ScDenseDeg2() override {
+        if (fold_pending) {  // never leave a waiting kernel behind: release it and let the queue drain
+            rs.publish(round_idx, fr_zero(), fold_ticket);
+            (void)hipStreamSynchronize(stream);
+        }
+    }
+
     int32_t bind(const Fr& t) override {
         if (!has_cached) return set_err(GM_ERR_STATE, "bind before unipoly (dense_eq.rs:105 unwrap)");
         multiplier = fr_mul(multiplier, eq_bind_factor(point.back(), t));
+        if (fold_pending) {
+            rs.publish(round_idx, t, fold_ticket);   // the waiting fold and the next round kernel take it from here
+            fold_pending = false;
+            cols.commit(fold_dst);
+            point.pop_back();
+            round_idx++;
+            loc_vars--;
+            glob_off >>= 1;
+            claim_ = evaluate_univar(cached, t);
+            has_cached = false;
+            return GM_OK;
+        }
         std::vector<Fr*> dst;
         cols.next(&dst);
         const uint64_t n_out = 1ull << (loc_vars - 1);
@@ -1101,10 +1284,7 @@ struct ScDenseDeg2 : gm_sc {
     }
 
     int32_t final_evals(std::vector<Fr>* out) override {
-        out->resize(cols.k);
-        for (int i = 0; i < cols.k; i++) GM_HIP(hipMemcpyAsync(&(*out)[i], cols.cur[i], sizeof(Fr), hipMemcpyDeviceToHost, stream));
-        GM_HIP(hipStreamSynchronize(stream));
-        return GM_OK;
+        return gather_finals(cols.cur.data(), cols.k, stream, out);
     }
 };
 
