@@ -45,22 +45,34 @@ inline int32_t set_err(int32_t code, const char* fmt, ...) {
 // Device memory for handles and workspaces.  Large blocks are cached instead of returned to the driver: a proof allocates
 // tens of GiB of witness trace, and on MI355X re-allocating memory the process has just freed costs ~40 ms per GiB
 // (measured: 43 GiB of gen-1 trace took 25 ms of hipMalloc on first use and 1.6 s after a free), while hipFree also
-// synchronises the device.  Blocks >= 1 MiB are rounded to 2 MiB and kept on an idle list (best fit, <= 12.5 % slack);
+// synchronises the device.  Blocks >= 1 MiB are rounded to a size class (eight per octave) and kept on an idle list;
 // gm_release_cached_memory() hands them back.  Same-stream reuse is safe by stream order, as with any caching allocator;
-// callers that share buffers across streams must synchronise before destroying handles (they already must for hipFree).
+// callers that share buffers across streams must synchronise before destroying handles (they already must for hipFree).  Blocks below 1 MiB are cached in power-of-two classes.
 struct DevPool {
     std::mutex mu;
     std::unordered_map<void*, size_t> live;
     std::multimap<size_t, void*> idle;
     size_t idle_bytes = 0;
-    static constexpr size_t MIN_CACHED = (size_t)1 << 20;
+    uint64_t n_driver_allocs = 0, driver_alloc_bytes = 0;  // pool misses (diagnostics)
+    static constexpr size_t SMALL = (size_t)1 << 20;
     hipError_t alloc(void** out, size_t b) {
-        if (b < MIN_CACHED) return hipMalloc(out, b ? b : 16);
-        b = (b + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+        // small blocks: power-of-two classes from 256 bytes (the provers create and drop hundreds of few-KiB buffers per
+        // proof; hipMalloc costs tens of microseconds and hipFree synchronises the device); large ones: 2 MiB granules
+        if (b < SMALL) {
+            size_t c = 256;
+            while (c < b) c <<= 1;
+            b = c;
+        } else {
+            // eight classes per octave (<= 12.5 % slack) and exact-class reuse: a repeated request sequence (proof after
+            // proof) settles on the same blocks instead of stealing slightly larger ones from later requests
+            int lg = 63 - __builtin_clzll((unsigned long long)b);
+            const size_t g = (size_t)1 << (lg - 3);
+            b = (b + g - 1) & ~(g - 1);
+        }
         {
             std::lock_guard<std::mutex> g(mu);
             auto it = idle.lower_bound(b);
-            if (it != idle.end() && it->first <= b + b / 8) {
+            if (it != idle.end() && it->first == b) {
                 *out = it->second;
                 live[it->second] = it->first;
                 idle_bytes -= it->first;
@@ -77,6 +89,8 @@ struct DevPool {
         }
         std::lock_guard<std::mutex> g(mu);
         live[*out] = b;
+        n_driver_allocs++;
+        driver_alloc_bytes += b;
         return hipSuccess;
     }
     void free(void* p) {

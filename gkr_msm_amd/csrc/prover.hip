@@ -1292,6 +1292,18 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     hipStream_t s = st->stream;
     void* stream = reinterpret_cast<void*>(s);
     GM_REQUIRE(y_log >= clm, "commitment_log_multiplicity exceeds y_logsize");
+    // GM_PROVE_TIMING=1: wall time of every stage on stderr (development aid; adds a stream synchronisation per stage)
+    static const bool timing = [] { const char* e = getenv("GM_PROVE_TIMING"); return e && e[0] == '1'; }();
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char* name) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gm prove] %-22s %8.2f ms   (pool misses so far: %llu, %.1f MiB)\n", name,
+                std::chrono::duration<double, std::milli>(now - t_prev).count(), (unsigned long long)dev_pool().n_driver_allocs,
+                dev_pool().driver_alloc_bytes / 1048576.0);
+        t_prev = now;
+    };
     // phase-1 commitments onto the transcript (pippenger.rs:126-133; ac_c is written twice there)
     tr->write_points(st->comm_c.data(), n_mat);
     tr->write_points(st->comm_d.data(), n_mat);
@@ -1307,6 +1319,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     c.evs.resize(3 * (d_log + 1));
     memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
     TRY(image_part_core(st->w, tr, &c));
+    stage("image part");
     // commit phase 2 (second_phase, pushforward.rs:596-605): msm_nonaff of the outer buckets with the eq tables
     std::vector<uint64_t> comm_cp(12 * (size_t)n_mat), comm_dp(12 * (size_t)n_mat);
     {
@@ -1333,12 +1346,14 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     }
     tr->write_points(comm_cp.data(), n_mat);
     tr->write_points(comm_dp.data(), n_mat);
+    stage("phase-2 commitments");
     // prove pushforward
     Fr gamma;
     Claims mx, acc, acd;
     PfCols cols;
     TRY(pushforward_prove(plan, st->d_points_xy, y_log, reinterpret_cast<const uint64_t*>(c.point.data()),
                           reinterpret_cast<const uint64_t*>(c.evs.data()), tr, &gamma, &mx, &acc, &acd, s, &cols));
+    stage("pushforward");
     // ---- open (pippenger.rs:162-286)
     const Fr p_folded_ev = mx.evs[0], c_pull_ev = mx.evs[1], d_pull_ev = mx.evs[2], c_ev = mx.evs[3], d_ev = mx.evs[4];
     const uint32_t nv = x_log + clm;
@@ -1397,12 +1412,14 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
                        cols.d_pull->fr(), d_multirow.fr(), us, x_log, y_size, clm, n, w3.fr());
     GM_LAUNCH_CHECK();
     GM_HIP(hipStreamSynchronize(s));  // multirow (host) is consumed
+    stage("opening witnesses");
     // MultiOpenReduction (pippenger.rs:224-258)
     std::vector<Fr> mo_evs = {fr_sub(p_folded_ev, fr_mul(gamma, gamma)), acc.evs[0], acd.evs[0], combined_ev};
     const uint64_t* wcols[4] = {(const uint64_t*)w0.p, (const uint64_t*)w1.p, (const uint64_t*)w2.p, (const uint64_t*)w3.p};
     std::vector<Fr> mo_pt, mo_out;
     TRY(multiopen_core(tr, nv, 4, wcols, reinterpret_cast<const uint64_t*>(pts.data()), reinterpret_cast<const uint64_t*>(mo_evs.data()),
                        &mo_pt, &mo_out, s));
+    stage("multi-open reduction");
     Fr q;
     TRY(tr->challenge(&q));
     Us qs;
@@ -1424,6 +1441,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     TRY(gm_knuckles_open_tr(st->d_basis, d_kn_inverses, h_k, nv, reinterpret_cast<const uint64_t*>(folded.p), n,
                             reinterpret_cast<const uint64_t*>(mo_pt.data()), reinterpret_cast<const uint64_t*>(&open_ev), fc_aff,
                             &adapter, proof, h_pair, stream));
+    stage("knuckles open");
     if (tr->cb_rc) return set_err(GM_ERR_STATE, "transcript callback failed with %d", tr->cb_rc);
     return GM_OK;
 }

@@ -606,7 +606,8 @@ struct PadCols {
 };
 __global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut out, const uint32_t* __restrict__ off_in,
                                                          const uint32_t* __restrict__ off_out, uint32_t nrows, Fr t,
-                                                         PadCols pad) {
+                                                         PadCols pad, const Fr* __restrict__ d_t) {
+    if (d_t) t = fr_load(d_t);  // pre-enqueued fold: the challenge arrives through the gate kernel (k_fold_gate)
     const uint32_t j = blockIdx.x * SC_THREADS + threadIdx.x;
     const uint32_t total = off_out[nrows];
     const uint32_t r = find_row_block(off_out, nrows, j, j < total, total);
@@ -1325,34 +1326,47 @@ struct ScVecVecDeg2 : gm_sc {
         if (dense2) return dense2->unipoly(coeffs);
         if (dense) return dense->unipoly(coeffs);
         if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (vecvec_eq.rs:305-307)");
-        // current eq level: row_eq_poly_seq[len - 1 - already_bound]  (vecvec.rs:129-135) and its prefix sums
-        const size_t lvl = eq_level_len.size() - 1 - already_bound;
-        const Fr* eq_row = d_eq_seq.fr() + eq_level_off[lvl];
-        const Fr* eq_pre = d_prefix.fr() + eq_level_off[lvl] + lvl;  // level l has len+1 prefix entries
-        ColPtrs cp;
-        for (int i = 0; i < k; i++) cp.p[i] = cur[i];
-        // grid from the capacity bound: the exact cell count lives on the device (off[nrows])
-        const uint64_t bound_pairs = cells_bound / 2 + 1;
-        const bool split = bound_pairs <= SC_SPLIT_MAX_PAIRS;
-        const uint64_t gx = bound_pairs > nrows ? bound_pairs : nrows;  // the tail-weight loop runs over rows
-        const dim3 grid = round_grid(gx, split ? 2 * sp.nseg : 1);
-        const VVArgs va{off_cur, nrows, d_row_coef.fr() + row_base, eq_pre};
-        const int lean = (!split && k <= 6) ? lean_prim_of(sp) : 0;
-        if (lean) {
-            LeanCols lc;
-            for (int i = 0; i < k; i++) lc.p[i] = cur[i];
-            int32_t rc = launch_deg2_lean<true>(lean, grid, stream, lc, eq_row, d_gamma.fr(), (uint64_t)0, va, rs.ctx());
+        const bool split_now = cells_bound / 2 + 1 <= SC_SPLIT_MAX_PAIRS;
+        const bool piped = split_now && !sh.comm && ScDenseDeg2::pipeline_enabled() &&
+                           (rs.own_pinned || pinned_exclusive() || k_enq > already_bound);
+        if (k_enq <= already_bound) {
+            int32_t rc = launch_sparse_round(cur.data(), off_cur, cells_bound, already_bound);
             if (rc) return rc;
-        } else if (split)
-            hipLaunchKernelGGL((k_round_deg2<true, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
-                               (uint64_t)0, va, rs.ctx());
-        else
-            hipLaunchKernelGGL((k_round_deg2<true, false>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
-                               (uint64_t)0, va, rs.ctx());
-        GM_LAUNCH_CHECK();
+            k_enq = already_bound + 1;
+        }
+        if (piped && !fold_pending && k_enq == already_bound + 1 && (uint32_t)binding_var_idx > col_logsize &&
+            already_bound + 1 < n_off_tables && (cells_bound / 2 + nrows) / 2 + 1 <= SC_SPLIT_MAX_PAIRS && k <= 16) {
+            // enqueue the fold of this round (behind a gate that waits for t) and the next round's kernel now
+            nx_to_a = !started || !cur_is_a;
+            nx_off = reinterpret_cast<const uint32_t*>(off_all.p) + (uint64_t)(already_bound + 1) * (nrows + 1);
+            nx_bound = cells_bound / 2 + nrows;
+            ColPtrs ci;
+            ColPtrsMut co;
+            PadCols pd;
+            nx_cur.resize(k);
+            for (int i = 0; i < k; i++) {
+                ci.p[i] = cur[i];
+                co.p[i] = nx_to_a ? bufA[i]->fr() : bufB[i]->fr();
+                pd.v[i] = row_pad[i];
+                nx_cur[i] = co.p[i];
+            }
+            fold_ticket = ++RoundScratch::ticket_counter();
+            if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
+            Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
+            hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(already_bound), rs.ticket_word(), fold_ticket,
+                               rs.ticket_word() + 1, d_t);
+            hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(nx_bound, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co, off_cur, nx_off,
+                               nrows, fr_zero(), pd, (const Fr*)d_t);
+            GM_LAUNCH_CHECK();
+            fold_pending = true;
+            int32_t rc = launch_sparse_round(nx_cur.data(), nx_off, nx_bound, already_bound + 1);
+            if (rc) return rc;
+            k_enq = already_bound + 2;
+        }
         Fr acc[4];
-        int32_t rc = rs.finish(3, stream, acc);
+        int32_t rc = rs.finish_seq(k_seq[already_bound & 63], 3, stream, acc, !fold_pending);
         if (rc) return rc;
+        if (rs.ticket_word()[1]) return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge");
         if (sh.comm) {
             rc = shard_sum_fr(sh, acc, 3);
             if (rc) return rc;
@@ -1381,6 +1395,51 @@ struct ScVecVecDeg2 : gm_sc {
     }
 
     uint64_t cells_bound = 0;  // upper bound of off_cur[nrows]
+
+    // ---- pre-enqueued small sparse rounds (same scheme as ScDenseDeg2's, see k_fold_gate); rounds are indexed by already_bound
+    uint32_t k_enq = 0;
+    uint32_t k_seq[64] = {};
+    bool fold_pending = false, nx_to_a = false;
+    uint32_t fold_ticket = 0;
+    const uint32_t* nx_off = nullptr;
+    uint64_t nx_bound = 0;
+    std::vector<const Fr*> nx_cur;
+    int32_t launch_sparse_round(const Fr* const* cols_now, const uint32_t* off, uint64_t cb, uint32_t ab) {
+        // eq level: row_eq_poly_seq[len - 1 - already_bound]  (vecvec.rs:129-135) and its prefix sums
+        const size_t lvl = eq_level_len.size() - 1 - ab;
+        const Fr* eq_row = d_eq_seq.fr() + eq_level_off[lvl];
+        const Fr* eq_pre = d_prefix.fr() + eq_level_off[lvl] + lvl;  // level l has len+1 prefix entries
+        ColPtrs cp;
+        for (int i = 0; i < k; i++) cp.p[i] = cols_now[i];
+        // grid from the capacity bound: the exact cell count lives on the device (off[nrows])
+        const uint64_t bound_pairs = cb / 2 + 1;
+        const bool split = bound_pairs <= SC_SPLIT_MAX_PAIRS;
+        const uint64_t gx = bound_pairs > nrows ? bound_pairs : nrows;  // the tail-weight loop runs over rows
+        const dim3 grid = round_grid(gx, split ? 2 * sp.nseg : 1);
+        const VVArgs va{off, nrows, d_row_coef.fr() + row_base, eq_pre};
+        const int lean = (!split && k <= 6) ? lean_prim_of(sp) : 0;
+        const FinishCtx fc = rs.ctx();
+        if (lean) {
+            LeanCols lc;
+            for (int i = 0; i < k; i++) lc.p[i] = cols_now[i];
+            int32_t rc = launch_deg2_lean<true>(lean, grid, stream, lc, eq_row, d_gamma.fr(), (uint64_t)0, va, fc);
+            if (rc) return rc;
+        } else if (split)
+            hipLaunchKernelGGL((k_round_deg2<true, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
+                               (uint64_t)0, va, fc);
+        else
+            hipLaunchKernelGGL((k_round_deg2<true, false>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
+                               (uint64_t)0, va, fc);
+        GM_LAUNCH_CHECK();
+        k_seq[ab & 63] = fc.seq;
+        return GM_OK;
+    }
+    ~ScVecVecDeg2() override {
+        if (fold_pending) {  // never leave a waiting gate behind
+            rs.publish(already_bound, fr_zero(), fold_ticket);
+            (void)hipStreamSynchronize(stream);
+        }
+    }
     uint32_t n_off_tables = 0;
 
     int32_t bind(const Fr& t) override {
@@ -1389,6 +1448,22 @@ struct ScVecVecDeg2 : gm_sc {
         if (!has_cached) return set_err(GM_ERR_STATE, "bind before unipoly (vecvec_eq.rs:299 unwrap)");
         if ((uint32_t)binding_var_idx > col_logsize) {
             // sparse bind (vecvec_eq.rs:295-300)
+            if (fold_pending) {  // the fold is already in the stream: hand it the challenge
+                rs.publish(already_bound, t, fold_ticket);
+                fold_pending = false;
+                for (int i = 0; i < k; i++) cur[i] = nx_cur[i];
+                off_cur = nx_off;
+                cur_is_a = nx_to_a;
+                started = true;
+                cells_bound = nx_bound;
+                row_logsize--;
+                multiplier = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));
+                binding_var_idx--;
+                already_bound++;
+                claim_ = evaluate_univar(cached, t);
+                has_cached = false;
+                return GM_OK;
+            }
             const bool to_a = !started || !cur_is_a;
             if (already_bound + 1 >= n_off_tables) return set_err(GM_ERR_STATE, "more sparse binds than row variables");
             const uint32_t* off_next = reinterpret_cast<const uint32_t*>(off_all.p) + (uint64_t)(already_bound + 1) * (nrows + 1);
@@ -1403,7 +1478,7 @@ struct ScVecVecDeg2 : gm_sc {
                 pd.v[i] = row_pad[i];
             }
             hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(new_bound, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co,
-                               off_cur, off_next, nrows, t, pd);
+                               off_cur, off_next, nrows, t, pd, (const Fr*)nullptr);
             GM_LAUNCH_CHECK();
             for (int i = 0; i < k; i++) cur[i] = co.p[i];
             off_cur = off_next;
