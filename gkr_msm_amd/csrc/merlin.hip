@@ -167,20 +167,73 @@ void g1_compress(const G1Aff& p, uint8_t out[48]) {
     if (fq_is_lex_largest(y)) out[0] |= 0x20;
 }
 
+// Affine::deserialize_compressed with validation (ark-ec short_weierstrass; flags in the top bits of byte 0: 0x80 compressed,
+// 0x40 infinity, 0x20 y is the lexicographically largest root); false = malformed
+bool g1_decompress(const uint8_t in[48], G1Aff* out) {
+    if (!(in[0] & 0x80)) return false;
+    if (in[0] & 0x40) {
+        if (in[0] & 0x20) return false;
+        for (int i = 0; i < 48; i++)
+            if ((i == 0 ? (in[0] & 0x1f) : in[i]) != 0) return false;
+        out->x = fq_zero(); out->y = fq_zero();
+        return true;
+    }
+    Fq xc;
+    for (int i = 0; i < 12; i++) {
+        uint32_t v = 0;
+        for (int b = 3; b >= 0; b--) {
+            uint8_t byte = in[47 - (4 * i + b)];
+            if (4 * i + b == 47) byte &= 0x1f;
+            v = (v << 8) | byte;
+        }
+        xc.l[i] = v;
+    }
+    for (int i = 11; i >= 0; i--) {  // canonical: x < q
+        if (xc.l[i] < fq_p(i)) break;
+        if (xc.l[i] > fq_p(i) || i == 0) return false;
+    }
+    const Fq x = fq_to_mont(xc);
+    const Fq rhs = fq_add(fq_mul(fq_sqr(x), x), fq_dbl(fq_dbl(fq_one())));
+    // q = 3 mod 4: sqrt = rhs^((q + 1) / 4)
+    static const uint64_t E[6] = {0xee7fbfffffffeaabull, 0x07aaffffac54ffffull, 0xd9cc34a83dac3d89ull,
+                                  0xd91dd2e13ce144afull, 0x92c6e9ed90d2eb35ull, 0x0680447a8e5ff9a6ull};
+    Fq y = fq_one();
+    for (int i = 5; i >= 0; i--)
+        for (int b = 63; b >= 0; b--) {
+            y = fq_sqr(y);
+            if ((E[i] >> b) & 1) y = fq_mul(y, rhs);
+        }
+    if (!fq_eq(fq_sqr(y), rhs)) return false;  // not on the curve
+    if (fq_is_lex_largest(fq_from_mont(y)) != ((in[0] & 0x20) != 0)) y = fq_neg(y);
+    out->x = x; out->y = y;
+    return true;
+}
+
 }  // namespace
 
 struct gm_merlin {
     Merlin m;
     std::vector<uint8_t> proof;
+    bool verifier = false;   // PTMode::Verifier (proof_transcript.rs:10-14): messages are read from `proof` at `ctr`
+    size_t ctr = 0;
     gm_merlin(const uint8_t* l, size_t n) : m(l, n) {}
     void write_raw(const uint8_t* d, size_t n) {
         m.append_message(nullptr, 0, d, n);
         proof.insert(proof.end(), d, d + n);
     }
+    // read_raw_msg (proof_transcript.rs:119-130)
+    const uint8_t* read_raw(size_t n) {
+        if (ctr + n > proof.size()) return nullptr;
+        const uint8_t* p = proof.data() + ctr;
+        ctr += n;
+        m.append_message(nullptr, 0, p, n);
+        return p;
+    }
 };
 
 static int32_t mt_write_scalars(void* ctx, const uint64_t* e, uint64_t n) {
     gm_merlin* t = static_cast<gm_merlin*>(ctx);
+    if (t->verifier) return 1;  // write_raw_msg panics in verifier mode (proof_transcript.rs:134)
     std::vector<uint8_t> buf(32 * n);
     for (uint64_t i = 0; i < n; i++) {
         Fr v;
@@ -193,6 +246,7 @@ static int32_t mt_write_scalars(void* ctx, const uint64_t* e, uint64_t n) {
 }
 static int32_t mt_write_points(void* ctx, const uint64_t* aff, uint64_t n) {
     gm_merlin* t = static_cast<gm_merlin*>(ctx);
+    if (t->verifier) return 1;
     std::vector<uint8_t> buf(48 * n);
     for (uint64_t i = 0; i < n; i++) {
         G1Aff p;
@@ -212,6 +266,60 @@ static int32_t mt_challenge(void* ctx, uint32_t n, uint32_t bits, uint64_t* out)
         memcpy(out + 4 * i, &c, 32);
     }
     return 0;
+}
+
+// read_scalars / read_points (proof_transcript.rs:46-49, 59-62): 1 = out of bounds, 2 = malformed element
+static int32_t mt_read_scalars(void* ctx, uint64_t n, uint64_t* out) {
+    gm_merlin* t = static_cast<gm_merlin*>(ctx);
+    if (!t->verifier) return 3;
+    const uint8_t* p = t->read_raw(32 * n);
+    if (!p) return 1;
+    for (uint64_t i = 0; i < n; i++) {
+        Fr v;
+        memcpy(&v, p + 32 * i, 32);
+        for (int l = 7; l >= 0; l--) {  // deserialize_compressed rejects values >= p
+            if (v.l[l] < fr_p(l)) break;
+            if (v.l[l] > fr_p(l) || l == 0) return 2;
+        }
+        v = fr_to_mont(v);
+        memcpy(out + 4 * i, &v, 32);
+    }
+    return 0;
+}
+static int32_t mt_read_points(void* ctx, uint64_t n, uint64_t* out) {
+    gm_merlin* t = static_cast<gm_merlin*>(ctx);
+    if (!t->verifier) return 3;
+    const uint8_t* p = t->read_raw(48 * n);
+    if (!p) return 1;
+    for (uint64_t i = 0; i < n; i++) {
+        G1Aff a;
+        if (!g1_decompress(p + 48 * i, &a)) return 2;
+        memcpy(out + 12 * i, &a, sizeof(G1Aff));
+    }
+    return 0;
+}
+
+extern "C" int32_t gm_merlin_create_verifier(const uint8_t* pparam, uint64_t len, const uint8_t* proof, uint64_t proof_len, gm_merlin** out) {
+    GM_REQUIRE(out && (pparam || len == 0) && (proof || proof_len == 0), "null argument");
+    gm_merlin* t = new gm_merlin(pparam, len);
+    t->verifier = true;
+    t->proof.assign(proof, proof + proof_len);
+    *out = t;
+    return GM_OK;
+}
+extern "C" int32_t gm_merlin_reader(gm_merlin* t, gm_transcript_reader* out) {
+    GM_REQUIRE(t && out && t->verifier, "not a verifier transcript");
+    out->ctx = t;
+    out->read_scalars = mt_read_scalars;
+    out->challenge = mt_challenge;
+    out->read_points = mt_read_points;
+    return GM_OK;
+}
+// bytes of the proof not read yet (a verifier may insist on 0)
+extern "C" int32_t gm_merlin_unread(const gm_merlin* t, uint64_t* n) {
+    GM_REQUIRE(t && n && t->verifier, "not a verifier transcript");
+    *n = t->proof.size() - t->ctr;
+    return GM_OK;
 }
 
 extern "C" int32_t gm_merlin_create(const uint8_t* pparam, uint64_t len, gm_merlin** out) {

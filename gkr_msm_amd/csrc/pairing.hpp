@@ -1,0 +1,180 @@
+// BLS12-381 optimal-ate pairing on the host, for the verifier's final check KzgVerifyingKey::verify_pair
+// (/root/reference/src/commitments/kzg.rs:61-67: e(A, h0) == e(B, h1)).  The reference gets it from ark-ec 0.4.2 /
+// ark-bls12-381 0.4.0 (Cargo.lock:112-113,135-136; not vendored); this is a restatement of the published construction, written
+// for clarity, not speed (a verifier computes two Miller loops per proof):
+//   Fq2 = Fq[u]/(u^2 + 1),  Fq6 = Fq2[v]/(v^3 - (u + 1)),  Fq12 = Fq6[w]/(w^2 - v)
+//   G2 on the M-twist  y^2 = x^3 + 4 (u + 1);  untwist (x', y') -> (x' / w^2, y' / w^3) in E(Fq12): y^2 = x^3 + 4
+//   Miller loop over |x| = 0xd201000000010000 with affine lines evaluated in Fq12 (vertical lines dropped: they lie in Fq6),
+//   conjugation for the negative x, final exponentiation (q^12 - 1) / r = (q^6 - 1)(q^2 + 1) * (q^4 - q^2 + 1) / r, the last
+//   two factors by plain square-and-multiply.
+// GT equality is only ever tested between outputs of this file, so the result is specified up to the choice of Fq12 basis.
+#pragma once
+#include <cstdint>
+
+#include "g1.cuh"
+
+namespace gm {
+
+struct Fq2 { Fq a, b; };            // a + b u
+struct Fq6 { Fq2 a, b, c; };        // a + b v + c v^2
+struct Fq12 { Fq6 a, b; };          // a + b w
+struct G2Aff { Fq2 x, y; };         // (0, 0) = infinity (wire form, like G1)
+
+// ---- Fq2
+inline Fq2 fq2_zero() { return {fq_zero(), fq_zero()}; }
+inline Fq2 fq2_one() { return {fq_one(), fq_zero()}; }
+inline bool fq2_is_zero(const Fq2& x) { return fq_is_zero(x.a) && fq_is_zero(x.b); }
+inline bool fq2_eq(const Fq2& x, const Fq2& y) { return fq_eq(x.a, y.a) && fq_eq(x.b, y.b); }
+inline Fq2 fq2_add(const Fq2& x, const Fq2& y) { return {fq_add(x.a, y.a), fq_add(x.b, y.b)}; }
+inline Fq2 fq2_sub(const Fq2& x, const Fq2& y) { return {fq_sub(x.a, y.a), fq_sub(x.b, y.b)}; }
+inline Fq2 fq2_neg(const Fq2& x) { return {fq_neg(x.a), fq_neg(x.b)}; }
+inline Fq2 fq2_mul(const Fq2& x, const Fq2& y) {
+    const Fq aa = fq_mul(x.a, y.a), bb = fq_mul(x.b, y.b);
+    const Fq cross = fq_mul(fq_add(x.a, x.b), fq_add(y.a, y.b));
+    return {fq_sub(aa, bb), fq_sub(fq_sub(cross, aa), bb)};
+}
+inline Fq2 fq2_sqr(const Fq2& x) { return fq2_mul(x, x); }
+inline Fq2 fq2_mul_fq(const Fq2& x, const Fq& s) { return {fq_mul(x.a, s), fq_mul(x.b, s)}; }
+inline Fq2 fq2_mul_xi(const Fq2& x) { return {fq_sub(x.a, x.b), fq_add(x.a, x.b)}; }  // * (1 + u)
+inline Fq2 fq2_inv(const Fq2& x) {
+    const Fq n = fq_inv(fq_add(fq_sqr(x.a), fq_sqr(x.b)));
+    return {fq_mul(x.a, n), fq_neg(fq_mul(x.b, n))};
+}
+
+// ---- Fq6
+inline Fq6 fq6_zero() { return {fq2_zero(), fq2_zero(), fq2_zero()}; }
+inline Fq6 fq6_one() { return {fq2_one(), fq2_zero(), fq2_zero()}; }
+inline bool fq6_is_zero(const Fq6& x) { return fq2_is_zero(x.a) && fq2_is_zero(x.b) && fq2_is_zero(x.c); }
+inline bool fq6_eq(const Fq6& x, const Fq6& y) { return fq2_eq(x.a, y.a) && fq2_eq(x.b, y.b) && fq2_eq(x.c, y.c); }
+inline Fq6 fq6_add(const Fq6& x, const Fq6& y) { return {fq2_add(x.a, y.a), fq2_add(x.b, y.b), fq2_add(x.c, y.c)}; }
+inline Fq6 fq6_sub(const Fq6& x, const Fq6& y) { return {fq2_sub(x.a, y.a), fq2_sub(x.b, y.b), fq2_sub(x.c, y.c)}; }
+inline Fq6 fq6_neg(const Fq6& x) { return {fq2_neg(x.a), fq2_neg(x.b), fq2_neg(x.c)}; }
+inline Fq6 fq6_mul(const Fq6& x, const Fq6& y) {  // schoolbook with v^3 = xi
+    const Fq2 aa = fq2_mul(x.a, y.a), ab = fq2_mul(x.a, y.b), ac = fq2_mul(x.a, y.c);
+    const Fq2 ba = fq2_mul(x.b, y.a), bb = fq2_mul(x.b, y.b), bc = fq2_mul(x.b, y.c);
+    const Fq2 ca = fq2_mul(x.c, y.a), cb = fq2_mul(x.c, y.b), cc = fq2_mul(x.c, y.c);
+    Fq6 r;
+    r.a = fq2_add(aa, fq2_mul_xi(fq2_add(bc, cb)));
+    r.b = fq2_add(fq2_add(ab, ba), fq2_mul_xi(cc));
+    r.c = fq2_add(fq2_add(ac, ca), bb);
+    return r;
+}
+inline Fq6 fq6_mul_v(const Fq6& x) { return {fq2_mul_xi(x.c), x.a, x.b}; }
+inline Fq6 fq6_inv(const Fq6& x) {
+    // adjugate: t0 = a^2 - xi b c, t1 = xi c^2 - a b, t2 = b^2 - a c; norm = a t0 + xi (c t1 + b t2)
+    const Fq2 t0 = fq2_sub(fq2_sqr(x.a), fq2_mul_xi(fq2_mul(x.b, x.c)));
+    const Fq2 t1 = fq2_sub(fq2_mul_xi(fq2_sqr(x.c)), fq2_mul(x.a, x.b));
+    const Fq2 t2 = fq2_sub(fq2_sqr(x.b), fq2_mul(x.a, x.c));
+    const Fq2 n = fq2_inv(fq2_add(fq2_mul(x.a, t0), fq2_mul_xi(fq2_add(fq2_mul(x.c, t1), fq2_mul(x.b, t2)))));
+    return {fq2_mul(t0, n), fq2_mul(t1, n), fq2_mul(t2, n)};
+}
+
+// ---- Fq12
+inline Fq12 fq12_one() { return {fq6_one(), fq6_zero()}; }
+inline bool fq12_eq(const Fq12& x, const Fq12& y) { return fq6_eq(x.a, y.a) && fq6_eq(x.b, y.b); }
+inline Fq12 fq12_sub(const Fq12& x, const Fq12& y) { return {fq6_sub(x.a, y.a), fq6_sub(x.b, y.b)}; }
+inline Fq12 fq12_mul(const Fq12& x, const Fq12& y) {
+    const Fq6 aa = fq6_mul(x.a, y.a), bb = fq6_mul(x.b, y.b);
+    const Fq6 cross = fq6_mul(fq6_add(x.a, x.b), fq6_add(y.a, y.b));
+    return {fq6_add(aa, fq6_mul_v(bb)), fq6_sub(fq6_sub(cross, aa), bb)};
+}
+inline Fq12 fq12_sqr(const Fq12& x) { return fq12_mul(x, x); }
+inline Fq12 fq12_conj(const Fq12& x) { return {x.a, fq6_neg(x.b)}; }  // x^(q^6)
+inline Fq12 fq12_inv(const Fq12& x) {
+    const Fq6 n = fq6_inv(fq6_sub(fq6_mul(x.a, x.a), fq6_mul_v(fq6_mul(x.b, x.b))));
+    return {fq6_mul(x.a, n), fq6_neg(fq6_mul(x.b, n))};
+}
+inline Fq12 fq12_pow(const Fq12& x, const uint64_t* e, int nlimbs) {
+    Fq12 acc = fq12_one();
+    for (int i = nlimbs - 1; i >= 0; i--)
+        for (int b = 63; b >= 0; b--) {
+            acc = fq12_sqr(acc);
+            if ((e[i] >> b) & 1) acc = fq12_mul(acc, x);
+        }
+    return acc;
+}
+// embeddings used by the untwist: s in Fq -> Fq12; t in Fq2 times w^-2 = v^-1 = v^2 / xi and w^-3 = w / v^2 = w v / xi
+inline Fq12 fq12_from_fq(const Fq& s) {
+    Fq12 r = {fq6_zero(), fq6_zero()};
+    r.a.a.a = s;
+    return r;
+}
+
+// ---- G2 (the twist), affine
+inline bool g2_aff_is_inf(const G2Aff& p) { return fq2_is_zero(p.x) && fq2_is_zero(p.y); }
+inline bool g2_aff_on_curve(const G2Aff& p) {
+    if (g2_aff_is_inf(p)) return true;
+    const Fq four = fq_dbl(fq_dbl(fq_one()));
+    const Fq2 b = fq2_mul_xi(Fq2{four, fq_zero()});
+    return fq2_eq(fq2_sqr(p.y), fq2_add(fq2_mul(fq2_sqr(p.x), p.x), b));
+}
+
+struct PtFq12 { Fq12 x, y; };
+inline PtFq12 g2_untwist(const G2Aff& q) {
+    const Fq2 xi_inv = fq2_inv(fq2_mul_xi(fq2_one()));
+    PtFq12 r = {{fq6_zero(), fq6_zero()}, {fq6_zero(), fq6_zero()}};
+    r.x.a.c = fq2_mul(q.x, xi_inv);   // x' * v^2 / xi
+    r.y.b.b = fq2_mul(q.y, xi_inv);   // y' * v w / xi
+    return r;
+}
+
+// f_{|x|, Q}(P) with the untwisted Q; P affine in G1, neither at infinity
+inline Fq12 miller_loop(const G1Aff& p, const G2Aff& q) {
+    static const uint64_t X_ABS = 0xd201000000010000ull;
+    const PtFq12 Q = g2_untwist(q);
+    const Fq12 px = fq12_from_fq(p.x), py = fq12_from_fq(p.y);
+    PtFq12 T = Q;
+    Fq12 f = fq12_one();
+    const Fq12 three = fq12_from_fq(fq_add(fq_dbl(fq_one()), fq_one())), two = fq12_from_fq(fq_dbl(fq_one()));
+    auto line = [&](const PtFq12& A, const Fq12& lam) {  // (yP - yA) - lam (xP - xA)
+        return fq12_sub(fq12_sub(py, A.y), fq12_mul(lam, fq12_sub(px, A.x)));
+    };
+    auto step = [&](const PtFq12& A, const PtFq12& B, const Fq12& lam) {
+        PtFq12 r;
+        r.x = fq12_sub(fq12_sub(fq12_sqr(lam), A.x), B.x);
+        r.y = fq12_sub(fq12_mul(lam, fq12_sub(A.x, r.x)), A.y);
+        return r;
+    };
+    for (int b = 62; b >= 0; b--) {  // bit 63 is the leading one
+        const Fq12 lam = fq12_mul(fq12_mul(three, fq12_sqr(T.x)), fq12_inv(fq12_mul(two, T.y)));
+        f = fq12_mul(fq12_sqr(f), line(T, lam));
+        T = step(T, T, lam);
+        if ((X_ABS >> b) & 1) {
+            const Fq12 lam2 = fq12_mul(fq12_sub(Q.y, T.y), fq12_inv(fq12_sub(Q.x, T.x)));
+            f = fq12_mul(f, line(T, lam2));
+            T = step(T, Q, lam2);
+        }
+    }
+    return fq12_conj(f);  // x < 0
+}
+
+inline Fq12 final_exponentiation(const Fq12& f) {
+    static const uint64_t EXP_Q2P1[12] = {0x26aa00001c718e3aull, 0x7ced6b1d76382eabull, 0x162c338362113cfdull, 0x66bf91ed3e71b743ull,
+                                          0x292e85a87091a049ull, 0x1d68619c86185c7bull, 0xf53149330978ef01ull, 0x50a62cfd16ddca6eull,
+                                          0x66e59e49349e8bd0ull, 0xe2dc90e50e7046b4ull, 0x4bd278eaa22f25e9ull, 0x02a437a4b8c35fc7ull};
+    static const uint64_t EXP_HARD[20] = {0xe516c3f438e3ba79ull, 0xfa9912aae208ccf1ull, 0x905ce937335d5b68ull, 0xc71a2629b0dea236ull,
+                                          0x83774940996754c8ull, 0x21d160aeb6a1e799ull, 0x2ed0b283ed237db4ull, 0x915c97f36c6f1821ull,
+                                          0x67f17fcbde783765ull, 0x2378b9039096d1b7ull, 0x7988f8761bdc51dcull, 0x2076995003fc77a1ull,
+                                          0x827eca0ba621315bull, 0xe5a72bce8d63cb9full, 0xf68f7764c28b6f8aull, 0x2f230063cf081517ull,
+                                          0x94506632528d6a9aull, 0xd3cde88eeb996ca3ull, 0xc0bd38c3195c899eull, 0x000f686b3d807d01ull};
+    const Fq12 t = fq12_mul(fq12_conj(f), fq12_inv(f));   // f^(q^6 - 1)
+    return fq12_pow(fq12_pow(t, EXP_Q2P1, 12), EXP_HARD, 20);
+}
+
+// e(P, Q); infinity on either side gives 1
+inline Fq12 pairing(const G1Aff& p, const G2Aff& q) {
+    if (g1_aff_is_inf(p) || g2_aff_is_inf(q)) return fq12_one();
+    return final_exponentiation(miller_loop(p, q));
+}
+
+// prod_i e(P_i, Q_i) == 1, with one final exponentiation
+inline bool pairing_product_is_one(const G1Aff* ps, const G2Aff* qs, int n) {
+    Fq12 f = fq12_one();
+    for (int i = 0; i < n; i++) {
+        if (g1_aff_is_inf(ps[i]) || g2_aff_is_inf(qs[i])) continue;
+        f = fq12_mul(f, miller_loop(ps[i], qs[i]));
+    }
+    return fq12_eq(final_exponentiation(f), fq12_one());
+}
+
+}  // namespace gm

@@ -49,6 +49,14 @@ class GmTranscript(C.Structure):
                 ("write_points", WRITE_SCALARS_CB)]
 
 
+READ_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
+
+
+class GmTranscriptReader(C.Structure):
+    """gm_transcript_reader: the caller's transcript in verifier mode"""
+    _fields_ = [("ctx", C.c_void_p), ("read_scalars", READ_CB), ("challenge", CHALLENGE_CB), ("read_points", READ_CB)]
+
+
 ALL_GATHER_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)
 
 
@@ -125,6 +133,13 @@ _SIGS = {
     "gm_merlin_append_message": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint64]),
     "gm_merlin_challenge_bytes": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint64]),
     "gm_keccak_f1600": (C.c_int32, [vp]),
+    "gm_pippenger_verify_tr": (C.c_int32, [C.c_uint32] * 5 + [vp, vp, vp, vp, C.POINTER(GmTranscriptReader), vp]),
+    "gm_pippenger_verify": (C.c_int32, [C.c_uint32] * 5 + [vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp, u64p]),
+    "gm_kzg_verify_pair": (C.c_int32, [vp, vp, vp]),
+    "gm_pairing": (C.c_int32, [vp, vp, vp]),
+    "gm_merlin_create_verifier": (C.c_int32, [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(vp)]),
+    "gm_merlin_reader": (C.c_int32, [vp, C.POINTER(GmTranscriptReader)]),
+    "gm_merlin_unread": (C.c_int32, [vp, u64p]),
     "gm_knuckles_setup": (C.c_int32, [vp, C.c_uint32, vp, vp]),
     "gm_knuckles_open": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]),
     "gm_knuckles_open_tr": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, C.POINTER(GmTranscript), vp, vp, vp]),

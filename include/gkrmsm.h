@@ -29,6 +29,7 @@ extern "C" {
 #define GM_ERR_HIP 2       /* HIP runtime failure */
 #define GM_ERR_NO_DEVICE 3 /* no gfx950 device visible */
 #define GM_ERR_STATE 4     /* call order violated (e.g. bind before unipoly: vecvec_eq.rs:305-307) */
+#define GM_ERR_VERIFY 5    /* the verifier rejected the proof (an assert! in the reference's verify functions) */
 
 /* ---------------------------------------------------------------- runtime */
 const char* gm_last_error(void);
@@ -256,6 +257,45 @@ int32_t gm_merlin_proof(const gm_merlin* t, const uint8_t** bytes, uint64_t* len
 int32_t gm_merlin_append_message(gm_merlin* t, const uint8_t* label, uint64_t label_len, const uint8_t* msg, uint64_t len);
 int32_t gm_merlin_challenge_bytes(gm_merlin* t, const uint8_t* label, uint64_t label_len, uint8_t* dest, uint64_t len);
 int32_t gm_keccak_f1600(uint8_t* state200);
+
+/* ---------------------------------------------------------------- the verifier
+ * Pippenger::verify (cleanup/protocols/pippenger.rs:296-406) and everything under it -- the sumcheck, GKR, logup, pushforward,
+ * multi-open and Knuckles verifiers -- on the host, as in the reference (no device work).  The transcript seam in verifier mode
+ * (TProofTranscript2::read_scalars / challenge / read_points, proof_transcript.rs:33-62; PTMode::Verifier reads the proof and
+ * feeds the sponge):
+ *   read_scalars: next n field elements of the proof -> Montgomery, 4 x u64 each
+ *   challenge:    as in gm_transcript
+ *   read_points:  next n G1 points of the proof -> affine wire form (12 x u64 each)
+ * A non-zero return from a read means the proof is too short or malformed: the verifier returns GM_ERR_VERIFY.
+ *
+ * gm_pippenger_verify_tr: claims = the point r_y (y_logsize elements) and the 3 (d_logsize + 1) evaluations of the MSM's dense
+ *   output there (verify_pippenger, pippenger.rs:562-587, forms them from the claimed result); h_g0_aff = the first SRS element
+ *   (KzgVerifyingKey::g0), h_k = the Knuckles generator k (Montgomery).  GM_OK: every check up to the deferred pairing passed and
+ *   h_pair = (A, B), affine, 2 x 12 u64; GM_ERR_VERIFY: a check failed (gm_last_error() names it).
+ * gm_pippenger_verify: the same over recorded messages and a challenge tape (the prover's outputs from gm_pippenger_prove);
+ *   additionally insists that every message was read.
+ * gm_kzg_verify_pair: KzgVerifyingKey::verify_pair (commitments/kzg.rs:61-67), e(A, h0) == e(B, h1) on BLS12-381; h0 = [1]_2 and
+ *   h1 = [tau]_2 as G2 affine points: x.c0, x.c1, y.c0, y.c1, each Montgomery 6 x u64.  GM_OK = equal.
+ * gm_merlin_create_verifier / gm_merlin_reader: ProofTranscript2::start_verifier over proof bytes (proof_transcript.rs:104-107). */
+typedef struct gm_transcript_reader {
+    void* ctx;
+    int32_t (*read_scalars)(void* ctx, uint64_t n, uint64_t* out);
+    int32_t (*challenge)(void* ctx, uint32_t n, uint32_t bitsize, uint64_t* out);
+    int32_t (*read_points)(void* ctx, uint64_t n, uint64_t* out_aff);
+} gm_transcript_reader;
+int32_t gm_pippenger_verify_tr(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_size, uint32_t y_logsize,
+                               uint32_t commitment_log_multiplicity, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                               const uint64_t* h_g0_aff, const uint64_t* h_k, const gm_transcript_reader* tr, uint64_t* h_pair);
+int32_t gm_pippenger_verify(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_size, uint32_t y_logsize,
+                            uint32_t commitment_log_multiplicity, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                            const uint64_t* h_g0_aff, const uint64_t* h_k, const uint64_t* h_scalars, uint64_t n_scalars,
+                            const uint64_t* h_points_aff, uint64_t n_points, const uint64_t* h_tape, uint64_t n_tape,
+                            uint64_t* h_pair, uint64_t* tape_used);
+int32_t gm_kzg_verify_pair(const uint64_t* h_pair, const uint64_t* h_h0, const uint64_t* h_h1);
+int32_t gm_pairing(const uint64_t* h_p_aff, const uint64_t* h_q_aff, uint64_t* h_gt);
+int32_t gm_merlin_create_verifier(const uint8_t* pparam, uint64_t len, const uint8_t* proof, uint64_t proof_len, gm_merlin** out);
+int32_t gm_merlin_reader(gm_merlin* t, gm_transcript_reader* out);
+int32_t gm_merlin_unread(const gm_merlin* t, uint64_t* n);
 
 /* ---------------------------------------------------------------- multi-GPU seam
  * One process per GPU.  The path shards by MSM window: rank g owns windows [g*y_size/G, (g+1)*y_size/G), i.e. the bucket

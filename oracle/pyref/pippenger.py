@@ -53,7 +53,7 @@ def pippenger_prove(tr, st, claims, y_size, y_logsize, d_logsize, x_logsize, clm
     c1 = st["comm"]
     assert len(c1["c"]) == n_mat and len(c1["d"]) == n_mat
     tr.write_points(c1["c"]); tr.write_points(c1["d"]); tr.write_points([c1["p_0"]]); tr.write_points([c1["p_1"]])
-    tr.write_points([c1["ac_c"]]); tr.write_points([c1["ac_c"]]); tr.write_points([c1["ac_d"]])   # ac_c twice, as pippenger.rs:131-132
+    tr.write_points([c1["ac_c"]]); tr.write_points([c1["ac_d"]])   # pippenger.rs:131-136
     claims = GK.prove_image_part(tr, y_logsize, d_logsize, x_logsize, claims, st["wg"])
     # commit phase 2
     p2 = PF.phase2_data(st["digits"], st["counter"], claims[0], y_logsize, d_logsize, x_logsize)

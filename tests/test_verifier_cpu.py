@@ -1,0 +1,106 @@
+"""The verifier runs on the host, so its tests run without a GPU: the library's Pippenger::verify and pairing
+against the Python oracle (pyref/verifier.py is written from the reference's verify functions, pyref/pairing.py is an
+independent pairing in a different Fq12 representation), on proofs made by the oracle prover.  GPU-made proofs are verified in
+tests/test_verifier_gpu.py."""
+import pytest
+
+from gkr_msm_amd import verifier as VF
+from pyref import field as F
+from pyref import g1 as G
+from pyref import gkr as GK
+from pyref import knuckles as KN
+from pyref import pairing as PR
+from pyref import pippenger as PP
+from pyref import verifier as V
+
+
+def test_pairing_matches_the_independent_oracle_value_for_value():
+    want = PR.pairing(G.GEN, PR.G2_GEN)
+    got = VF.pairing(G.GEN, PR.G2_GEN)
+    assert PR.tower_to_poly(got) == want
+    a, b = 0x1234567, 0x7654321
+    got_ab = VF.pairing(G.mul(G.GEN, a), PR.g2_mul(PR.G2_GEN, b))
+    assert PR.tower_to_poly(got_ab) == PR.f12_pow(want, a * b)          # bilinear
+    assert PR.f12_pow(want, PR.R_ORDER) == PR.ONE12 and want != PR.ONE12   # order r, non-degenerate
+
+
+def test_kzg_verify_pair():
+    tau = 0x1F3A9C7754BB21 * 3 + 11
+    b = G.mul(G.GEN, 0xABCDEF12345)
+    a = G.mul(b, tau)
+    h1 = PR.g2_mul(PR.G2_GEN, tau)
+    assert VF.kzg_verify_pair((a, b), PR.G2_GEN, h1)
+    assert not VF.kzg_verify_pair((G.add(a, G.GEN), b), PR.G2_GEN, h1)
+    assert not VF.kzg_verify_pair((a, b), PR.G2_GEN, PR.g2_mul(PR.G2_GEN, tau + 1))
+    assert VF.kzg_verify_pair((None, None), PR.G2_GEN, h1)               # e(0, .) = 1 on both sides
+
+
+def _oracle_proof(x_log, d_log, nbits, clm, seed):
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = (y_size - 1).bit_length()
+    n = 1 << x_log
+    rng = F.SplitMix64(seed)
+    pts = F.random_points(n, 2)
+    sc = F.random_scalars(n, nbits, 3)
+    nv = x_log + clm
+    tau, k = rng.next_fr(), 2
+    basis, cur = [], G.GEN
+    for _ in range((2 << nv) - 1):
+        basis.append(cur)
+        cur = G.mul(cur, tau)
+    st = PP.pippenger_wg(pts, sc, y_size, y_log, d_log, x_log, clm, basis)
+    out = GK.pippenger_dense_output(st["wg"], y_log, d_log)
+    r = [rng.next_fr() for _ in range(y_log)]
+    claims = GK.pippenger_claims(out, r)
+    tape = [rng.next_bits(512) for _ in range(4000)]
+    tr = PP.Transcript(tape)
+    pair = PP.pippenger_prove(tr, st, claims, y_size, y_log, d_log, x_log, clm, basis, KN.setup_inverses(k, nv), k)
+    dev_tape = [t % F.P if i in tr.wide else t & ((1 << 128) - 1) for i, t in enumerate(tape[: tr.pos])]
+    return dict(shape=(x_log, d_log, y_size, y_log, clm), claims=claims, scalars=[v for m in tr.msgs for v in m], points=list(tr.points),
+                tape=dev_tape, raw_tape=tape, pair=pair, g0=basis[0], k=k, tau=tau)
+
+
+@pytest.fixture(scope="module", params=[(3, 2, 8, 0), (3, 2, 8, 1), (4, 3, 12, 2)])
+def proof(request):
+    return _oracle_proof(*request.param, seed=123 + sum(request.param))
+
+
+def test_verifier_accepts_the_oracle_proof_and_returns_its_pair(proof):
+    p = proof
+    # the Python restatement of the reference verifier reads exactly what the prover wrote
+    rt = V.ReadTranscript(p["scalars"], p["points"], p["raw_tape"])
+    assert V.pippenger_verify(rt, p["claims"], p["shape"][2], p["shape"][3], p["shape"][1], p["shape"][0], p["shape"][4], p["g0"],
+                              p["k"]) == p["pair"]
+    got = VF.pippenger_verify(*p["shape"], p["claims"][0], p["claims"][1], p["g0"], p["k"], p["scalars"], p["points"], p["tape"])
+    assert got["pair"] == p["pair"] and got["tape_used"] == len(p["tape"]) == rt.pos
+    assert VF.kzg_verify_pair(got["pair"], PR.G2_GEN, PR.g2_mul(PR.G2_GEN, p["tau"]))     # the real pairing check
+
+
+def test_verifier_rejects_tampered_proofs(proof):
+    p = proof
+    args = lambda **kw: (*p["shape"], kw.get("cp", p["claims"][0]), kw.get("ce", p["claims"][1]), p["g0"], p["k"],
+                         kw.get("scalars", p["scalars"]), kw.get("points", p["points"]), kw.get("tape", p["tape"]))
+    n = len(p["scalars"])
+    for idx in (0, 1, n // 3, n // 2, n - 6, n - 1):           # a round message, final evaluations, the opening's scalars
+        bad = list(p["scalars"])
+        bad[idx] = (bad[idx] + 1) % F.P
+        with pytest.raises(VF.Rejected):
+            VF.pippenger_verify(*args(scalars=bad))
+        with pytest.raises(V.VerifyError):
+            V.pippenger_verify(V.ReadTranscript(bad, p["points"], p["raw_tape"]), p["claims"], p["shape"][2], p["shape"][3],
+                               p["shape"][1], p["shape"][0], p["shape"][4], p["g0"], p["k"])
+    bad_claim = list(p["claims"][1])
+    bad_claim[0] = (bad_claim[0] + 1) % F.P
+    with pytest.raises(VF.Rejected):
+        VF.pippenger_verify(*args(ce=bad_claim))
+    with pytest.raises(VF.Rejected):                            # truncated
+        VF.pippenger_verify(*args(scalars=p["scalars"][:-1]))
+    with pytest.raises(VF.Rejected):                            # trailing garbage
+        VF.pippenger_verify(*args(scalars=p["scalars"] + [1]))
+    with pytest.raises(VF.Rejected):                            # a point off the curve
+        VF.pippenger_verify(*args(points=[(p["points"][0][0], (p["points"][0][1] + 1) % G.Q)] + p["points"][1:]))
+    # a different commitment passes the algebraic checks (they never open it) but not the pairing
+    swapped = [G.add(p["points"][0], G.GEN)] + p["points"][1:]
+    got = VF.pippenger_verify(*args(points=swapped))
+    assert got["pair"] != p["pair"]
+    assert not VF.kzg_verify_pair(got["pair"], PR.G2_GEN, PR.g2_mul(PR.G2_GEN, p["tau"]))
