@@ -100,3 +100,8 @@ def g1_jac_from_limbs(arr):
             zi = pow(z, -1, Q)
             out.append((x * zi * zi % Q, y * zi * zi * zi % Q))
     return out
+
+
+# the standard BLS12-381 G1 generator (affine, canonical)
+G1_GEN = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+          0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)

@@ -109,6 +109,47 @@ inline bool g2_aff_on_curve(const G2Aff& p) {
     return fq2_eq(fq2_sqr(p.y), fq2_add(fq2_mul(fq2_sqr(p.x), p.x), b));
 }
 
+inline G2Aff g2_generator() {
+    static const uint32_t X0[12] = {0xc121bdb8u, 0xd48056c8u, 0xa805bbefu, 0x0bac0326u, 0x7ae3d177u, 0xb4510b64u, 0xfa403b02u, 0xc6e47ad4u, 0x2dc51051u, 0x26080527u, 0xf08f0a91u, 0x024aa2b2u};
+    static const uint32_t X1[12] = {0x5d042b7eu, 0xe5ac7d05u, 0x13945d57u, 0x334cf112u, 0xdc7f5049u, 0xb5da61bbu, 0x9920b61au, 0x596bd0d0u, 0x88274f65u, 0x7dacd3a0u, 0x52719f60u, 0x13e02b60u};
+    static const uint32_t Y0[12] = {0x08b82801u, 0xe1935486u, 0x3baca289u, 0x923ac9ccu, 0x5160d12cu, 0x6d429a69u, 0x8cbdd3a7u, 0xadfd9baau, 0xda2e351au, 0x8cc9cdc6u, 0x727d6e11u, 0x0ce5d527u};
+    static const uint32_t Y1[12] = {0xf05f79beu, 0xaaa9075fu, 0x5cec1da1u, 0x3f370d27u, 0x572e99abu, 0x267492abu, 0x85a763afu, 0xcb3e287eu, 0x2bc28b99u, 0x32acd2b0u, 0x2ea734ccu, 0x0606c4a0u};
+    auto mk = [](const uint32_t* l) {
+        Fq c;
+        for (int i = 0; i < 12; i++) c.l[i] = l[i];
+        return fq_to_mont(c);
+    };
+    return G2Aff{{mk(X0), mk(X1)}, {mk(Y0), mk(Y1)}};
+}
+
+// affine chord-and-tangent addition on the twist (one Fq2 inversion each; used for the few scalar multiplications a setup needs)
+inline G2Aff g2_add(const G2Aff& p, const G2Aff& q) {
+    if (g2_aff_is_inf(p)) return q;
+    if (g2_aff_is_inf(q)) return p;
+    Fq2 lam;
+    if (fq2_eq(p.x, q.x)) {
+        if (!fq2_eq(p.y, q.y) || fq2_is_zero(p.y)) return G2Aff{fq2_zero(), fq2_zero()};
+        const Fq2 xx = fq2_sqr(p.x);
+        lam = fq2_mul(fq2_add(fq2_add(xx, xx), xx), fq2_inv(fq2_add(p.y, p.y)));
+    } else {
+        lam = fq2_mul(fq2_sub(q.y, p.y), fq2_inv(fq2_sub(q.x, p.x)));
+    }
+    G2Aff r;
+    r.x = fq2_sub(fq2_sub(fq2_sqr(lam), p.x), q.x);
+    r.y = fq2_sub(fq2_mul(lam, fq2_sub(p.x, r.x)), p.y);
+    return r;
+}
+// k canonical (not Montgomery), 8 x u32 little-endian
+inline G2Aff g2_mul(const G2Aff& p, const uint32_t* k, int nlimbs) {
+    G2Aff acc = {fq2_zero(), fq2_zero()};
+    for (int i = nlimbs - 1; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+            acc = g2_add(acc, acc);
+            if ((k[i] >> b) & 1) acc = g2_add(acc, p);
+        }
+    return acc;
+}
+
 struct PtFq12 { Fq12 x, y; };
 inline PtFq12 g2_untwist(const G2Aff& q) {
     const Fq2 xi_inv = fq2_inv(fq2_mul_xi(fq2_one()));

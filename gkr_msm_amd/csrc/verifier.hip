@@ -490,6 +490,20 @@ extern "C" int32_t gm_kzg_verify_pair(const uint64_t* h_pair, const uint64_t* h_
     return GM_OK;
 }
 
+// The G2 half of KzgProvingKey::mock_setup's verifying key (kzg.rs: h0 = [1]_2, h1 = [tau]_2) for a known tau: tests and benches
+// that generate their own SRS (gm_g1_mock_srs) need it for gm_kzg_verify_pair.  h_tau: Montgomery Fr.
+extern "C" int32_t gm_kzg_mock_vk(const uint64_t* h_tau, uint64_t* h_h0, uint64_t* h_h1) {
+    GM_REQUIRE(h_tau && h_h0 && h_h1, "null argument");
+    Fr t;
+    memcpy(&t, h_tau, sizeof(Fr));
+    t = fr_from_mont(t);
+    const G2Aff g = g2_generator();
+    const G2Aff h1 = g2_mul(g, t.l, 8);
+    memcpy(h_h0, &g, sizeof(G2Aff));
+    memcpy(h_h1, &h1, sizeof(G2Aff));
+    return GM_OK;
+}
+
 // e(P, Q) as 12 Fq coordinates (Montgomery, tower order a.a.a, a.a.b, a.b.a, ... b.c.b): test hook for the pairing itself
 extern "C" int32_t gm_pairing(const uint64_t* h_p_aff, const uint64_t* h_q_aff, uint64_t* h_gt) {
     GM_REQUIRE(h_p_aff && h_q_aff && h_gt, "null argument");
@@ -501,4 +515,114 @@ extern "C" int32_t gm_pairing(const uint64_t* h_p_aff, const uint64_t* h_q_aff, 
     const Fq12 e = pairing(p, q);
     memcpy(h_gt, &e, sizeof(Fq12));
     return GM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- gen-1
+// The verifier side of gkr_msm_prove's GKR (gkr_msm_simple.rs:248-338): BintreeVerifier::round (protocol/bintree.rs:313-395)
+// over SumcheckPolyMapVerifier::round (protocol/sumcheck.rs:595-657) and SplitVerifier::round (protocol/split.rs:99-115), on the
+// transcript stream gm_gkr_msm_prove emits: the output polynomials, then per mapping layer the round polynomials (all
+// coefficients, as `append_scalars(b"poly", ..)` sees them) and the final evaluations.  The reference's proof object stores the
+// round polynomials compressed and rebuilds the linear coefficient from the running sum (sumcheck.rs:649); on the full
+// coefficients that is the check p(0) + p(1) == sum.
+namespace {
+
+int32_t gkr_msm_verify(Reader* tr, uint32_t lp, uint32_t lb, Fr* out_point, uint32_t* n_point, Fr* out_evs, uint64_t* rounds) {
+    GM_REQUIRE(lp >= 1 && lb >= 1 && lp + lb <= 40, "bad log_num_points / log_num_scalar_bits");
+    struct L1 { bool is_map; int prim; uint32_t nv; };
+    std::vector<L1> layers;   // gkr_msm_simple.rs:248-269 unrolled (bintree.rs:81-123)
+    {
+        uint32_t nv = lp + lb;
+        auto map = [&](int id) { layers.push_back(L1{true, id, nv}); };
+        auto split = [&]() { layers.push_back(L1{false, 0, nv}); nv--; };
+        map(GM_FN_PT_BIT_CHOICE);
+        split();
+        map(GM_FN_AFF_L1); map(GM_FN_AFF_L2); map(GM_FN_AFF_L3);
+        for (uint32_t i = 0; i + 1 < lp; i++) { split(); map(GM_FN_PROJ_L1); map(GM_FN_PROJ_L2); map(GM_FN_PROJ_L3); }
+    }
+    const uint64_t nout = 1ull << lb;
+    std::vector<std::vector<Fr>> out(3, std::vector<Fr>(nout));
+    for (int c = 0; c < 3; c++) TRY(tr->read_scalars(nout, out[c].data()));
+    std::vector<Fr> point(lb), evs(3);
+    for (uint32_t i = 0; i < lb; i++) TRY(tr->challenge(&point[i], 1, 512));
+    for (int c = 0; c < 3; c++) {  // FragmentedPoly::evaluate (fragmented.rs:748-761)
+        std::vector<Fr> v = out[c];
+        for (int k = (int)lb - 1; k >= 0; k--) {
+            for (size_t i = 0; i < v.size() / 2; i++) v[i] = fr_add(v[2 * i], fr_mul(point[k], fr_sub(v[2 * i + 1], v[2 * i])));
+            v.resize(v.size() / 2);
+        }
+        evs[c] = v[0];
+    }
+    uint64_t nrounds = 0;
+    for (size_t li = layers.size(); li-- > 0;) {
+        const L1& L = layers[li];
+        Fr c0;
+        TRY(tr->challenge(&c0, 1, 512));
+        if (!L.is_map) {  // SplitVerifier::round
+            const size_t h = evs.size() / 2;
+            std::vector<Fr> nw(h);
+            for (size_t i = 0; i < h; i++) nw[i] = fr_add(evs[i], fr_mul(c0, fr_sub(evs[h + i], evs[i])));
+            evs = nw;
+            point.push_back(c0);
+            continue;
+        }
+        const SegPlan sp = plan_of(mkfn(L.prim, 1));
+        VERIFY((int)evs.size() == sp.n_outs && point.size() == L.nv, "Verifier failure. Claim ill-formed at layer %zu (sumcheck.rs:546-558)", li);
+        Fr sum = fr_zero(), gp = fr_one();   // make_folded_claim (sumcheck.rs:659-673)
+        for (size_t i = 0; i < evs.size(); i++) { sum = fr_add(sum, fr_mul(evs[i], gp)); gp = fr_mul(gp, c0); }
+        std::vector<Fr> rs;
+        const uint32_t ncoef = (uint32_t)sp.deg + 2;   // degree f.degree + 1
+        for (uint32_t rd = 0; rd < L.nv; rd++) {
+            std::vector<Fr> poly(ncoef);
+            TRY(tr->read_scalars(ncoef, poly.data()));
+            Fr at1 = fr_zero();
+            for (const Fr& c : poly) at1 = fr_add(at1, c);
+            VERIFY(fr_eq(fr_add(poly[0], at1), sum), "Verifier failure: round polynomial does not sum to the claim (layer %zu, round %u)", li, rd);
+            Fr r;
+            TRY(tr->challenge(&r, 1, 512));
+            rs.insert(rs.begin(), r);   // fix_var_bot
+            sum = evaluate_univar(poly, r);
+            nrounds++;
+        }
+        std::vector<Fr> fe(sp.n_ins), fo(sp.n_outs);
+        TRY(tr->read_scalars(sp.n_ins, fe.data()));
+        seg_plan_exec_host(sp, fe.data(), fo.data());
+        Fr folded = fr_zero();
+        gp = fr_one();
+        for (int o = 0; o < sp.n_outs; o++) { folded = fr_add(folded, fr_mul(fo[o], gp)); gp = fr_mul(gp, c0); }
+        VERIFY(fr_eq(fr_mul(folded, eq_eval(point, rs)), sum), "Verifier failure: final check incorrect (layer %zu, sumcheck.rs:638)", li);
+        evs = fe;
+        point = rs;
+    }
+    if (n_point) *n_point = (uint32_t)point.size();
+    if (out_point) memcpy(out_point, point.data(), point.size() * sizeof(Fr));
+    if (out_evs) memcpy(out_evs, evs.data(), evs.size() * sizeof(Fr));
+    if (rounds) *rounds = nrounds;
+    return GM_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t gm_gkr_msm_verify(uint32_t log_num_points, uint32_t log_num_scalar_bits, const uint64_t* h_msgs, uint64_t n_msgs,
+                                     const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_final_point, uint32_t* n_final_point,
+                                     uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds) {
+    GM_REQUIRE((h_msgs || !n_msgs) && (h_tape || !n_tape), "null argument");
+    Reader rd;
+    rd.scalars = reinterpret_cast<const Fr*>(h_msgs);
+    rd.tape = h_tape;
+    rd.n_scalars = n_msgs; rd.n_tape = n_tape;
+    TRY(gkr_msm_verify(&rd, log_num_points, log_num_scalar_bits, reinterpret_cast<Fr*>(h_final_point), n_final_point,
+                       reinterpret_cast<Fr*>(h_final_evs), rounds));
+    if (rd.si != n_msgs) return set_err(GM_ERR_VERIFY, "transcript has unread messages (%llu of %llu read)", (unsigned long long)rd.si,
+                                        (unsigned long long)n_msgs);
+    if (tape_used) *tape_used = rd.pos;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_gkr_msm_verify_tr(uint32_t log_num_points, uint32_t log_num_scalar_bits, const gm_transcript_reader* tr,
+                                        uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* rounds) {
+    GM_REQUIRE(tr && tr->read_scalars && tr->challenge, "null argument");
+    Reader rd;
+    rd.cb = tr;
+    return gkr_msm_verify(&rd, log_num_points, log_num_scalar_bits, reinterpret_cast<Fr*>(h_final_point), n_final_point,
+                          reinterpret_cast<Fr*>(h_final_evs), rounds);
 }

@@ -136,7 +136,10 @@ _SIGS = {
     "gm_pippenger_verify_tr": (C.c_int32, [C.c_uint32] * 5 + [vp, vp, vp, vp, C.POINTER(GmTranscriptReader), vp]),
     "gm_pippenger_verify": (C.c_int32, [C.c_uint32] * 5 + [vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp, u64p]),
     "gm_kzg_verify_pair": (C.c_int32, [vp, vp, vp]),
+    "gm_gkr_msm_verify": (C.c_int32, [C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, vp, u32p, vp, u64p, u64p]),
+    "gm_gkr_msm_verify_tr": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(GmTranscriptReader), vp, u32p, vp, u64p]),
     "gm_pairing": (C.c_int32, [vp, vp, vp]),
+    "gm_kzg_mock_vk": (C.c_int32, [vp, vp, vp]),
     "gm_merlin_create_verifier": (C.c_int32, [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(vp)]),
     "gm_merlin_reader": (C.c_int32, [vp, C.POINTER(GmTranscriptReader)]),
     "gm_merlin_unread": (C.c_int32, [vp, u64p]),

@@ -68,6 +68,19 @@ def pippenger_verify_merlin(x_log, d_log, y_size, y_log, clm, claim_point, claim
         L.gm_merlin_destroy(h)
 
 
+def g2_from_limbs(arr):
+    v = codec.fq_from_mont_limbs(np.asarray(arr, dtype=np.uint64).reshape(4, 6))
+    return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
+
+
+def kzg_mock_vk(tau):
+    """([1]_2, [tau]_2): the G2 part of KzgProvingKey::mock_setup's verifying key for a known tau"""
+    t = codec.to_mont_limbs([tau])
+    h0, h1 = np.zeros(24, dtype=np.uint64), np.zeros(24, dtype=np.uint64)
+    ffi.check(ffi.lib().gm_kzg_mock_vk(t.ctypes.data, h0.ctypes.data, h1.ctypes.data))
+    return g2_from_limbs(h0), g2_from_limbs(h1)
+
+
 def kzg_verify_pair(pair, h0, h1):
     """KzgVerifyingKey::verify_pair: True iff e(A, h0) == e(B, h1)"""
     pl = codec.g1_aff_to_limbs(list(pair)).reshape(-1)
@@ -86,3 +99,17 @@ def pairing(p, q):
     out = np.zeros(72, dtype=np.uint64)
     ffi.check(ffi.lib().gm_pairing(pl.ctypes.data, ql.ctypes.data, out.ctypes.data))
     return codec.fq_from_mont_limbs(out.reshape(12, 6))
+
+
+def gkr_msm_verify(log_num_points, log_num_scalar_bits, msgs, tape):
+    """gen-1: gm_gkr_msm_verify over the prover's message stream + challenge tape; returns the final claim"""
+    L = ffi.lib()
+    ms = codec.to_mont_limbs(list(msgs)) if len(msgs) else np.zeros((1, 4), dtype=np.uint64)
+    tp = codec.ints_to_limbs(list(tape))
+    fpt = np.zeros((64, 4), dtype=np.uint64)
+    fev = np.zeros((8, 4), dtype=np.uint64)
+    npt, used, rounds = C.c_uint32(), C.c_uint64(), C.c_uint64()
+    _check(L.gm_gkr_msm_verify(log_num_points, log_num_scalar_bits, ms.ctypes.data, len(msgs), tp.ctypes.data, len(tape),
+                               fpt.ctypes.data, C.byref(npt), fev.ctypes.data, C.byref(used), C.byref(rounds)))
+    return dict(point=codec.from_mont_limbs(fpt[: npt.value]), evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value,
+                rounds=rounds.value)

@@ -291,7 +291,17 @@ int32_t gm_pippenger_verify(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_s
                             const uint64_t* h_g0_aff, const uint64_t* h_k, const uint64_t* h_scalars, uint64_t n_scalars,
                             const uint64_t* h_points_aff, uint64_t n_points, const uint64_t* h_tape, uint64_t n_tape,
                             uint64_t* h_pair, uint64_t* tape_used);
+/* gen-1: the verifier side of gkr_msm_prove's GKR -- BintreeVerifier / SumcheckPolyMapVerifier / SplitVerifier ::round
+ * (protocol/bintree.rs:313-395, protocol/sumcheck.rs:595-657, protocol/split.rs:99-115) -- over the stream gm_gkr_msm_prove
+ * emits (h_msgs) and its challenges; returns the final EvalClaim about the base layer (point of lp + lb elements, 3 evaluations:
+ * bit, px, py), which the caller checks against its commitments (the reference's gkr_msm_prove stops there too). */
+int32_t gm_gkr_msm_verify(uint32_t log_num_points, uint32_t log_num_scalar_bits, const uint64_t* h_msgs, uint64_t n_msgs,
+                          const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_final_point, uint32_t* n_final_point,
+                          uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds);
+int32_t gm_gkr_msm_verify_tr(uint32_t log_num_points, uint32_t log_num_scalar_bits, const gm_transcript_reader* tr,
+                             uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* rounds);
 int32_t gm_kzg_verify_pair(const uint64_t* h_pair, const uint64_t* h_h0, const uint64_t* h_h1);
+int32_t gm_kzg_mock_vk(const uint64_t* h_tau, uint64_t* h_h0, uint64_t* h_h1);   /* [1]_2, [tau]_2 of KzgProvingKey::mock_setup */
 int32_t gm_pairing(const uint64_t* h_p_aff, const uint64_t* h_q_aff, uint64_t* h_gt);
 int32_t gm_merlin_create_verifier(const uint8_t* pparam, uint64_t len, const uint8_t* proof, uint64_t proof_len, gm_merlin** out);
 int32_t gm_merlin_reader(gm_merlin* t, gm_transcript_reader* out);

@@ -53,3 +53,25 @@ def test_gen1_live_transcript_matches_tape():
     assert [v for m in live.writes for v in m] == ref["msgs"]
     assert (res["output"], res["point"], res["evs"]) == (ref["output"], ref["point"], ref["evs"])
     assert res["n_challenges"] == len(drawn) == ref["tape_used"]
+
+
+def test_gpu_gen1_stream_verifies():
+    """the library's gen-1 verifier (host) accepts the GPU prover's transcript stream at a size beyond the Python oracle and ends
+    on the prover's final claim; a flipped message is rejected"""
+    from gkr_msm_amd import verifier as VF
+    lp, lb = 10, 4
+    n = 1 << lp
+    d_pts = H.dev_empty(n * 8)
+    import ctypes as C
+    from gkr_msm_amd import ffi
+    ffi.check(ffi.lib().gm_gen_points(C.c_void_p(d_pts.data_ptr()), n, 5, H.cur_stream()))
+    d_bits = torch.from_numpy(np.random.default_rng(3).integers(0, 2, size=n << lb, dtype=np.uint8)).cuda()
+    rng = F.SplitMix64(8)
+    tape = [rng.next_fr() for _ in range(1000)]
+    res = H.gkr_msm_prove(d_pts, d_bits, lp, lb, tape)
+    got = VF.gkr_msm_verify(lp, lb, res["msgs"], tape[: res["tape_used"]])
+    assert got["point"] == res["point"] and got["evs"] == res["evs"] and got["rounds"] == res["rounds"]
+    bad = list(res["msgs"])
+    bad[len(bad) // 3] = (bad[len(bad) // 3] + 1) % F.P
+    with pytest.raises(VF.Rejected):
+        VF.gkr_msm_verify(lp, lb, bad, tape[: res["tape_used"]])

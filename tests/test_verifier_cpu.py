@@ -104,3 +104,33 @@ def test_verifier_rejects_tampered_proofs(proof):
     got = VF.pippenger_verify(*args(points=swapped))
     assert got["pair"] != p["pair"]
     assert not VF.kzg_verify_pair(got["pair"], PR.G2_GEN, PR.g2_mul(PR.G2_GEN, p["tau"]))
+
+
+@pytest.mark.parametrize("lp,lb", [(1, 1), (3, 2), (4, 3)])
+def test_gen1_verifier_on_the_oracle_prover_stream(lp, lb):
+    """gm_gkr_msm_verify (BintreeVerifier / SumcheckPolyMapVerifier / SplitVerifier) accepts what pyref's gkr_msm_prove writes,
+    ends on the same claim, and rejects an altered stream"""
+    from pyref import gen1 as G1
+    pts = F.random_points(1 << lp, 3 + lp)
+    rng = F.SplitMix64(40 + lb)
+    bits = [[bool(rng.next() & 1) for _ in range(1 << lb)] for _ in range(1 << lp)]
+    tape = [rng.next_fr() for _ in range(3000)]
+    claim, out, tr = G1.gkr_msm_prove(bits, pts, lp, lb, tape)
+    got = VF.gkr_msm_verify(lp, lb, tr.msgs, tape[: tr.pos])
+    assert got["point"] == claim[0] and got["evs"] == claim[1] and got["tape_used"] == tr.pos
+    base = G1.base_layer(bits, pts, lp, lb)
+    assert [G1.evaluate(b, got["point"]) for b in base] == got["evs"]   # the claim the caller checks against its commitments
+    n = len(tr.msgs)
+    for idx in (0, 3 << lb, n // 2, n - 1):
+        bad = list(tr.msgs)
+        bad[idx] = (bad[idx] + 1) % F.P
+        with pytest.raises(VF.Rejected):
+            VF.gkr_msm_verify(lp, lb, bad, tape[: tr.pos])
+    with pytest.raises(VF.Rejected):
+        VF.gkr_msm_verify(lp, lb, tr.msgs[:-1], tape[: tr.pos])
+
+
+def test_mock_vk_is_the_generator_and_its_tau_multiple():
+    tau = 0x5A5A5A5A1234567890ABCDEF
+    h0, h1 = VF.kzg_mock_vk(tau)
+    assert h0 == PR.G2_GEN and h1 == PR.g2_mul(PR.G2_GEN, tau)
