@@ -363,6 +363,138 @@ __global__ void __launch_bounds__(64) k_gather_finals(ColPtrs cols, int k, Fr* _
     if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ------------------------------------------------------------------------------------------ persistent tail rounds
+// Rounds of at most 256 pairs (the last 9 of every dense stage: ~40 % of all rounds of a proof) cost three dispatches each
+// (round kernel, gate, fold), 33 us of which a few are arithmetic.  One launch runs ALL of them: block (segment, point)
+// keeps its segment's input pairs in registers, and per round (i) evaluates the layer function, reduces over the block and
+// writes its partial sum + a sequence word straight into pinned host memory (the host adds the <= 64 partials), (ii) waits
+// for the challenge -- block 0 polls the host's ticket and relays it through device memory, so only one wave crosses PCIe --
+// (iii) folds its own inputs and regroups the pairs through LDS.  No inter-block data dependency, hence no grid barrier.
+// Waits are bounded; on timeout the block flags `status` and leaves.  After the last fold the (segment, 0) blocks write the
+// final evaluations of their input columns.
+struct TailArgs {
+    const Fr* eq[10];          // eq table of tail round r (offset applied)
+    Fr* h_part;                // pinned: partial sum of block y
+    uint32_t* h_seq;           // pinned: sequence word of block y (= ticket0 + r after round r)
+    Fr* h_finals;              // pinned: final evaluation of column c
+    uint32_t* h_fin_seq;       // pinned: per segment, = ticket0 + nrounds when its finals are written
+    const Fr* h_t;             // pinned: challenge slots, round r in slot r & 3
+    const uint32_t* h_ticket;  // pinned: host publishes ticket0 + r with t_r
+    uint32_t* h_status;
+    uint32_t* d_relay;         // device: [0] relayed ticket, [8..16) relayed challenge (32 bytes)
+    uint32_t ticket0;
+    int nrounds;
+    uint32_t npairs0;
+};
+
+__global__ void __launch_bounds__(256) k_tail_rounds(SegPlan sp, ColPtrs cols, const Fr* __restrict__ gp, TailArgs a) {
+    __shared__ Fr xch[6][256];
+    __shared__ Fr red[4];
+    __shared__ Fr ts;
+    __shared__ int ok;
+    const int sgi = blockIdx.x >> 1, h = blockIdx.x & 1;
+    const Seg g = sp.seg[sgi];
+    const uint32_t i = threadIdx.x, lane = i & 63, wave = i >> 6;
+    uint32_t np = a.npairs0;
+    Fr p0[6], p1[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        p0[q] = fr_zero(); p1[q] = fr_zero();
+        if (q < g.n_in && i < np) {
+            p0[q] = fr_load(cols.p[g.in[q]] + 2 * i);
+            p1[q] = fr_load(cols.p[g.in[q]] + 2 * i + 1);
+        }
+    }
+    for (int r = 0; r < a.nrounds; r++) {
+        Fr acc = fr_zero();
+        if (i < np) {
+            Fr v[6], o[4];
+#pragma unroll
+            for (int q = 0; q < 6; q++) v[q] = h ? fr_sub(fr_dbl(p1[q]), p0[q]) : p1[q];
+            prim_exec(g.prim, v, o);
+            Fr A = fr_zero();
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (q < g.n_out) {
+                    const int oc = g.out0 + q;
+                    A = fr_add(A, oc == 0 ? o[q] : fr_mul(fr_load(gp + oc), o[q]));
+                }
+            acc = fr_mul(A, fr_load(a.eq[r] + i));
+        }
+        const Fr w = wave_sum(acc);
+        if (lane == 0) red[wave] = w;
+        __syncthreads();
+        if (i == 0) {
+            const Fr tot = fr_add(fr_add(red[0], red[1]), fr_add(red[2], red[3]));
+#pragma unroll
+            for (int l = 0; l < 8; l++) __hip_atomic_store(&a.h_part[blockIdx.x].l[l], tot.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(a.h_seq + blockIdx.x, a.ticket0 + (uint32_t)r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // the challenge
+            const uint32_t want = a.ticket0 + (uint32_t)r;
+            int good = 0;
+            Fr t = fr_zero();
+            if (blockIdx.x == 0) {
+                for (int it = 0; it < (1 << 22); it++) {
+                    const uint32_t f = __hip_atomic_load(a.h_ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((int32_t)(f - want) >= 0) { good = 1; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (good) {
+#pragma unroll
+                    for (int l = 0; l < 8; l++) t.l[l] = __hip_atomic_load(&a.h_t[r & 3].l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // slot r & 1 of the relay: a block still reading t_(r-1) is never overwritten (t_(r+1) needs every block's round-r+1 sum)
+#pragma unroll
+                    for (int l = 0; l < 8; l++) __hip_atomic_store(a.d_relay + 8 + 8 * (r & 1) + l, t.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.d_relay, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    __hip_atomic_store(a.h_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(a.d_relay, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // let the others go
+                }
+            } else {
+                for (int it = 0; it < (1 << 24); it++) {
+                    const uint32_t f = __hip_atomic_load(a.d_relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (f == 0xffffffffu) break;
+                    if ((int32_t)(f - want) >= 0) { good = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (good) {
+#pragma unroll
+                    for (int l = 0; l < 8; l++) t.l[l] = __hip_atomic_load(a.d_relay + 8 + 8 * (r & 1) + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            ts = t;
+            ok = good;
+        }
+        __syncthreads();
+        if (!ok) return;
+        const Fr t = ts;
+        if (i < np) {
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                if (q < g.n_in) xch[q][i] = fr_add(p0[q], fr_mul(t, fr_sub(p1[q], p0[q])));
+        }
+        __syncthreads();
+        np >>= 1;
+        if (i < np) {
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                if (q < g.n_in) { p0[q] = xch[q][2 * i]; p1[q] = xch[q][2 * i + 1]; }
+        }
+    }
+    // finals: the single element left of every input column of this segment
+    if (h == 0) {
+        if (i < (uint32_t)g.n_in) {
+            const Fr v = xch[i][0];
+#pragma unroll
+            for (int l = 0; l < 8; l++) __hip_atomic_store(&a.h_finals[g.in[i]].l[l], v.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (i == 0) __hip_atomic_store(a.h_fin_seq + sgi, a.ticket0 + (uint32_t)a.nrounds, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ lean large-round kernels
 // The generic kernels above keep every segment's inputs, outputs and both evaluation points live at once (256 VGPRs plus
 // AGPR spills: one wave per SIMD, ~45 G mul/s).  Large rounds of single-primitive layers -- every bintree layer and every
@@ -740,9 +872,9 @@ struct RoundScratch {
     int32_t init(hipStream_t s) {
         int32_t rc = partial.alloc((size_t)SC_MAX_BLOCKS * 3 * sizeof(Fr));
         if (rc) return rc;
-        rc = counter.alloc(128);  // [0] last-block counter, [64..96) the device copy of a pre-enqueued fold's challenge
-        if (rc) return rc;
-        GM_HIP(hipMemsetAsync(counter.p, 0, 128, s));
+        rc = counter.alloc(256);  // [0] last-block counter, [64..96) the device copy of a pre-enqueued fold's challenge,
+        if (rc) return rc;        // [128..224) the relay of k_tail_rounds
+        GM_HIP(hipMemsetAsync(counter.p, 0, 256, s));
         if (shared_pinned()) {
             h_result = shared_pinned();
             own_pinned = false;
@@ -840,6 +972,30 @@ static int32_t gather_finals(const Fr* const* cur, int k, hipStream_t s, std::ve
     for (int i = 0; i < k; i++) (*out)[i] = st.h[i];
     return GM_OK;
 }
+
+// pinned staging of k_tail_rounds: one per host thread, kept for the life of the process
+struct TailStage {
+    char* base = nullptr;
+    Fr* part() const { return reinterpret_cast<Fr*>(base); }                          // 64 partial sums
+    Fr* finals() const { return reinterpret_cast<Fr*>(base) + 64; }                   // GM_MAX_COLS finals
+    Fr* t() const { return reinterpret_cast<Fr*>(base) + 64 + GM_MAX_COLS; }          // 4 challenge slots
+    uint32_t* seq() const { return reinterpret_cast<uint32_t*>(t() + 4); }            // 64 words
+    uint32_t* fin_seq() const { return seq() + 64; }                                  // GM_MAX_SEGS words
+    uint32_t* ticket() const { return fin_seq() + GM_MAX_SEGS; }
+    uint32_t* status() const { return ticket() + 16; }
+    uint32_t counter = 0;
+    static constexpr size_t BYTES = (64 + GM_MAX_COLS + 4) * sizeof(Fr) + (64 + GM_MAX_SEGS + 32) * 4;
+};
+static int32_t tail_stage(TailStage** out) {
+    static thread_local TailStage st;
+    if (!st.base) {
+        GM_HIP(hipHostMalloc((void**)&st.base, TailStage::BYTES, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(st.base, 0, TailStage::BYTES);
+    }
+    *out = &st;
+    return GM_OK;
+}
+static constexpr uint32_t TAIL_MAX_PAIRS = 256;
 
 // grid for a round: x over pairs (grid-stride beyond the cap), y = sub-units in split mode
 static uint64_t sc_split_max_pairs() {
@@ -1209,8 +1365,94 @@ struct ScDenseDeg2 : gm_sc {
         k_seq[round & 63] = fc.seq;
         return GM_OK;
     }
+    // ---- persistent tail (see k_tail_rounds): rounds [tail_r0, num_vars) run inside one launch
+    bool tail_active = false;
+    uint32_t tail_r0 = 0, tail_ticket0 = 0;
+    TailStage* tail = nullptr;
+    static bool tail_enabled() {
+        static const bool v = [] { const char* e = getenv("GM_SC_NO_TAIL"); return !(e && e[0] == '1'); }();
+        return v;
+    }
+    // cp: the columns as they are at round r0 (npairs0 pairs); everything before it in the stream has been enqueued
+    int32_t launch_tail(const ColPtrs& cp, uint32_t r0, uint64_t npairs0) {
+        int32_t rc = tail_stage(&tail);
+        if (rc) return rc;
+        TailArgs a;
+        memset(&a, 0, sizeof(a));
+        const int nr = (int)(num_vars - r0);
+        if (nr < 1 || nr > 10 || (1ull << (nr - 1)) != npairs0) return set_err(GM_ERR_STATE, "tail rounds: inconsistent shape");
+        const uint64_t g0 = glob_off >> (r0 - round_idx);   // glob_off at round r0
+        for (int q = 0; q < nr; q++) a.eq[q] = eq_level(num_vars - 1 - (r0 + q)) + (g0 >> (q + 1));
+        if (tail->counter > 0x7fff0000u) {   // tickets compare as signed differences: restart well before the wrap
+            tail->counter = 0;               // (no launch of this thread is waiting: objects run one after the other)
+            *reinterpret_cast<volatile uint32_t*>(tail->ticket()) = 0;
+        }
+        tail->counter += (uint32_t)nr + 2;
+        tail_ticket0 = tail->counter - (uint32_t)nr - 1;
+        a.h_part = tail->part(); a.h_seq = tail->seq(); a.h_finals = tail->finals(); a.h_fin_seq = tail->fin_seq();
+        a.h_t = tail->t(); a.h_ticket = tail->ticket(); a.h_status = tail->status();
+        a.d_relay = reinterpret_cast<uint32_t*>(static_cast<char*>(rs.counter.p) + 128);
+        a.ticket0 = tail_ticket0; a.nrounds = nr; a.npairs0 = (uint32_t)npairs0;
+        GM_HIP(hipMemsetAsync(a.d_relay, 0, 96, stream));
+        hipLaunchKernelGGL(k_tail_rounds, dim3(2 * sp.nseg), dim3(256), 0, stream, sp, cp, d_gamma.fr(), a);
+        GM_LAUNCH_CHECK();
+        tail_active = true;
+        tail_r0 = r0;
+        return GM_OK;
+    }
+    static bool spin_for(volatile uint32_t* slot, uint32_t want) {
+        for (int spin = 0; spin < 400000; spin++) {
+            if (*slot == want) return true;
+            __builtin_ia32_pause();
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20))
+            for (int spin = 0; spin < 10000; spin++) {
+                if (*slot == want) return true;
+                __builtin_ia32_pause();
+            }
+        return false;
+    }
+    int32_t tail_round_sums(Fr* s1, Fr* s2) {
+        const uint32_t want = tail_ticket0 + (round_idx - tail_r0);
+        const int ny = 2 * sp.nseg;
+        for (int y = 0; y < ny; y++)
+            if (!spin_for(tail->seq() + y, want)) return set_err(GM_ERR_STATE, "tail round result did not arrive within 20 s");
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*reinterpret_cast<volatile uint32_t*>(tail->status())) return set_err(GM_ERR_STATE, "the tail kernel timed out waiting for a challenge");
+        *s1 = fr_zero(); *s2 = fr_zero();
+        for (int y = 0; y < ny; y++) {
+            const Fr v = tail->part()[y];
+            if (y & 1) *s2 = fr_add(*s2, v); else *s1 = fr_add(*s1, v);
+        }
+        return GM_OK;
+    }
+    void tail_publish(const Fr& t) {
+        const uint32_t r = round_idx - tail_r0;
+        tail->t()[r & 3] = t;
+        std::atomic_thread_fence(std::memory_order_release);
+        *reinterpret_cast<volatile uint32_t*>(tail->ticket()) = tail_ticket0 + r;
+    }
+
     int32_t unipoly_pipelined(std::vector<Fr>* coeffs, uint64_t npairs, const Fr* eq_cur, const ColPtrs& cp) {
         const uint32_t r = round_idx;
+        const bool tail_ok = tail_enabled() && sp.nseg <= 32 && (rs.own_pinned || pinned_exclusive());
+        if (!tail_active && tail_ok && npairs <= TAIL_MAX_PAIRS && k_enq <= r) {
+            int32_t rc = launch_tail(cp, r, npairs);   // the object starts small: everything runs in the tail
+            if (rc) return rc;
+            k_enq = num_vars;
+        }
+        if (tail_active && r >= tail_r0) {
+            Fr a1, a2;
+            int32_t rc = tail_round_sums(&a1, &a2);
+            if (rc) return rc;
+            const Fr total1 = fr_mul(a1, multiplier), total2 = fr_mul(a2, multiplier);
+            if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);
+            cached = from12_inv(total1, total2, point.back(), inv_eq0[point.size() - 1], claim_);
+            has_cached = true;
+            *coeffs = cached;
+            return GM_OK;
+        }
         if (k_enq <= r) {  // the first small round of this object: nothing was enqueued ahead
             int32_t rc = launch_small_round(cp, eq_cur, npairs, r);
             if (rc) return rc;
@@ -1231,10 +1473,16 @@ struct ScDenseDeg2 : gm_sc {
             hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(n_out, 256), cols.k), dim3(256), 0, stream, ci, co, n_out, d_t);
             GM_LAUNCH_CHECK();
             fold_pending = true;
-            const Fr* eq_next = eq_level(num_vars - 2 - r) + (glob_off >> 2);
-            int32_t rc = launch_small_round(cn, eq_next, npairs >> 1, r + 1);
-            if (rc) return rc;
-            k_enq = r + 2;
+            if (tail_ok && (npairs >> 1) <= TAIL_MAX_PAIRS) {   // everything after this fold runs in one launch
+                int32_t rc = launch_tail(cn, r + 1, npairs >> 1);
+                if (rc) return rc;
+                k_enq = num_vars;
+            } else {
+                const Fr* eq_next = eq_level(num_vars - 2 - r) + (glob_off >> 2);
+                int32_t rc = launch_small_round(cn, eq_next, npairs >> 1, r + 1);
+                if (rc) return rc;
+                k_enq = r + 2;
+            }
         }
         Fr acc[4];
         int32_t rc = rs.finish_seq(k_seq[r & 63], 2, stream, acc, !fold_pending);
@@ -1248,15 +1496,28 @@ struct ScDenseDeg2 : gm_sc {
         return GM_OK;
     }
     ~ScDenseDeg2() override {
-        if (fold_pending) {  // never leave a waiting kernel behind: release it and let the queue drain
-            rs.publish(round_idx, fr_zero(), fold_ticket);
-            (void)hipStreamSynchronize(stream);
+        const bool tail_waiting = tail_active && round_idx < num_vars;
+        if (fold_pending) rs.publish(round_idx, fr_zero(), fold_ticket);  // never leave a waiting kernel behind
+        if (tail_waiting) {   // a ticket past every round of this launch lets all its waits through
+            std::atomic_thread_fence(std::memory_order_release);
+            *reinterpret_cast<volatile uint32_t*>(tail->ticket()) = tail_ticket0 + (num_vars - tail_r0);
         }
+        if (fold_pending || tail_waiting) (void)hipStreamSynchronize(stream);
     }
 
     int32_t bind(const Fr& t) override {
         if (!has_cached) return set_err(GM_ERR_STATE, "bind before unipoly (dense_eq.rs:105 unwrap)");
         multiplier = fr_mul(multiplier, eq_bind_factor(point.back(), t));
+        if (tail_active && round_idx >= tail_r0) {   // the fold happens inside the tail kernel
+            tail_publish(t);
+            point.pop_back();
+            round_idx++;
+            loc_vars--;
+            glob_off >>= 1;
+            claim_ = evaluate_univar(cached, t);
+            has_cached = false;
+            return GM_OK;
+        }
         if (fold_pending) {
             rs.publish(round_idx, t, fold_ticket);   // the waiting fold and the next round kernel take it from here
             fold_pending = false;
@@ -1285,6 +1546,15 @@ struct ScDenseDeg2 : gm_sc {
     }
 
     int32_t final_evals(std::vector<Fr>* out) override {
+        if (tail_active) {
+            if (round_idx != num_vars) return set_err(GM_ERR_STATE, "final_evals before the last round");
+            const uint32_t want = tail_ticket0 + (num_vars - tail_r0);
+            for (int sg = 0; sg < sp.nseg; sg++)
+                if (!spin_for(tail->fin_seq() + sg, want)) return set_err(GM_ERR_STATE, "tail final evaluations did not arrive within 20 s");
+            std::atomic_thread_fence(std::memory_order_acquire);
+            out->assign(tail->finals(), tail->finals() + cols.k);
+            return GM_OK;
+        }
         return gather_finals(cols.cur.data(), cols.k, stream, out);
     }
 };
