@@ -17,6 +17,7 @@
 // finds its row by binary search in the offsets table.  Each level is one launch; the three layer
 // functions l1/l2/l3 are fused in registers (the per-layer outputs are only materialised by the
 // witness builder in witness.hip, which the sumcheck needs; the MSM does not).
+#include <algorithm>
 #include <vector>
 
 #include "algfn.cuh"
@@ -765,6 +766,18 @@ __global__ void __launch_bounds__(256) k_neg_count_to_fr(const uint32_t* __restr
     fr_store(out + i, fr_neg(fr_from_u64(cnt[i])));
 }
 
+// out[k] = -(number of entries of sorted[0..n) greater than k)
+__global__ void __launch_bounds__(256) k_ac_c_from_sorted(const uint32_t* __restrict__ sorted, uint32_t n, uint64_t N, Fr* __restrict__ out) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    uint32_t lo = 0, hi = n;   // first index with sorted[i] > k
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sorted[mid] <= k) lo = mid + 1; else hi = mid;
+    }
+    fr_store(out + k, fr_neg(fr_from_u64(n - lo)));
+}
+
 __global__ void __launch_bounds__(256) k_pull(const uint16_t* __restrict__ dg, const uint32_t* __restrict__ ct, uint64_t n,
                                                const Fr* __restrict__ eq_d, const Fr* __restrict__ eq_c,
                                                Fr* __restrict__ d_pull, Fr* __restrict__ c_pull) {
@@ -790,29 +803,24 @@ extern "C" int32_t gm_msm_phase1_polys(const gm_msm_plan* p, uint64_t* d_c, uint
     // access counts (pushforward.rs:496-508) from the bucket populations instead of 2^25 contended atomics:
     //   ac_d[digit] = sum over windows of the population of bucket (window, digit)
     //   ac_c[k]     = number of buckets with more than k points (counter value k occurs once in each of them)
+    //               = nrows - upper_bound(sorted populations, k): the host sorts the nrows populations (a few thousand),
+    //                 the device does one binary search per k
     uint32_t* cnt = nullptr;
-    const uint64_t nc = p->N + p->nd;
+    const uint64_t nc = (uint64_t)p->nrows + p->nd;
     GM_HIP(dev_alloc((void**)&cnt, nc * 4));
     {
         std::vector<uint32_t> rl(p->nrows), h(nc, 0);
         GM_HIP(hipMemcpyAsync(rl.data(), p->row_len, (size_t)p->nrows * 4, hipMemcpyDeviceToHost, s));
         GM_HIP(hipStreamSynchronize(s));
-        std::vector<uint32_t> by_len(p->N + 2, 0);
-        for (uint32_t r = 0; r < p->nrows; r++) {
-            h[p->N + (r % p->nd)] += rl[r];
-            by_len[rl[r]]++;
-        }
-        uint32_t longer = 0;  // buckets with population > k, walking k down from N
-        for (uint64_t k = p->N; k-- > 0;) {
-            longer += by_len[k + 1];
-            h[k] = longer;
-        }
+        for (uint32_t r = 0; r < p->nrows; r++) h[p->nrows + (r % p->nd)] += rl[r];
+        std::sort(rl.begin(), rl.end());
+        memcpy(h.data(), rl.data(), (size_t)p->nrows * 4);
         GM_HIP(hipMemcpyAsync(cnt, h.data(), nc * 4, hipMemcpyHostToDevice, s));
         GM_HIP(hipStreamSynchronize(s));
     }
-    hipLaunchKernelGGL(k_neg_count_to_fr, dim3(ceil_div(p->N, 256)), dim3(256), 0, s, cnt, p->N, reinterpret_cast<Fr*>(d_ac_c));
+    hipLaunchKernelGGL(k_ac_c_from_sorted, dim3(ceil_div(p->N, 256)), dim3(256), 0, s, cnt, p->nrows, p->N, reinterpret_cast<Fr*>(d_ac_c));
     GM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_neg_count_to_fr, dim3(ceil_div(p->nd, 256)), dim3(256), 0, s, cnt + p->N, (uint64_t)p->nd,
+    hipLaunchKernelGGL(k_neg_count_to_fr, dim3(ceil_div(p->nd, 256)), dim3(256), 0, s, cnt + p->nrows, (uint64_t)p->nd,
                        reinterpret_cast<Fr*>(d_ac_d));
     GM_LAUNCH_CHECK();
     GM_HIP(hipStreamSynchronize(s));

@@ -52,6 +52,29 @@ namespace {
         if (rc__) return rc__;      \
     } while (0)
 
+// GM_PROVE_TIMING=1: wall time of the stages of the whole-protocol drivers on stderr (development aid; each mark
+// synchronises the stream)
+struct StageTimer {
+    const char* who;
+    hipStream_t s;
+    bool on;
+    std::chrono::steady_clock::time_point prev;
+    StageTimer(const char* w, hipStream_t st) : who(w), s(st) {
+        static const bool v = [] { const char* e = getenv("GM_PROVE_TIMING"); return e && e[0] == '1'; }();
+        on = v;
+        if (on) { (void)hipStreamSynchronize(s); prev = std::chrono::steady_clock::now(); }
+    }
+    void mark(const char* name) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gm %s] %-24s %8.2f ms   (pool misses so far: %llu, %.1f MiB)\n", who, name,
+                std::chrono::duration<double, std::milli>(now - prev).count(), (unsigned long long)dev_pool().n_driver_allocs,
+                dev_pool().driver_alloc_bytes / 1048576.0);
+        prev = now;
+    }
+};
+
 struct VVHolder {
     gm_vv* v = nullptr;
     VVHolder() = default;
@@ -664,6 +687,7 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     std::vector<Fr> r(y_log + d_log + x_log), evs(3);
     memcpy(r.data(), h_claim_point, r.size() * sizeof(Fr));
     memcpy(evs.data(), h_claim_evs, 3 * sizeof(Fr));
+    StageTimer pf_timer("pushforward", s);
     evs[1] = fr_sub(evs[1], fr_one());  // claims.evs[1] -= 1 (pushforward.rs:641)
 
     // phase-1 / phase-2 columns, padded with zeros to 2^mlog (pushforward.rs:706-709)
@@ -676,8 +700,11 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     if (M > msize) {
         for (auto* b : {&c, &d, &c_pull, &d_pull}) GM_HIP(hipMemsetAsync((*b)->fr() + msize, 0, (M - msize) * sizeof(Fr), s));
     }
+    pf_timer.mark("alloc");
     TRY(gm_msm_phase1_polys(plan, (uint64_t*)c->p, (uint64_t*)d->p, (uint64_t*)ac_c->p, (uint64_t*)ac_d->p, stream));
+    pf_timer.mark("phase1 polys");
     TRY(gm_msm_second_phase(plan, h_claim_point, y_log, (uint64_t*)c_pull->p, (uint64_t*)d_pull->p, stream));
+    pf_timer.mark("second phase");
 
     // challenges (pushforward.rs:684-685)
     Fr psi, tau_c, tau_d, tau_s, gamma;
@@ -717,6 +744,7 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
         hipLaunchKernelGGL(k_pf_table, dim3(ceil_div(D, 256)), dim3(256), 0, s, eq_d, psi, tau_d, D, table_d->fr());
         GM_LAUNCH_CHECK();
     }
+    pf_timer.mark("adj + tables");
     // suppression_term_total = 2 (2^mlog - matrix_size) / tau_suppression_term (pushforward.rs:730)
     const Fr supp_total = fr_mul(fr_from_u64(2 * (M - msize)), fr_inv(tau_s));
 
@@ -765,9 +793,11 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     GM_REQUIRE(fr_eq(nd[0], fr_mul(nd[1], supp_total)), "logup total does not match the suppression term (logup_mainphase.rs:162)");
     tr->write_scalars({nd[0], nd[1]});
 
+    pf_timer.mark("logup witness");
     // workspace of the sumcheck objects: fold buffers of the widest layer + eq levels
     Arena arena;
     TRY(arena.init((size_t)32 * (5 * (M / 2 + M / 4) + 2 * M) + ((size_t)64 << 20)));
+    pf_timer.mark("arena");
     Fr* pinned = nullptr;
     GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
     memset(pinned, 0, 16 * sizeof(Fr));
@@ -835,6 +865,7 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     TRY(split_at_prove(tr, &cd, true, 0, 2));   // SplitAt(HI(0), 2) (pushforward.rs:744-746)
     GM_REQUIRE(cd.evs.size() == 2 && cd.point.size() == mlog, "cd claims have the wrong shape");
 
+    pf_timer.mark("logup prove");
     // ---- combined sumcheck (pushforward.rs:748-801)
     const Fr g1 = gamma, g2 = fr_mul(gamma, gamma);
     TRY(mk(M, &p_sel));
@@ -911,6 +942,7 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     out_matrix->point = out_pt;
     out_matrix->evs = {p_folded_ev, c_pull_ev, d_pull_ev, c_ev, d_ev};
     tr->write_scalars(out_matrix->evs);
+    pf_timer.mark("combined sumcheck");
     *out_gamma = gamma;
     if (keep) { keep->c = c; keep->d = d; keep->c_pull = c_pull; keep->d_pull = d_pull; keep->ac_c = ac_c; keep->ac_d = ac_d; }
     return GM_OK;
@@ -1196,18 +1228,8 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     hipStream_t s = st->stream;
     void* stream = reinterpret_cast<void*>(s);
     GM_REQUIRE(y_log >= clm, "commitment_log_multiplicity exceeds y_logsize");
-    // GM_PROVE_TIMING=1: wall time of every stage on stderr (development aid; adds a stream synchronisation per stage)
-    static const bool timing = [] { const char* e = getenv("GM_PROVE_TIMING"); return e && e[0] == '1'; }();
-    auto t_prev = std::chrono::steady_clock::now();
-    auto stage = [&](const char* name) {
-        if (!timing) return;
-        (void)hipStreamSynchronize(s);
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[gm prove] %-22s %8.2f ms   (pool misses so far: %llu, %.1f MiB)\n", name,
-                std::chrono::duration<double, std::milli>(now - t_prev).count(), (unsigned long long)dev_pool().n_driver_allocs,
-                dev_pool().driver_alloc_bytes / 1048576.0);
-        t_prev = now;
-    };
+    StageTimer timer("prove", s);
+    auto stage = [&](const char* name) { timer.mark(name); };
     // phase-1 commitments onto the transcript (pippenger.rs:131-136)
     tr->write_points(st->comm_c.data(), n_mat);
     tr->write_points(st->comm_d.data(), n_mat);

@@ -1120,6 +1120,13 @@ static std::vector<Fr> make_gamma_pows(const Fr& gamma, int count) {
 }
 
 // ---- DenseSumcheckObjectSO (sumcheck.rs:237-347) ------------------------------------------------
+struct ScDensePipe {
+    static bool enabled() {
+        static const bool v = [] { const char* e = getenv("GM_SC_NO_PIPELINE"); return !(e && e[0] == '1'); }();
+        return v;
+    }
+};
+
 struct ScDense : gm_sc {
     int kind = 0;  // 0: EqWrapper(GammaWrapper(f, gamma)) with the eq column last; 1: Prod3
     SegPlan sp{};
@@ -1167,6 +1174,59 @@ struct ScDense : gm_sc {
         return GM_OK;
     }
 
+    // ---- pre-enqueued small rounds, as in ScDenseDeg2
+    uint32_t k_enq = 0;
+    uint32_t k_seq[64] = {};
+    bool fold_pending = false;
+    uint32_t fold_ticket = 0;
+    std::vector<Fr*> fold_dst;
+    int32_t launch_round(const Fr* const* cur_cols, uint64_t npairs, uint32_t round) {
+        ColPtrs cp;
+        for (int i = 0; i < cols.k; i++) cp.p[i] = cur_cols[i];
+        const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
+        const int ny = split ? D * (kind == 1 ? 1 : sp.nseg) : 1;
+        const dim3 grid = round_grid(npairs, ny);
+        const FinishCtx fc = rs.ctx();
+        const int lean = (kind == 0 && D == 3 && !split && cols.k <= 7) ? lean_prim_of(sp) : 0;
+        if (kind == 2) {
+            FoldedCols fcols;
+            for (int i = 0; i < cols.k; i++) fcols.p[i] = cur_cols[i];
+            hipLaunchKernelGGL(k_round_folded_prod, round_grid(npairs, 1), dim3(SC_THREADS), 0, stream, fcols, cols.k / 2,
+                               d_gamma.fr(), npairs, fc);
+        } else if (kind == 1 && D == 3 && !split) {
+            LeanCols lc;
+            for (int i = 0; i < 3; i++) lc.p[i] = cur_cols[i];
+            hipLaunchKernelGGL(k_round_prod3_lean, grid, dim3(SC_THREADS), 0, stream, lc, npairs, fc);
+        } else if (lean && lean != LEAN_AFF_L1_BC) {
+            LeanCols lc;
+            for (int i = 0; i < cols.k; i++) lc.p[i] = cur_cols[i];
+            int32_t rc = launch_generic3_lean(lean, grid, stream, lc, d_gamma.fr(), npairs, fc);
+            if (rc) return rc;
+        } else if (D == 3 && split)
+            hipLaunchKernelGGL((k_round_generic<3, true>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                               d_gamma.fr(), npairs, fc);
+        else if (D == 3)
+            hipLaunchKernelGGL((k_round_generic<3, false>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                               d_gamma.fr(), npairs, fc);
+        else if (D == 2 && split)
+            hipLaunchKernelGGL((k_round_generic<2, true>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                               d_gamma.fr(), npairs, fc);
+        else if (D == 2)
+            hipLaunchKernelGGL((k_round_generic<2, false>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
+                               d_gamma.fr(), npairs, fc);
+        else
+            return set_err(GM_ERR_INVALID, "unsupported degree %d", D);
+        GM_LAUNCH_CHECK();
+        k_seq[round & 63] = fc.seq;
+        return GM_OK;
+    }
+    ~ScDense() override {
+        if (fold_pending) {  // never leave a waiting gate behind
+            rs.publish(round_idx, fr_zero(), fold_ticket);
+            (void)hipStreamSynchronize(stream);
+        }
+    }
+
     int32_t unipoly(std::vector<Fr>* coeffs) override {
         if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended (sumcheck.rs:279)");
         if (!has_cached) {
@@ -1175,45 +1235,36 @@ struct ScDense : gm_sc {
                 if (rc) return rc;
             }
             const uint64_t npairs = 1ull << (loc_vars - 1);
-            ColPtrs cp;
-            for (int i = 0; i < cols.k; i++) cp.p[i] = cols.cur[i];
             const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
-            const int ny = split ? D * (kind == 1 ? 1 : sp.nseg) : 1;
-            const dim3 grid = round_grid(npairs, ny);
-            const FinishCtx fc = rs.ctx();
-            const int lean = (kind == 0 && D == 3 && !split && cols.k <= 7) ? lean_prim_of(sp) : 0;
-            if (kind == 2) {
-                FoldedCols fcols;
-                for (int i = 0; i < cols.k; i++) fcols.p[i] = cols.cur[i];
-                hipLaunchKernelGGL(k_round_folded_prod, round_grid(npairs, 1), dim3(SC_THREADS), 0, stream, fcols, cols.k / 2,
-                                   d_gamma.fr(), npairs, fc);
-            } else if (kind == 1 && D == 3 && !split) {
-                LeanCols lc;
-                for (int i = 0; i < 3; i++) lc.p[i] = cols.cur[i];
-                hipLaunchKernelGGL(k_round_prod3_lean, grid, dim3(SC_THREADS), 0, stream, lc, npairs, fc);
-            } else if (lean && lean != LEAN_AFF_L1_BC) {
-                LeanCols lc;
-                for (int i = 0; i < cols.k; i++) lc.p[i] = cols.cur[i];
-                int32_t rc = launch_generic3_lean(lean, grid, stream, lc, d_gamma.fr(), npairs, fc);
+            const bool piped = split && !sh.comm && ScDensePipe::enabled() && (rs.own_pinned || pinned_exclusive() || k_enq > round_idx);
+            if (k_enq <= round_idx) {
+                int32_t rc = launch_round(cols.cur.data(), npairs, round_idx);
                 if (rc) return rc;
-            } else if (D == 3 && split)
-                hipLaunchKernelGGL((k_round_generic<3, true>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
-                                   d_gamma.fr(), npairs, fc);
-            else if (D == 3)
-                hipLaunchKernelGGL((k_round_generic<3, false>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
-                                   d_gamma.fr(), npairs, fc);
-            else if (D == 2 && split)
-                hipLaunchKernelGGL((k_round_generic<2, true>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
-                                   d_gamma.fr(), npairs, fc);
-            else if (D == 2)
-                hipLaunchKernelGGL((k_round_generic<2, false>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
-                                   d_gamma.fr(), npairs, fc);
-            else
-                return set_err(GM_ERR_INVALID, "unsupported degree %d", D);
-            GM_LAUNCH_CHECK();
+                k_enq = round_idx + 1;
+            }
+            if (piped && !fold_pending && round_idx + 1 < num_vars && k_enq == round_idx + 1) {
+                // small rounds: enqueue this round's fold behind a gate (k_fold_gate) and the next round's kernel now
+                cols.next(&fold_dst);
+                ColPtrs ci;
+                ColPtrsMut co;
+                std::vector<const Fr*> cn(cols.k);
+                for (int i = 0; i < cols.k; i++) { ci.p[i] = cols.cur[i]; co.p[i] = fold_dst[i]; cn[i] = fold_dst[i]; }
+                fold_ticket = ++RoundScratch::ticket_counter();
+                if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
+                Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
+                hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(round_idx), rs.ticket_word(), fold_ticket,
+                                   rs.ticket_word() + 1, d_t);
+                hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(npairs, 256), cols.k), dim3(256), 0, stream, ci, co, npairs, d_t);
+                GM_LAUNCH_CHECK();
+                fold_pending = true;
+                int32_t rc = launch_round(cn.data(), npairs >> 1, round_idx + 1);
+                if (rc) return rc;
+                k_enq = round_idx + 2;
+            }
             Fr acc[4];
-            int32_t rc = rs.finish(D, stream, acc);
+            int32_t rc = rs.finish_seq(k_seq[round_idx & 63], D, stream, acc, !fold_pending);
             if (rc) return rc;
+            if (rs.ticket_word()[1]) return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge");
             if (sh.comm) {
                 rc = shard_sum_fr(sh, acc, D);
                 if (rc) return rc;
@@ -1231,12 +1282,18 @@ struct ScDense : gm_sc {
     int32_t bind(const Fr& t) override {
         if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended (sumcheck.rs:264)");
         if (!has_cached) return set_err(GM_ERR_STATE, "should evaluate unipoly before binding (sumcheck.rs:271)");
-        std::vector<Fr*> dst;
-        cols.next(&dst);
-        const uint64_t n_out = 1ull << (loc_vars - 1);
-        int32_t rc = launch_dense_fold(cols.cur.data(), dst.data(), cols.k, n_out, t, stream);
-        if (rc) return rc;
-        cols.commit(dst);
+        if (fold_pending) {
+            rs.publish(round_idx, t, fold_ticket);
+            fold_pending = false;
+            cols.commit(fold_dst);
+        } else {
+            std::vector<Fr*> dst;
+            cols.next(&dst);
+            const uint64_t n_out = 1ull << (loc_vars - 1);
+            int32_t rc = launch_dense_fold(cols.cur.data(), dst.data(), cols.k, n_out, t, stream);
+            if (rc) return rc;
+            cols.commit(dst);
+        }
         round_idx++;
         loc_vars--;
         claim_ = evaluate_univar(cached, t);

@@ -30,7 +30,7 @@ nv = x_log + clm
 d_basis = H.g1_gen_points((2 << nv) - 1, 7)
 d_inv = H.knuckles_setup(2, nv)
 P = codec.P
-for it in range(2):
+for it in range(int(os.environ.get("ITERS", "2"))):
     torch.cuda.synchronize()
     t = time.time()
     plan.run(d_pts, d_sc)
