@@ -22,6 +22,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -445,6 +446,27 @@ static size_t g1_engine_bytes(uint64_t ntasks, uint32_t nkeys) {
     return L.total + al((size_t)nkeys * sizeof(G1Jac));
 }
 
+// Host-side combination loops (a few thousand G1 operations per call, ~0.5 us each) spread over a handful of threads.
+template <class F>
+static void host_parallel_for(uint32_t n, F&& body, uint32_t grain = 16) {
+    unsigned hw = std::thread::hardware_concurrency();
+    uint32_t nt = hw ? (hw > 12 ? 12 : hw) : 4;
+    if (n < 4 * grain || nt < 2) {
+        for (uint32_t i = 0; i < n; i++) body(i);
+        return;
+    }
+    if (nt > n / grain) nt = n / grain ? n / grain : 1;
+    std::vector<std::thread> th;
+    const uint32_t per = (n + nt - 1) / nt;
+    for (uint32_t t = 1; t < nt; t++)
+        th.emplace_back([&, t] {
+            const uint32_t hi = (t + 1) * per < n ? (t + 1) * per : n;
+            for (uint32_t i = t * per; i < hi; i++) body(i);
+        });
+    for (uint32_t i = 0; i < per && i < n; i++) body(i);
+    for (auto& x : th) x.join();
+}
+
 // acc = sum_pos 2^pos S[pos] on the host (Horner from the top bit)
 static G1Jac g1_horner_bits(const std::vector<G1Jac>& S) {
     G1Jac acc = g1_inf();
@@ -473,8 +495,9 @@ static int32_t g1_weighted_sums(G1Scratch& ws, const G1Jac* d_buckets, uint32_t 
     GM_HIP(hipMemcpyAsync(S.data(), d_S, (size_t)nkeys * sizeof(G1Jac), hipMemcpyDeviceToHost, s));
     GM_HIP(hipStreamSynchronize(s));
     out->resize(ngroups);
-    for (uint32_t g = 0; g < ngroups; g++)
+    host_parallel_for(ngroups, [&](uint32_t g) {
         (*out)[g] = g1_horner_bits(std::vector<G1Jac>(S.begin() + (size_t)g * nbits, S.begin() + (size_t)(g + 1) * nbits));
+    });
     return GM_OK;
 }
 static size_t g1_weighted_bytes(uint32_t ngroups, uint32_t glen) {
@@ -580,14 +603,14 @@ static int32_t g1_msm_grouped_core(const G1Jac* jac, uint64_t stride, const uint
     std::vector<G1Jac> wsum;
     rc = g1_weighted_sums(ws, buckets, ngroups * nwin, 1u << c, &wsum, s);
     if (rc) return rc;
-    for (uint32_t g = 0; g < ngroups; g++) {
+    host_parallel_for(ngroups, [&](uint32_t g) {
         G1Jac acc = g1_inf();
         for (uint32_t w = nwin; w-- > 0;) {
             for (uint32_t k = 0; k < c; k++) acc = g1_dbl(acc);
             acc = g1_add(acc, wsum[(size_t)g * nwin + w]);
         }
         h_out[g] = acc;
-    }
+    }, 2);
     return GM_OK;
 }
 

@@ -1384,7 +1384,9 @@ extern "C" int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_
     st->clm = commitment_log_multiplicity; st->stream = s;
     const uint32_t cm = 1u << st->clm;
     st->n_mat = (plan->y_size + cm - 1) / cm;
+    StageTimer wt("wg::new", s);
     TRY(pip_witness_create(plan, d_points_xy, y_logsize, nullptr, &st->w, stream));
+    wt.mark("witness");
     // outer buckets + c / d commitments
     {
         std::vector<uint32_t> rl(plan->nrows);
@@ -1406,6 +1408,7 @@ extern "C" int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_
         TRY(gm_msm_g1_outer(plan, d_kzg_basis_aff, st->clm, (uint64_t*)st->d_outer->p, (uint64_t*)st->c_outer->p,
                             (uint64_t)st->n_mat * cmax, &st->c_stride, st->comm_d.data(), st->comm_c.data(), stream));
     }
+    wt.mark("outer buckets + c/d comm");
     // p_0, p_1, ac_c, ac_d commitments (pushforward.rs:533-536)
     const uint64_t X = plan->N, D = 1ull << plan->d_log;
     st->p0.reset(new DevBuf());
@@ -1420,8 +1423,10 @@ extern "C" int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_
         const uint64_t msize = (uint64_t)plan->y_size * X;
         TRY(c.alloc(msize * sizeof(Fr))); TRY(d.alloc(msize * sizeof(Fr))); TRY(ac_c.alloc(X * sizeof(Fr))); TRY(ac_d.alloc(D * sizeof(Fr)));
         TRY(gm_msm_phase1_polys(plan, (uint64_t*)c.p, (uint64_t*)d.p, (uint64_t*)ac_c.p, (uint64_t*)ac_d.p, stream));
+        wt.mark("phase-1 polys");
         TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)st->p0->p, X, 1, 255, st->comm_p0, stream));
         TRY(gm_g1_msm(d_kzg_basis_aff, (const uint64_t*)st->p1->p, X, 1, 255, st->comm_p1, stream));
+        wt.mark("p_0, p_1 commitments");
         // ac_c / ac_d are negated access counts (pushforward.rs:507-508): commit(-v) = -commit(v) with v < 2^32, so the MSM
         // runs over 32-bit scalars and the result is negated -- the same group element at a sixth of the work
         auto commit_negated_counts = [&](DevBuf& col, uint64_t len, uint64_t* out12) -> int32_t {
@@ -1435,6 +1440,7 @@ extern "C" int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_
         };
         TRY(commit_negated_counts(ac_c, X, st->comm_ac_c));
         TRY(commit_negated_counts(ac_d, D, st->comm_ac_d));
+        wt.mark("ac_c, ac_d commitments");
     }
     *out = st.release();
     return GM_OK;
