@@ -115,6 +115,7 @@ int32_t gm_eq_table(const uint64_t* h_multiplier, const uint64_t* h_point, uint3
  *   gm_vv_slice / gm_vv_concat  &polys[a..b] / Vec::extend as used by GlueSplit::witness (splits.rs:172-176)
  *   gm_vv_to_dense            Densify::to_dense             vecvec.rs:446-476 */
 typedef struct gm_vv gm_vv;
+struct gm_msm_plan;   /* the MSM plan handle, declared with the MSM section below */
 int32_t gm_vv_from_host(uint32_t k, uint32_t nrows, const uint32_t* h_row_len, const uint64_t* const* h_data,
                         const uint64_t* h_row_pad, const uint64_t* h_col_pad, uint32_t row_logsize,
                         uint32_t col_logsize, gm_vv** out, void* stream);

@@ -123,3 +123,31 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.gm_comm_sum_fr(None, None, 0) == 1
     assert L.gm_release_cached_memory() == 0 and L.gm_g1_release_scratch() == 0   # nothing cached: no device call
     assert b"argument" in L.gm_last_error() or b"null" in L.gm_last_error() or len(L.gm_last_error()) > 0
+
+
+def test_header_is_plain_c_and_cpp():
+    """the drop-in boundary is a C ABI: the header must compile, warning-free, as C11 and as C++17"""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "gkrmsm.h")
+    for cmd in (["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+def test_verifier_entry_points_validate_arguments():
+    import ctypes as C
+    from gkr_msm_amd import ffi
+    L = ffi.lib()
+    z = C.c_void_p(None)
+    assert L.gm_pippenger_verify(4, 2, 4, 2, 0, z, z, z, z, z, 0, z, 0, z, 0, z, None) == 1          # GM_ERR_INVALID: null claims
+    assert L.gm_pippenger_verify_tr(4, 2, 4, 2, 0, z, z, z, z, None, z) == 1
+    assert L.gm_kzg_verify_pair(z, z, z) == 1 and L.gm_gkr_msm_verify_tr(3, 2, None, z, None, z, None) == 1
+    buf = (C.c_uint64 * 64)()
+    # shape checks come before any read: x_logsize < d_logsize is the reference's assert (pippenger.rs:93)
+    tape = (C.c_uint64 * 4)()
+    assert L.gm_pippenger_verify(2, 3, 4, 2, 0, buf, buf, buf, buf, buf, 0, buf, 0, tape, 1, buf, None) == 1
+    # an empty proof is rejected, not crashed on
+    assert L.gm_pippenger_verify(4, 2, 4, 2, 0, buf, buf, buf, buf, buf, 0, buf, 0, tape, 1, buf, None) == 5   # GM_ERR_VERIFY
+    assert b"ran out of points" in L.gm_last_error()
+    assert L.gm_gkr_msm_verify(3, 2, buf, 0, tape, 1, buf, None, buf, None, None) == 5
