@@ -69,7 +69,10 @@ def run_rounds(gpu, ref, num_rounds, rng):
 
 
 @pytest.mark.parametrize("name,nv", [("proj_l1", 6), ("proj_l2", 5), ("proj_l3", 7), ("tri_l1_r2", 4), ("l2_r5", 3),
-                                     ("l3_r5", 5), ("proj_l1", 1), ("aff_l1_bc", 4)])
+                                     ("l3_r5", 5), ("proj_l1", 1), ("aff_l1_bc", 4),
+                                     # 9 variables: the whole object runs in the persistent tail kernel; 10 and 12: pre-enqueued
+                                     # (gated) folds first, then the hand-over to the tail; tri_l1_r2 has 9 segments
+                                     ("proj_l2", 9), ("aff_l1_bc", 10), ("proj_l3", 12), ("tri_l1_r2", 11)])
 def test_dense_deg2_sumcheck_object(name, nv):
     fn, pyf = FN[name]
     rng = F.SplitMix64(100 + nv)
