@@ -7,7 +7,7 @@ OBJ := $(patsubst gkr_msm_amd/csrc/%.hip,build/%.o,$(SRC))
 HDR := $(wildcard gkr_msm_amd/csrc/*.inc) $(wildcard gkr_msm_amd/csrc/*.cuh) $(wildcard gkr_msm_amd/csrc/*.hpp) include/gkrmsm.h
 LIB := gkr_msm_amd/libgkrmsm_hip.so
 
-all: $(LIB) oracle
+all: $(LIB) oracle examples
 
 $(LIB): $(OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
@@ -19,8 +19,14 @@ build/%.o: gkr_msm_amd/csrc/%.hip $(HDR)
 oracle:
 	$(MAKE) -s -C oracle
 
+# plain C callers of the C ABI (no HIP headers, no C++): gcc only
+examples: build/examples/pippenger
+build/examples/pippenger: examples/pippenger.c include/gkrmsm.h $(LIB)
+	@mkdir -p build/examples
+	gcc -std=c11 -O2 -Wall -Wextra -D_POSIX_C_SOURCE=199309L -Iinclude $< -o $@ -Lgkr_msm_amd -lgkrmsm_hip -Wl,-rpath,'$$ORIGIN/../../gkr_msm_amd'
+
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle examples clean

@@ -708,6 +708,22 @@ extern "C" int32_t gm_g1_gen_points(uint64_t* d_points_aff, uint64_t n, uint64_t
     return GM_OK;
 }
 
+// the standard G1 generator in the affine wire form
+extern "C" int32_t gm_g1_generator(uint64_t* h_out_aff) {
+    GM_REQUIRE(h_out_aff, "null argument");
+    static const uint32_t X[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+                                   0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
+    static const uint32_t Y[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
+                                   0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+    G1Aff g;
+    for (int i = 0; i < 12; i++) { g.x.l[i] = X[i]; g.y.l[i] = Y[i]; }
+    g.x = fq_to_mont(g.x);
+    g.y = fq_to_mont(g.y);
+    GM_REQUIRE(g1_aff_on_curve(g), "generator constant is wrong");
+    memcpy(h_out_aff, &g, sizeof(G1Aff));
+    return GM_OK;
+}
+
 extern "C" int32_t gm_g1_mock_srs(const uint64_t* h_tau, const uint64_t* h_g0_aff, uint64_t n, uint64_t* d_out_aff, void* stream) {
     GM_REQUIRE(h_tau && h_g0_aff && d_out_aff, "null argument");
     if (n == 0) return GM_OK;

@@ -57,7 +57,7 @@ void keccak_f1600(uint64_t st[25]) {
 // STROBE-128 as merlin uses it (merlin/src/strobe.rs)
 struct Strobe128 {
     static constexpr int R = 166;
-    static constexpr uint8_t FI = 1, FA = 2, FC = 4, FT = 8, FM = 16, FK = 32;
+    static constexpr uint8_t FI = 1, FA = 2, FC = 4, FM = 16, FK = 32;   // STROBE flags (T = 8 is unused by merlin)
     uint8_t st[200];
     uint8_t pos = 0, pos_begin = 0, cur_flags = 0;
     void permute() {

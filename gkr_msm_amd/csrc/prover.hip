@@ -512,6 +512,28 @@ extern "C" int32_t gm_pip_witness_outputs(const gm_pip_witness* w, const uint64_
     return GM_OK;
 }
 
+// "claim computation" of run_pippenger (pippenger.rs:531-541): evaluate_poly(output, r) for every column of the dense output
+extern "C" int32_t gm_pip_witness_claims(const gm_pip_witness* w, const uint64_t* h_point, uint64_t* h_evs, uint32_t* n_evs) {
+    GM_REQUIRE(w && h_point && h_evs, "null argument");
+    const uint64_t len = w->dense_output.len;
+    GM_REQUIRE(len == (1ull << w->y_log), "dense output length is not 2^y_logsize");
+    std::vector<Fr> r(w->y_log), col(len);
+    memcpy(r.data(), h_point, r.size() * sizeof(Fr));
+    Fr* out = reinterpret_cast<Fr*>(h_evs);
+    for (size_t c = 0; c < w->dense_output.cols.size(); c++) {
+        GM_HIP(hipMemcpyAsync(col.data(), w->dense_output.cols[c]->p, len * sizeof(Fr), hipMemcpyDeviceToHost, w->stream));
+        GM_HIP(hipStreamSynchronize(w->stream));
+        std::vector<Fr> cur = col;   // r[0] is the most significant variable (cleanup/utils/arith.rs:6-9)
+        for (size_t k = r.size(); k-- > 0;) {
+            for (size_t i = 0; i < cur.size() / 2; i++) cur[i] = fr_add(cur[2 * i], fr_mul(r[k], fr_sub(cur[2 * i + 1], cur[2 * i])));
+            cur.resize(cur.size() / 2);
+        }
+        out[c] = cur[0];
+    }
+    if (n_evs) *n_evs = (uint32_t)w->dense_output.cols.size();
+    return GM_OK;
+}
+
 // bytes of witness trace held on the device
 extern "C" uint64_t gm_pip_witness_bytes(const gm_pip_witness* w) {
     if (!w) return 0;
@@ -1224,7 +1246,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
                         const uint64_t* d_kn_inverses, const uint64_t* h_k, Tape* tr, uint64_t* h_pair) {
     const gm_msm_plan* plan = st->plan;
     const uint32_t x_log = plan->x_log, d_log = plan->d_log, y_log = st->y_log, y_size = plan->y_size, clm = st->clm;
-    const uint32_t n_mat = st->n_mat, cm = 1u << clm;
+    const uint32_t n_mat = st->n_mat;
     hipStream_t s = st->stream;
     void* stream = reinterpret_cast<void*>(s);
     GM_REQUIRE(y_log >= clm, "commitment_log_multiplicity exceeds y_logsize");

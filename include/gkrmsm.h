@@ -345,6 +345,9 @@ int32_t gm_pip_witness_create(const gm_msm_plan* plan, const uint64_t* d_points_
 int32_t gm_pip_witness_create_sharded(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
                                       const gm_comm* comm, gm_pip_witness** out, void* stream);
 int32_t gm_pip_witness_destroy(gm_pip_witness* w);
+/* "claim computation" of run_pippenger (pippenger.rs:531-541): h_evs[c] = evaluate_poly(dense_output[c], h_point), point of
+ * y_logsize elements, 3 (d_logsize + 1) evaluations out -- the ClaimsBefore of Pippenger::prove / verify */
+int32_t gm_pip_witness_claims(const gm_pip_witness* w, const uint64_t* h_point, uint64_t* h_evs, uint32_t* n_evs);
 int32_t gm_pip_witness_outputs(const gm_pip_witness* w, const uint64_t** d_output_cols, uint32_t* n_output_cols,
                                uint64_t* output_len, const uint64_t** d_bucket_sum_cols);
 uint64_t gm_pip_witness_bytes(const gm_pip_witness* w);
@@ -497,6 +500,7 @@ int32_t gm_g1_binary_msm(const uint8_t* d_coefs, const uint64_t* d_tables_aff, u
 int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_basis_aff, uint32_t commitment_log_multiplicity,
                         uint64_t* d_d_outer_jac, uint64_t* d_c_outer_jac, uint64_t c_outer_cap, uint32_t* c_stride,
                         uint64_t* h_d_comm_aff, uint64_t* h_c_comm_aff, void* stream);
+int32_t gm_g1_generator(uint64_t* h_out_aff);   /* the standard generator, affine wire form (mock_setup's g0) */
 int32_t gm_g1_to_affine(const uint64_t* d_in_jac, uint64_t n, uint64_t* d_out_aff, void* stream);
 int32_t gm_g1_from_affine(const uint64_t* d_in_aff, uint64_t n, uint64_t* d_out_jac, void* stream);
 int32_t gm_g1_host(int32_t op, const uint64_t* h_a, const uint64_t* h_b, uint64_t* h_out, uint64_t n);

@@ -121,3 +121,19 @@ def test_mid_size_gpu_proof_verifies():
     got = VF.pippenger_verify_merlin(*s["shape"], s["claims"][0], s["claims"][1], G.GEN, 2, b"mid", proof)
     assert got == pair
     assert VF.kzg_verify_pair(got, PR.G2_GEN, PR.g2_mul(PR.G2_GEN, s["tau"]))
+
+
+def test_c_example_proves_and_verifies():
+    """examples/pippenger.c: the reference's example flow (build data, run_pippenger, verify_pippenger) written in plain C against
+    include/gkrmsm.h -- real merlin Fiat-Shamir, proof bytes, host verifier, pairing; exit code 0 iff the proof verifies and a
+    tampered one does not"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "examples", "pippenger")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", root, "examples"])
+    r = subprocess.run([exe, "--x-logsize", "9", "--d-logsize", "3", "--nbits", "24", "--commitment-log-multiplicity", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "proof verified" in r.stdout and "tampered proof rejected" in r.stdout
