@@ -20,8 +20,8 @@ oracle:
 	$(MAKE) -s -C oracle
 
 # plain C callers of the C ABI (no HIP headers, no C++): gcc only
-examples: build/examples/pippenger
-build/examples/pippenger: examples/pippenger.c include/gkrmsm.h $(LIB)
+examples: build/examples/pippenger build/examples/gkr_msm_simple
+build/examples/%: examples/%.c include/gkrmsm.h $(LIB)
 	@mkdir -p build/examples
 	gcc -std=c11 -O2 -Wall -Wextra -D_POSIX_C_SOURCE=199309L -Iinclude $< -o $@ -Lgkr_msm_amd -lgkrmsm_hip -Wl,-rpath,'$$ORIGIN/../../gkr_msm_amd'
 

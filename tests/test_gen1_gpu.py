@@ -75,3 +75,16 @@ def test_gpu_gen1_stream_verifies():
     bad[len(bad) // 3] = (bad[len(bad) // 3] + 1) % F.P
     with pytest.raises(VF.Rejected):
         VF.gkr_msm_verify(lp, lb, bad, tape[: res["tape_used"]])
+
+
+def test_c_example_gen1():
+    """examples/gkr_msm_simple.c: the reference test's flow (commitments, gkr_msm_prove) plus the verifier, in plain C"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "examples", "gkr_msm_simple")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", root, "examples"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "transcript verified" in r.stdout and "tampered transcript rejected" in r.stdout
