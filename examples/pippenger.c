@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
     CHECK(gm_fr_host(5, two, NULL, k, 1));
     CHECK(gm_g1_generator(g0));
     CHECK(gm_g1_mock_srs(tau, g0, srs_len, (uint64_t*)d_srs, NULL));
+    CHECK(gm_g1_fixed_base_register((const uint64_t*)d_srs, srs_len, NULL));   /* proving-key precomputation */
     CHECK(gm_knuckles_setup(k, (uint32_t)nv, (uint64_t*)d_inv, NULL));
     CHECK(gm_kzg_mock_vk(tau, h0, h1));
     uint64_t* r = (uint64_t*)calloc(y_log ? y_log : 1, 32);
@@ -168,6 +169,7 @@ int main(int argc, char** argv) {
     gm_merlin_destroy(pt);
     gm_pippenger_wg_destroy(wg);
     gm_msm_plan_destroy(plan);
+    gm_g1_fixed_base_release((const uint64_t*)d_srs);
     gm_free(d_inv); gm_free(d_srs); gm_free(d_sc); gm_free(d_pts);
     free(bad); free(cols); free(evs); free(r); free(sc);
     return (rc == GM_OK && rc_bad == GM_ERR_VERIFY) ? 0 : 1;

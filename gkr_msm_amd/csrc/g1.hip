@@ -190,6 +190,46 @@ __global__ void __launch_bounds__(256) k_g1_msm_tasks_grouped(const uint32_t* __
     }
 }
 
+// ---- fixed-base MSM (a registered proving key): tab[w * n_reg + i] = 2^(c w) * base_i, affine.  With the window multiples
+// precomputed, every window of every scalar lands in ONE set of 2^c buckets (key = digit), so a call costs n * nwin mixed
+// additions into 2^16 long rows plus a single bucket reduction -- ~28 % fewer field multiplications than per-window buckets
+// at 2^21 points, for 96 * nwin bytes of table per base (3.2 GB at 2^21: HBM is what this machine has plenty of).
+__global__ void __launch_bounds__(128) k_g1_fixed_tables(const G1Aff* __restrict__ bases, uint64_t n, uint32_t c, uint32_t nwin,
+                                                          G1Aff* __restrict__ tab) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Aff a = g1_aff_load(bases + i);
+    g1_aff_store(tab + i, a);
+    for (uint32_t w = 1; w < nwin; w++) {
+        G1Jac p = g1_from_aff(a);
+        for (uint32_t k = 0; k < c; k++) p = g1_dbl(p);
+        a = g1_to_aff(p);
+        g1_aff_store(tab + (uint64_t)w * n + i, a);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_g1_msm_tasks_fixed(const uint32_t* __restrict__ scalars, uint64_t n, uint64_t n_reg, uint32_t c,
+                                                             uint32_t nwin, int mont, uint32_t sentinel,
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = fr_load(reinterpret_cast<const Fr*>(scalars) + i);
+    if (mont) s = fr_from_mont(s);
+    for (uint32_t w = 0; w < nwin; w++) {
+        const uint32_t bit = w * c;
+        uint32_t d = 0;
+        if (bit < 256) {
+            const uint32_t li = bit >> 5, sh = bit & 31;
+            uint64_t v = s.l[li];
+            if (li + 1 < 8) v |= (uint64_t)s.l[li + 1] << 32;
+            d = (uint32_t)(v >> sh) & ((1u << c) - 1);
+        }
+        const uint64_t t = (uint64_t)w * n + i;
+        keys[t] = d ? d : sentinel;
+        idx[t] = (uint32_t)((uint64_t)w * n_reg + i);
+    }
+}
+
 // weighted sum sum_i i * B[g][i] over groups g of `glen` buckets by bit decomposition: task (g, i, b) -> key g * nbits + b
 __global__ void __launch_bounds__(256) k_g1_bit_tasks(uint32_t ngroups, uint32_t glen, uint32_t nbits, uint32_t sentinel,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
@@ -614,6 +654,61 @@ static int32_t g1_msm_grouped_core(const G1Jac* jac, uint64_t stride, const uint
     return GM_OK;
 }
 
+// ---- registry of fixed bases: gm_g1_msm looks its base pointer up here
+struct G1FixedBase {
+    const G1Aff* bases = nullptr;
+    uint64_t n = 0;
+    uint32_t c = 16, nwin = 16;
+    G1Aff* tab = nullptr;
+};
+static std::mutex& g1_fixed_mu() {
+    static std::mutex m;
+    return m;
+}
+static std::vector<G1FixedBase>& g1_fixed_registry() {
+    static std::vector<G1FixedBase> r;
+    return r;
+}
+static bool g1_fixed_lookup(const G1Aff* bases, uint64_t n, G1FixedBase* out) {
+    std::lock_guard<std::mutex> lock(g1_fixed_mu());
+    for (const G1FixedBase& f : g1_fixed_registry())
+        if (f.bases == bases && n <= f.n) { *out = f; return true; }
+    return false;
+}
+
+static int32_t g1_msm_fixed_core(const G1FixedBase& fb, const uint64_t* d_scalars, uint64_t n, int scalars_mont, uint32_t nbits,
+                                 G1Jac* h_out, hipStream_t s) {
+    if (n == 0) { *h_out = g1_inf(); return GM_OK; }
+    GM_REQUIRE(nbits >= 1 && nbits <= 256, "bad scalar width %u", nbits);
+    uint32_t nwin = (nbits + fb.c - 1) / fb.c;
+    if (nwin > fb.nwin) nwin = fb.nwin;
+    const uint64_t ntasks = (uint64_t)nwin * n;
+    const uint32_t nkeys = 1u << fb.c;
+    GM_REQUIRE(ntasks < (1ull << 31) && fb.n * fb.nwin < (1ull << 31), "fixed-base MSM too large for one call");
+    G1Scratch& ws = g1_scratch();
+    std::lock_guard<std::mutex> lock(ws.mu);
+    const size_t need = 2 * al(ntasks * 4) + al((size_t)nkeys * sizeof(G1Jac)) + g1_engine_bytes(ntasks, nkeys) +
+                        g1_weighted_bytes(1, nkeys) + 8192;
+    int32_t rc = ws.reserve(need);
+    if (rc) return rc;
+    ws.used = 0;
+    uint32_t* keys = (uint32_t*)ws.carve(ntasks * 4);
+    uint32_t* idx = (uint32_t*)ws.carve(ntasks * 4);
+    G1Jac* buckets = (G1Jac*)ws.carve((size_t)nkeys * sizeof(G1Jac));
+    hipLaunchKernelGGL(k_g1_msm_tasks_fixed, dim3(ceil_div(n, 256)), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(d_scalars), n,
+                       fb.n, fb.c, nwin, scalars_mont, nkeys, keys, idx);
+    GM_LAUNCH_CHECK();
+    const size_t mark = ws.used;
+    rc = g1_sum_by_key(ws, fb.tab, nullptr, keys, idx, ntasks, nkeys, buckets, s);
+    if (rc) return rc;
+    ws.used = mark;
+    std::vector<G1Jac> wsum;
+    rc = g1_weighted_sums(ws, buckets, 1, nkeys, &wsum, s);   // sum_d d * B[d]: the whole MSM
+    if (rc) return rc;
+    *h_out = wsum[0];
+    return GM_OK;
+}
+
 }  // namespace gm
 
 using namespace gm;
@@ -742,11 +837,53 @@ extern "C" int32_t gm_g1_msm(const uint64_t* d_bases_aff, const uint64_t* d_scal
     GM_REQUIRE((d_bases_aff && d_scalars) || n == 0, "null argument");
     GM_REQUIRE(h_out_aff, "null output");
     G1Jac r;
-    int32_t rc = g1_msm_core(reinterpret_cast<const G1Aff*>(d_bases_aff), nullptr, d_scalars, n, scalars_mont, nbits, &r,
-                             as_stream(stream));
+    G1FixedBase fb;
+    int32_t rc;
+    if (g1_fixed_lookup(reinterpret_cast<const G1Aff*>(d_bases_aff), n, &fb))
+        rc = g1_msm_fixed_core(fb, d_scalars, n, scalars_mont, nbits, &r, as_stream(stream));
+    else
+        rc = g1_msm_core(reinterpret_cast<const G1Aff*>(d_bases_aff), nullptr, d_scalars, n, scalars_mont, nbits, &r, as_stream(stream));
     if (rc) return rc;
     put_aff(h_out_aff, r);
     return GM_OK;
+}
+
+// Precompute the window multiples of a base array that many MSMs will use (a KZG proving key): afterwards every gm_g1_msm whose
+// d_bases_aff is this pointer (any n up to the registered one) takes the fixed-base path.  The bases must stay unchanged and
+// allocated until gm_g1_fixed_base_release.  Table: 16 windows of 16 bits, 96 * 16 bytes per base.
+extern "C" int32_t gm_g1_fixed_base_register(const uint64_t* d_bases_aff, uint64_t n, void* stream) {
+    GM_REQUIRE(d_bases_aff && n >= 1, "bad argument");
+    G1FixedBase fb;
+    fb.bases = reinterpret_cast<const G1Aff*>(d_bases_aff);
+    fb.n = n;
+    GM_REQUIRE(fb.n * fb.nwin < (1ull << 31), "base array too long for a fixed-base table");
+    {
+        std::lock_guard<std::mutex> lock(g1_fixed_mu());
+        for (const G1FixedBase& f : g1_fixed_registry())
+            if (f.bases == fb.bases) return set_err(GM_ERR_STATE, "these bases are already registered");
+    }
+    hipError_t e = dev_alloc((void**)&fb.tab, (size_t)fb.n * fb.nwin * sizeof(G1Aff));
+    if (e != hipSuccess) return set_err(GM_ERR_HIP, "fixed-base table (%.1f GiB): %s", fb.n * fb.nwin * 96.0 / (1 << 30), hipGetErrorString(e));
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_g1_fixed_tables, dim3(ceil_div(n, 128)), dim3(128), 0, s, fb.bases, n, fb.c, fb.nwin, fb.tab);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        dev_free(fb.tab);
+        return set_err(GM_ERR_HIP, "fixed-base table kernel failed");
+    }
+    std::lock_guard<std::mutex> lock(g1_fixed_mu());
+    g1_fixed_registry().push_back(fb);
+    return GM_OK;
+}
+extern "C" int32_t gm_g1_fixed_base_release(const uint64_t* d_bases_aff) {
+    std::lock_guard<std::mutex> lock(g1_fixed_mu());
+    auto& r = g1_fixed_registry();
+    for (size_t i = 0; i < r.size(); i++)
+        if (r[i].bases == reinterpret_cast<const G1Aff*>(d_bases_aff)) {
+            dev_free(r[i].tab);
+            r.erase(r.begin() + i);
+            return GM_OK;
+        }
+    return set_err(GM_ERR_INVALID, "these bases are not registered");
 }
 
 extern "C" int32_t gm_g1_msm_nonaff(const uint64_t* d_bases_jac, const uint64_t* d_scalars, uint64_t n, int32_t scalars_mont,

@@ -179,6 +179,8 @@ _SIGS = {
     "gm_g1_gen_points": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp]),
     "gm_g1_release_scratch": (C.c_int32, []),
     "gm_g1_generator": (C.c_int32, [vp]),
+    "gm_g1_fixed_base_register": (C.c_int32, [vp, C.c_uint64, vp]),
+    "gm_g1_fixed_base_release": (C.c_int32, [vp]),
     "gm_pip_witness_claims": (C.c_int32, [vp, vp, vp, u32p]),
     "gm_bs_scalars_into_bigint": (C.c_int32, [vp, vp, C.c_uint64, vp]),
     "gm_gen_points": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp]),

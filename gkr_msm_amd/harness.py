@@ -678,3 +678,12 @@ def msm_g1_outer(plan, d_basis_aff, clm, c_cap_per_mat):
     ffi.check(ffi.lib().gm_msm_g1_outer(plan.h, _p(d_basis_aff), clm, _p(d_d), _p(d_c), n_mat * c_cap_per_mat, C.byref(stride),
                                         hd.ctypes.data, hc.ctypes.data, cur_stream()))
     return d_d, d_c, stride.value, codec.g1_aff_from_limbs(hd), codec.g1_aff_from_limbs(hc)
+
+
+def g1_fixed_base_register(d_bases_aff, n):
+    """precompute the window multiples of a base array (a proving key); later g1_msm calls on the same tensor take the fixed-base path"""
+    ffi.check(ffi.lib().gm_g1_fixed_base_register(_p(d_bases_aff), n, cur_stream()))
+
+
+def g1_fixed_base_release(d_bases_aff):
+    ffi.check(ffi.lib().gm_g1_fixed_base_release(_p(d_bases_aff)))

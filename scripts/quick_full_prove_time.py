@@ -28,6 +28,12 @@ d_sc = H.to_dev(sc)
 plan = H.MsmPlan(x_log, d_log, y_size)
 nv = x_log + clm
 d_basis = H.g1_gen_points((2 << nv) - 1, 7)
+if os.environ.get("FIXED_BASE", "1") == "1":
+    torch.cuda.synchronize()
+    t = time.time()
+    H.g1_fixed_base_register(d_basis, (2 << nv) - 1)
+    torch.cuda.synchronize()
+    print("fixed-base tables %.1f ms" % ((time.time() - t) * 1e3))
 d_inv = H.knuckles_setup(2, nv)
 P = codec.P
 for it in range(int(os.environ.get("ITERS", "2"))):

@@ -242,3 +242,41 @@ def test_mock_srs_is_powers_of_tau():
     for p in got:
         assert p == cur
         cur = G.mul(cur, tau)
+
+
+def test_fixed_base_msm_is_the_same_group_element():
+    """gm_g1_fixed_base_register: the MSMs over a registered proving key (16 x 16-bit windows of precomputed multiples, one bucket
+    set) return the element the per-window path returns -- oracle-checked at a small size, path against path at 2^13, for full,
+    prefix and narrow (access-count style) scalars, an infinity among the bases and zero scalars"""
+    n = 40
+    bases = G.random_points(n, 21)
+    bases[7] = None
+    rng = F.SplitMix64(77)
+    sc = [rng.next_fr() for _ in range(n)]
+    sc[3] = 0
+    sc[4] = F.P - 1
+    d_b = H.g1_aff_dev(bases)
+    d_sc = H.to_dev(codec.ints_to_limbs(sc))
+    want = G.naive_msm(bases, sc)
+    assert H.g1_msm(d_b, d_sc, n) == want
+    H.g1_fixed_base_register(d_b, n)
+    try:
+        assert H.g1_msm(d_b, d_sc, n) == want
+        assert H.g1_msm(d_b, d_sc, 17) == G.naive_msm(bases[:17], sc[:17])            # a prefix of the key
+        assert H.g1_msm(d_b, H.to_dev(codec.to_mont_limbs(sc)), n, mont=True) == want
+        small = [rng.next() & 0xFFFFFFFF for _ in range(n)]
+        assert H.g1_msm(d_b, H.to_dev(codec.ints_to_limbs(small)), n, nbits=32) == G.naive_msm(bases, small)
+    finally:
+        H.g1_fixed_base_release(d_b)
+    n = 1 << 13
+    d_b = H.g1_gen_points(n, 9)
+    s = np.random.default_rng(5).integers(0, 2 ** 64, size=(n, 4), dtype=np.uint64)
+    s[:, 3] &= np.uint64((1 << 62) - 1)
+    d_s = H.to_dev(s)
+    plain = H.g1_msm(d_b, d_s, n)
+    H.g1_fixed_base_register(d_b, n)
+    try:
+        assert H.g1_msm(d_b, d_s, n) == plain and plain is not None
+        assert H.g1_msm(d_b, d_s, n - 5) == H.g1_msm(H.g1_gen_points(n, 9), d_s, n - 5)
+    finally:
+        H.g1_fixed_base_release(d_b)
