@@ -320,14 +320,14 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs c
 // launch the fold and the next round kernel, and each launch takes ~5 us of API time plus ~4 us until the GPU starts it.
 // Small rounds therefore enqueue the fold of round r and the round kernel of round r + 1 BEFORE the challenge t_r exists:
 // a gate kernel in front of the fold waits (bounded) for the host to publish t_r in pinned memory.  The launch latency is
-// spent while round r's kernel is still running.  The wait is bounded (2^21 polls, a few seconds); on timeout the fold reports through a
+// spent while round r's kernel is still running.  The wait is bounded (2^23 polls, ~20 s); on timeout the fold reports through a
 // status word and exits, so a host that never answers cannot wedge the GPU.
 // One wave (the gate) polls the host's ticket word -- thousands of fold blocks polling over PCIe would queue behind each
 // other's reads -- and copies the challenge into device memory; the fold behind it in the stream is an ordinary kernel.
 __global__ void __launch_bounds__(64) k_fold_gate(const Fr* __restrict__ t_slot, const uint32_t* __restrict__ ticket_word, uint32_t ticket,
                                                   uint32_t* __restrict__ status, Fr* __restrict__ d_t) {
     if (threadIdx.x != 0) return;
-    for (int it = 0; it < (1 << 22); it++) {
+    for (int it = 0; it < (1 << 23); it++) {   // ~20 s
         const uint32_t f = __hip_atomic_load(ticket_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int32_t)(f - ticket) >= 0) {
             Fr t;
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) k_tail_rounds(SegPlan sp, ColPtrs cols, c
             int good = 0;
             Fr t = fr_zero();
             if (blockIdx.x == 0) {
-                for (int it = 0; it < (1 << 22); it++) {
+                for (int it = 0; it < (1 << 23); it++) {   // ~20 s of polling over PCIe: a slow (interpreted, traced) transcript is fine
                     const uint32_t f = __hip_atomic_load(a.h_ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                     if ((int32_t)(f - want) >= 0) { good = 1; break; }
                     __builtin_amdgcn_s_sleep(2);
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(256) k_tail_rounds(SegPlan sp, ColPtrs cols, c
                     __hip_atomic_store(a.d_relay, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // let the others go
                 }
             } else {
-                for (int it = 0; it < (1 << 24); it++) {
+                for (int it = 0; it < (1 << 27); it++) {   // outlasts block 0's wait; block 0 releases the others when it gives up
                     const uint32_t f = __hip_atomic_load(a.d_relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                     if (f == 0xffffffffu) break;
                     if ((int32_t)(f - want) >= 0) { good = 1; break; }

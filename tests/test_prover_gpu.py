@@ -90,3 +90,47 @@ def test_live_transcript_matches_tape():
     bad = H.LiveTranscript(lambda: None)
     with pytest.raises(Exception):
         H.prove_image_part_tr(w, claims[0], claims[1], bad)
+
+
+def test_slow_and_failing_transcripts_with_kernels_waiting_on_the_device():
+    """Small rounds keep kernels waiting on the device for the next challenge (gate kernels, the persistent tail kernel).
+    A transcript that takes its time (sleeps) must not time them out, and one that fails in the middle -- at every kind of
+    round -- must leave nothing waiting: the next proof on the same witness is the normal one."""
+    import time
+    x_log, d_log, nbits = 11, 4, 32     # dense stages of 7 variables (tail only) and sparse rounds above and below the split size
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = PL.log2_exact(y_size)
+    n = 1 << x_log
+    pts = F.random_points(n, 31)
+    sc = F.random_scalars(n, nbits, 32)
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    plan = H.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, H.to_dev(codec.ints_to_limbs(sc)))
+    w = H.PipWitness(plan, d_pts, y_log)
+    outs, _ = w.outputs()
+    rng = F.SplitMix64(9)
+    r = [rng.next_fr() for _ in range(y_log)]
+    claims = G.pippenger_claims(outs, r)
+    tape = [rng.next_bits(128) for _ in range(3000)]
+    ref = w.prove_image_part(claims[0], claims[1], tape)
+    used = ref["tape_used"]
+
+    def make(fail_at=None, sleep_every=0):
+        it = iter(tape)
+        count = [0]
+
+        def draw():
+            count[0] += 1
+            if fail_at is not None and count[0] > fail_at:
+                return None
+            if sleep_every and count[0] % sleep_every == 0:
+                time.sleep(0.02)
+            return next(it)
+        return H.LiveTranscript(draw)
+    slow = H.prove_image_part_tr(w, claims[0], claims[1], make(sleep_every=37))
+    assert (slow["point"], slow["evs"]) == (ref["point"], ref["evs"])
+    for fail_at in (3, used // 5, used // 2, used - 4):
+        with pytest.raises(Exception):
+            H.prove_image_part_tr(w, claims[0], claims[1], make(fail_at=fail_at))
+        again = w.prove_image_part(claims[0], claims[1], tape)
+        assert again["msgs"] == ref["msgs"] and again["evs"] == ref["evs"]
