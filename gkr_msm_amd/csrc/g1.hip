@@ -1075,6 +1075,23 @@ __global__ void __launch_bounds__(256) k_g1_pack_coefs(const uint8_t* __restrict
     }
     coefs[t] = (uint8_t)v;
 }
+// all bit columns at once: task (column, chunk) -> key column, table entry of the chunk's packed bits (prepare_coefs + binary_msm's
+// lookup, binary_msm.rs:19-29, 51-53); zero chunks produce no task
+__global__ void __launch_bounds__(256) k_g1_binary_tasks_cols(const uint8_t* __restrict__ bits, uint64_t col_size, uint32_t gamma,
+                                                               uint64_t nchunks, uint32_t ncols, uint32_t tab_len,
+                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks * ncols) return;
+    const uint64_t col = t / nchunks, ch = t % nchunks;
+    const uint8_t* b8 = bits + col * col_size;
+    uint32_t v = 0;
+    for (uint32_t b = 0; b < gamma; b++) {
+        const uint64_t i = ch * gamma + b;
+        if (i < col_size) v = (v << 1) + (b8[i] ? 1u : 0u);
+    }
+    keys[t] = v ? (uint32_t)col : ncols;
+    idx[t] = (uint32_t)(ch * tab_len + (v ? v - 1 : 0));
+}
 // pts_prep = x coordinates, then y coordinates, then zeros up to col_size (gkr_msm_simple.rs:139-146)
 __global__ void __launch_bounds__(256) k_g1_pts_prep(const Fr* __restrict__ points_xy, uint64_t npts, uint64_t col_size,
                                                       Fr* __restrict__ out) {
@@ -1103,16 +1120,38 @@ extern "C" int32_t gm_gkr_msm_commit(const uint64_t* d_points_xy, const uint8_t*
     GM_REQUIRE(col_size >= 2 * npts, "Points should fit in a single column. Please reduce the amount of columns. (gkr_msm_simple.rs:134-137)");
     hipStream_t s = as_stream(stream);
     const uint64_t nchunks = (col_size + gamma - 1) / gamma;
-    uint8_t* coefs = nullptr;
     Fr* prep = nullptr;
-    GM_HIP(dev_alloc((void**)&coefs, nchunks + 64));
     GM_HIP(dev_alloc((void**)&prep, col_size * sizeof(Fr)));
     int32_t rc = GM_OK;
-    for (uint64_t i = 0; i < ncols && rc == GM_OK; i++) {
-        hipLaunchKernelGGL(k_g1_pack_coefs, dim3(ceil_div(nchunks, 256)), dim3(256), 0, s, d_scalar_bits + col_size * i, col_size, gamma,
-                           nchunks, coefs);
-        if (hipGetLastError() != hipSuccess) { rc = set_err(GM_ERR_HIP, "k_g1_pack_coefs launch failed"); break; }
-        rc = gm_g1_binary_msm(coefs, d_binary_tables_aff, nchunks, gamma, h_bit_comms_aff + 12 * i, stream);
+    {   // every bit column in one engine pass (one launch sequence instead of ncols of them)
+        const uint64_t ntasks = nchunks * ncols;
+        const uint32_t tab_len = (1u << gamma) - 1;
+        if (ntasks >= (1ull << 31) || nchunks * tab_len >= (1ull << 31)) rc = set_err(GM_ERR_INVALID, "bit columns too large for one call");
+        G1Scratch& ws = g1_scratch();
+        std::vector<G1Jac> sums(ncols);
+        if (rc == GM_OK) {
+            std::lock_guard<std::mutex> lock(ws.mu);
+            rc = ws.reserve(2 * al(ntasks * 4 + 4) + al(ncols * sizeof(G1Jac)) + g1_engine_bytes(ntasks, (uint32_t)ncols) + 8192);
+            if (rc == GM_OK) {
+                ws.used = 0;
+                uint32_t* keys = (uint32_t*)ws.carve(ntasks * 4 + 4);
+                uint32_t* idx = (uint32_t*)ws.carve(ntasks * 4 + 4);
+                G1Jac* d_r = (G1Jac*)ws.carve(ncols * sizeof(G1Jac));
+                hipLaunchKernelGGL(k_g1_binary_tasks_cols, dim3(ceil_div(ntasks, 256)), dim3(256), 0, s, d_scalar_bits, col_size, gamma,
+                                   nchunks, (uint32_t)ncols, tab_len, keys, idx);
+                if (hipGetLastError() != hipSuccess) rc = set_err(GM_ERR_HIP, "k_g1_binary_tasks_cols launch failed");
+                if (rc == GM_OK)
+                    rc = g1_sum_by_key(ws, reinterpret_cast<const G1Aff*>(d_binary_tables_aff), nullptr, keys, idx, ntasks, (uint32_t)ncols,
+                                       d_r, s);
+                if (rc == GM_OK) {
+                    if (hipMemcpyAsync(sums.data(), d_r, ncols * sizeof(G1Jac), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                        hipStreamSynchronize(s) != hipSuccess)
+                        rc = set_err(GM_ERR_HIP, "reading the column sums failed");
+                }
+            }
+        }
+        if (rc == GM_OK)
+            host_parallel_for((uint32_t)ncols, [&](uint32_t i) { put_aff(h_bit_comms_aff + 12 * (size_t)i, sums[i]); }, 4);
     }
     if (rc == GM_OK) {
         hipLaunchKernelGGL(k_g1_pts_prep, dim3(ceil_div(col_size, 256)), dim3(256), 0, s, reinterpret_cast<const Fr*>(d_points_xy), npts,
@@ -1121,7 +1160,6 @@ extern "C" int32_t gm_gkr_msm_commit(const uint64_t* d_points_xy, const uint8_t*
     }
     if (rc == GM_OK) rc = gm_g1_msm(d_bases_aff, reinterpret_cast<const uint64_t*>(prep), col_size, 1, 255, h_pts_comm_aff, stream);
     (void)hipStreamSynchronize(s);
-    dev_free(coefs);
     dev_free(prep);
     return rc;
 }
