@@ -28,6 +28,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "common.hpp"
+#include "internal.hpp"
 #include "g1.cuh"
 #include "msm_plan.hpp"
 
@@ -484,27 +485,6 @@ static size_t g1_engine_bytes(uint64_t ntasks, uint32_t nkeys) {
     G1Layout L;
     if (g1_engine_layout(ntasks ? ntasks : 1, nkeys, &L)) return 0;
     return L.total + al((size_t)nkeys * sizeof(G1Jac));
-}
-
-// Host-side combination loops (a few thousand G1 operations per call, ~0.5 us each) spread over a handful of threads.
-template <class F>
-static void host_parallel_for(uint32_t n, F&& body, uint32_t grain = 16) {
-    unsigned hw = std::thread::hardware_concurrency();
-    uint32_t nt = hw ? (hw > 12 ? 12 : hw) : 4;
-    if (n < 4 * grain || nt < 2) {
-        for (uint32_t i = 0; i < n; i++) body(i);
-        return;
-    }
-    if (nt > n / grain) nt = n / grain ? n / grain : 1;
-    std::vector<std::thread> th;
-    const uint32_t per = (n + nt - 1) / nt;
-    for (uint32_t t = 1; t < nt; t++)
-        th.emplace_back([&, t] {
-            const uint32_t hi = (t + 1) * per < n ? (t + 1) * per : n;
-            for (uint32_t i = t * per; i < hi; i++) body(i);
-        });
-    for (uint32_t i = 0; i < per && i < n; i++) body(i);
-    for (auto& x : th) x.join();
 }
 
 // acc = sum_pos 2^pos S[pos] on the host (Horner from the top bit)

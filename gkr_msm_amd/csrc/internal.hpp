@@ -1,5 +1,6 @@
 // Cross-translation-unit declarations inside libgkrmsm_hip.so (not part of the ABI).
 #pragma once
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -144,5 +145,27 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     Fr* fr() const { return reinterpret_cast<Fr*>(p); }
 };
+
+// Host-side combination loops (a few thousand G1 operations per call, ~0.5 us each) spread over a handful of threads.
+template <class F>
+inline void host_parallel_for(uint32_t n, F&& body, uint32_t grain = 16) {
+    unsigned hw = std::thread::hardware_concurrency();
+    uint32_t nt = hw ? (hw > 12 ? 12 : hw) : 4;
+    if (n < 4 * grain || nt < 2) {
+        for (uint32_t i = 0; i < n; i++) body(i);
+        return;
+    }
+    if (nt > n / grain) nt = n / grain ? n / grain : 1;
+    std::vector<std::thread> th;
+    const uint32_t per = (n + nt - 1) / nt;
+    for (uint32_t t = 1; t < nt; t++)
+        th.emplace_back([&, t] {
+            const uint32_t hi = (t + 1) * per < n ? (t + 1) * per : n;
+            for (uint32_t i = t * per; i < hi; i++) body(i);
+        });
+    for (uint32_t i = 0; i < per && i < n; i++) body(i);
+    for (auto& x : th) x.join();
+}
+
 
 }  // namespace gm

@@ -400,12 +400,18 @@ int32_t pippenger_verify(Reader* tr, uint32_t x_log, uint32_t d_log, uint32_t y_
             multirow[2 * j] = fr_sub(w, m);
             multirow[2 * j + 1] = m;
         }
-    auto comb = [&](const std::vector<G1Aff>& cs) {
+    // sum_m multirow_evs[m] * commitment[m] for the four commitment vectors (pippenger.rs:344-347): 4 n_mat scalar
+    // multiplications, the bulk of the verifier's time, spread over a few host threads
+    const std::vector<G1Aff>* vecs[4] = {&c, &d, &c_pull, &d_pull};
+    const uint32_t n_comb = (uint32_t)(n_mat < multirow.size() ? n_mat : multirow.size());
+    std::vector<G1Jac> prod(4 * (size_t)n_comb);
+    host_parallel_for(4 * n_comb, [&](uint32_t t) { prod[t] = mul_fr(jac((*vecs[t / n_comb])[t % n_comb]), multirow[t % n_comb]); }, 2);
+    auto comb = [&](int which) {
         G1Jac acc = g1_inf();
-        for (size_t i = 0; i < cs.size() && i < multirow.size(); i++) acc = g1_add(acc, mul_fr(jac(cs[i]), multirow[i]));
+        for (uint32_t i = 0; i < n_comb; i++) acc = g1_add(acc, prod[(size_t)which * n_comb + i]);
         return acc;
     };
-    const G1Jac c_comb = comb(c), d_comb = comb(d), cp_comb = comb(c_pull), dp_comb = comb(d_pull);
+    const G1Jac c_comb = comb(0), d_comb = comb(1), cp_comb = comb(2), dp_comb = comb(3);
     Fr u;
     TRY(tr->challenge(&u, 1, 512));
     const Fr u2 = fr_mul(u, u), u3 = fr_mul(u2, u);
