@@ -4,9 +4,9 @@
 // for clarity, not speed (a verifier computes two Miller loops per proof):
 //   Fq2 = Fq[u]/(u^2 + 1),  Fq6 = Fq2[v]/(v^3 - (u + 1)),  Fq12 = Fq6[w]/(w^2 - v)
 //   G2 on the M-twist  y^2 = x^3 + 4 (u + 1);  untwist (x', y') -> (x' / w^2, y' / w^3) in E(Fq12): y^2 = x^3 + 4
-//   Miller loop over |x| = 0xd201000000010000 with affine lines evaluated in Fq12 (vertical lines dropped: they lie in Fq6),
-//   conjugation for the negative x, final exponentiation (q^12 - 1) / r = (q^6 - 1)(q^2 + 1) * (q^4 - q^2 + 1) / r, the last
-//   two factors by plain square-and-multiply.
+//   Miller loop over |x| = 0xd201000000010000: affine steps on the twist (slopes in Fq2), lines embedded as sparse Fq12
+//   elements (vertical lines dropped: they lie in Fq6), conjugation for the negative x; final exponentiation
+//   (q^12 - 1) / r = (q^6 - 1)(q^2 + 1) * (q^4 - q^2 + 1) / r: conjugate / inverse, q^2-Frobenius, windowed power.
 // GT equality is only ever tested between outputs of this file, so the result is specified up to the choice of Fq12 basis.
 #pragma once
 #include <cstdint>
@@ -93,12 +93,6 @@ inline Fq12 fq12_pow(const Fq12& x, const uint64_t* e, int nlimbs) {
         }
     return acc;
 }
-// embeddings used by the untwist: s in Fq -> Fq12; t in Fq2 times w^-2 = v^-1 = v^2 / xi and w^-3 = w / v^2 = w v / xi
-inline Fq12 fq12_from_fq(const Fq& s) {
-    Fq12 r = {fq6_zero(), fq6_zero()};
-    r.a.a.a = s;
-    return r;
-}
 
 // ---- G2 (the twist), affine
 inline bool g2_aff_is_inf(const G2Aff& p) { return fq2_is_zero(p.x) && fq2_is_zero(p.y); }
@@ -150,56 +144,86 @@ inline G2Aff g2_mul(const G2Aff& p, const uint32_t* k, int nlimbs) {
     return acc;
 }
 
-struct PtFq12 { Fq12 x, y; };
-inline PtFq12 g2_untwist(const G2Aff& q) {
-    const Fq2 xi_inv = fq2_inv(fq2_mul_xi(fq2_one()));
-    PtFq12 r = {{fq6_zero(), fq6_zero()}, {fq6_zero(), fq6_zero()}};
-    r.x.a.c = fq2_mul(q.x, xi_inv);   // x' * v^2 / xi
-    r.y.b.b = fq2_mul(q.y, xi_inv);   // y' * v w / xi
-    return r;
-}
-
-// f_{|x|, Q}(P) with the untwisted Q; P affine in G1, neither at infinity
+// f_{|x|, Q}(P); P affine in G1, Q affine on the twist, neither at infinity.  The slopes are computed on the twist in Fq2 (one
+// Fq2 inversion per step); with the untwist X = x' w^-2, Y = y' w^-3 the line through T with twist-slope lam, evaluated at P, is
+//   (yP - Y_T) - lam w^-1 (xP - X_T) = yP  +  [(lam x'_T - y'_T) / xi] v w  +  [-lam xP / xi] v^2 w
+// (w^-1 = v^2 w / xi, w^-3 = v w / xi): three non-zero coefficients of the twelve.  Vertical lines are dropped (they lie in Fq6).
 inline Fq12 miller_loop(const G1Aff& p, const G2Aff& q) {
     static const uint64_t X_ABS = 0xd201000000010000ull;
-    const PtFq12 Q = g2_untwist(q);
-    const Fq12 px = fq12_from_fq(p.x), py = fq12_from_fq(p.y);
-    PtFq12 T = Q;
+    const Fq2 xi_inv = fq2_inv(fq2_mul_xi(fq2_one()));
+    const Fq2 three = {fq_add(fq_dbl(fq_one()), fq_one()), fq_zero()};
+    G2Aff T = q;
     Fq12 f = fq12_one();
-    const Fq12 three = fq12_from_fq(fq_add(fq_dbl(fq_one()), fq_one())), two = fq12_from_fq(fq_dbl(fq_one()));
-    auto line = [&](const PtFq12& A, const Fq12& lam) {  // (yP - yA) - lam (xP - xA)
-        return fq12_sub(fq12_sub(py, A.y), fq12_mul(lam, fq12_sub(px, A.x)));
+    auto line = [&](const G2Aff& A, const Fq2& lam) {
+        Fq12 l = {fq6_zero(), fq6_zero()};
+        l.a.a.a = p.y;
+        l.b.b = fq2_mul(fq2_sub(fq2_mul(lam, A.x), A.y), xi_inv);
+        l.b.c = fq2_neg(fq2_mul(fq2_mul_fq(lam, p.x), xi_inv));
+        return l;
     };
-    auto step = [&](const PtFq12& A, const PtFq12& B, const Fq12& lam) {
-        PtFq12 r;
-        r.x = fq12_sub(fq12_sub(fq12_sqr(lam), A.x), B.x);
-        r.y = fq12_sub(fq12_mul(lam, fq12_sub(A.x, r.x)), A.y);
+    auto step = [&](const G2Aff& A, const G2Aff& B, const Fq2& lam) {
+        G2Aff r;
+        r.x = fq2_sub(fq2_sub(fq2_sqr(lam), A.x), B.x);
+        r.y = fq2_sub(fq2_mul(lam, fq2_sub(A.x, r.x)), A.y);
         return r;
     };
     for (int b = 62; b >= 0; b--) {  // bit 63 is the leading one
-        const Fq12 lam = fq12_mul(fq12_mul(three, fq12_sqr(T.x)), fq12_inv(fq12_mul(two, T.y)));
+        const Fq2 lam = fq2_mul(fq2_mul(three, fq2_sqr(T.x)), fq2_inv(fq2_add(T.y, T.y)));
         f = fq12_mul(fq12_sqr(f), line(T, lam));
         T = step(T, T, lam);
         if ((X_ABS >> b) & 1) {
-            const Fq12 lam2 = fq12_mul(fq12_sub(Q.y, T.y), fq12_inv(fq12_sub(Q.x, T.x)));
+            const Fq2 lam2 = fq2_mul(fq2_sub(q.y, T.y), fq2_inv(fq2_sub(q.x, T.x)));
             f = fq12_mul(f, line(T, lam2));
-            T = step(T, Q, lam2);
+            T = step(T, q, lam2);
         }
     }
     return fq12_conj(f);  // x < 0
 }
 
+// f^(q^2): w^(q^2) = zeta w with zeta = xi^((q^2 - 1) / 6), a primitive sixth root of unity in Fq; the coefficient of w^i
+// (tower order: a = (w^0, w^2, w^4), b = (w^1, w^3, w^5)) is multiplied by zeta^i, the Fq2 coefficients themselves are fixed
+inline Fq12 fq12_frob2(const Fq12& x) {
+    static const uint32_t Z[12] = {0xfffeffffu, 0x2e01ffffu, 0x620a0002u, 0xde17d813u, 0xe6f89688u, 0xddb3a93bu,
+                                   0x6a0f77eau, 0xba69c607u, 0xdf76ce51u, 0x5f19672fu, 0x00000000u, 0x00000000u};
+    Fq z1;
+    for (int i = 0; i < 12; i++) z1.l[i] = Z[i];
+    z1 = fq_to_mont(z1);
+    const Fq z2 = fq_sqr(z1), z3 = fq_mul(z2, z1), z4 = fq_sqr(z2), z5 = fq_mul(z4, z1);
+    Fq12 r;
+    r.a.a = x.a.a;
+    r.a.b = fq2_mul_fq(x.a.b, z2);
+    r.a.c = fq2_mul_fq(x.a.c, z4);
+    r.b.a = fq2_mul_fq(x.b.a, z1);
+    r.b.b = fq2_mul_fq(x.b.b, z3);
+    r.b.c = fq2_mul_fq(x.b.c, z5);
+    return r;
+}
+
+// x^e with a 4-bit fixed window
+inline Fq12 fq12_pow_w4(const Fq12& x, const uint64_t* e, int nlimbs) {
+    Fq12 tab[16];
+    tab[0] = fq12_one();
+    for (int i = 1; i < 16; i++) tab[i] = fq12_mul(tab[i - 1], x);
+    Fq12 acc = fq12_one();
+    for (int i = nlimbs - 1; i >= 0; i--)
+        for (int b = 60; b >= 0; b -= 4) {
+            acc = fq12_sqr(fq12_sqr(fq12_sqr(fq12_sqr(acc))));
+            const unsigned d = (unsigned)(e[i] >> b) & 15u;
+            if (d) acc = fq12_mul(acc, tab[d]);
+        }
+    return acc;
+}
+
+// (q^12 - 1) / r = (q^6 - 1) (q^2 + 1) * (q^4 - q^2 + 1) / r
 inline Fq12 final_exponentiation(const Fq12& f) {
-    static const uint64_t EXP_Q2P1[12] = {0x26aa00001c718e3aull, 0x7ced6b1d76382eabull, 0x162c338362113cfdull, 0x66bf91ed3e71b743ull,
-                                          0x292e85a87091a049ull, 0x1d68619c86185c7bull, 0xf53149330978ef01ull, 0x50a62cfd16ddca6eull,
-                                          0x66e59e49349e8bd0ull, 0xe2dc90e50e7046b4ull, 0x4bd278eaa22f25e9ull, 0x02a437a4b8c35fc7ull};
     static const uint64_t EXP_HARD[20] = {0xe516c3f438e3ba79ull, 0xfa9912aae208ccf1ull, 0x905ce937335d5b68ull, 0xc71a2629b0dea236ull,
                                           0x83774940996754c8ull, 0x21d160aeb6a1e799ull, 0x2ed0b283ed237db4ull, 0x915c97f36c6f1821ull,
                                           0x67f17fcbde783765ull, 0x2378b9039096d1b7ull, 0x7988f8761bdc51dcull, 0x2076995003fc77a1ull,
                                           0x827eca0ba621315bull, 0xe5a72bce8d63cb9full, 0xf68f7764c28b6f8aull, 0x2f230063cf081517ull,
                                           0x94506632528d6a9aull, 0xd3cde88eeb996ca3ull, 0xc0bd38c3195c899eull, 0x000f686b3d807d01ull};
     const Fq12 t = fq12_mul(fq12_conj(f), fq12_inv(f));   // f^(q^6 - 1)
-    return fq12_pow(fq12_pow(t, EXP_Q2P1, 12), EXP_HARD, 20);
+    const Fq12 u = fq12_mul(fq12_frob2(t), t);            // ^(q^2 + 1)
+    return fq12_pow_w4(u, EXP_HARD, 20);
 }
 
 // e(P, Q); infinity on either side gives 1
