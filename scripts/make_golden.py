@@ -118,8 +118,45 @@ def msm_fixture(x_log, d_log, nbits, seed):
     }
 
 
+def proof_fixture(x_log, d_log, nbits, clm, seed):
+    """a whole gen-2 proof (PippengerWG::new + Pippenger::prove of the oracle) with everything a verifier needs: shape, claims,
+    every transcript scalar and G1 point in write order, the challenges as drawn, the deferred pairing pair and the mock-setup tau"""
+    from pyref import g1 as G1
+    from pyref import knuckles as KN
+    from pyref import pippenger as PP
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = (y_size - 1).bit_length()
+    n = 1 << x_log
+    rng = F.SplitMix64(seed)
+    pts = F.random_points(n, seed + 1)
+    sc = F.random_scalars(n, nbits, seed + 2)
+    nv = x_log + clm
+    tau, k = rng.next_fr(), 2
+    basis, cur = [], G1.GEN
+    for _ in range((2 << nv) - 1):
+        basis.append(cur)
+        cur = G1.mul(cur, tau)
+    st = PP.pippenger_wg(pts, sc, y_size, y_log, d_log, x_log, clm, basis)
+    out = G.pippenger_dense_output(st["wg"], y_log, d_log)
+    r = [rng.next_fr() for _ in range(y_log)]
+    claims = G.pippenger_claims(out, r)
+    tape = [rng.next_bits(512) for _ in range(4000)]
+    tr = PP.Transcript(tape)
+    pair = PP.pippenger_prove(tr, st, claims, y_size, y_log, d_log, x_log, clm, basis, KN.setup_inverses(k, nv), k)
+    drawn = [t % F.P if i in tr.wide else t & ((1 << 128) - 1) for i, t in enumerate(tape[: tr.pos])]
+    h96 = lambda v: "%096x" % v
+    pt = lambda p: None if p is None else [h96(p[0]), h96(p[1])]
+    return {"x_logsize": x_log, "d_logsize": d_log, "nbits": nbits, "y_size": y_size, "y_logsize": y_log,
+            "commitment_log_multiplicity": clm, "k": k, "tau": hx(tau),
+            "points_xy": [[hx(p[0]), hx(p[1])] for p in pts], "scalars_in": [hx(v) for v in sc],
+            "claim_point": [hx(v) for v in claims[0]], "claim_evs": [hx(v) for v in claims[1]],
+            "transcript_scalars": [hx(v) for m in tr.msgs for v in m], "transcript_points": [pt(p) for p in tr.points],
+            "challenges": [hx(v) for v in drawn], "pair": [pt(pair[0]), pt(pair[1])]}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    dump("proof_x3_d2_n8_clm1.json", proof_fixture(3, 2, 8, 1, 4242))
     dump("field.json", field_fixture())
     dump("layers.json", layer_fixture())
     dump("poly.json", poly_fixture())

@@ -134,3 +134,31 @@ def test_mock_vk_is_the_generator_and_its_tau_multiple():
     tau = 0x5A5A5A5A1234567890ABCDEF
     h0, h1 = VF.kzg_mock_vk(tau)
     assert h0 == PR.G2_GEN and h1 == PR.g2_mul(PR.G2_GEN, tau)
+
+
+def _load_proof_fixture():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proof_x3_d2_n8_clm1.json")) as f:
+        fx = json.load(f)
+    h = lambda v: int(v, 16)
+    pt = lambda p: None if p is None else (h(p[0]), h(p[1]))
+    return dict(shape=(fx["x_logsize"], fx["d_logsize"], fx["y_size"], fx["y_logsize"], fx["commitment_log_multiplicity"]),
+                claims=([h(v) for v in fx["claim_point"]], [h(v) for v in fx["claim_evs"]]), k=fx["k"], tau=h(fx["tau"]),
+                scalars=[h(v) for v in fx["transcript_scalars"]], points=[pt(p) for p in fx["transcript_points"]],
+                tape=[h(v) for v in fx["challenges"]], pair=(pt(fx["pair"][0]), pt(fx["pair"][1])),
+                pts=[(h(p[0]), h(p[1])) for p in fx["points_xy"]], sc=[h(v) for v in fx["scalars_in"]], nbits=fx["nbits"])
+
+
+def test_committed_proof_fixture_verifies():
+    """tests/golden/proof_x3_d2_n8_clm1.json (scripts/make_golden.py): a whole proof as data -- both verifiers accept it, return
+    the recorded pairing pair, and the pairing check passes under the recorded tau"""
+    p = _load_proof_fixture()
+    got = VF.pippenger_verify(*p["shape"], p["claims"][0], p["claims"][1], G.GEN, p["k"], p["scalars"], p["points"], p["tape"])
+    assert got["pair"] == p["pair"] and got["tape_used"] == len(p["tape"])
+    rt = V.ReadTranscript(p["scalars"], p["points"], p["tape"])
+    assert V.pippenger_verify(rt, p["claims"], p["shape"][2], p["shape"][3], p["shape"][1], p["shape"][0], p["shape"][4], G.GEN,
+                              p["k"]) == p["pair"]
+    h0, h1 = VF.kzg_mock_vk(p["tau"])
+    assert VF.kzg_verify_pair(p["pair"], h0, h1)
+    assert p["pair"][0] == G.mul(p["pair"][1], p["tau"])

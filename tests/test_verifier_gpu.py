@@ -137,3 +137,22 @@ def test_c_example_proves_and_verifies():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "proof verified" in r.stdout and "tampered proof rejected" in r.stdout
+
+
+def test_gpu_prover_reproduces_the_committed_proof_fixture():
+    """from the fixture's inputs, SRS (tau) and challenges the GPU prover writes exactly the recorded transcript"""
+    from test_verifier_cpu import _load_proof_fixture
+    p = _load_proof_fixture()
+    x_log, d_log, y_size, y_log, clm = p["shape"]
+    nv = x_log + clm
+    basis, cur = [], G.GEN
+    for _ in range((2 << nv) - 1):
+        basis.append(cur)
+        cur = G.mul(cur, p["tau"])
+    d_pts = H.to_dev(codec.points_to_mont(p["pts"]))
+    plan = H.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, H.to_dev(codec.ints_to_limbs(p["sc"])))
+    wg = H.PippengerWG(plan, d_pts, y_log, clm, H.g1_aff_dev(basis))
+    res = wg.prove(p["claims"][0], p["claims"][1], H.knuckles_setup(p["k"], nv), p["k"], p["tape"] + [0] * 8)
+    assert res["msgs"] == p["scalars"] and res["points"] == p["points"] and res["pair"] == p["pair"]
+    assert res["tape_used"] == len(p["tape"])
