@@ -738,7 +738,7 @@ struct PadCols {
 };
 __global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut out, const uint32_t* __restrict__ off_in,
                                                          const uint32_t* __restrict__ off_out, uint32_t nrows, Fr t,
-                                                         PadCols pad, const Fr* __restrict__ d_t) {
+                                                         PadCols pad, const Fr* __restrict__ d_t, int ncols) {
     if (d_t) t = fr_load(d_t);  // pre-enqueued fold: the challenge arrives through the gate kernel (k_fold_gate)
     const uint32_t j = blockIdx.x * SC_THREADS + threadIdx.x;
     const uint32_t total = off_out[nrows];
@@ -746,15 +746,19 @@ __global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut o
     if (j >= total) return;
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
-    const int c = blockIdx.y;
-    Fr v;
+    // two columns per thread (grid y = ceil(k / 2)): four loads in flight per thread, one row lookup for both
+    const int c0 = 2 * blockIdx.y, c1 = c0 + 1;
+    const bool has1 = c1 < ncols;
     if (p < half) {
-        const Fr p0 = fr_load(in.p[c] + in0 + 2 * p), p1 = fr_load(in.p[c] + in0 + 2 * p + 1);
-        v = fr_add(p0, fr_mul(t, fr_sub(p1, p0)));
+        const Fr a0 = fr_load(in.p[c0] + in0 + 2 * p), a1 = fr_load(in.p[c0] + in0 + 2 * p + 1);
+        Fr b0 = a0, b1 = a1;
+        if (has1) { b0 = fr_load(in.p[c1] + in0 + 2 * p); b1 = fr_load(in.p[c1] + in0 + 2 * p + 1); }
+        fr_store(out.p[c0] + j, fr_add(a0, fr_mul(t, fr_sub(a1, a0))));
+        if (has1) fr_store(out.p[c1] + j, fr_add(b0, fr_mul(t, fr_sub(b1, b0))));
     } else {
-        v = pad.v[c];
+        fr_store(out.p[c0] + j, pad.v[c0]);
+        if (has1) fr_store(out.p[c1] + j, pad.v[c1]);
     }
-    fr_store(out.p[c] + j, v);
 }
 
 // bind_into_dense (vecvec_eq.rs:157-175): rows of 0 or 2 cells -> one dense value per row
@@ -1682,8 +1686,8 @@ struct ScVecVecDeg2 : gm_sc {
             Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
             hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(already_bound), rs.ticket_word(), fold_ticket,
                                rs.ticket_word() + 1, d_t);
-            hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(nx_bound, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co, off_cur, nx_off,
-                               nrows, fr_zero(), pd, (const Fr*)d_t);
+            hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(nx_bound, SC_THREADS), (k + 1) / 2), dim3(SC_THREADS), 0, stream, ci, co, off_cur,
+                               nx_off, nrows, fr_zero(), pd, (const Fr*)d_t, k);
             GM_LAUNCH_CHECK();
             fold_pending = true;
             int32_t rc = launch_sparse_round(nx_cur.data(), nx_off, nx_bound, already_bound + 1);
@@ -1804,8 +1808,8 @@ struct ScVecVecDeg2 : gm_sc {
                 co.p[i] = to_a ? bufA[i]->fr() : bufB[i]->fr();
                 pd.v[i] = row_pad[i];
             }
-            hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(new_bound, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co,
-                               off_cur, off_next, nrows, t, pd, (const Fr*)nullptr);
+            hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(new_bound, SC_THREADS), (k + 1) / 2), dim3(SC_THREADS), 0, stream, ci, co,
+                               off_cur, off_next, nrows, t, pd, (const Fr*)nullptr, k);
             GM_LAUNCH_CHECK();
             for (int i = 0; i < k; i++) cur[i] = co.p[i];
             off_cur = off_next;
