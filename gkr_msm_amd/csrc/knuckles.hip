@@ -302,6 +302,18 @@ int32_t knuckles_open(const uint64_t* d_basis_aff, const uint64_t* d_inverses, c
 
 }  // namespace
 
+// div_by_linear (kzg.rs:73-81) and ev (kzg.rs:142-150) on a device polynomial of `len` coefficients (lowest first):
+// h_ev <- poly(pt) (== the remainder), d_quotient (len - 1 coefficients, may be NULL) <- poly / (X - pt)
+extern "C" int32_t gm_kzg_div_by_linear(const uint64_t* d_poly, uint64_t len, const uint64_t* h_pt, uint64_t* d_quotient,
+                                        uint64_t* h_ev, void* stream) {
+    GM_REQUIRE(d_poly && h_pt && h_ev && len >= 1, "bad argument");
+    Fr x, e;
+    memcpy(&x, h_pt, sizeof(Fr));
+    TRY(eval_and_divide(reinterpret_cast<const Fr*>(d_poly), len, x, &e, reinterpret_cast<Fr*>(d_quotient), as_stream(stream)));
+    memcpy(h_ev, &e, sizeof(Fr));
+    return GM_OK;
+}
+
 extern "C" int32_t gm_knuckles_setup(const uint64_t* h_k, uint32_t num_vars, uint64_t* d_inverses, void* stream) {
     GM_REQUIRE(h_k && d_inverses && num_vars >= 1 && num_vars <= 26, "bad argument");
     Fr k;

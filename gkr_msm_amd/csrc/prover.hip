@@ -633,6 +633,167 @@ extern "C" int32_t gm_pip_prove_image_part_tr(const gm_pip_witness* w, const uin
 }
 
 // =================================================================================================================
+// The two GKR circuits as protocols of their own: TriangleAddWG / TriangleAdd (gkrs/triangle_add.rs:160-250) and
+// VecVecBintreeAddWG / VecVecBintreeAdd (gkrs/bintree_add.rs:85-126, 377-...).  The reference's tests and benches drive them
+// directly (triangle_add.rs:277-393, bintree_add.rs:401-505); inside the Pippenger prover they are reached through
+// gm_pip_witness.  Same builders, same layer lists, same SimpleGKR loop as above.
+struct gm_gkr_witness {
+    hipStream_t stream = nullptr;
+    Arena arena;
+    Fr* pinned = nullptr;
+    std::vector<Advice> advices;
+    std::vector<Layer> layers;
+    Advice output;                      // last_step of the circuit, dense columns
+    uint32_t out_vars = 0, n_claims = 0;
+    ~gm_gkr_witness() { if (pinned) (void)hipHostFree(pinned); }
+};
+
+static int32_t gkr_witness_finish(gm_gkr_witness* w, size_t arena_bytes) {
+    TRY(w->arena.init(arena_bytes));
+    GM_HIP(hipHostMalloc((void**)&w->pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(w->pinned, 0, 16 * sizeof(Fr));
+    GM_HIP(hipStreamSynchronize(w->stream));
+    return GM_OK;
+}
+
+// TriangleAddWG::new(inputs, num_vars, split_var = HI(split_hi)) (triangle_add.rs:160-171) + last_step (:88-99).
+// d_cols: the 12 columns (a, b, c, d) x (X, Y, Z) of 2^num_vars elements each, as produced by two HI splits.
+extern "C" int32_t gm_triangle_witness_create(const uint64_t* const* d_cols, uint32_t num_vars, uint32_t split_hi,
+                                              gm_gkr_witness** out, void* stream) {
+    GM_REQUIRE(d_cols && out, "null argument");
+    GM_REQUIRE(split_hi <= num_vars && num_vars < 40, "split index HI(%u) outside %u variables", split_hi, num_vars);
+    std::unique_ptr<gm_gkr_witness> w(new gm_gkr_witness());
+    hipStream_t s = w->stream = as_stream(stream);
+    Advice in;
+    in.kind = Advice::DENSE;
+    in.len = (uint64_t)1 << num_vars;
+    for (int i = 0; i < 12; i++) {
+        in.cols.emplace_back(new DevBuf());
+        in.cols.back()->p = const_cast<uint64_t*>(d_cols[i]);  // borrowed: the caller keeps the inputs alive
+        in.cols.back()->owned = false;
+        in.cols.back()->bytes = (size_t)in.len * sizeof(Fr);
+    }
+    TRY(triangle_witness_build(in, num_vars, split_hi, &w->advices, s));
+    const uint32_t num_layers = num_vars - split_hi;
+    TRY(dense_map_adv(mkfn(GM_FN_PROJ_L3, (int)num_layers + 3), w->advices.back(), &w->output, s));
+    w->layers = triangle_layers(num_vars, split_hi);
+    w->out_vars = split_hi;
+    w->n_claims = 3 * (num_layers + 3);
+    TRY(gkr_witness_finish(w.get(), ((size_t)12 * 96 << num_vars) + ((size_t)48 << 20)));
+    *out = w.release();
+    return GM_OK;
+}
+
+// VecVecBintreeAddWG::new_common(VecVecMAP(inputs), row_logsize, num_adds, do_bitcheck) (bintree_add.rs:98-125) + last_step.
+// inputs: 4 polynomials (x_even, y_even, x_odd, y_odd), or 6 with (z_even, z_odd) appended when do_bitcheck.
+extern "C" int32_t gm_bintree_witness_create(const gm_vv* inputs, uint32_t num_adds, int32_t do_bitcheck, gm_gkr_witness** out,
+                                             void* stream) {
+    GM_REQUIRE(inputs && out, "null argument");
+    GM_REQUIRE(inputs->k == (do_bitcheck ? 6u : 4u), "%u input polynomials, expected %u", inputs->k, do_bitcheck ? 6u : 4u);
+    GM_REQUIRE(num_adds >= 1 && num_adds <= inputs->row_logsize + inputs->col_logsize + 1, "bad num_adds %u", num_adds);
+    GM_REQUIRE(!inputs->sharded, "standalone circuit over a sharded polynomial");
+    std::unique_ptr<gm_gkr_witness> w(new gm_gkr_witness());
+    hipStream_t s = w->stream = as_stream(stream);
+    gm_vv* share = nullptr;
+    TRY(gm_vv_slice(inputs, 0, inputs->k, &share));  // shares the caller's columns
+    Advice in;
+    in.kind = Advice::VECVEC;
+    in.vv.reset(new VVHolder(share));
+    // the inputs are the LO(0) split of the point columns: they carry row_logsize - 1 horizontal variables, the circuit is
+    // parametrised by the row_logsize BEFORE the split (bintree_add.rs:411-413)
+    const uint32_t row_logsize = inputs->row_logsize + 1, num_vars = row_logsize + inputs->col_logsize;
+    TRY(bintree_witness_build(in, row_logsize, num_adds, do_bitcheck != 0, &w->advices, s));
+    Advice last;
+    TRY(adv_map(mkfn(num_adds - 1 == 0 ? GM_FN_AFF_L3 : GM_FN_PROJ_L3, 1), w->advices.back(), &last, s));
+    w->out_vars = num_vars - num_adds;
+    if (last.kind == Advice::VECVEC) {  // densify (the reference's tests call to_dense on it)
+        w->output.kind = Advice::DENSE;
+        w->output.len = (uint64_t)1 << w->out_vars;
+        TRY(dense_alloc(3, w->output.len, &w->output.cols));
+        std::vector<uint64_t*> co;
+        for (auto& c : w->output.cols) co.push_back(reinterpret_cast<uint64_t*>(c->p));
+        TRY(gm_vv_to_dense(last.vv->v, co.data(), s));
+    } else {
+        w->output = last;
+    }
+    w->layers = bintree_layers(num_vars, num_adds, row_logsize, do_bitcheck != 0);
+    w->n_claims = 3;
+    const uint64_t T = inputs->total, nr = inputs->nrows;
+    const size_t bytes = (size_t)6 * 32 * (T + 4 * nr + 64) + ((size_t)48 << 20) + ((size_t)6 * 96 << (num_vars > 0 ? num_vars - 1 : 0));
+    TRY(gkr_witness_finish(w.get(), bytes));
+    *out = w.release();
+    return GM_OK;
+}
+
+extern "C" int32_t gm_gkr_witness_destroy(gm_gkr_witness* w) {
+    delete w;
+    return GM_OK;
+}
+
+// the circuit's output (last_step): n_cols dense device columns of 2^num_vars elements
+extern "C" int32_t gm_gkr_witness_output(const gm_gkr_witness* w, const uint64_t** d_cols, uint32_t cols_cap, uint32_t* n_cols,
+                                         uint32_t* num_vars) {
+    GM_REQUIRE(w, "null witness");
+    if (n_cols) *n_cols = (uint32_t)w->output.cols.size();
+    if (num_vars) *num_vars = w->out_vars;
+    if (d_cols) {
+        GM_REQUIRE(cols_cap >= w->output.cols.size(), "column pointer array too small");
+        for (size_t i = 0; i < w->output.cols.size(); i++) d_cols[i] = reinterpret_cast<const uint64_t*>(w->output.cols[i]->p);
+    }
+    return GM_OK;
+}
+
+static int32_t gkr_prove(const gm_gkr_witness* w, const uint64_t* h_point, const uint64_t* h_evs, const uint64_t* h_tape,
+                         uint64_t n_tape, const gm_transcript* cb, uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs,
+                         uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs, uint32_t* n_final_evs,
+                         uint64_t* tape_used, uint64_t* rounds) {
+    std::vector<Fr> msgs;
+    Tape tr{h_tape, n_tape, 0, &msgs, 0, cb, 0};
+    Claims c;
+    c.point.resize(w->out_vars);
+    if (w->out_vars) memcpy(c.point.data(), h_point, 32 * (size_t)w->out_vars);
+    c.evs.resize(w->output.cols.size());
+    memcpy(c.evs.data(), h_evs, 32 * c.evs.size());
+    gm_gkr_witness* wm = const_cast<gm_gkr_witness*>(w);
+    shared_pinned() = wm->pinned;
+    struct PinnedReset { ~PinnedReset() { shared_pinned() = nullptr; } } pinned_reset;
+    TRY(simple_gkr_prove(&tr, w->layers, w->advices, &c, &wm->arena, w->stream));
+    if (n_msgs) *n_msgs = msgs.size();
+    if (h_msgs) {
+        GM_REQUIRE(msgs.size() <= msgs_cap, "message buffer too small: %zu > %llu", msgs.size(), (unsigned long long)msgs_cap);
+        memcpy(h_msgs, msgs.data(), msgs.size() * sizeof(Fr));
+    }
+    if (n_final_point) *n_final_point = (uint32_t)c.point.size();
+    if (h_final_point) memcpy(h_final_point, c.point.data(), c.point.size() * sizeof(Fr));
+    if (n_final_evs) *n_final_evs = (uint32_t)c.evs.size();
+    if (h_final_evs) memcpy(h_final_evs, c.evs.data(), c.evs.size() * sizeof(Fr));
+    if (tr.cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", tr.cb_rc);
+    if (tape_used) *tape_used = tr.pos;
+    if (rounds) *rounds = tr.rounds;
+    return GM_OK;
+}
+
+// TriangleAdd::prove / VecVecBintreeAdd::prove = SimpleGKR::prove (gkrs/gkr.rs:45-50) over the witness's advices.
+// claims in: point (gm_gkr_witness_output's num_vars elements) + one evaluation per output column; claims out: the input
+// polynomials' point and evaluations (12 for the triangle; 4 or 6 for the bintree).
+extern "C" int32_t gm_gkr_prove(const gm_gkr_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs,
+                                uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs, uint32_t* n_final_evs,
+                                uint64_t* tape_used, uint64_t* rounds) {
+    GM_REQUIRE(w && h_claim_evs && h_tape && (h_claim_point || !w->out_vars), "null argument");
+    return gkr_prove(w, h_claim_point, h_claim_evs, h_tape, n_tape, nullptr, h_msgs, msgs_cap, n_msgs, h_final_point, n_final_point,
+                     h_final_evs, n_final_evs, tape_used, rounds);
+}
+
+extern "C" int32_t gm_gkr_prove_tr(const gm_gkr_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                   const gm_transcript* tr, uint64_t* h_final_point, uint32_t* n_final_point,
+                                   uint64_t* h_final_evs, uint32_t* n_final_evs, uint64_t* n_challenges, uint64_t* rounds) {
+    GM_REQUIRE(w && h_claim_evs && tr && tr->challenge && (h_claim_point || !w->out_vars), "null argument");
+    return gkr_prove(w, h_claim_point, h_claim_evs, nullptr, 0, tr, nullptr, 0, nullptr, h_final_point, n_final_point, h_final_evs,
+                     n_final_evs, n_challenges, rounds);
+}
+
+// =================================================================================================================
 // "prove pushforward" (pippenger.rs:147-160): PushforwardProtocol::prove (pushforward/pushforward.rs:640-846) with the
 // logup main phase (pushforward/logup_mainphase.rs:83-208).  The Fr columns come from the plan's last gm_msm_run
 // (gm_msm_phase1_polys, gm_msm_second_phase); the G1 commitments of those columns are gm_msm_g1_outer / gm_g1_msm.

@@ -60,6 +60,12 @@ class GmTranscriptReader(C.Structure):
 ALL_GATHER_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)
 
 
+class GmFragment(C.Structure):
+    """gm_fragment: Fragment{mem_idx, len, content, start} of a gen-1 Shape (content 0 = Data, 1 = Consts)"""
+    _fields_ = [("mem_idx", C.c_uint64), ("len", C.c_uint64), ("start", C.c_uint64), ("content", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 class GmComm(C.Structure):
     """gm_comm: rank / world and one host-buffer all-gather"""
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", ALL_GATHER_CB)]
@@ -143,6 +149,7 @@ _SIGS = {
     "gm_merlin_create_verifier": (C.c_int32, [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(vp)]),
     "gm_merlin_reader": (C.c_int32, [vp, C.POINTER(GmTranscriptReader)]),
     "gm_merlin_unread": (C.c_int32, [vp, u64p]),
+    "gm_kzg_div_by_linear": (C.c_int32, [vp, C.c_uint64, vp, vp, vp, vp]),
     "gm_knuckles_setup": (C.c_int32, [vp, C.c_uint32, vp, vp]),
     "gm_knuckles_open": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]),
     "gm_knuckles_open_tr": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, C.POINTER(GmTranscript), vp, vp, vp]),
@@ -177,6 +184,19 @@ _SIGS = {
     "gm_g1_batch": (C.c_int32, [C.c_int32, vp, vp, vp, C.c_uint64, vp]),
     "gm_g1_mock_srs": (C.c_int32, [vp, vp, C.c_uint64, vp, vp]),
     "gm_g1_gen_points": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp]),
+    "gm_frag_shape_full_split": (C.c_int32, [C.POINTER(GmFragment), C.c_uint32, C.c_uint64, C.POINTER(GmFragment), C.c_uint32, u32p,
+                                             u64p, C.c_uint32, u32p, u64p]),
+    "gm_frag_split": (C.c_int32, [C.POINTER(GmFragment), C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]),
+    "gm_frag_bind": (C.c_int32, [C.POINTER(GmFragment), C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp]),
+    "gm_frag_to_dense": (C.c_int32, [C.POINTER(GmFragment), C.c_uint32, C.c_uint64, vp, vp, vp, vp]),
+    "gm_segment_split": (C.c_int32, [C.c_uint64, C.c_uint64, u64p, C.POINTER(C.c_uint8), C.c_uint32, u32p]),
+    "gm_frag_eq_materialize": (C.c_int32, [C.POINTER(GmFragment), C.c_uint32, C.c_uint64, vp, vp, C.c_uint32, vp, vp, vp]),
+    "gm_triangle_witness_create": (C.c_int32, [vp, C.c_uint32, C.c_uint32, C.POINTER(vp), vp]),
+    "gm_bintree_witness_create": (C.c_int32, [vp, C.c_uint32, C.c_int32, C.POINTER(vp), vp]),
+    "gm_gkr_witness_destroy": (C.c_int32, [vp]),
+    "gm_gkr_witness_output": (C.c_int32, [vp, vp, C.c_uint32, u32p, u32p]),
+    "gm_gkr_prove": (C.c_int32, [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, u32p, vp, u32p, u64p, u64p]),
+    "gm_gkr_prove_tr": (C.c_int32, [vp, vp, vp, C.POINTER(GmTranscript), vp, u32p, vp, u32p, u64p, u64p]),
     "gm_g1_release_scratch": (C.c_int32, []),
     "gm_g1_generator": (C.c_int32, [vp]),
     "gm_g1_fixed_base_register": (C.c_int32, [vp, C.c_uint64, vp]),

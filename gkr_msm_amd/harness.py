@@ -687,3 +687,138 @@ def g1_fixed_base_register(d_bases_aff, n):
 
 def g1_fixed_base_release(d_bases_aff):
     ffi.check(ffi.lib().gm_g1_fixed_base_release(_p(d_bases_aff)))
+
+
+# ------------------------------------------------------------------ gen-1 fragmented polynomials (include/gkrmsm.h, fragmented section)
+def _frag_array(frags):
+    """[(mem_idx, len, content, start)] with content 'Data' / 'Consts' -> ctypes array of gm_fragment"""
+    arr = (ffi.GmFragment * max(len(frags), 1))()
+    for i, (m, ln, c, s) in enumerate(frags):
+        arr[i] = ffi.GmFragment(m, ln, s, 0 if c == "Data" else 1, 0)
+    return arr
+
+
+def frag_shape_full_split(frags, num_consts):
+    """Shape::full_split -> (fragments of the halves, perm, data_len)"""
+    cap = 2 * len(frags) + 4
+    out = (ffi.GmFragment * cap)()
+    perm = np.zeros(max(num_consts, 1), dtype=np.uint64)
+    n_out, n_perm, dl = C.c_uint32(), C.c_uint32(), C.c_uint64()
+    ffi.check(ffi.lib().gm_frag_shape_full_split(_frag_array(frags), len(frags), num_consts, out, cap, C.byref(n_out),
+                                                 perm.ctypes.data_as(ffi.u64p), len(perm), C.byref(n_perm), C.byref(dl)))
+    res = [(int(f.mem_idx), int(f.len), "Data" if f.content == 0 else "Consts", int(f.start)) for f in out[: n_out.value]]
+    return res, [int(v) for v in perm[: n_perm.value]], dl.value
+
+
+def segment_split(start, end):
+    st = np.zeros(130, dtype=np.uint64)
+    ll = np.zeros(130, dtype=np.uint8)
+    n = C.c_uint32()
+    ffi.check(ffi.lib().gm_segment_split(start, end, st.ctypes.data_as(ffi.u64p), ll.ctypes.data_as(C.POINTER(C.c_uint8)), 130,
+                                         C.byref(n)))
+    return [(int(st[i]), int(ll[i])) for i in range(n.value)]
+
+
+class FragPoly:
+    """FragmentedPoly with data / consts on the device (canonical ints in and out)"""
+
+    def __init__(self, frags, num_consts, d_data, d_consts):
+        self.frags, self.num_consts, self.d_data, self.d_consts = list(frags), num_consts, d_data, d_consts
+
+    @staticmethod
+    def from_host(frags, data, consts):
+        z = np.zeros((1, 4), dtype=np.uint64)
+        return FragPoly(frags, len(consts), to_dev(codec.to_mont_limbs(data) if data else z),
+                        to_dev(codec.to_mont_limbs(consts) if consts else z))
+
+    def _args(self):
+        return _frag_array(self.frags), len(self.frags), self.num_consts, _p(self.d_data), _p(self.d_consts)
+
+    def data(self):
+        n = sum(f[1] for f in self.frags if f[2] == "Data")
+        return codec.from_mont_limbs(to_host(self.d_data).reshape(-1, 4)[:n]) if n else []
+
+    def consts(self):
+        return codec.from_mont_limbs(to_host(self.d_consts).reshape(-1, 4)[: self.num_consts]) if self.num_consts else []
+
+    def split(self):
+        tf, perm, dl = frag_shape_full_split(self.frags, self.num_consts)
+        outs = [dev_empty(4 * max(dl, 1)) for _ in range(2)] + [dev_empty(4 * max(len(perm), 1)) for _ in range(2)]
+        ffi.check(ffi.lib().gm_frag_split(*self._args(), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), cur_stream()))
+        return FragPoly(tf, len(perm), outs[0], outs[2]), FragPoly(tf, len(perm), outs[1], outs[3])
+
+    def bind(self, t):
+        tf, perm, dl = frag_shape_full_split(self.frags, self.num_consts)
+        od, oc = dev_empty(4 * max(dl, 1)), dev_empty(4 * max(len(perm), 1))
+        ta = fr_arg([t])
+        ffi.check(ffi.lib().gm_frag_bind(*self._args(), ta.ctypes.data, _p(od), _p(oc), cur_stream()))
+        return FragPoly(tf, len(perm), od, oc)
+
+    def to_dense(self):
+        n = sum(f[1] for f in self.frags)
+        out = dev_empty(4 * max(n, 1))
+        ffi.check(ffi.lib().gm_frag_to_dense(*self._args(), _p(out), cur_stream()))
+        return codec.from_mont_limbs(to_host(out).reshape(-1, 4)[:n])
+
+
+def frag_eq_materialize(frags, num_consts, multiplier, point):
+    """EqPoly::materialize_eq_with_shape -> (values, sums)"""
+    dl = sum(f[1] for f in frags if f[2] == "Data")
+    d_vals = dev_empty(4 * max(dl, 1))
+    sums = np.zeros((max(num_consts, 1), 4), dtype=np.uint64)
+    m, p = fr_arg([multiplier]), fr_arg(point if point else [0])
+    ffi.check(ffi.lib().gm_frag_eq_materialize(_frag_array(frags), len(frags), num_consts, m.ctypes.data, p.ctypes.data, len(point),
+                                               _p(d_vals), sums.ctypes.data, cur_stream()))
+    vals = codec.from_mont_limbs(to_host(d_vals).reshape(-1, 4)[:dl]) if dl else []
+    return vals, codec.from_mont_limbs(sums[:num_consts]) if num_consts else []
+
+
+# ------------------------------------------------------------------ the two GKR circuits on their own
+class GkrWitness:
+    """gm_gkr_witness: TriangleAddWG / VecVecBintreeAddWG + their SimpleGKR prover"""
+
+    def __init__(self, handle, keep):
+        self.h, self.keep, self.L = handle, keep, ffi.lib()
+
+    @staticmethod
+    def triangle(cols, num_vars, split_hi):
+        h = C.c_void_p()
+        ffi.check(ffi.lib().gm_triangle_witness_create(ptr_array(cols), num_vars, split_hi, C.byref(h), cur_stream()))
+        return GkrWitness(h, tuple(cols))
+
+    @staticmethod
+    def bintree(vv, num_adds, do_bitcheck=False):
+        h = C.c_void_p()
+        ffi.check(ffi.lib().gm_bintree_witness_create(vv.h, num_adds, 1 if do_bitcheck else 0, C.byref(h), cur_stream()))
+        return GkrWitness(h, (vv,))
+
+    def close(self):
+        if self.h:
+            self.L.gm_gkr_witness_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def output(self):
+        """(last_step columns as canonical ints, num_vars)"""
+        n, nv = C.c_uint32(), C.c_uint32()
+        ffi.check(self.L.gm_gkr_witness_output(self.h, None, 0, C.byref(n), C.byref(nv)))
+        ptrs = (C.c_void_p * n.value)()
+        ffi.check(self.L.gm_gkr_witness_output(self.h, ptrs, n.value, C.byref(n), C.byref(nv)))
+        return [codec.from_mont_limbs(read_dev(ptrs[i], 32 << nv.value)) for i in range(n.value)], nv.value
+
+    def prove(self, claim_point, claim_evs, tape, msgs_cap=1 << 16):
+        cp, ce = fr_arg(claim_point if claim_point else [0]), fr_arg(claim_evs)
+        tp = codec.ints_to_limbs(tape)
+        msgs = np.zeros((msgs_cap, 4), dtype=np.uint64)
+        fpt, fev = np.zeros((64, 4), dtype=np.uint64), np.zeros((64, 4), dtype=np.uint64)
+        nm, used, rounds, npt, nev = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        ffi.check(self.L.gm_gkr_prove(self.h, cp.ctypes.data, ce.ctypes.data, tp.ctypes.data, len(tape), msgs.ctypes.data, msgs_cap,
+                                      C.byref(nm), fpt.ctypes.data, C.byref(npt), fev.ctypes.data, C.byref(nev), C.byref(used),
+                                      C.byref(rounds)))
+        return dict(msgs=codec.from_mont_limbs(msgs[: nm.value]), point=codec.from_mont_limbs(fpt[: npt.value]),
+                    evs=codec.from_mont_limbs(fev[: nev.value]), tape_used=used.value, rounds=rounds.value)

@@ -360,6 +360,31 @@ int32_t gm_pip_prove_image_part_tr(const gm_pip_witness* w, const uint64_t* h_cl
                                    const gm_transcript* tr, uint64_t* h_final_point, uint32_t* n_final_point,
                                    uint64_t* h_final_evs, uint64_t* n_challenges, uint64_t* rounds);
 
+/* ---------------------------------------------------------------- the two GKR circuits on their own (a10, a11)
+ * TriangleAddWG / TriangleAdd (gkrs/triangle_add.rs:160-250) and VecVecBintreeAddWG / VecVecBintreeAdd (gkrs/bintree_add.rs:85-126):
+ * the witness generators and SimpleGKR provers the Pippenger prover is built from, callable directly as the reference's
+ * own tests and benches call them (triangle_add.rs:277-393, bintree_add.rs:401-505).
+ *   gm_triangle_witness_create  TriangleAddWG::new(inputs, num_vars, HI(split_hi)); d_cols = 12 device columns of 2^num_vars
+ *                               (the output of two HI(split_hi) split-maps of the X, Y, Z bucket columns); borrowed, not copied
+ *   gm_bintree_witness_create   VecVecBintreeAddWG::new_common(VecVecMAP(inputs), row_logsize, num_adds, do_bitcheck) with
+ *                               row_logsize = inputs' row_logsize + 1 (inputs are the LO(0) split of the point columns)
+ *   gm_gkr_witness_output       builder::witness::last_step of the last advice, as dense device columns (a VecVec result is
+ *                               densified): 3 (num_layers + 3) columns for the triangle, 3 for the bintree
+ *   gm_gkr_prove(_tr)           TriangleAdd::prove / VecVecBintreeAdd::prove: claims on the output -> claims on the inputs */
+typedef struct gm_gkr_witness gm_gkr_witness;
+int32_t gm_triangle_witness_create(const uint64_t* const* d_cols, uint32_t num_vars, uint32_t split_hi, gm_gkr_witness** out,
+                                   void* stream);
+int32_t gm_bintree_witness_create(const gm_vv* inputs, uint32_t num_adds, int32_t do_bitcheck, gm_gkr_witness** out, void* stream);
+int32_t gm_gkr_witness_destroy(gm_gkr_witness* w);
+int32_t gm_gkr_witness_output(const gm_gkr_witness* w, const uint64_t** d_cols, uint32_t cols_cap, uint32_t* n_cols,
+                              uint32_t* num_vars);
+int32_t gm_gkr_prove(const gm_gkr_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs, const uint64_t* h_tape,
+                     uint64_t n_tape, uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_final_point,
+                     uint32_t* n_final_point, uint64_t* h_final_evs, uint32_t* n_final_evs, uint64_t* tape_used, uint64_t* rounds);
+int32_t gm_gkr_prove_tr(const gm_gkr_witness* w, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                        const gm_transcript* tr, uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs,
+                        uint32_t* n_final_evs, uint64_t* n_challenges, uint64_t* rounds);
+
 /* ---------------------------------------------------------------- "prove pushforward" (a7, a10, a12, a13)
  * PushforwardProtocol::prove (pushforward/pushforward.rs:640-846) with LogupMainphaseProtocol (pushforward/logup_mainphase.rs:83-208)
  * on the Fr columns of the plan's last gm_msm_run: c / d / ac_c / ac_d (PushForwardState::new :489-510), c_pull / d_pull
@@ -391,6 +416,11 @@ int32_t gm_multiopen_prove(uint32_t nvars, uint32_t nargs, const uint64_t* const
 int32_t gm_multiopen_prove_tr(uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
                               const uint64_t* h_evs, const gm_transcript* tr, uint64_t* h_out_point, uint64_t* h_out_evs,
                               uint64_t* n_challenges, uint64_t* rounds, void* stream);
+
+/* div_by_linear + ev (commitments/kzg.rs:73-81, 142-150) on a device polynomial (coefficients lowest first): h_ev = poly(pt) = the
+ * remainder; d_quotient (len - 1 coefficients; may be NULL) = poly / (X - pt).  KzgProvingKey::open = this + gm_g1_msm. */
+int32_t gm_kzg_div_by_linear(const uint64_t* d_poly, uint64_t len, const uint64_t* h_pt, uint64_t* d_quotient, uint64_t* h_ev,
+                             void* stream);
 
 /* Knuckles opening: KnucklesOpeningProtocol::prove (cleanup/protocols/opening.rs:39-98) = compute_t
  * (commitments/knuckles.rs:111-154), three KZG commitments / openings (kzg.rs:73-81, 123-132) and the deferred pairing pair.
@@ -455,6 +485,42 @@ int32_t gm_gkr_msm_prove_tr(const uint64_t* d_points_xy, const uint8_t* d_scalar
                             uint32_t log_num_scalar_bits, const gm_transcript* tr, uint64_t* h_output,
                             uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* n_challenges,
                             uint64_t* rounds, void* stream);
+
+/* ---------------------------------------------------------------- gen-1 fragmented polynomials, any shape (a3, a4, a5)
+ * FragmentedPoly{data, consts, shape} (src/polynomial/fragmented.rs:383-388) with `data` / `consts` in device memory and the
+ * shape -- a short list of fragments -- on the host, exactly the reference's Fragment{mem_idx, len, content, start}
+ * (fragmented.rs:36-41).  Fragments must tile the index range in order; a Data fragment's mem_idx is the number of data
+ * cells before it, a Consts fragment's mem_idx indexes `consts` (the invariants Shape::finalize asserts, :168-183).
+ *   gm_frag_shape_full_split  Shape::full_split + prune_consts   fragmented.rs:285-364  -> fragments of both halves, the
+ *                             permutation of the constants (new consts[i] = old consts[perm[i]]) and the new data length
+ *   gm_frag_split             FragmentedPoly::split              fragmented.rs:676-732  (even / odd halves; outputs sized by
+ *                             gm_frag_shape_full_split: data_len cells and n_perm constants each)
+ *   gm_frag_bind              FragmentedPoly::bind               fragmented.rs:736-746  l + t (r - l) on data and consts
+ *   gm_frag_to_dense          FragmentedPoly::into_vec           fragmented.rs:831-846
+ *   gm_segment_split          compute_segment_split              src/copoly.rs:139-148  (host only)
+ *   gm_frag_eq_materialize    EqPoly::materialize_eq_with_shape  src/copoly.rs:492-567: CopolyData{values (device, one per
+ *                             data cell), sums (host, one per constant)} of multiplier * eq(point, .), point[0] = MSB */
+#define GM_FRAG_DATA 0
+#define GM_FRAG_CONSTS 1
+typedef struct gm_fragment {
+    uint64_t mem_idx, len, start;
+    uint32_t content; /* GM_FRAG_DATA / GM_FRAG_CONSTS */
+    uint32_t reserved;
+} gm_fragment;
+int32_t gm_frag_shape_full_split(const gm_fragment* frags, uint32_t n_frags, uint64_t num_consts, gm_fragment* out_frags,
+                                 uint32_t out_cap, uint32_t* n_out, uint64_t* out_perm, uint32_t perm_cap, uint32_t* n_perm,
+                                 uint64_t* out_data_len);
+int32_t gm_frag_split(const gm_fragment* frags, uint32_t n_frags, uint64_t num_consts, const uint64_t* d_data,
+                      const uint64_t* d_consts, uint64_t* d_l_data, uint64_t* d_r_data, uint64_t* d_l_consts,
+                      uint64_t* d_r_consts, void* stream);
+int32_t gm_frag_bind(const gm_fragment* frags, uint32_t n_frags, uint64_t num_consts, const uint64_t* d_data,
+                     const uint64_t* d_consts, const uint64_t* h_t, uint64_t* d_out_data, uint64_t* d_out_consts, void* stream);
+int32_t gm_frag_to_dense(const gm_fragment* frags, uint32_t n_frags, uint64_t num_consts, const uint64_t* d_data,
+                         const uint64_t* d_consts, uint64_t* d_out, void* stream);
+int32_t gm_segment_split(uint64_t start, uint64_t end, uint64_t* out_starts, uint8_t* out_loglengths, uint32_t cap,
+                         uint32_t* n_out);
+int32_t gm_frag_eq_materialize(const gm_fragment* frags, uint32_t n_frags, uint64_t num_consts, const uint64_t* h_multiplier,
+                               const uint64_t* h_point, uint32_t nvars, uint64_t* d_values, uint64_t* h_sums, void* stream);
 
 /* ---------------------------------------------------------------- BLS12-381 G1 (a12 G1 part, a13, a14, a15, a17)
  * The reference reaches G1 through ark-ec 0.4.2 (un-vendored).  Wire forms here (the Rust shim marshals, ark's structs are

@@ -1,0 +1,192 @@
+"""BASELINE.json's named configurations at their FULL sizes on one GPU, bit for bit against the C oracle (oracle/gkrmsm_oracle*.c,
+OpenMP on the host cores):
+
+  configs[1]  x_logsize=20, d_logsize=8, nbits=256 Pippenger MSM     -> digits, counter, row lengths, bucket sums, window
+                                                                        points, final point AND every message of the image-part
+                                                                        prover (1518 sumcheck rounds)
+  configs[0]  x_logsize=16, d_logsize=8, nbits=128 (examples/pippenger.rs defaults of README.md:5)
+                                                                     -> the same, plus the whole gen-2 proof through the
+                                                                        library's verifier and the pairing check
+  configs[2]  gen-1 gkr_msm_prove at the largest size of the reference's own bench grid (benches/gkr_msm_simple.rs:97-107:
+              log_num_points 13..17 exclusive, 256-bit scalars) -> every transcript message
+
+The x = 20 prover check needs ~30 s of CPU and ~20 GiB of host memory for the oracle's witness trace; when the host has less
+than 40 GiB available the prover leg (only) drops to x_logsize = 18 and says so."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_ffi as O
+from gkr_msm_amd import codec, ffi, harness as H
+
+pytestmark = pytest.mark.gpu
+P = codec.P
+
+
+def host_threads():
+    return max(1, min(os.cpu_count() or 1, 32))
+
+
+def avail_gib():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        return 0.0
+
+
+def device_inputs(x_log, nbits, seed):
+    """points: gm_gen_points (k_i * G from SplitMix64 `seed`); scalars: uniform nbits-bit canonical bigints"""
+    n = 1 << x_log
+    d_pts = H.dev_empty(n * 8)
+    ffi.check(ffi.lib().gm_gen_points(C.c_void_p(d_pts.data_ptr()), n, seed, H.cur_stream()))
+    sc = np.random.default_rng(seed).integers(0, 2 ** 64, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)           # < 2^252 < the Bandersnatch group order
+    for limb in range(4):
+        lo = max(0, min(64, nbits - 64 * limb))
+        if lo < 64:
+            sc[:, limb] &= np.uint64((1 << lo) - 1)
+    sc[1] = 0                                      # a zero scalar: bucket 0 of every window
+    sc[3] = sc[2]                                  # a collision
+    return d_pts, H.to_dev(sc), sc
+
+
+def check_msm(x_log, d_log, nbits, seed):
+    y_size = (nbits + d_log - 1) // d_log
+    d_pts, d_sc, sc = device_inputs(x_log, nbits, seed)
+    pts_host = H.to_host(d_pts).reshape(-1, 8)
+    plan = H.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, d_sc)
+    t0 = time.perf_counter()
+    ref = O.msm(pts_host, sc, x_log, d_log, y_size, threads=host_threads(), want_aux=True)
+    cpu_s = time.perf_counter() - t0
+    dg, ct, rl = plan.digits_counter_rowlen()
+    assert np.array_equal(dg, ref["digits"]), "digits"
+    assert np.array_equal(ct, ref["counter"]), "counter"
+    assert np.array_equal(rl, ref["row_len"]), "bucket populations"
+    px, py, pz, nb = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    ffi.check(plan.L.gm_msm_bucket_sums(plan.h, C.byref(px), C.byref(py), C.byref(pz), C.byref(nb)))
+    assert nb.value == y_size << d_log
+    for p, k in ((px, "bx"), (py, "by"), (pz, "bz")):
+        assert np.array_equal(H.read_dev(p, nb.value * 32).reshape(-1, 4), ref[k]), "bucket sums " + k
+    raw = plan.window_points_raw()
+    assert np.array_equal(raw, ref["window_cols"]), "window points"
+    got = H.combine_host(raw, d_log)
+    assert got == tuple(codec.from_mont_limbs(O.msm_combine(ref["window_cols"], d_log))), "final point"
+    print("[at-size] MSM x=%d d=%d nbits=%d bit-exact vs the C oracle (%d threads, %.2f s on the CPU)" % (
+        x_log, d_log, nbits, host_threads(), cpu_s))
+    return plan, d_pts, d_sc, pts_host, sc
+
+
+def check_image_part(plan, d_pts, pts_host, sc, x_log, d_log, nbits, seed):
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = (y_size - 1).bit_length()
+    w = H.PipWitness(plan, d_pts, y_log)
+    outs, _ = w.outputs()
+    pr = np.random.default_rng(seed)
+    r_pt = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(y_log)]
+
+    def ev(poly):
+        cur = list(poly)
+        for f in reversed(r_pt):
+            cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
+        return cur[0]
+    r_evs = [ev(o) for o in outs]
+    tape = [int.from_bytes(pr.bytes(16), "little") for _ in range(4000)]
+    g = w.prove_image_part(r_pt, r_evs, tape)
+    w.close()
+    H.ffi.lib().gm_release_cached_memory()
+    t0 = time.perf_counter()
+    cw = O.PipWitness(pts_host, sc, x_log, d_log, y_size, y_log, host_threads())
+    assert np.array_equal(np.array([codec.to_mont_limbs(o) for o in outs]).reshape(len(outs), -1, 4), cw.output()), "dense output"
+    c = cw.prove_image_part(codec.to_mont_limbs(r_pt), codec.to_mont_limbs(r_evs), codec.ints_to_limbs(tape))
+    cpu_s = time.perf_counter() - t0
+    cw.close()
+    assert g["tape_used"] == c["tape_used"] and g["rounds"] == c["rounds"]
+    assert codec.from_mont_limbs(c["msgs"]) == g["msgs"], "prover messages"
+    assert codec.from_mont_limbs(c["point"]) == g["point"] and codec.from_mont_limbs(c["evs"]) == g["evs"], "final claims"
+    print("[at-size] image-part prover x=%d d=%d nbits=%d: %d rounds, %d messages bit-exact vs the C oracle (%.1f s on the CPU)" % (
+        x_log, d_log, nbits, g["rounds"], len(g["msgs"]), cpu_s))
+    return g
+
+
+def test_config_b_msm_and_image_part_at_full_size():
+    """BASELINE.json configs[1] (pippenger.rs:462-559 at x_logsize=20, d_logsize=8, nbits=256)"""
+    x_log, d_log, nbits = 20, 8, 256
+    plan, d_pts, d_sc, pts_host, sc = check_msm(x_log, d_log, nbits, 0x474B524D534D)
+    if avail_gib() >= 40:
+        g = check_image_part(plan, d_pts, pts_host, sc, x_log, d_log, nbits, 7)
+        assert g["rounds"] == 1518
+    else:
+        print("[at-size] host has %.0f GiB available: the prover leg runs at x_logsize=18 instead of 20" % avail_gib())
+        plan.close()
+        plan, d_pts, d_sc, pts_host, sc = check_msm(18, d_log, nbits, 0x474B524D534D)
+        check_image_part(plan, d_pts, pts_host, sc, 18, d_log, nbits, 7)
+    plan.close()
+    ffi.lib().gm_release_cached_memory()
+    torch.cuda.empty_cache()
+
+
+def test_config_a_msm_image_part_and_whole_proof():
+    """BASELINE.json configs[0]: --x-logsize 16 --d-logsize 8 --nbits 128 (examples/pippenger.rs:19-94, README.md:5); the whole
+    gen-2 proof of that shape is made on the GPU under the built-in merlin transcript and accepted by the library's verifier and
+    the pairing check (verify_pippenger, pippenger.rs:562-606)"""
+    from test_verifier_gpu import _prove_merlin, _setup
+    from gkr_msm_amd import verifier as VF
+    from pyref import g1 as G
+    from pyref import pairing as PR
+    x_log, d_log, nbits = 16, 8, 128
+    plan, d_pts, d_sc, pts_host, sc = check_msm(x_log, d_log, nbits, 0xA11CE)
+    g = check_image_part(plan, d_pts, pts_host, sc, x_log, d_log, nbits, 8)
+    y_size = nbits // d_log
+    assert g["rounds"] > 1000
+    plan.close()
+    s = _setup(x_log, d_log, nbits, 0, 16, device_srs=True)
+    proof, pair = _prove_merlin(s, b"config-a")
+    got = VF.pippenger_verify_merlin(*s["shape"], s["claims"][0], s["claims"][1], G.GEN, 2, b"config-a", proof)
+    assert got == pair
+    assert VF.kzg_verify_pair(got, PR.G2_GEN, PR.g2_mul(PR.G2_GEN, s["tau"]))
+    bad = bytearray(proof)
+    bad[len(bad) // 3] ^= 4
+    try:
+        alt = VF.pippenger_verify_merlin(*s["shape"], s["claims"][0], s["claims"][1], G.GEN, 2, b"config-a", bytes(bad))
+        assert not VF.kzg_verify_pair(alt, PR.G2_GEN, PR.g2_mul(PR.G2_GEN, s["tau"]))
+    except VF.Rejected:
+        pass
+    print("[at-size] config A whole proof: %d bytes, verified (y_size %d)" % (len(proof), y_size))
+    del s
+    ffi.lib().gm_release_cached_memory()
+    torch.cuda.empty_cache()
+
+
+def test_gen1_at_the_reference_bench_size():
+    """gkr_msm_prove at log_num_points = 16, 2^8 scalar bits: the top of the reference's bench grid
+    (benches/gkr_msm_simple.rs:97-107), every transcript message vs the C oracle"""
+    lp, lb = 16, 8
+    if avail_gib() < 24:
+        lp = 14
+        print("[at-size] host has %.0f GiB available: gen-1 runs at log_num_points=14" % avail_gib())
+    n = 1 << lp
+    d_pts = H.dev_empty(n * 8)
+    ffi.check(ffi.lib().gm_gen_points(C.c_void_p(d_pts.data_ptr()), n, 0x6E31, H.cur_stream()))
+    pts_host = H.to_host(d_pts).reshape(-1, 8)
+    rng = np.random.default_rng(11)
+    bits = rng.integers(0, 2, size=(n << lb), dtype=np.uint8)
+    tape = [int.from_bytes(rng.bytes(64), "little") % P for _ in range(6000)]
+    g = H.gkr_msm_prove(d_pts, torch.from_numpy(bits).cuda(), lp, lb, tape, msgs_cap=1 << 16)
+    ffi.lib().gm_release_cached_memory()
+    t0 = time.perf_counter()
+    c = O.gkr_msm_prove(pts_host, bits, lp, lb, codec.ints_to_limbs(tape), threads=host_threads(), msgs_cap=1 << 16)
+    cpu_s = time.perf_counter() - t0
+    assert g["tape_used"] == c["tape_used"] and g["rounds"] == c["rounds"]
+    assert codec.from_mont_limbs(c["msgs"]) == g["msgs"], "transcript messages"
+    nout = 1 << lb
+    assert [codec.from_mont_limbs(c["output"][k * nout:(k + 1) * nout]) for k in range(3)] == g["output"]
+    assert codec.from_mont_limbs(c["point"]) == g["point"] and codec.from_mont_limbs(c["evs"]) == g["evs"]
+    print("[at-size] gen-1 gkr_msm_prove 2^%d points x 2^%d bits: %d rounds, %d messages bit-exact vs the C oracle (%.1f s on the CPU)" % (
+        lp, lb, g["rounds"], len(g["msgs"]), cpu_s))
+    torch.cuda.empty_cache()
