@@ -48,10 +48,12 @@ inline int32_t set_err(int32_t code, const char* fmt, ...) {
 // synchronises the device.  Blocks >= 1 MiB are rounded to a size class (eight per octave) and kept on an idle list;
 // gm_release_cached_memory() hands them back.  Same-stream reuse is safe by stream order, as with any caching allocator;
 // callers that share buffers across streams must synchronise before destroying handles (they already must for hipFree).  Blocks below 1 MiB are cached in power-of-two classes.
+// Idle blocks are keyed by the device that was current when they were allocated (gm_set_device): a block is only ever reused on its own GPU.
 struct DevPool {
     std::mutex mu;
-    std::unordered_map<void*, size_t> live;
-    std::multimap<size_t, void*> idle;
+    struct Block { size_t bytes; int dev; };
+    std::unordered_map<void*, Block> live;
+    std::multimap<std::pair<int, size_t>, void*> idle;   // keyed by (device, size class): a block never crosses devices
     size_t idle_bytes = 0;
     uint64_t n_driver_allocs = 0, driver_alloc_bytes = 0;  // pool misses (diagnostics)
     static constexpr size_t SMALL = (size_t)1 << 20;
@@ -69,13 +71,15 @@ struct DevPool {
             const size_t g = (size_t)1 << (lg - 3);
             b = (b + g - 1) & ~(g - 1);
         }
+        int dev = 0;
+        (void)hipGetDevice(&dev);
         {
             std::lock_guard<std::mutex> g(mu);
-            auto it = idle.lower_bound(b);
-            if (it != idle.end() && it->first == b) {
+            auto it = idle.find({dev, b});
+            if (it != idle.end()) {
                 *out = it->second;
-                live[it->second] = it->first;
-                idle_bytes -= it->first;
+                live[it->second] = Block{b, dev};
+                idle_bytes -= b;
                 idle.erase(it);
                 return hipSuccess;
             }
@@ -88,7 +92,7 @@ struct DevPool {
             if (e != hipSuccess) return e;
         }
         std::lock_guard<std::mutex> g(mu);
-        live[*out] = b;
+        live[*out] = Block{b, dev};
         n_driver_allocs++;
         driver_alloc_bytes += b;
         return hipSuccess;
@@ -99,8 +103,8 @@ struct DevPool {
             std::lock_guard<std::mutex> g(mu);
             auto it = live.find(p);
             if (it != live.end()) {
-                idle.insert({it->second, p});
-                idle_bytes += it->second;
+                idle.insert({{it->second.dev, it->second.bytes}, p});
+                idle_bytes += it->second.bytes;
                 live.erase(it);
                 return;
             }
@@ -108,7 +112,7 @@ struct DevPool {
         (void)hipFree(p);
     }
     void release() {
-        std::multimap<size_t, void*> take;
+        std::multimap<std::pair<int, size_t>, void*> take;
         {
             std::lock_guard<std::mutex> g(mu);
             take.swap(idle);

@@ -124,6 +124,35 @@ GM_HD bool g1_aff_on_curve(const G1Aff& p) {
     return fq_eq(fq_sqr(p.y), fq_add(fq_mul(fq_sqr(p.x), p.x), four));
 }
 
+// Prime-order subgroup membership of an on-curve point, host only: ark-bls12-381 0.4.0 `is_in_correct_subgroup_assuming_on_curve`
+// (g1.rs; un-vendored dependency; reached through G1Affine::deserialize_compressed with Validate::Yes in the reference's
+// read_points, cleanup/proof_transcript.rs:59-69) = Section 6 of eprint 2021/1130:  phi(P) == -[x^2] P  with phi(x, y) = (beta x, y),
+// x = 0xd201000000010000 (|BLS parameter|), beta the cube root of unity below; early out: [x]P == P != O is outside the subgroup.
+inline G1Jac g1_mul_u64_host(const G1Aff& p, uint64_t k) {
+    G1Jac acc = g1_inf();
+    for (int b = 63; b >= 0; b--) {
+        acc = g1_dbl(acc);
+        if ((k >> b) & 1) acc = g1_add_mixed(acc, p);
+    }
+    return acc;
+}
+inline bool g1_aff_in_subgroup_host(const G1Aff& p) {
+    if (g1_aff_is_inf(p)) return true;
+    static const Fq beta = [] {
+        Fq b;
+        const uint32_t c[12] = {0xfffefffeu, 0x2e01ffffu, 0x620a0002u, 0xde17d813u, 0xe6f89688u, 0xddb3a93bu,
+                                0x6a0f77eau, 0xba69c607u, 0xdf76ce51u, 0x5f19672fu, 0x00000000u, 0x00000000u};
+        for (int i = 0; i < 12; i++) b.l[i] = c[i];
+        return fq_to_mont(b);
+    }();
+    const uint64_t X = 0xd201000000010000ull;
+    const G1Aff xp = g1_to_aff(g1_mul_u64_host(p, X));
+    if (fq_eq(xp.x, p.x) && fq_eq(xp.y, p.y)) return false;
+    const G1Aff x2p = g1_to_aff(g1_mul_u64_host(xp, X));
+    if (g1_aff_is_inf(x2p)) return false;  // phi(P) is a finite point
+    return fq_eq(x2p.x, fq_mul(beta, p.x)) && fq_eq(fq_neg(x2p.y), p.y);
+}
+
 #if defined(__HIPCC__)
 __device__ __forceinline__ G1Aff g1_aff_load(const G1Aff* p) {
     G1Aff r;

@@ -640,6 +640,8 @@ struct G1FixedBase {
     uint64_t n = 0;
     uint32_t c = 16, nwin = 16;
     G1Aff* tab = nullptr;
+    int dev = 0;                 // device the bases live on
+    G1Aff first{}, last{};       // fingerprint: bases[0] and bases[n - 1] at registration
 };
 static std::mutex& g1_fixed_mu() {
     static std::mutex m;
@@ -649,11 +651,30 @@ static std::vector<G1FixedBase>& g1_fixed_registry() {
     static std::vector<G1FixedBase> r;
     return r;
 }
-static bool g1_fixed_lookup(const G1Aff* bases, uint64_t n, G1FixedBase* out) {
-    std::lock_guard<std::mutex> lock(g1_fixed_mu());
-    for (const G1FixedBase& f : g1_fixed_registry())
-        if (f.bases == bases && n <= f.n) { *out = f; return true; }
-    return false;
+// A registered key is recognised by its pointer, its device AND its content fingerprint: the caching allocator makes address
+// reuse likely, so a buffer that was freed or overwritten without gm_g1_fixed_base_release must not silently get the old
+// tables (two 96-byte reads, ~20 us, against an MSM of milliseconds).
+static bool g1_fixed_lookup(const G1Aff* bases, uint64_t n, G1FixedBase* out, hipStream_t s) {
+    G1FixedBase cand;
+    {
+        std::lock_guard<std::mutex> lock(g1_fixed_mu());
+        bool found = false;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        for (const G1FixedBase& f : g1_fixed_registry())
+            if (f.bases == bases && n <= f.n && f.dev == dev) { cand = f; found = true; break; }
+        if (!found) return false;
+    }
+    G1Aff now[2];
+    if (hipMemcpyAsync(&now[0], cand.bases, sizeof(G1Aff), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(&now[1], cand.bases + (cand.n - 1), sizeof(G1Aff), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (memcmp(&now[0], &cand.first, sizeof(G1Aff)) != 0 || memcmp(&now[1], &cand.last, sizeof(G1Aff)) != 0) return false;
+    *out = cand;
+    return true;
 }
 
 static int32_t g1_msm_fixed_core(const G1FixedBase& fb, const uint64_t* d_scalars, uint64_t n, int scalars_mont, uint32_t nbits,
@@ -819,7 +840,7 @@ extern "C" int32_t gm_g1_msm(const uint64_t* d_bases_aff, const uint64_t* d_scal
     G1Jac r;
     G1FixedBase fb;
     int32_t rc;
-    if (g1_fixed_lookup(reinterpret_cast<const G1Aff*>(d_bases_aff), n, &fb))
+    if (n && g1_fixed_lookup(reinterpret_cast<const G1Aff*>(d_bases_aff), n, &fb, as_stream(stream)))
         rc = g1_msm_fixed_core(fb, d_scalars, n, scalars_mont, nbits, &r, as_stream(stream));
     else
         rc = g1_msm_core(reinterpret_cast<const G1Aff*>(d_bases_aff), nullptr, d_scalars, n, scalars_mont, nbits, &r, as_stream(stream));
@@ -846,7 +867,11 @@ extern "C" int32_t gm_g1_fixed_base_register(const uint64_t* d_bases_aff, uint64
     if (e != hipSuccess) return set_err(GM_ERR_HIP, "fixed-base table (%.1f GiB): %s", fb.n * fb.nwin * 96.0 / (1 << 30), hipGetErrorString(e));
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(k_g1_fixed_tables, dim3(ceil_div(n, 128)), dim3(128), 0, s, fb.bases, n, fb.c, fb.nwin, fb.tab);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    (void)hipGetDevice(&fb.dev);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(&fb.first, fb.bases, sizeof(G1Aff), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(&fb.last, fb.bases + (n - 1), sizeof(G1Aff), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
         dev_free(fb.tab);
         return set_err(GM_ERR_HIP, "fixed-base table kernel failed");
     }

@@ -168,7 +168,7 @@ void g1_compress(const G1Aff& p, uint8_t out[48]) {
 }
 
 // Affine::deserialize_compressed with validation (ark-ec short_weierstrass; flags in the top bits of byte 0: 0x80 compressed,
-// 0x40 infinity, 0x20 y is the lexicographically largest root); false = malformed
+// 0x40 infinity, 0x20 y is the lexicographically largest root); false = malformed, off the curve or outside the subgroup
 bool g1_decompress(const uint8_t in[48], G1Aff* out) {
     if (!(in[0] & 0x80)) return false;
     if (in[0] & 0x40) {
@@ -206,7 +206,7 @@ bool g1_decompress(const uint8_t in[48], G1Aff* out) {
     if (!fq_eq(fq_sqr(y), rhs)) return false;  // not on the curve
     if (fq_is_lex_largest(fq_from_mont(y)) != ((in[0] & 0x20) != 0)) y = fq_neg(y);
     out->x = x; out->y = y;
-    return true;
+    return g1_aff_in_subgroup_host(*out);  // Validate::Yes also rejects points outside the prime-order subgroup
 }
 
 }  // namespace

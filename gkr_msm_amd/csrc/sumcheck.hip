@@ -132,6 +132,16 @@ Fr eq_sum_host(const Fr* pt, uint32_t n, uint64_t k) {
     return acc;
 }
 
+// ------------------------------------------------------------------------------------------ wait bound
+// Kernels that wait on the device for the host's next challenge (k_fold_gate, k_tail_rounds) and the host loops that wait for
+// their results give up after this long (gm_set_wait_timeout_ms; default 20 s).  Device side: wall_clock64() ticks (100 MHz).
+static std::atomic<uint32_t>& wait_timeout_ms() {
+    static std::atomic<uint32_t> v{20000};
+    return v;
+}
+static inline uint64_t wait_timeout_ticks() { return (uint64_t)wait_timeout_ms().load() * 100000ull; }
+static inline std::chrono::milliseconds wait_timeout_host() { return std::chrono::milliseconds(wait_timeout_ms().load()); }
+
 // ------------------------------------------------------------------------------------------ kernels
 #define SC_THREADS 256
 
@@ -320,14 +330,16 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs c
 // launch the fold and the next round kernel, and each launch takes ~5 us of API time plus ~4 us until the GPU starts it.
 // Small rounds therefore enqueue the fold of round r and the round kernel of round r + 1 BEFORE the challenge t_r exists:
 // a gate kernel in front of the fold waits (bounded) for the host to publish t_r in pinned memory.  The launch latency is
-// spent while round r's kernel is still running.  The wait is bounded (2^23 polls, ~20 s); on timeout the fold reports through a
+// spent while round r's kernel is still running.  The wait is bounded (gm_set_wait_timeout_ms, default 20 s); on timeout the fold reports through a
 // status word and exits, so a host that never answers cannot wedge the GPU.
 // One wave (the gate) polls the host's ticket word -- thousands of fold blocks polling over PCIe would queue behind each
 // other's reads -- and copies the challenge into device memory; the fold behind it in the stream is an ordinary kernel.
 __global__ void __launch_bounds__(64) k_fold_gate(const Fr* __restrict__ t_slot, const uint32_t* __restrict__ ticket_word, uint32_t ticket,
-                                                  uint32_t* __restrict__ status, Fr* __restrict__ d_t) {
+                                                  uint32_t* __restrict__ status, Fr* __restrict__ d_t, uint64_t timeout_ticks) {
     if (threadIdx.x != 0) return;
-    for (int it = 0; it < (1 << 23); it++) {   // ~20 s
+    const uint64_t t_begin = wall_clock64();
+    for (uint32_t it = 0;; it++) {
+        if ((it & 255u) == 255u && wall_clock64() - t_begin > timeout_ticks) break;
         const uint32_t f = __hip_atomic_load(ticket_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int32_t)(f - ticket) >= 0) {
             Fr t;
@@ -385,6 +397,7 @@ struct TailArgs {
     uint32_t ticket0;
     int nrounds;
     uint32_t npairs0;
+    uint64_t timeout_ticks;    // bound of every wait (100 MHz wall clock)
 };
 
 __global__ void __launch_bounds__(256) k_tail_rounds(SegPlan sp, ColPtrs cols, const Fr* __restrict__ gp, TailArgs a) {
@@ -435,7 +448,9 @@ __global__ void __launch_bounds__(256) k_tail_rounds(SegPlan sp, ColPtrs cols, c
             int good = 0;
             Fr t = fr_zero();
             if (blockIdx.x == 0) {
-                for (int it = 0; it < (1 << 23); it++) {   // ~20 s of polling over PCIe: a slow (interpreted, traced) transcript is fine
+                const uint64_t t_begin = wall_clock64();
+                for (uint32_t it = 0;; it++) {   // polling over PCIe until the bound: a slow (interpreted, traced) transcript is fine
+                    if ((it & 255u) == 255u && wall_clock64() - t_begin > a.timeout_ticks) break;
                     const uint32_t f = __hip_atomic_load(a.h_ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                     if ((int32_t)(f - want) >= 0) { good = 1; break; }
                     __builtin_amdgcn_s_sleep(2);
@@ -452,7 +467,9 @@ __global__ void __launch_bounds__(256) k_tail_rounds(SegPlan sp, ColPtrs cols, c
                     __hip_atomic_store(a.d_relay, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // let the others go
                 }
             } else {
-                for (int it = 0; it < (1 << 27); it++) {   // outlasts block 0's wait; block 0 releases the others when it gives up
+                const uint64_t t_begin = wall_clock64();
+                for (uint32_t it = 0;; it++) {   // outlasts block 0's wait (4x); block 0 releases the others when it gives up
+                    if ((it & 1023u) == 1023u && wall_clock64() - t_begin > 4 * a.timeout_ticks) break;
                     const uint32_t f = __hip_atomic_load(a.d_relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                     if (f == 0xffffffffu) break;
                     if ((int32_t)(f - want) >= 0) { good = 1; break; }
@@ -930,13 +947,13 @@ struct RoundScratch {
         }
         if (!seen && !can_sync) {
             const auto t0 = std::chrono::steady_clock::now();
-            while (!seen && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20)) {
+            while (!seen && std::chrono::steady_clock::now() - t0 < wait_timeout_host()) {
                 for (int spin = 0; spin < 10000 && !seen; spin++) {
                     if (*slot == want) seen = true;
                     __builtin_ia32_pause();
                 }
             }
-            if (!seen) return set_err(GM_ERR_STATE, "round kernel result did not arrive within 20 s");
+            if (!seen) return set_err(GM_ERR_STATE, "round kernel result did not arrive within %u ms (gm_set_wait_timeout_ms)", wait_timeout_ms().load());
         }
         if (!seen) GM_HIP(hipStreamSynchronize(s));
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -1257,7 +1274,7 @@ struct ScDense : gm_sc {
                 if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
                 Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
                 hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(round_idx), rs.ticket_word(), fold_ticket,
-                                   rs.ticket_word() + 1, d_t);
+                                   rs.ticket_word() + 1, d_t, wait_timeout_ticks());
                 hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(npairs, 256), cols.k), dim3(256), 0, stream, ci, co, npairs, d_t);
                 GM_LAUNCH_CHECK();
                 fold_pending = true;
@@ -1268,7 +1285,10 @@ struct ScDense : gm_sc {
             Fr acc[4];
             int32_t rc = rs.finish_seq(k_seq[round_idx & 63], D, stream, acc, !fold_pending);
             if (rc) return rc;
-            if (rs.ticket_word()[1]) return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge");
+            if (rs.ticket_word()[1]) {
+                rs.ticket_word()[1] = 0;   // the staging may be shared with later objects: report once
+                return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge (gm_set_wait_timeout_ms)");
+            }
             if (sh.comm) {
                 rc = shard_sum_fr(sh, acc, D);
                 if (rc) return rc;
@@ -1454,6 +1474,9 @@ struct ScDenseDeg2 : gm_sc {
         a.h_t = tail->t(); a.h_ticket = tail->ticket(); a.h_status = tail->status();
         a.d_relay = reinterpret_cast<uint32_t*>(static_cast<char*>(rs.counter.p) + 128);
         a.ticket0 = tail_ticket0; a.nrounds = nr; a.npairs0 = (uint32_t)npairs0;
+        a.timeout_ticks = wait_timeout_ticks();
+        // the stage outlives this object (one per host thread): a timeout flagged by an earlier launch must not fail this one
+        *reinterpret_cast<volatile uint32_t*>(tail->status()) = 0;
         GM_HIP(hipMemsetAsync(a.d_relay, 0, 96, stream));
         hipLaunchKernelGGL(k_tail_rounds, dim3(2 * sp.nseg), dim3(256), 0, stream, sp, cp, d_gamma.fr(), a);
         GM_LAUNCH_CHECK();
@@ -1467,7 +1490,7 @@ struct ScDenseDeg2 : gm_sc {
             __builtin_ia32_pause();
         }
         const auto t0 = std::chrono::steady_clock::now();
-        while (std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20))
+        while (std::chrono::steady_clock::now() - t0 < wait_timeout_host() + std::chrono::milliseconds(200))
             for (int spin = 0; spin < 10000; spin++) {
                 if (*slot == want) return true;
                 __builtin_ia32_pause();
@@ -1478,9 +1501,12 @@ struct ScDenseDeg2 : gm_sc {
         const uint32_t want = tail_ticket0 + (round_idx - tail_r0);
         const int ny = 2 * sp.nseg;
         for (int y = 0; y < ny; y++)
-            if (!spin_for(tail->seq() + y, want)) return set_err(GM_ERR_STATE, "tail round result did not arrive within 20 s");
+            if (!spin_for(tail->seq() + y, want)) return set_err(GM_ERR_STATE, "tail round result did not arrive in time (gm_set_wait_timeout_ms)");
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (*reinterpret_cast<volatile uint32_t*>(tail->status())) return set_err(GM_ERR_STATE, "the tail kernel timed out waiting for a challenge");
+        if (*reinterpret_cast<volatile uint32_t*>(tail->status())) {
+            *reinterpret_cast<volatile uint32_t*>(tail->status()) = 0;
+            return set_err(GM_ERR_STATE, "the tail kernel timed out waiting for a challenge (gm_set_wait_timeout_ms)");
+        }
         *s1 = fr_zero(); *s2 = fr_zero();
         for (int y = 0; y < ny; y++) {
             const Fr v = tail->part()[y];
@@ -1530,7 +1556,8 @@ struct ScDenseDeg2 : gm_sc {
             if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
             const uint64_t n_out = npairs;
             Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
-            hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(r), rs.ticket_word(), fold_ticket, rs.ticket_word() + 1, d_t);
+            hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(r), rs.ticket_word(), fold_ticket, rs.ticket_word() + 1, d_t,
+                               wait_timeout_ticks());
             hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(n_out, 256), cols.k), dim3(256), 0, stream, ci, co, n_out, d_t);
             GM_LAUNCH_CHECK();
             fold_pending = true;
@@ -1548,7 +1575,10 @@ struct ScDenseDeg2 : gm_sc {
         Fr acc[4];
         int32_t rc = rs.finish_seq(k_seq[r & 63], 2, stream, acc, !fold_pending);
         if (rc) return rc;
-        if (rs.ticket_word()[1]) return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge");
+        if (rs.ticket_word()[1]) {
+                rs.ticket_word()[1] = 0;   // the staging may be shared with later objects: report once
+                return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge (gm_set_wait_timeout_ms)");
+            }
         const Fr total1 = fr_mul(acc[0], multiplier), total2 = fr_mul(acc[1], multiplier);
         if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);
         cached = from12_inv(total1, total2, point.back(), inv_eq0[point.size() - 1], claim_);
@@ -1611,7 +1641,7 @@ struct ScDenseDeg2 : gm_sc {
             if (round_idx != num_vars) return set_err(GM_ERR_STATE, "final_evals before the last round");
             const uint32_t want = tail_ticket0 + (num_vars - tail_r0);
             for (int sg = 0; sg < sp.nseg; sg++)
-                if (!spin_for(tail->fin_seq() + sg, want)) return set_err(GM_ERR_STATE, "tail final evaluations did not arrive within 20 s");
+                if (!spin_for(tail->fin_seq() + sg, want)) return set_err(GM_ERR_STATE, "tail final evaluations did not arrive in time (gm_set_wait_timeout_ms)");
             std::atomic_thread_fence(std::memory_order_acquire);
             out->assign(tail->finals(), tail->finals() + cols.k);
             return GM_OK;
@@ -1685,7 +1715,7 @@ struct ScVecVecDeg2 : gm_sc {
             if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
             Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
             hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(already_bound), rs.ticket_word(), fold_ticket,
-                               rs.ticket_word() + 1, d_t);
+                               rs.ticket_word() + 1, d_t, wait_timeout_ticks());
             hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(nx_bound, SC_THREADS), (k + 1) / 2), dim3(SC_THREADS), 0, stream, ci, co, off_cur,
                                nx_off, nrows, fr_zero(), pd, (const Fr*)d_t, k);
             GM_LAUNCH_CHECK();
@@ -1697,7 +1727,10 @@ struct ScVecVecDeg2 : gm_sc {
         Fr acc[4];
         int32_t rc = rs.finish_seq(k_seq[already_bound & 63], 3, stream, acc, !fold_pending);
         if (rc) return rc;
-        if (rs.ticket_word()[1]) return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge");
+        if (rs.ticket_word()[1]) {
+                rs.ticket_word()[1] = 0;   // the staging may be shared with later objects: report once
+                return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge (gm_set_wait_timeout_ms)");
+            }
         if (sh.comm) {
             rc = shard_sum_fr(sh, acc, 3);
             if (rc) return rc;
@@ -2217,6 +2250,11 @@ extern "C" int32_t gm_sc_claim(const gm_sc* so, uint64_t* h_claim) {
     GM_REQUIRE(so && h_claim, "null argument");
     Fr c = so->claim();
     memcpy(h_claim, &c, 32);
+    return GM_OK;
+}
+
+extern "C" int32_t gm_set_wait_timeout_ms(uint32_t ms) {
+    wait_timeout_ms().store(ms ? ms : 20000u);
     return GM_OK;
 }
 

@@ -54,7 +54,12 @@ struct Reader {
             VERIFY(pi + n <= n_points, "proof ran out of points (proof_transcript.rs:123 \"Out of bounds\")");
             memcpy(out, points + pi, n * sizeof(G1Aff));
         }
-        for (uint64_t i = 0; i < n; i++) VERIFY(g1_aff_on_curve(out[i]), "a proof point is not on the curve (deserialize_compressed)");
+        for (uint64_t i = 0; i < n; i++) {
+            VERIFY(g1_aff_on_curve(out[i]), "a proof point is not on the curve (deserialize_compressed)");
+            // recorded mode holds raw affine points; a reader callback delivers points its deserializer has validated (the
+            // built-in one does: g1_decompress), so the ~70 us membership test is not repeated behind it
+            if (!cb) VERIFY(g1_aff_in_subgroup_host(out[i]), "a proof point is outside the prime-order subgroup (deserialize_compressed, Validate::Yes)");
+        }
         pi += n;
         return GM_OK;
     }
@@ -348,7 +353,12 @@ int32_t knuckles_verify(Reader* tr, const G1Jac& g0, const Fr& k, uint32_t num_v
 int32_t pippenger_verify(Reader* tr, uint32_t x_log, uint32_t d_log, uint32_t y_size, uint32_t y_log, uint32_t clm, const Fr* claim_point,
                          const Fr* claim_evs, const G1Aff& g0_aff, const Fr& k, uint64_t* h_pair) {
     GM_REQUIRE(x_log >= d_log && x_log >= 2 && d_log >= 2, "x_logsize >= d_logsize >= 2 required (pippenger.rs:93)");
-    GM_REQUIRE(y_size >= 1 && y_size <= (1u << y_log) && y_log >= clm, "bad y_size / y_logsize / commitment_log_multiplicity");
+    // size bounds first: the shapes below are allocated and shifted by these (nothing crosses the C ABI as an exception)
+    GM_REQUIRE(x_log <= 30 && d_log <= 16 && y_log <= 16 && clm <= y_log, "shape out of range (x_logsize <= 30, d_logsize <= 16, y_logsize <= 16, clm <= y_logsize)");
+    GM_REQUIRE(y_size >= 1 && y_size <= (1u << y_log) && (uint64_t)y_size * d_log <= 256, "bad y_size / y_logsize (y_size * d_logsize <= 256, pushforward.rs:358)");
+    // GM_OK is NOT acceptance by itself: Pippenger::verify ends with vkey.kzg_vk.verify_pair(ps_pair) (pippenger.rs:403-405); here the
+    // pair is handed back for gm_kzg_verify_pair, so the caller must take it
+    GM_REQUIRE(h_pair, "h_pair is required: the proof is accepted only if gm_kzg_verify_pair(h_pair, h0, h1) also returns GM_OK");
     const uint32_t cm = 1u << clm, n_mat = (y_size + cm - 1) / cm;
     std::vector<G1Aff> c(n_mat), d(n_mat), c_pull(n_mat), d_pull(n_mat);
     G1Aff p_0, p_1, ac_c, ac_d;
@@ -441,16 +451,20 @@ int32_t pippenger_verify(Reader* tr, uint32_t x_log, uint32_t d_log, uint32_t y_
 extern "C" int32_t gm_pippenger_verify_tr(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_size, uint32_t y_logsize,
                                           uint32_t commitment_log_multiplicity, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
                                           const uint64_t* h_g0_aff, const uint64_t* h_k, const gm_transcript_reader* tr, uint64_t* h_pair) {
-    GM_REQUIRE(h_claim_point && h_claim_evs && h_g0_aff && h_k && tr && tr->read_scalars && tr->read_points && tr->challenge,
-               "null argument");
-    Reader rd;
-    rd.cb = tr;
-    G1Aff g0;
-    Fr k;
-    memcpy(&g0, h_g0_aff, sizeof(G1Aff));
-    memcpy(&k, h_k, sizeof(Fr));
-    return pippenger_verify(&rd, x_logsize, d_logsize, y_size, y_logsize, commitment_log_multiplicity,
-                            reinterpret_cast<const Fr*>(h_claim_point), reinterpret_cast<const Fr*>(h_claim_evs), g0, k, h_pair);
+    try {
+        GM_REQUIRE(h_claim_point && h_claim_evs && h_g0_aff && h_k && tr && tr->read_scalars && tr->read_points && tr->challenge,
+                   "null argument");
+        Reader rd;
+        rd.cb = tr;
+        G1Aff g0;
+        Fr k;
+        memcpy(&g0, h_g0_aff, sizeof(G1Aff));
+        memcpy(&k, h_k, sizeof(Fr));
+        return pippenger_verify(&rd, x_logsize, d_logsize, y_size, y_logsize, commitment_log_multiplicity,
+                                reinterpret_cast<const Fr*>(h_claim_point), reinterpret_cast<const Fr*>(h_claim_evs), g0, k, h_pair);
+    } catch (const std::exception& e) {
+        return set_err(GM_ERR_INVALID, "gm_pippenger_verify_tr: %s", e.what());
+    }
 }
 
 extern "C" int32_t gm_pippenger_verify(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_size, uint32_t y_logsize,
@@ -458,25 +472,29 @@ extern "C" int32_t gm_pippenger_verify(uint32_t x_logsize, uint32_t d_logsize, u
                                        const uint64_t* h_g0_aff, const uint64_t* h_k, const uint64_t* h_scalars, uint64_t n_scalars,
                                        const uint64_t* h_points_aff, uint64_t n_points, const uint64_t* h_tape, uint64_t n_tape,
                                        uint64_t* h_pair, uint64_t* tape_used) {
-    GM_REQUIRE(h_claim_point && h_claim_evs && h_g0_aff && h_k && (h_scalars || !n_scalars) && (h_points_aff || !n_points) &&
-                   (h_tape || !n_tape),
-               "null argument");
-    Reader rd;
-    rd.scalars = reinterpret_cast<const Fr*>(h_scalars);
-    rd.points = reinterpret_cast<const G1Aff*>(h_points_aff);
-    rd.tape = h_tape;
-    rd.n_scalars = n_scalars; rd.n_points = n_points; rd.n_tape = n_tape;
-    G1Aff g0;
-    Fr k;
-    memcpy(&g0, h_g0_aff, sizeof(G1Aff));
-    memcpy(&k, h_k, sizeof(Fr));
-    TRY(pippenger_verify(&rd, x_logsize, d_logsize, y_size, y_logsize, commitment_log_multiplicity,
-                         reinterpret_cast<const Fr*>(h_claim_point), reinterpret_cast<const Fr*>(h_claim_evs), g0, k, h_pair));
-    if (rd.si != n_scalars || rd.pi != n_points)
-        return set_err(GM_ERR_VERIFY, "proof has unread messages (%llu of %llu scalars, %llu of %llu points read)",
-                       (unsigned long long)rd.si, (unsigned long long)n_scalars, (unsigned long long)rd.pi, (unsigned long long)n_points);
-    if (tape_used) *tape_used = rd.pos;
-    return GM_OK;
+    try {
+        GM_REQUIRE(h_claim_point && h_claim_evs && h_g0_aff && h_k && (h_scalars || !n_scalars) && (h_points_aff || !n_points) &&
+                       (h_tape || !n_tape),
+                   "null argument");
+        Reader rd;
+        rd.scalars = reinterpret_cast<const Fr*>(h_scalars);
+        rd.points = reinterpret_cast<const G1Aff*>(h_points_aff);
+        rd.tape = h_tape;
+        rd.n_scalars = n_scalars; rd.n_points = n_points; rd.n_tape = n_tape;
+        G1Aff g0;
+        Fr k;
+        memcpy(&g0, h_g0_aff, sizeof(G1Aff));
+        memcpy(&k, h_k, sizeof(Fr));
+        TRY(pippenger_verify(&rd, x_logsize, d_logsize, y_size, y_logsize, commitment_log_multiplicity,
+                             reinterpret_cast<const Fr*>(h_claim_point), reinterpret_cast<const Fr*>(h_claim_evs), g0, k, h_pair));
+        if (rd.si != n_scalars || rd.pi != n_points)
+            return set_err(GM_ERR_VERIFY, "proof has unread messages (%llu of %llu scalars, %llu of %llu points read)",
+                           (unsigned long long)rd.si, (unsigned long long)n_scalars, (unsigned long long)rd.pi, (unsigned long long)n_points);
+        if (tape_used) *tape_used = rd.pos;
+        return GM_OK;
+    } catch (const std::exception& e) {
+        return set_err(GM_ERR_INVALID, "gm_pippenger_verify: %s", e.what());
+    }
 }
 
 // KzgVerifyingKey::verify_pair (kzg.rs:61-67): e(A, h0) == e(B, h1), as e(A, h0) e(-B, h1) == 1 with one final exponentiation.
@@ -533,7 +551,7 @@ extern "C" int32_t gm_pairing(const uint64_t* h_p_aff, const uint64_t* h_q_aff, 
 namespace {
 
 int32_t gkr_msm_verify(Reader* tr, uint32_t lp, uint32_t lb, Fr* out_point, uint32_t* n_point, Fr* out_evs, uint64_t* rounds) {
-    GM_REQUIRE(lp >= 1 && lb >= 1 && lp + lb <= 40, "bad log_num_points / log_num_scalar_bits");
+    GM_REQUIRE(lp >= 1 && lb >= 1 && lp <= 30 && lb <= 16, "bad log_num_points / log_num_scalar_bits (<= 30 / <= 16)");
     struct L1 { bool is_map; int prim; uint32_t nv; };
     std::vector<L1> layers;   // gkr_msm_simple.rs:248-269 unrolled (bintree.rs:81-123)
     {
@@ -611,24 +629,32 @@ int32_t gkr_msm_verify(Reader* tr, uint32_t lp, uint32_t lb, Fr* out_point, uint
 extern "C" int32_t gm_gkr_msm_verify(uint32_t log_num_points, uint32_t log_num_scalar_bits, const uint64_t* h_msgs, uint64_t n_msgs,
                                      const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_final_point, uint32_t* n_final_point,
                                      uint64_t* h_final_evs, uint64_t* tape_used, uint64_t* rounds) {
-    GM_REQUIRE((h_msgs || !n_msgs) && (h_tape || !n_tape), "null argument");
-    Reader rd;
-    rd.scalars = reinterpret_cast<const Fr*>(h_msgs);
-    rd.tape = h_tape;
-    rd.n_scalars = n_msgs; rd.n_tape = n_tape;
-    TRY(gkr_msm_verify(&rd, log_num_points, log_num_scalar_bits, reinterpret_cast<Fr*>(h_final_point), n_final_point,
-                       reinterpret_cast<Fr*>(h_final_evs), rounds));
-    if (rd.si != n_msgs) return set_err(GM_ERR_VERIFY, "transcript has unread messages (%llu of %llu read)", (unsigned long long)rd.si,
-                                        (unsigned long long)n_msgs);
-    if (tape_used) *tape_used = rd.pos;
-    return GM_OK;
+    try {
+        GM_REQUIRE((h_msgs || !n_msgs) && (h_tape || !n_tape), "null argument");
+        Reader rd;
+        rd.scalars = reinterpret_cast<const Fr*>(h_msgs);
+        rd.tape = h_tape;
+        rd.n_scalars = n_msgs; rd.n_tape = n_tape;
+        TRY(gkr_msm_verify(&rd, log_num_points, log_num_scalar_bits, reinterpret_cast<Fr*>(h_final_point), n_final_point,
+                           reinterpret_cast<Fr*>(h_final_evs), rounds));
+        if (rd.si != n_msgs) return set_err(GM_ERR_VERIFY, "transcript has unread messages (%llu of %llu read)", (unsigned long long)rd.si,
+                                            (unsigned long long)n_msgs);
+        if (tape_used) *tape_used = rd.pos;
+        return GM_OK;
+    } catch (const std::exception& e) {
+        return set_err(GM_ERR_INVALID, "gm_gkr_msm_verify: %s", e.what());
+    }
 }
 
 extern "C" int32_t gm_gkr_msm_verify_tr(uint32_t log_num_points, uint32_t log_num_scalar_bits, const gm_transcript_reader* tr,
                                         uint64_t* h_final_point, uint32_t* n_final_point, uint64_t* h_final_evs, uint64_t* rounds) {
-    GM_REQUIRE(tr && tr->read_scalars && tr->challenge, "null argument");
-    Reader rd;
-    rd.cb = tr;
-    return gkr_msm_verify(&rd, log_num_points, log_num_scalar_bits, reinterpret_cast<Fr*>(h_final_point), n_final_point,
-                          reinterpret_cast<Fr*>(h_final_evs), rounds);
+    try {
+        GM_REQUIRE(tr && tr->read_scalars && tr->challenge, "null argument");
+        Reader rd;
+        rd.cb = tr;
+        return gkr_msm_verify(&rd, log_num_points, log_num_scalar_bits, reinterpret_cast<Fr*>(h_final_point), n_final_point,
+                              reinterpret_cast<Fr*>(h_final_evs), rounds);
+    } catch (const std::exception& e) {
+        return set_err(GM_ERR_INVALID, "gm_gkr_msm_verify_tr: %s", e.what());
+    }
 }

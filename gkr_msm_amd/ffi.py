@@ -80,6 +80,7 @@ _SIGS = {
     "gm_malloc": (C.c_int32, [C.POINTER(vp), C.c_size_t]),
     "gm_free": (C.c_int32, [vp]),
     "gm_release_cached_memory": (C.c_int32, []),
+    "gm_set_wait_timeout_ms": (C.c_int32, [C.c_uint32]),
     "gm_memcpy_h2d": (C.c_int32, [vp, vp, C.c_size_t, vp]),
     "gm_memcpy_d2h": (C.c_int32, [vp, vp, C.c_size_t, vp]),
     "gm_memcpy_d2d": (C.c_int32, [vp, vp, C.c_size_t, vp]),

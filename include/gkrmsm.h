@@ -43,6 +43,11 @@ int32_t gm_free(void* d_ptr);
 /* Handles and workspaces keep the large device blocks they free on an idle list (re-allocating freshly freed HBM is slow
  * and hipFree synchronises); this returns the idle blocks to the driver. */
 int32_t gm_release_cached_memory(void);
+/* Small sumcheck rounds keep kernels WAITING on the device for the caller's next challenge (a one-wave gate in front of a
+ * pre-enqueued fold; the persistent tail-round kernel), and the host waits for their results.  Every such wait is bounded: after
+ * `ms` milliseconds (default 20000; 0 restores the default) the waiting kernel flags a status word and leaves, and the call in
+ * progress returns GM_ERR_STATE -- a caller whose transcript dies never wedges the GPU.  Process-wide; affects later launches. */
+int32_t gm_set_wait_timeout_ms(uint32_t ms);
 int32_t gm_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
 int32_t gm_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 int32_t gm_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream); /* asynchronous */
@@ -266,13 +271,17 @@ int32_t gm_keccak_f1600(uint8_t* state200);
  * feeds the sponge):
  *   read_scalars: next n field elements of the proof -> Montgomery, 4 x u64 each
  *   challenge:    as in gm_transcript
- *   read_points:  next n G1 points of the proof -> affine wire form (12 x u64 each)
+ *   read_points:  next n G1 points of the proof -> affine wire form (12 x u64 each); like TProofTranscript2::read_points
+ *                 (deserialize_compressed with Validate::Yes) the callback hands over VALIDATED points: on the curve and in the
+ *                 prime-order subgroup (the built-in reader does; the recorded form, gm_pippenger_verify, checks both itself)
  * A non-zero return from a read means the proof is too short or malformed: the verifier returns GM_ERR_VERIFY.
  *
  * gm_pippenger_verify_tr: claims = the point r_y (y_logsize elements) and the 3 (d_logsize + 1) evaluations of the MSM's dense
  *   output there (verify_pippenger, pippenger.rs:562-587, forms them from the claimed result); h_g0_aff = the first SRS element
  *   (KzgVerifyingKey::g0), h_k = the Knuckles generator k (Montgomery).  GM_OK: every check up to the deferred pairing passed and
- *   h_pair = (A, B), affine, 2 x 12 u64; GM_ERR_VERIFY: a check failed (gm_last_error() names it).
+ *   h_pair = (A, B), affine, 2 x 12 u64 (required: Pippenger::verify ends with verify_pair(ps_pair), pippenger.rs:403-405, so the
+ *   proof is ACCEPTED only when gm_kzg_verify_pair(h_pair, h0, h1) returns GM_OK as well); GM_ERR_VERIFY: a check failed
+ *   (gm_last_error() names it).  Shapes are bounded: x_logsize <= 30, d_logsize, y_logsize <= 16, y_size * d_logsize <= 256.
  * gm_pippenger_verify: the same over recorded messages and a challenge tape (the prover's outputs from gm_pippenger_prove);
  *   additionally insists that every message was read.
  * gm_kzg_verify_pair: KzgVerifyingKey::verify_pair (commitments/kzg.rs:61-67), e(A, h0) == e(B, h1) on BLS12-381; h0 = [1]_2 and

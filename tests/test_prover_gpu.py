@@ -134,3 +134,50 @@ def test_slow_and_failing_transcripts_with_kernels_waiting_on_the_device():
             H.prove_image_part_tr(w, claims[0], claims[1], make(fail_at=fail_at))
         again = w.prove_image_part(claims[0], claims[1], tape)
         assert again["msgs"] == ref["msgs"] and again["evs"] == ref["evs"]
+
+
+def test_a_timed_out_wait_does_not_poison_later_proofs():
+    """gm_set_wait_timeout_ms: with a 150 ms bound a transcript that sleeps longer makes the waiting kernels (gate / persistent
+    tail) give up -- the proof call fails with an error, nothing hangs -- and the NEXT proof on the same host thread, with the
+    default bound restored, is the normal one (the per-thread pinned stages carry no stale time-out flag)"""
+    import time
+    from gkr_msm_amd import ffi
+    x_log, d_log, nbits = 11, 4, 32
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = PL.log2_exact(y_size)
+    n = 1 << x_log
+    pts = F.random_points(n, 31)
+    sc = F.random_scalars(n, nbits, 32)
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    plan = H.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, H.to_dev(codec.ints_to_limbs(sc)))
+    w = H.PipWitness(plan, d_pts, y_log)
+    outs, _ = w.outputs()
+    rng = F.SplitMix64(9)
+    r = [rng.next_fr() for _ in range(y_log)]
+    claims = G.pippenger_claims(outs, r)
+    tape = [rng.next_bits(128) for _ in range(3000)]
+    ref = w.prove_image_part(claims[0], claims[1], tape)
+    L = ffi.lib()
+    timeouts = []
+    for sleep_at in (3, 5, ref["tape_used"] // 2, ref["tape_used"] // 2 + 1, ref["tape_used"] - 3):
+        ffi.check(L.gm_set_wait_timeout_ms(150))
+        it = iter(tape)
+        count = [0]
+
+        def draw():
+            count[0] += 1
+            if count[0] == sleep_at:
+                time.sleep(0.6)
+            return next(it)
+        try:   # a draw with no kernel waiting behind it (a gamma, a split challenge) just takes longer
+            res = H.prove_image_part_tr(w, claims[0], claims[1], H.LiveTranscript(draw))
+            assert (res["point"], res["evs"]) == (ref["point"], ref["evs"])
+        except ffi.GmError as e:
+            assert "timed out" in str(e) or "did not arrive" in str(e), str(e)
+            timeouts.append(sleep_at)
+        finally:
+            ffi.check(L.gm_set_wait_timeout_ms(0))
+        again = w.prove_image_part(claims[0], claims[1], tape)
+        assert again["msgs"] == ref["msgs"] and again["evs"] == ref["evs"]
+    assert timeouts, "no wait timed out: the bound is not honoured"

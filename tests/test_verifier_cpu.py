@@ -106,6 +106,64 @@ def test_verifier_rejects_tampered_proofs(proof):
     assert not VF.kzg_verify_pair(got["pair"], PR.G2_GEN, PR.g2_mul(PR.G2_GEN, p["tau"]))
 
 
+def _cofactor_torsion_point():
+    """a point of the curve y^2 = x^3 + 4 outside the prime-order subgroup: [r] P for an arbitrary curve point P (order | h)"""
+    x = 5
+    while True:
+        x += 1
+        rhs = (x ** 3 + 4) % G.Q
+        y = pow(rhs, (G.Q + 1) // 4, G.Q)
+        if y * y % G.Q != rhs:
+            continue
+        acc, p, k = None, (x, y), G.R_ORDER      # plain double-and-add: G.mul reduces its scalar mod r
+        while k:
+            if k & 1:
+                acc = G.add(acc, p)
+            p = G.double(p)
+            k >>= 1
+        if acc is not None:
+            return acc
+
+
+def test_verifier_rejects_points_outside_the_prime_order_subgroup(proof):
+    """read_points deserialises with Validate::Yes (proof_transcript.rs:59-69 -> ark-ec): a commitment moved by a cofactor-torsion
+    point is still on the curve but must be refused, in the recorded form and through the merlin reader's decompression"""
+    import ctypes as C
+    import numpy as np
+    from gkr_msm_amd import codec, ffi
+    p = proof
+    t = _cofactor_torsion_point()
+    assert G.on_curve(t)
+    bad_pt = G.add(p["points"][0], t)
+    assert G.on_curve(bad_pt)
+    with pytest.raises(VF.Rejected) as e:
+        VF.pippenger_verify(*p["shape"], p["claims"][0], p["claims"][1], p["g0"], p["k"], p["scalars"], [bad_pt] + p["points"][1:],
+                            p["tape"])
+    assert "subgroup" in str(e.value)
+    # the compressed encoding of that point through the built-in ProofTranscript2 reader
+    L = ffi.lib()
+
+    def compress(pt):
+        x, y = pt
+        b = bytearray(x.to_bytes(48, "big"))
+        b[0] |= 0x80
+        if y > (G.Q - 1) // 2:
+            b[0] |= 0x20
+        return bytes(b)
+    for pt, ok in ((p["points"][0], True), (bad_pt, False), (t, False)):
+        proof_bytes = compress(pt)
+        h = C.c_void_p()
+        ffi.check(L.gm_merlin_create_verifier(b"x", 1, proof_bytes, len(proof_bytes), C.byref(h)))
+        rd = ffi.GmTranscriptReader()
+        ffi.check(L.gm_merlin_reader(h, C.byref(rd)))
+        out = np.zeros(12, dtype=np.uint64)
+        rc = rd.read_points(rd.ctx, 1, out.ctypes.data_as(ffi.u64p))
+        assert (rc == 0) == ok
+        if ok:
+            assert codec.g1_aff_from_limbs(out)[0] == pt
+        L.gm_merlin_destroy(h)
+
+
 @pytest.mark.parametrize("lp,lb", [(1, 1), (3, 2), (4, 3)])
 def test_gen1_verifier_on_the_oracle_prover_stream(lp, lb):
     """gm_gkr_msm_verify (BintreeVerifier / SumcheckPolyMapVerifier / SplitVerifier) accepts what pyref's gkr_msm_prove writes,
