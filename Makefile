@@ -4,7 +4,7 @@ ARCH ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -DGM_FR_MUL_ASM -mllvm -enable-misched=0
 SRC := $(wildcard gkr_msm_amd/csrc/*.hip)
 OBJ := $(patsubst gkr_msm_amd/csrc/%.hip,build/%.o,$(SRC))
-HDR := $(wildcard gkr_msm_amd/csrc/*.inc) $(wildcard gkr_msm_amd/csrc/*.cuh) $(wildcard gkr_msm_amd/csrc/*.hpp) include/gkrmsm.h
+HDR := $(wildcard gkr_msm_amd/csrc/*.inc) $(wildcard gkr_msm_amd/csrc/*.hip.h) $(wildcard gkr_msm_amd/csrc/*.hpp) include/gkrmsm.h
 LIB := gkr_msm_amd/libgkrmsm_hip.so
 
 all: $(LIB) oracle examples

@@ -6,7 +6,7 @@
 //   /root/reference/src/gkr_msm_simple.rs:82-84          (pt_bit_choice, gen-1)
 // A function is selected by a small descriptor (GmFn) instead of a Rust generic.
 #pragma once
-#include "fr.cuh"
+#include "fr.hip.h"
 
 namespace gm {
 

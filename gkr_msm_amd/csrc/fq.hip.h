@@ -6,12 +6,12 @@
 // (/root/reference/src/cleanup/protocols/pushforward/pushforward.rs:395-456), msm_nonaffine.rs, binary_msm.rs,
 // KzgProvingKey::commit (commitments/kzg.rs:123-126).
 //
-// Same multiplier shape as Fr (fr.cuh): CIOS over 32-bit limbs, every 32x32 product one v_mad_u64_u32 that also absorbs
+// Same multiplier shape as Fr (fr.hip.h): CIOS over 32-bit limbs, every 32x32 product one v_mad_u64_u32 that also absorbs
 // the matching accumulator limb, high halves folded with one add-with-carry chain per row.  q is not 1 mod 2^32, so
 // the quotient digit costs one v_mul_lo_u32 (m = t0 * (-q^-1 mod 2^32)).  q < 2^381: sums of two elements and the CIOS
 // accumulator never need a 13th/14th limb.
 #pragma once
-#include "fr.cuh"
+#include "fr.hip.h"
 
 namespace gm {
 

@@ -1,6 +1,6 @@
 // Runtime entry points, elementwise field batch ops, synthetic inputs and the host-side scalar glue
 // (final MSM recombination).  See include/gkrmsm.h.
-#include "algfn.cuh"
+#include "algfn.hip.h"
 #include "common.hpp"
 
 using namespace gm;

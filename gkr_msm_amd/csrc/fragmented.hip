@@ -14,7 +14,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "fr.cuh"
+#include "fr.hip.h"
 #include "internal.hpp"
 
 namespace gm {

@@ -13,7 +13,7 @@
 // mapping goes through the per-level row offsets, so the work is perfectly balanced whatever the bucket skew (d_outer
 // has 256 rows of 4096 points per window, an MSM window has 8192 rows of ~128).  Weighted sums sum_i i*B_i use the
 // same engine on the bit decomposition of i:  sum_i i B_i = sum_b 2^b (sum_{i : bit b set} B_i).
-// G1 results are group elements (g1.cuh): the tree order is free, unlike the Bandersnatch bucket sums of msm.hip whose
+// G1 results are group elements (g1.hip.h): the tree order is free, unlike the Bandersnatch bucket sums of msm.hip whose
 // projective coordinates are part of the proof.
 //
 // Bound: integer VALU (a Jacobian addition is 16 Fq multiplications of ~290 v_mad_u64_u32 each); HBM traffic is
@@ -29,7 +29,7 @@
 
 #include "common.hpp"
 #include "internal.hpp"
-#include "g1.cuh"
+#include "g1.hip.h"
 #include "msm_plan.hpp"
 
 namespace gm {

@@ -10,7 +10,7 @@
 //   affine:   x, y  Montgomery 6 x u64 each = 96 bytes; the point at infinity is (0, 0) (not on the curve)
 //   jacobian: X, Y, Z = 144 bytes; infinity is Z = 0
 #pragma once
-#include "fq.cuh"
+#include "fq.hip.h"
 
 namespace gm {
 

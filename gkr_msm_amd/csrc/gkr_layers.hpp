@@ -4,7 +4,7 @@
 #include <vector>
 
 #include "internal.hpp"
-#include "segfn.cuh"
+#include "segfn.hip.h"
 
 namespace gm {
 

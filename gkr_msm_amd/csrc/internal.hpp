@@ -4,7 +4,7 @@
 #include <vector>
 
 #include "common.hpp"
-#include "segfn.cuh"
+#include "segfn.hip.h"
 
 namespace gm {
 

@@ -11,7 +11,7 @@
 // same group elements.
 #include <vector>
 
-#include "g1.cuh"
+#include "g1.hip.h"
 #include "internal.hpp"
 
 using namespace gm;

@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "g1.cuh"
+#include "g1.hip.h"
 #include "internal.hpp"
 
 using namespace gm;

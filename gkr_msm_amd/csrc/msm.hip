@@ -20,10 +20,10 @@
 #include <algorithm>
 #include <vector>
 
-#include "algfn.cuh"
+#include "algfn.hip.h"
 #include "common.hpp"
 #include "msm_plan.hpp"
-#include "ragged.cuh"
+#include "ragged.hip.h"
 
 namespace gm {
 

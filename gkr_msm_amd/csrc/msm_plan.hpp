@@ -1,7 +1,7 @@
 // The MSM plan (workspaces of gm_msm_run); shared with the witness builders that start from the bucket image.
 #pragma once
 #include "common.hpp"
-#include "fr.cuh"
+#include "fr.hip.h"
 
 using gm::Fr;
 

@@ -11,7 +11,7 @@
 #pragma once
 #include <cstdint>
 
-#include "g1.cuh"
+#include "g1.hip.h"
 
 namespace gm {
 

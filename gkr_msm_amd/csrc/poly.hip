@@ -8,7 +8,7 @@
 // column): a lane moves whole elements with two 16-byte accesses and consecutive lanes touch consecutive
 // elements, so every wave-level load covers one contiguous 2 KiB span.
 #include "common.hpp"
-#include "segfn.cuh"
+#include "segfn.hip.h"
 
 namespace gm {
 

@@ -1283,7 +1283,7 @@ extern "C" int32_t gm_multiopen_prove_tr(uint32_t nvars, uint32_t nargs, const u
 // (gm_msm_run, done by the caller), phase-1 commitments (gm_msm_g1_outer, gm_g1_msm), the image part, second_phase and its
 // commitments (gm_g1_msm_nonaff over the outer buckets), the pushforward argument, MultiOpenReduction and the Knuckles
 // opening; plus the host-side scalar / G1 glue of the "open" span.
-#include "g1.cuh"
+#include "g1.hip.h"
 
 extern "C" {
 int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_basis_aff, uint32_t clm, uint64_t* d_d_outer, uint64_t* d_c_outer,

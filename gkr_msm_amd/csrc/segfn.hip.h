@@ -8,7 +8,7 @@
 // at a time with at most 6 input elements live in registers, whatever the width of the layer
 // (the widest triangle layer at d_logsize = 10 has 60 input columns).
 #pragma once
-#include "algfn.cuh"
+#include "algfn.hip.h"
 
 namespace gm {
 

@@ -18,7 +18,7 @@
 #include <chrono>
 
 #include "internal.hpp"
-#include "ragged.cuh"
+#include "ragged.hip.h"
 #include "vecvec.hpp"
 
 namespace gm {

@@ -12,7 +12,7 @@
 // are separate arrays over the same cells, so one offsets table and one binary search serve all of them.
 #include "internal.hpp"
 #include "msm_plan.hpp"
-#include "ragged.cuh"
+#include "ragged.hip.h"
 #include "vecvec.hpp"
 
 namespace gm {

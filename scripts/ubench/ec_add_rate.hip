@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
-#include "../../gkr_msm_amd/csrc/fr.cuh"
+#include "../../gkr_msm_amd/csrc/fr.hip.h"
 using namespace gm;
 struct P3 { Fr x, y, z; };
 __device__ __forceinline__ P3 padd(const P3& p, const P3& g) {

@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "../../gkr_msm_amd/csrc/fr.cuh"
+#include "../../gkr_msm_amd/csrc/fr.hip.h"
 using namespace gm;
 
 __device__ __forceinline__ Fr fr_mul_asm(const Fr& a, const Fr& b) {
