@@ -10,7 +10,7 @@ LIB := gkr_msm_amd/libgkrmsm_hip.so
 all: $(LIB) oracle examples
 
 $(LIB): $(OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ) -ldl
 
 build/%.o: gkr_msm_amd/csrc/%.hip $(HDR)
 	@mkdir -p build

@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: Pippenger MSM points/sec on MI355X (BASELINE.json metric).
+"""bench.py -- headline benchmark: Pippenger MSM points/sec + sumcheck rounds/sec on MI355X (BASELINE.json metric).
 
 A "step" is one full pass of the MSM hot path over one batch of synthetic input resident in HBM:
 digits -> stable bucket scatter -> bucket sums (x_logsize levels of pairwise adds) -> bucket reduction ->
-all-gather of the window points (N > 1) -> D2H of 27 x n_windows field elements -> host recombination.
+all-gather of the window points (N > 1, ncclAllGather inside the library) -> D2H of 27 x n_windows field elements -> host
+recombination.
 
 N = 1 : BASELINE.json configs[1]: x_logsize=20, d_logsize=8, nbits=256 (32 windows of 8 bits).
-N > 1 : the path shards by MSM window: rank g owns windows [g*32/N, (g+1)*32/N); points/scalars
-        are replicated; the only exchange is the all-gather of (d+1) points per window (RCCL).  Weak scaling:
-        x_logsize = 20 + log2(N), so every rank keeps 2^25 bucket cells per step, as at N = 1.
+N > 1 : the path shards by MSM window: rank g owns windows [g*32/N, (g+1)*32/N); points/scalars are replicated
+        (ncclBroadcast); the only exchange of a step is the all-gather of (d+1) points per window.  `value` is the metric's
+        own configuration -- x_logsize=20 on N GPUs, total work fixed: "scaling": "strong" -- and the same line carries
+        `weak` (x_logsize = 20 + log2 N: 2^25 bucket cells per rank, as at N = 1) and `config_d` (BASELINE.json configs[3]:
+        x_logsize=24, windows sharded N ways), plus the window/row-sharded image-part prover's rounds/sec.
 
-One JSON line on rank 0 (see README / DESIGN.md for the field meanings).  `roofline` is for the dominant kernel
-(level-0 bucket add, k_add_level0) timed with HIP events on the launch stream inside the timed steps;
-`cpu_baseline` is the C oracle (oracle/gkrmsm_oracle.c, OpenMP) on this host, rank 0, N = 1 only.
+One JSON line on rank 0 (see README / DESIGN.md for the field meanings).  `roofline` is for the dominant MSM kernel (level-0
+bucket add, k_add_level0) and `sumcheck.roofline` for the dominant round kernel of the prover, both timed with HIP events on
+the launch stream inside the timed runs; `cpu_baseline` is the C oracle (oracle/gkrmsm_oracle*.c, OpenMP) on this host,
+rank 0, N = 1 only.
 """
 import argparse
 import ctypes as C
 import json
 import math
 import os
+import platform
 import sys
 import time
 
@@ -31,11 +36,65 @@ import torch  # noqa: E402
 from gkr_msm_amd import codec, ffi, harness  # noqa: E402
 from gkr_msm_amd import dist as gdist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FR_MUL_CEILING = 115e9     # measured: scripts/ubench/instr_rate.hip, 302-instruction multiplier, all 256 CUs
+P = codec.P
+SEED = 0x474B524D534D      # "GKRMSM"
+
+# HBM traffic per launch of the dominant kernels at config B from the committed PMC passes (profiles/r02/*_pmc_hbm.csv:
+# (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction); None for any other shape
+PMC_TRAFFIC_MSM_B = 5741469043
+PMC_TRAFFIC_SC_B = {}      # kernel name -> bytes per launch (filled from profiles/r02/prover_pmc_hbm.csv)
+try:
+    with open(os.path.join(ROOT, "profiles", "r02", "prover_pmc_per_launch.json")) as _f:
+        PMC_TRAFFIC_SC_B = json.load(_f)
+except Exception:
+    pass
 
 
 def log(msg):
     print(msg, file=sys.stderr, flush=True)
+
+
+def host_info():
+    model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cpu_model": model}
+
+
+def make_scalars(n, nbits, seed=0x474B524D):
+    rng = np.random.default_rng(seed)
+    sc = rng.integers(0, 2 ** 64, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)  # uniform below 2^252 (< Bandersnatch order): canonical bigints
+    if nbits < 256:
+        full = nbits // 64
+        for limb in range(4):
+            if limb > full:
+                sc[:, limb] = 0
+            elif limb == full:
+                sc[:, limb] &= np.uint64((1 << (nbits % 64)) - 1)
+    return sc
+
+
+def claims_for(w_, y_log_, seed):
+    outs, _ = w_.outputs()
+    pr = np.random.default_rng(seed)
+    r = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(y_log_)]
+
+    def ev(poly):
+        cur = list(poly)
+        for f in reversed(r):
+            cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
+        return cur[0]
+    tape = [int.from_bytes(pr.bytes(16), "little") for _ in range(4000)]
+    return r, [ev(o) for o in outs], tape
 
 
 def main():
@@ -49,12 +108,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-sumcheck", action="store_true")
-    ap.add_argument("--cpu-sumcheck-xlog", type=int, default=17)
-    ap.add_argument("--gen1-log-points", type=int, default=18, help="gen-1 gkr_msm_prove size (0 = skip; 20 needs ~210 GiB)")
+    ap.add_argument("--cpu-sumcheck-xlog", type=int, default=20, help="CPU prover sample (config B itself by default: ~25 s)")
+    ap.add_argument("--cpu-faithful-xlog", type=int, default=17, help="sample of the 'reference-faithful' CPU variant (serial round loops)")
+    ap.add_argument("--gen1-log-points", type=int, default=18, help="gen-1 gkr_msm_prove size (0 = skip)")
     ap.add_argument("--cpu-gen1-log-points", type=int, default=12)
     ap.add_argument("--g1-log-points", type=int, default=21, help="BLS12-381 G1 MSM size (KZG commit shape; 0 = skip)")
     ap.add_argument("--cpu-g1-log-points", type=int, default=19)
     ap.add_argument("--cpu-g1-outer-xlog", type=int, default=17)
+    ap.add_argument("--no-extra-shapes", action="store_true", help="N > 1: only the metric's x_logsize=20 line (skip weak / config D)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -63,12 +124,13 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     # GM_BENCH_BACKEND=gloo rehearses the N > 1 flow on a box with fewer GPUs than ranks (ranks then share devices and the
-    # small exchanges go over gloo on host tensors); the real runs use "nccl" = RCCL over xGMI, one GPU per rank.
+    # small exchanges go over gloo on host tensors); the real runs use RCCL over xGMI, one GPU per rank.
     backend = os.environ.get("GM_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
-    xdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")  # where collective payloads live
+    xdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")  # where torch collective payloads live
     dist = None
+    rcomm = None     # the library's own RCCL communicator (data path); torch.distributed only bootstraps it and syncs the clock
     if world > 1:
         import datetime
         import torch.distributed as dist_mod
@@ -77,126 +139,161 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
                                     timeout=datetime.timedelta(seconds=300))
+            try:
+                rcomm = gdist.RcclComm(dist, rank, world, bcast_device=xdev)
+            except Exception as e:  # keep going over torch.distributed; the line says which transport was used
+                log("rank %d: native RCCL communicator unavailable (%r); falling back to torch.distributed" % (rank, e))
+                rcomm = None
+            ok = torch.tensor([1 if rcomm is not None else 0], dtype=torch.int32, device=xdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                rcomm = None
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    transport = "none" if world == 1 else ("rccl-native (ncclAllGather / ncclBroadcast inside libgkrmsm_hip.so)" if rcomm is not None
+                                            else "torch.distributed/%s callback" % backend)
 
     L = ffi.lib()
     d_log, nbits = args.d_logsize, args.nbits
-    x_log = args.x_logsize if args.x_logsize is not None else 20 + int(round(math.log2(world)))
     y_size = (nbits + d_log - 1) // d_log
     y0, y1 = gdist.window_range(rank, world, y_size)
     wpr = y1 - y0
-    n = 1 << x_log
-
-    # ---- synthetic inputs, identical on every rank (replicated operands)
-    stream = harness.cur_stream()
-    d_pts = harness.dev_empty(n * 8)
-    ffi.check(L.gm_gen_points(C.c_void_p(d_pts.data_ptr()), n, 0x474B524D534D, stream))
-    rng = np.random.default_rng(0x474B524D)
-    sc = rng.integers(0, 2 ** 64, size=(n, 4), dtype=np.uint64)
-    sc[:, 3] &= np.uint64((1 << 60) - 1)  # uniform below 2^252 (< Bandersnatch order): canonical bigints
-    if nbits < 256:
-        full = nbits // 64
-        for limb in range(4):
-            if limb > full:
-                sc[:, limb] = 0
-            elif limb == full:
-                sc[:, limb] &= np.uint64((1 << (nbits % 64)) - 1)
-    d_sc = harness.to_dev(sc)
-    plan = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
     ncols = 3 * (d_log + 1)
-
-    def step():
-        plan.run(d_pts, d_sc)
-        p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
-        ffi.check(L.gm_msm_window_points(plan.h, C.byref(p), C.byref(nc), C.byref(cl)))
-        if world > 1:
-            mine = torch.empty((ncols, wpr, 4), dtype=torch.int64, device="cuda")
-            ffi.check(L.gm_memcpy_d2d(C.c_void_p(mine.data_ptr()), p, ncols * wpr * 32, harness.cur_stream()))
-            raw = gdist.gather_window_points(dist, mine.to(xdev), world)
-        else:
-            raw = harness.read_dev(p, ncols * wpr * 32).reshape(ncols, wpr, 4)
-        return harness.combine_host(raw, d_log), raw
 
     def sync_all():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ffi.check(L.gm_msm_profile(plan.h, 1))
-    dom_ms = []
-    prof = (C.c_float * 7)()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result, raw = step()
-        ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
-        dom_ms.append(prof[4])
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
 
-    # ---- stage breakdown (one extra, untimed pass)
-    ffi.check(L.gm_msm_profile(plan.h, 2))
-    step()
-    ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
-    stages = dict(zip(["digits", "histogram", "chunk_scan_offsets", "scatter", "add_level0", "add_levels_ge1",
-                       "triangle"], [round(float(x), 4) for x in prof]))
-    ffi.check(L.gm_msm_profile(plan.h, 0))
+    def make_inputs(x_log):
+        """synthetic operands, identical on every rank: generated on rank 0 and replicated with ncclBroadcast when the native
+        communicator is up (the path's one link-bound transfer), generated in place otherwise (same seeds)"""
+        n = 1 << x_log
+        d_pts = harness.dev_empty(n * 8)
+        sc = make_scalars(n, nbits)
+        bcast_ms = None
+        if rcomm is not None:
+            if rank == 0:
+                ffi.check(L.gm_gen_points(C.c_void_p(d_pts.data_ptr()), n, SEED, harness.cur_stream()))
+                d_sc = harness.to_dev(sc)
+            else:
+                d_sc = harness.dev_empty(n * 4)
+            sync_all()
+            t0 = time.perf_counter()
+            rcomm.broadcast_dev(d_pts, 0)
+            rcomm.broadcast_dev(d_sc, 0)
+            sync_all()
+            bcast_ms = (time.perf_counter() - t0) * 1e3
+        else:
+            ffi.check(L.gm_gen_points(C.c_void_p(d_pts.data_ptr()), n, SEED, harness.cur_stream()))
+            d_sc = harness.to_dev(sc)
+        return d_pts, d_sc, sc, bcast_ms
 
-    ms_per_step = dt / args.steps * 1e3
-    value = n * args.steps / dt
-    dom = float(np.mean(dom_ms)) if dom_ms and dom_ms[0] > 0 else None
-    # algorithmic bytes of one k_add_level0 launch: per output cell 2 gathered affine points (2 x 64 B),
-    # 2 cell indices (2 x 4 B), one projective point written (96 B); cells = windows * N / 2
-    cells0 = wpr * n // 2
-    alg_bytes = cells0 * (128 + 8 + 96)
-    fr_mul0 = cells0 * 9
-    # HBM traffic per k_add_level0 launch from the committed PMC passes (profiles/r01/msm_bench_pmc_hbm.csv, config B,
-    # 32 windows on this GPU): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction.
-    # Raw (uncorrected) it is 3.68e9; the gather pattern is uncalibrated, the truth lies between the two.
-    pmc_traffic = 5741469043 if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None
-    roofline = None
-    if dom:
-        ach = alg_bytes / (dom * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_add_level0", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic,
-                    "avg_launch_ms": round(dom, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                    "fr_mul_per_launch": fr_mul0, "fr_mul_per_s": round(fr_mul0 / (dom * 1e-3), 1)}
+    def msm_leg(x_log, steps, warmup, keep=False):
+        """the timed MSM loop at one shape; returns the result dict (+ plan / operands when keep)"""
+        n = 1 << x_log
+        d_pts, d_sc, sc, bcast_ms = make_inputs(x_log)
+        plan = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
+
+        def step():
+            plan.run(d_pts, d_sc)
+            if world > 1 and rcomm is not None:
+                raw = rcomm.gather_window_points(plan)
+            elif world > 1:
+                p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
+                ffi.check(L.gm_msm_window_points(plan.h, C.byref(p), C.byref(nc), C.byref(cl)))
+                mine = torch.empty((ncols, wpr, 4), dtype=torch.int64, device="cuda")
+                ffi.check(L.gm_memcpy_d2d(C.c_void_p(mine.data_ptr()), p, ncols * wpr * 32, harness.cur_stream()))
+                raw = gdist.gather_window_points(dist, mine.to(xdev), world)
+            else:
+                raw = plan.window_points_raw()
+            return harness.combine_host(raw, d_log), raw
+
+        for _ in range(warmup):
+            step()
+        ffi.check(L.gm_msm_profile(plan.h, 1))
+        dom_ms = []
+        prof = (C.c_float * 7)()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            result, raw = step()
+            ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
+            dom_ms.append(prof[4])
+        sync_all()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        # stage breakdown (one extra, untimed pass)
+        ffi.check(L.gm_msm_profile(plan.h, 2))
+        step()
+        ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
+        stages = dict(zip(["digits", "histogram", "chunk_scan_offsets", "scatter", "add_level0", "add_levels_ge1", "triangle"],
+                          [round(float(v), 4) for v in prof]))
+        ffi.check(L.gm_msm_profile(plan.h, 0))
+        ms_per_step = dt / steps * 1e3
+        dom = float(np.mean(dom_ms)) if dom_ms and dom_ms[0] > 0 else None
+        # algorithmic bytes of one k_add_level0 launch: per output cell 2 gathered affine points (2 x 64 B), 2 cell indices
+        # (2 x 4 B), one projective point written (96 B); cells = windows * N / 2.  Field multiplications: 8 per level-0 add,
+        # 12 per add above (shared sub-products; the layer-by-layer evaluation needs 9 / 13).
+        cells0 = wpr * n // 2
+        alg_bytes = cells0 * (128 + 8 + 96)
+        fr_mul0 = cells0 * 8
+        fr_mul_step = cells0 * 8 + (cells0 - (wpr << d_log)) * 12 if cells0 > (wpr << d_log) else cells0 * 8
+        roofline = None
+        if dom:
+            ach = alg_bytes / (dom * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_add_level0", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": PMC_TRAFFIC_MSM_B if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None,
+                        "avg_launch_ms": round(dom, 4), "algorithmic_bytes_per_launch": alg_bytes, "fr_mul_per_launch": fr_mul0,
+                        "fr_mul_per_s": round(fr_mul0 / (dom * 1e-3), 1),
+                        "valu_frac_of_measured_ceiling": round(fr_mul0 / (dom * 1e-3) / FR_MUL_CEILING, 3)}
+        res = {"x_logsize": x_log, "value": round(n * steps / dt, 1), "ms_per_step": round(ms_per_step, 4), "roofline": roofline,
+               "stage_ms": stages, "result_x": hex(result[0]),
+               # SURVEY 8(d)'s whole-MSM unit: 96 B of compulsory HBM traffic per point (64 B point + 32 B scalar)
+               "whole_msm": {"algorithmic_bytes_per_point": 96, "achieved_GBps": round(96 * n / (ms_per_step * 1e-3) / 1e9, 2),
+                             "frac_of_hbm_peak": round(96 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             "fr_mul_per_step_per_gpu": fr_mul_step,
+                             "fr_mul_per_s_per_gpu": round(fr_mul_step / (ms_per_step * 1e-3), 1),
+                             "valu_frac_of_measured_ceiling": round(fr_mul_step / (ms_per_step * 1e-3) / FR_MUL_CEILING, 3),
+                             "bound": "integer VALU (8-12 Fr multiplications per bucket add; MFMA not applicable)"}}
+        if bcast_ms is not None:
+            res["operand_broadcast_ms"] = round(bcast_ms, 2)
+            res["operand_bytes"] = n * 96
+        if keep:
+            return res, plan, d_pts, d_sc, sc, raw
+        plan.close()
+        del d_pts, d_sc
+        L.gm_release_cached_memory()
+        torch.cuda.empty_cache()
+        return res
+
+    x_main = args.x_logsize if args.x_logsize is not None else 20
+    main_res, plan, d_pts, d_sc, sc, raw = msm_leg(x_main, args.steps, args.warmup, keep=True)
+    x_log, n = x_main, 1 << x_main
 
     out = {
-        "metric": "msm_points_per_sec", "value": round(value, 1), "unit": "points/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery, BLS12-381 Fr)",
-        "data": "synthetic",
+        "metric": "msm_points_per_sec", "value": main_res["value"], "unit": "points/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "u32 limbs (256-bit Montgomery, BLS12-381 Fr)", "data": "synthetic",
         "config": {"workload": "pippenger_msm x_logsize=%d d_logsize=%d nbits=%d (bandersnatch, %d windows)" % (
             x_log, d_log, nbits, y_size), "x_logsize": x_log, "d_logsize": d_log, "nbits": nbits,
-            "windows_per_gpu": wpr, "sharding": "windows" if world > 1 else "none"},
-        "roofline": roofline, "stage_ms": stages,
-        "result_x": hex(result[0]),
+            "windows_per_gpu": wpr, "sharding": "windows" if world > 1 else "none", "transport": transport},
+        "roofline": main_res["roofline"], "stage_ms": main_res["stage_ms"], "result_x": main_res["result_x"],
+        "whole_msm": main_res["whole_msm"],
     }
+    for k in ("operand_broadcast_ms", "operand_bytes"):
+        if k in main_res:
+            out[k] = main_res[k]
 
     # ---- second headline: sumcheck rounds/sec of the image-part prover (triangle + bintree GKR) at the same config
-    P = codec.P
-
-    def claims_for(w_, y_log_, seed):
-        outs, _ = w_.outputs()
-        pr = np.random.default_rng(seed)
-        r = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(y_log_)]
-
-        def ev(poly):
-            cur = list(poly)
-            for f in reversed(r):
-                cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
-            return cur[0]
-        tape = [int.from_bytes(pr.bytes(16), "little") for _ in range(4000)]
-        return r, [ev(o) for o in outs], tape
-
     if world == 1 and not args.no_sumcheck:
         y_log = (y_size - 1).bit_length()
         torch.cuda.synchronize()
@@ -213,17 +310,55 @@ def main():
         r_pt, r_evs, tape = claims_for(w, y_log, 7)
         w.prove_image_part(r_pt, r_evs, tape)          # warmup
         reps = 3
+        harness.sc_profile(1)                          # HIP events around the large round kernels, inside the timed proofs
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(reps):
             res = w.prove_image_part(r_pt, r_evs, tape)
         prove_dt = (time.perf_counter() - t1) / reps
+        rows, _, _ = harness.sc_profile_read()
+        harness.sc_profile(2)                          # one extra, untimed proof: algorithmic bytes of EVERY round and fold
+        w.prove_image_part(r_pt, r_evs, tape)
+        rows2, other_bytes, fold_bytes = harness.sc_profile_read()
+        harness.sc_profile(0)
         out["sumcheck"] = {"metric": "sumcheck_rounds_per_sec", "value": round(res["rounds"] / prove_dt, 1),
                            "rounds": res["rounds"], "prove_ms": round(prove_dt * 1e3, 2),
                            "witness_build_ms": round(wit_ms, 2), "witness_first_build_ms_incl_allocation": round(wit_cold_ms, 2),
                            "witness_trace_GiB": round(L.gm_pip_witness_bytes(w.h) / 2 ** 30, 2),
                            "workload": "prove image part (triangle + bintree GKR) x_logsize=%d d_logsize=%d nbits=%d" % (
                                x_log, d_log, nbits)}
+        if rows:
+            kern = []
+            for r_ in sorted(rows, key=lambda r_: -r_["total_ms"]):
+                per = r_["launches"]
+                gbps = r_["alg_bytes"] / (r_["total_ms"] * 1e-3) / 1e9 if r_["total_ms"] > 0 else 0.0
+                kern.append({"kernel": r_["kernel"], "launches_per_proof": per // reps, "k_cols": r_["k_cols"],
+                             "total_ms_per_proof": round(r_["total_ms"] / reps, 3), "avg_launch_ms": round(r_["total_ms"] / per, 4),
+                             "algorithmic_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 4),
+                             "fr_mul_per_s": round(r_["fr_mul"] / (r_["total_ms"] * 1e-3), 1),
+                             "valu_frac_of_measured_ceiling": round(r_["fr_mul"] / (r_["total_ms"] * 1e-3) / FR_MUL_CEILING, 3)})
+            dom_r = max(rows, key=lambda r_: r_["total_ms"])
+            ach = dom_r["alg_bytes"] / (dom_r["total_ms"] * 1e-3) / 1e9
+            out["sumcheck"]["roofline"] = {
+                "bound": "hbm", "kernel": dom_r["kernel"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": PMC_TRAFFIC_SC_B.get(dom_r["kernel"]) if (x_log, d_log, nbits) == (20, 8, 256) else None,
+                "avg_launch_ms": round(dom_r["total_ms"] / dom_r["launches"], 4),
+                "algorithmic_bytes_per_launch": int(dom_r["alg_bytes"] / dom_r["launches"]),
+                "algorithmic_bytes_per_pair": int(64 * dom_r["k_cols"] + 32), "launches_per_proof": dom_r["launches"] // reps,
+                "fr_mul_per_s": round(dom_r["fr_mul"] / (dom_r["total_ms"] * 1e-3), 1),
+                "valu_frac_of_measured_ceiling": round(dom_r["fr_mul"] / (dom_r["total_ms"] * 1e-3) / FR_MUL_CEILING, 3),
+                "note": "average over the large (> 2^14 pairs) launches of this kernel in the timed proofs, HIP events on the launch stream"}
+            out["sumcheck"]["large_round_kernels"] = kern
+            big_bytes = sum(r_["alg_bytes"] for r_ in rows2)
+            tot = big_bytes + other_bytes + fold_bytes
+            out["sumcheck"]["whole_prover"] = {
+                "algorithmic_bytes": int(tot), "large_round_bytes": int(big_bytes), "other_round_bytes": int(other_bytes),
+                "fold_bytes": int(fold_bytes), "bytes_weighted_GBps": round(tot / prove_dt / 1e9, 1),
+                "frac_of_hbm_peak": round(tot / prove_dt / 1e9 / HBM_PEAK_GBS, 4),
+                "large_kernels_ms_per_proof": round(sum(r_["total_ms"] for r_ in rows) / reps, 2),
+                "note": "64 k B per pair read by a round kernel (+32 eq weight), 96 B per cell and column moved by a fold; small sparse "
+                        "rounds counted at their capacity bound"}
         # "prove pushforward" chained on the image part's final claims (pippenger.rs:147-160): logup main phase + combined sumcheck
         pr = np.random.default_rng(9)
         pf_tape = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(4)] + [int.from_bytes(pr.bytes(16), "little")
@@ -246,7 +381,7 @@ def main():
     if world > 1 and not args.no_sumcheck:
         try:
             y_log = (y_size - 1).bit_length()
-            comm = gdist.Comm(dist, rank, world, device=xdev if backend == "nccl" else None)
+            comm = rcomm if rcomm is not None else gdist.Comm(dist, rank, world, device=xdev if backend == "nccl" else None)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             w = harness.PipWitness(plan, d_pts, y_log, comm=comm)
@@ -254,18 +389,16 @@ def main():
             wit_ms = (time.perf_counter() - t1) * 1e3
             r_pt, r_evs, tape = claims_for(w, y_log, 7)
             w.prove_image_part(r_pt, r_evs, tape)      # warmup
+            calls0 = comm.calls
             sync_all()
             t1 = time.perf_counter()
             res = w.prove_image_part(r_pt, r_evs, tape)
             sync_all()
-            p_dt = time.perf_counter() - t1
-            tt = torch.tensor([p_dt], dtype=torch.float64, device=xdev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            p_dt = float(tt.item())
+            p_dt = max_over_ranks(time.perf_counter() - t1)
             out["sumcheck"] = {"metric": "sumcheck_rounds_per_sec", "value": round(res["rounds"] / p_dt, 1),
                                "rounds": res["rounds"], "prove_ms": round(p_dt * 1e3, 2), "witness_build_ms": round(wit_ms, 2),
                                "sharding": "bucket rows of %d windows per rank; %d all-gathers of <= 96 B per rank per proof" % (
-                                   wpr, comm.calls // 2),
+                                   wpr, comm.calls - calls0), "transport": transport,
                                "workload": "prove image part (triangle + bintree GKR) x_logsize=%d d_logsize=%d nbits=%d" % (
                                    x_log, d_log, nbits)}
             w.close()
@@ -273,9 +406,29 @@ def main():
         except Exception as e:  # keep the MSM line even if the sharded prover leg fails on this node
             out["sumcheck"] = {"error": repr(e)[:300]}
 
+    # ---- N > 1: the other named shapes in the same line (weak: fixed work per GPU; config D: x_logsize = 24)
+    if world > 1 and not args.no_extra_shapes:
+        plan.close()
+        del d_pts, d_sc
+        L.gm_release_cached_memory()
+        torch.cuda.empty_cache()
+        plan = None
+        for key, xl in (("weak", 20 + int(round(math.log2(world)))), ("config_d", 24)):
+            try:
+                steps_x = max(3, args.steps // (4 if xl >= 24 else 1))
+                r_ = msm_leg(xl, steps_x, min(args.warmup, 2))
+                r_["steps"] = steps_x
+                r_["scaling"] = "weak" if key == "weak" else "BASELINE.json configs[3]"
+                r_["windows_per_gpu"] = wpr
+                out[key] = r_
+            except Exception as e:
+                out[key] = {"error": repr(e)[:300]}
+
     # ---- gen-1 prover (gkr_msm_simple.rs gkr_msm_prove, Fr part): BASELINE.json configs[2]
     if world == 1 and not args.no_sumcheck and args.gen1_log_points > 0:
         plan.close()
+        plan = None
+        L.gm_release_cached_memory()
         torch.cuda.empty_cache()
         lp, lb = args.gen1_log_points, 8
         g_rng = np.random.default_rng(11)
@@ -284,23 +437,28 @@ def main():
         d_pts_g = d_pts[: (1 << lp) * 8] if lp <= x_log else None
         if d_pts_g is None:
             d_pts_g = harness.dev_empty((1 << lp) * 8)
-            ffi.check(L.gm_gen_points(C.c_void_p(d_pts_g.data_ptr()), 1 << lp, 0x474B524D534D, harness.cur_stream()))
-        # first call: the library's device-memory pool grows by the ~43 GiB trace (the driver hands out recycled HBM at
-        # ~40 GiB/s); steady state = the second call, as for a prover that proves more than once
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        harness.gkr_msm_prove(d_pts_g, d_bits, lp, lb, g_tape, msgs_cap=1 << 16)
-        g_cold = time.perf_counter() - t1
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        g1 = harness.gkr_msm_prove(d_pts_g, d_bits, lp, lb, g_tape, msgs_cap=1 << 16)
-        g_dt = time.perf_counter() - t1
-        out["gen1"] = {"workload": "gkr_msm_prove log_num_points=%d log_num_scalar_bits=%d (witness + prover)" % (lp, lb),
-                       "total_ms": round(g_dt * 1e3, 2), "first_call_ms_incl_allocation": round(g_cold * 1e3, 2),
-                       "witness_ms": round(g1["witness_ms"], 2), "rounds": g1["rounds"],
-                       "rounds_per_sec": round(g1["rounds"] / max(g_dt - g1["witness_ms"] * 1e-3, 1e-9), 1),
-                       "points_per_sec": round((1 << lp) / g_dt, 1)}
+            ffi.check(L.gm_gen_points(C.c_void_p(d_pts_g.data_ptr()), 1 << lp, SEED, harness.cur_stream()))
+        # first call: the library's device-memory pool grows by the trace (the driver hands out recycled HBM at ~40 GiB/s);
+        # steady state = the second call, as for a prover that proves more than once
+        try:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            harness.gkr_msm_prove(d_pts_g, d_bits, lp, lb, g_tape, msgs_cap=1 << 16)
+            g_cold = time.perf_counter() - t1
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            g1 = harness.gkr_msm_prove(d_pts_g, d_bits, lp, lb, g_tape, msgs_cap=1 << 16)
+            g_dt = time.perf_counter() - t1
+            out["gen1"] = {"workload": "gkr_msm_prove log_num_points=%d log_num_scalar_bits=%d (witness + prover)" % (lp, lb),
+                           "total_ms": round(g_dt * 1e3, 2), "first_call_ms_incl_allocation": round(g_cold * 1e3, 2),
+                           "witness_ms": round(g1["witness_ms"], 2), "rounds": g1["rounds"],
+                           "rounds_per_sec": round(g1["rounds"] / max(g_dt - g1["witness_ms"] * 1e-3, 1e-9), 1),
+                           "points_per_sec": round((1 << lp) / g_dt, 1)}
+        except Exception as e:
+            out["gen1"] = {"error": repr(e)[:300]}
         del d_bits
+        L.gm_release_cached_memory()
+        torch.cuda.empty_cache()
 
     # ---- BLS12-381 G1 side: KZG-commit-shaped MSM and the outer buckets of PushForwardState::new
     if world == 1 and args.g1_log_points > 0:
@@ -366,7 +524,7 @@ def main():
             assert codec.g1_aff_from_limbs(c_res)[0] == g_same, "GPU G1 MSM differs from the CPU oracle"
             out["g1"]["msm"]["cpu_baseline"] = {
                 "value": round(n2 / c_dt, 1), "unit": "points/s", "cores": threads, "kind": "port",
-                "sample": "msm_bigint_wnaf_nonaff, first 2^%d bases, %.2f s" % (lg2, c_dt),
+                "sample": "msm_bigint_wnaf_nonaff, first 2^%d bases (GPU figure above is at 2^%d), %.2f s" % (lg2, args.g1_log_points, c_dt),
                 "gpu_same_sample_points_per_sec": round(n2 / gs_dt, 1), "parity": "same group element"}
             if "outer_buckets" in out["g1"]:
                 xo = min(args.cpu_g1_outer_xlog, x_log)
@@ -387,7 +545,7 @@ def main():
                 assert same, "GPU outer buckets differ from the CPU oracle"
                 out["g1"]["outer_buckets"]["cpu_baseline"] = {
                     "value": round(2 * no * y_size / co_dt, 1), "unit": "g1_adds/s", "cores": threads, "kind": "port",
-                    "sample": "same accumulation at x_logsize=%d: %.2f s" % (xo, co_dt),
+                    "sample": "same accumulation at x_logsize=%d (GPU figure above is at %d): %.2f s" % (xo, x_log, co_dt),
                     "gpu_same_sample_g1_adds_per_sec": round(2 * no * y_size / go_dt, 1),
                     "parity": "same group elements (d_outer buckets, c_comm, d_comm)"}
                 plan_s.close()
@@ -463,45 +621,79 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_ffi as O
+        L.gm_release_cached_memory()
+        torch.cuda.empty_cache()
         threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+        hinfo = host_info()
         pts_h = harness.to_host(d_pts).reshape(n, 8)
-        # bounded sample: the first 2^xs points of the same inputs, all windows
+        # MSM: the whole workload on the CPU (windows in parallel = the reference's own granularity, pushforward.rs:401 /
+        # msm_nonaffine.rs:123: for this leg "reference-faithful" and "fair" coincide)
         xs = min(x_log, 20)
         t1 = time.perf_counter()
         ref = O.msm(pts_h[: 1 << xs], sc[: 1 << xs], xs, d_log, y_size, threads=threads, want_aux=False)
         O.msm_combine(ref["window_cols"], d_log)
         cpu_dt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round((1 << xs) / cpu_dt, 1), "unit": "points/s", "cores": threads,
-                               "kind": "port", "sample": "same inputs, first 2^%d points x %d windows, %.2f s" % (
-                                   xs, y_size, cpu_dt)}
+                               "kind": "port", "variant": "fair = reference-faithful (parallel over the %d windows, as the reference)" % y_size,
+                               "sample": "the whole workload: same inputs, 2^%d points x %d windows, %.2f s" % (xs, y_size, cpu_dt),
+                               "host": hinfo}
         if xs == x_log:
             ok = np.array_equal(raw, ref["window_cols"])
             out["parity"] = "bit-exact vs oracle (window points, %d x %d Fr)" % raw.shape[:2] if ok else "MISMATCH"
             assert ok, "GPU window points differ from the CPU oracle"
-        out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        del ref
         if not args.no_sumcheck:
-            # bounded sumcheck sample: the same prover at x_logsize = 16 on the CPU oracle and on the GPU
-            xs2 = min(x_log, args.cpu_sumcheck_xlog)
             y_log = (y_size - 1).bit_length()
-            n2 = 1 << xs2
-            plan2 = harness.MsmPlan(xs2, d_log, y_size)
-            d_pts2, d_sc2 = harness.to_dev(pts_h[:n2]), harness.to_dev(sc[:n2])
-            plan2.run(d_pts2, d_sc2)
-            w2 = harness.PipWitness(plan2, d_pts2, y_log)
-            r_pt, r_evs, tape = claims_for(w2, y_log, 8)
-            w2.prove_image_part(r_pt, r_evs, tape)
-            t1 = time.perf_counter()
-            g = w2.prove_image_part(r_pt, r_evs, tape)
-            gpu_dt = time.perf_counter() - t1
-            t1 = time.perf_counter()
-            cw = O.PipWitness(pts_h[:n2], sc[:n2], xs2, d_log, y_size, y_log, threads)
-            cpu_wit = time.perf_counter() - t1
-            t1 = time.perf_counter()
-            c = cw.prove_image_part(codec.to_mont_limbs(r_pt), codec.to_mont_limbs(r_evs), codec.ints_to_limbs(tape))
-            cpu_prove = time.perf_counter() - t1
-            same = codec.from_mont_limbs(c["msgs"]) == g["msgs"] and codec.from_mont_limbs(c["evs"]) == g["evs"]
-            assert same, "GPU prover messages differ from the CPU oracle"
-            if "gen1" in out:
+
+            def cpu_vs_gpu_prover(xs2, faithful):
+                n2 = 1 << xs2
+                plan2 = harness.MsmPlan(xs2, d_log, y_size)
+                d_pts2, d_sc2 = harness.to_dev(pts_h[:n2]), harness.to_dev(sc[:n2])
+                plan2.run(d_pts2, d_sc2)
+                w2 = harness.PipWitness(plan2, d_pts2, y_log)
+                r_pt, r_evs, tape = claims_for(w2, y_log, 8)
+                w2.prove_image_part(r_pt, r_evs, tape)
+                t1 = time.perf_counter()
+                g = w2.prove_image_part(r_pt, r_evs, tape)
+                gpu_dt = time.perf_counter() - t1
+                w2.close()
+                plan2.close()
+                L.gm_release_cached_memory()
+                O.lib().or_set_reference_faithful(1 if faithful else 0)
+                try:
+                    t1 = time.perf_counter()
+                    cw = O.PipWitness(pts_h[:n2], sc[:n2], xs2, d_log, y_size, y_log, threads)
+                    cpu_wit = time.perf_counter() - t1
+                    t1 = time.perf_counter()
+                    c = cw.prove_image_part(codec.to_mont_limbs(r_pt), codec.to_mont_limbs(r_evs), codec.ints_to_limbs(tape))
+                    cpu_prove = time.perf_counter() - t1
+                    cw.close()
+                finally:
+                    O.lib().or_set_reference_faithful(0)
+                same = codec.from_mont_limbs(c["msgs"]) == g["msgs"] and codec.from_mont_limbs(c["evs"]) == g["evs"]
+                assert same, "GPU prover messages differ from the CPU oracle"
+                return {"value": round(c["rounds"] / cpu_prove, 1), "unit": "rounds/s", "cores": threads, "kind": "port",
+                        "variant": "reference-faithful (round sums and vecvec_map_split serial, as dense_eq.rs:121-139 / "
+                                   "vecvec_eq.rs:320-361 / vecvec.rs:579-594)" if faithful else "fair (every loop threaded)",
+                        "sample": "same prover at x_logsize=%d (%d rounds): cpu witness %.2f s + prove %.2f s" % (
+                            xs2, c["rounds"], cpu_wit, cpu_prove),
+                        "cpu_witness_s": round(cpu_wit, 3), "cpu_prove_s": round(cpu_prove, 3),
+                        "gpu_same_sample_rounds_per_sec": round(g["rounds"] / gpu_dt, 1),
+                        "parity": "bit-exact (%d prover messages + final claims)" % len(g["msgs"]), "host": hinfo}
+            out["sumcheck"]["cpu_baseline"] = cpu_vs_gpu_prover(min(x_log, args.cpu_sumcheck_xlog), False)
+            out["sumcheck"]["cpu_baseline_reference_faithful"] = cpu_vs_gpu_prover(min(x_log, args.cpu_faithful_xlog), True)
+            out["sumcheck"]["speedup_vs_cpu_fair"] = round(out["sumcheck"]["value"] / out["sumcheck"]["cpu_baseline"]["value"], 1)
+            # the north star's "host-CPU Pippenger + sumcheck wall clock" at config B, CPU fair variant vs GPU
+            cb = out["sumcheck"]["cpu_baseline"]
+            if min(x_log, args.cpu_sumcheck_xlog) == x_log:
+                cpu_wall = cpu_dt + cb["cpu_witness_s"] + cb["cpu_prove_s"]
+                gpu_wall = (out["ms_per_step"] + out["sumcheck"]["witness_build_ms"] + out["sumcheck"]["prove_ms"]) * 1e-3
+                out["pippenger_plus_sumcheck_wall"] = {"cpu_s": round(cpu_wall, 2), "gpu_s": round(gpu_wall, 4),
+                                                       "speedup": round(cpu_wall / gpu_wall, 1),
+                                                       "what": "MSM + witness build + image-part prover at x_logsize=%d d_logsize=%d nbits=%d, "
+                                                               "C port with %d threads vs 1 MI355X" % (x_log, d_log, nbits, threads)}
+            if "gen1" in out and "error" not in out["gen1"]:
                 lp2, lb2 = min(args.cpu_gen1_log_points, args.gen1_log_points), 8
                 b8 = np.random.default_rng(12).integers(0, 2, size=(1 << (lp2 + lb2)), dtype=np.uint8)
                 r13 = np.random.default_rng(13)
@@ -517,17 +709,16 @@ def main():
                 gpu_g = time.perf_counter() - t1
                 assert codec.from_mont_limbs(cg["msgs"]) == gg["msgs"], "gen-1 GPU transcript differs from the CPU oracle"
                 out["gen1"]["cpu_baseline"] = {"value": round((1 << lp2) / cpu_g, 1), "unit": "points/s", "cores": threads,
-                                               "kind": "port", "sample": "gkr_msm_prove log_num_points=%d: cpu %.2f s" % (lp2, cpu_g),
+                                               "kind": "port",
+                                               "sample": "gkr_msm_prove log_num_points=%d (GPU figure above is at %d): cpu %.2f s" % (
+                                                   lp2, args.gen1_log_points, cpu_g),
                                                "gpu_same_sample_points_per_sec": round((1 << lp2) / gpu_g, 1),
                                                "parity": "bit-exact (%d transcript messages)" % len(gg["msgs"])}
-            out["sumcheck"]["cpu_baseline"] = {
-                "value": round(c["rounds"] / cpu_prove, 1), "unit": "rounds/s", "cores": threads, "kind": "port",
-                "sample": "same prover at x_logsize=%d (%d rounds): cpu witness %.2f s + prove %.2f s" % (
-                    xs2, c["rounds"], cpu_wit, cpu_prove),
-                "gpu_same_sample_rounds_per_sec": round(g["rounds"] / gpu_dt, 1),
-                "parity": "bit-exact (%d prover messages + final claims)" % len(g["msgs"])}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if rcomm is not None:
+        sync_all()
+        rcomm.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1084,6 +1084,89 @@ static int32_t launch_generic3_lean(int prim, dim3 grid, hipStream_t s, const Le
     return GM_OK;
 }
 
+// ---- profiler (gm_sc_profile): the large round kernels timed with HIP events on their launch stream --------------------
+// mode 1: every large (non-split) round-kernel launch is bracketed by two events; exact pair counts of sparse launches are
+//         copied from the device (off[nrows], 4 bytes, asynchronous).  ~300 event records per proof at config B: cheap enough
+//         to stay on during timed runs.
+// mode 2: additionally every small round and every fold is accounted (algorithmic bytes only, no events).
+// Rows are per kernel class; algorithmic bytes per SURVEY 8(d): a round kernel reads both cells of every pair of every input
+// column (64 k bytes per pair; + 32 for the eq column of the generic object), a fold moves 96 bytes per output cell.
+struct ScProf {
+    int mode = 0;
+    struct Rec {
+        hipEvent_t e0, e1;
+        int cls, k;
+        uint64_t pairs;          // dense: exact; sparse: filled from *h_cells at read time
+        uint32_t* h_cells;       // pinned slot receiving off[nrows] (cells), or nullptr
+        int fr_mul_per_pair;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> free_events;
+    uint32_t* h_slots = nullptr;  // pinned, SLOT_CAP words
+    uint32_t n_slots = 0;
+    static constexpr uint32_t SLOT_CAP = 8192;
+    double small_round_bytes = 0, fold_bytes = 0, small_rounds = 0, folds = 0;
+    hipEvent_t get_event() {
+        if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+static ScProf& sc_prof() {
+    static thread_local ScProf p;
+    return p;
+}
+static const char* sc_class_name(int cls) {
+    // cls = prim * 4 + variant; variant 0: k_round_deg2_lean dense, 1: k_round_deg2_lean VecVec, 2: k_round_generic3_lean, 3: k_round_prod3_lean
+    static thread_local char buf[64];
+    const int prim = cls >> 2, var = cls & 3;
+    const char* pn = prim == FN_AFF_L1 ? "AFF_L1" : prim == FN_AFF_L2 ? "AFF_L2" : prim == FN_AFF_L3 ? "AFF_L3" : prim == FN_PROJ_L1 ? "PROJ_L1"
+                   : prim == FN_PROJ_L2 ? "PROJ_L2" : prim == FN_PROJ_L3 ? "PROJ_L3" : prim == FN_PT_BIT_CHOICE ? "PT_BIT_CHOICE"
+                   : prim == LEAN_AFF_L1_BC ? "AFF_L1+BITCHECK" : prim == FN_ADD_INVERSES ? "ADD_INVERSES" : prim == FN_LOGUP_LAYER ? "LOGUP_LAYER" : "?";
+    if (var == 3) snprintf(buf, sizeof(buf), "k_round_prod3_lean");
+    else if (var == 2) snprintf(buf, sizeof(buf), "k_round_generic3_lean<%s>", pn);
+    else snprintf(buf, sizeof(buf), "k_round_deg2_lean<%s,%s>", pn, var == 1 ? "vecvec" : "dense");
+    return buf;
+}
+// Fr multiplications of lean_gamma_eval<PRIM> (one evaluation of the gamma-combined layer function)
+static int lean_eval_muls(int prim) {
+    switch (prim) {
+        case FN_AFF_L1: return 6; case LEAN_AFF_L1_BC: return 10; case FN_AFF_L2: return 3; case FN_AFF_L3: return 6;
+        case FN_PROJ_L1: return 8; case FN_PROJ_L2: return 7; case FN_PROJ_L3: return 6; case FN_ADD_INVERSES: return 2;
+        case FN_LOGUP_LAYER: return 4; case FN_PT_BIT_CHOICE: return 3; default: return 0;
+    }
+}
+// returns the record index to close with prof_end, or -1
+static int prof_begin(hipStream_t s, int cls, int k, uint64_t pairs, const uint32_t* d_cells_word, int fr_mul_per_pair) {
+    ScProf& p = sc_prof();
+    if (p.mode < 1) return -1;
+    ScProf::Rec r;
+    r.e0 = p.get_event(); r.e1 = p.get_event();
+    r.cls = cls; r.k = k; r.pairs = pairs; r.h_cells = nullptr; r.fr_mul_per_pair = fr_mul_per_pair;
+    if (d_cells_word) {
+        if (!p.h_slots && hipHostMalloc((void**)&p.h_slots, ScProf::SLOT_CAP * 4, hipHostMallocDefault) != hipSuccess) p.h_slots = nullptr;
+        if (p.h_slots && p.n_slots < ScProf::SLOT_CAP) {
+            r.h_cells = p.h_slots + p.n_slots++;
+            (void)hipMemcpyAsync(r.h_cells, d_cells_word, 4, hipMemcpyDeviceToHost, s);
+        }
+    }
+    (void)hipEventRecord(r.e0, s);
+    p.recs.push_back(r);
+    return (int)p.recs.size() - 1;
+}
+static void prof_end(hipStream_t s, int idx) {
+    if (idx >= 0) (void)hipEventRecord(sc_prof().recs[idx].e1, s);
+}
+static inline void prof_small_round(double bytes) {
+    ScProf& p = sc_prof();
+    if (p.mode >= 2) { p.small_round_bytes += bytes; p.small_rounds += 1; }
+}
+static inline void prof_fold(double bytes) {
+    ScProf& p = sc_prof();
+    if (p.mode >= 2) { p.fold_bytes += bytes; p.folds += 1; }
+}
+
 // ---- columns with ping-pong fold buffers --------------------------------------------------------
 struct FoldCols {
     int k = 0;
@@ -1217,11 +1300,15 @@ struct ScDense : gm_sc {
         } else if (kind == 1 && D == 3 && !split) {
             LeanCols lc;
             for (int i = 0; i < 3; i++) lc.p[i] = cur_cols[i];
+            const int pi = prof_begin(stream, 3, 3, npairs, nullptr, 3 * 2);
             hipLaunchKernelGGL(k_round_prod3_lean, grid, dim3(SC_THREADS), 0, stream, lc, npairs, fc);
+            prof_end(stream, pi);
         } else if (lean && lean != LEAN_AFF_L1_BC) {
             LeanCols lc;
             for (int i = 0; i < cols.k; i++) lc.p[i] = cur_cols[i];
+            const int pi = prof_begin(stream, lean * 4 + 2, cols.k, npairs, nullptr, 3 * (lean_eval_muls(lean) + 1));
             int32_t rc = launch_generic3_lean(lean, grid, stream, lc, d_gamma.fr(), npairs, fc);
+            prof_end(stream, pi);
             if (rc) return rc;
         } else if (D == 3 && split)
             hipLaunchKernelGGL((k_round_generic<3, true>), grid, dim3(SC_THREADS), 0, stream, kind, sp, cp, cols.k,
@@ -1239,6 +1326,7 @@ struct ScDense : gm_sc {
             return set_err(GM_ERR_INVALID, "unsupported degree %d", D);
         GM_LAUNCH_CHECK();
         k_seq[round & 63] = fc.seq;
+        if (split || !(lean || (kind == 1 && D == 3))) prof_small_round(64.0 * cols.k * (double)npairs);
         return GM_OK;
     }
     ~ScDense() override {
@@ -1276,6 +1364,7 @@ struct ScDense : gm_sc {
                 hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(round_idx), rs.ticket_word(), fold_ticket,
                                    rs.ticket_word() + 1, d_t, wait_timeout_ticks());
                 hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(npairs, 256), cols.k), dim3(256), 0, stream, ci, co, npairs, d_t);
+                prof_fold(96.0 * cols.k * (double)npairs);
                 GM_LAUNCH_CHECK();
                 fold_pending = true;
                 int32_t rc = launch_round(cn.data(), npairs >> 1, round_idx + 1);
@@ -1316,6 +1405,7 @@ struct ScDense : gm_sc {
             const uint64_t n_out = 1ull << (loc_vars - 1);
             int32_t rc = launch_dense_fold(cols.cur.data(), dst.data(), cols.k, n_out, t, stream);
             if (rc) return rc;
+            prof_fold(96.0 * cols.k * (double)n_out);
             cols.commit(dst);
         }
         round_idx++;
@@ -1401,8 +1491,10 @@ struct ScDenseDeg2 : gm_sc {
         if (lean) {
             LeanCols lc;
             for (int i = 0; i < cols.k; i++) lc.p[i] = cols.cur[i];
+            const int pi = prof_begin(stream, lean * 4 + 0, cols.k, npairs, nullptr, 2 * lean_eval_muls(lean) + 2);
             int32_t rc = launch_deg2_lean<false>(lean, grid, stream, lc, eq_cur, d_gamma.fr(), npairs, none,
                                                  rs.ctx());
+            prof_end(stream, pi);
             if (rc) return rc;
         } else if (split)
             hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp,
@@ -1411,6 +1503,7 @@ struct ScDenseDeg2 : gm_sc {
             hipLaunchKernelGGL((k_round_deg2<false, false>), grid, dim3(SC_THREADS), 0, stream, sp, cp,
                                eq_cur, d_gamma.fr(), npairs, none, rs.ctx());
         GM_LAUNCH_CHECK();
+        if (!lean) prof_small_round(64.0 * cols.k * (double)npairs);
         Fr acc[4];
         int32_t rc = rs.finish(2, stream, acc);
         if (rc) return rc;
@@ -1444,6 +1537,7 @@ struct ScDenseDeg2 : gm_sc {
         hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq, d_gamma.fr(), npairs, none, fc);
         GM_LAUNCH_CHECK();
         k_seq[round & 63] = fc.seq;
+        prof_small_round(64.0 * cols.k * (double)npairs);
         return GM_OK;
     }
     // ---- persistent tail (see k_tail_rounds): rounds [tail_r0, num_vars) run inside one launch
@@ -1480,6 +1574,10 @@ struct ScDenseDeg2 : gm_sc {
         GM_HIP(hipMemsetAsync(a.d_relay, 0, 96, stream));
         hipLaunchKernelGGL(k_tail_rounds, dim3(2 * sp.nseg), dim3(256), 0, stream, sp, cp, d_gamma.fr(), a);
         GM_LAUNCH_CHECK();
+        for (int q = 0; q < nr; q++) {   // rounds and folds that happen inside the launch
+            prof_small_round(64.0 * cols.k * (double)(npairs0 >> q));
+            prof_fold(96.0 * cols.k * (double)(npairs0 >> q));
+        }
         tail_active = true;
         tail_r0 = r0;
         return GM_OK;
@@ -1559,6 +1657,7 @@ struct ScDenseDeg2 : gm_sc {
             hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(r), rs.ticket_word(), fold_ticket, rs.ticket_word() + 1, d_t,
                                wait_timeout_ticks());
             hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(n_out, 256), cols.k), dim3(256), 0, stream, ci, co, n_out, d_t);
+            prof_fold(96.0 * cols.k * (double)n_out);
             GM_LAUNCH_CHECK();
             fold_pending = true;
             if (tail_ok && (npairs >> 1) <= TAIL_MAX_PAIRS) {   // everything after this fold runs in one launch
@@ -1626,6 +1725,7 @@ struct ScDenseDeg2 : gm_sc {
         const uint64_t n_out = 1ull << (loc_vars - 1);
         int32_t rc = launch_dense_fold(cols.cur.data(), dst.data(), cols.k, n_out, t, stream);
         if (rc) return rc;
+        prof_fold(96.0 * cols.k * (double)n_out);
         cols.commit(dst);
         point.pop_back();
         round_idx++;
@@ -1719,6 +1819,7 @@ struct ScVecVecDeg2 : gm_sc {
             hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(nx_bound, SC_THREADS), (k + 1) / 2), dim3(SC_THREADS), 0, stream, ci, co, off_cur,
                                nx_off, nrows, fr_zero(), pd, (const Fr*)d_t, k);
             GM_LAUNCH_CHECK();
+            prof_fold(96.0 * k * (double)(cells_bound / 2));
             fold_pending = true;
             int32_t rc = launch_sparse_round(nx_cur.data(), nx_off, nx_bound, already_bound + 1);
             if (rc) return rc;
@@ -1786,7 +1887,9 @@ struct ScVecVecDeg2 : gm_sc {
         if (lean) {
             LeanCols lc;
             for (int i = 0; i < k; i++) lc.p[i] = cols_now[i];
+            const int pi = prof_begin(stream, lean * 4 + 1, k, cb / 2, off + nrows, 2 * lean_eval_muls(lean) + 3);
             int32_t rc = launch_deg2_lean<true>(lean, grid, stream, lc, eq_row, d_gamma.fr(), (uint64_t)0, va, fc);
+            prof_end(stream, pi);
             if (rc) return rc;
         } else if (split)
             hipLaunchKernelGGL((k_round_deg2<true, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
@@ -1796,6 +1899,7 @@ struct ScVecVecDeg2 : gm_sc {
                                (uint64_t)0, va, fc);
         GM_LAUNCH_CHECK();
         k_seq[ab & 63] = fc.seq;
+        if (!lean) prof_small_round(64.0 * k * (double)(cb / 2));   // capacity bound of the cells (exact count lives on the device)
         return GM_OK;
     }
     ~ScVecVecDeg2() override {
@@ -1844,6 +1948,7 @@ struct ScVecVecDeg2 : gm_sc {
             hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(new_bound, SC_THREADS), (k + 1) / 2), dim3(SC_THREADS), 0, stream, ci, co,
                                off_cur, off_next, nrows, t, pd, (const Fr*)nullptr, k);
             GM_LAUNCH_CHECK();
+            prof_fold(96.0 * k * (double)(cells_bound / 2));
             for (int i = 0; i < k; i++) cur[i] = co.p[i];
             off_cur = off_next;
             cur_is_a = to_a;
@@ -1897,6 +2002,7 @@ struct ScVecVecDeg2 : gm_sc {
         hipLaunchKernelGGL(k_vv_fold_to_dense, dim3(ceil_div(nd, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co,
                            off_cur, nrows, nd, t, rp, cpad);
         GM_LAUNCH_CHECK();
+        prof_fold(96.0 * k * (double)nd);
         // eq over the vertical variables, scaled by the multiplier after this bind (vecvec_eq.rs:177-180)
         const Fr mult = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));
         d->owned.emplace_back(new DevBuf());
@@ -1967,6 +2073,7 @@ int32_t ScVecVecDeg2::bind_into_dense_deg2(const Fr& t) {
     hipLaunchKernelGGL(k_vv_fold_to_dense, dim3(ceil_div(nd, SC_THREADS), k), dim3(SC_THREADS), 0, stream, ci, co, off_cur, nrows,
                        nd, t, rp, cpad);
     GM_LAUNCH_CHECK();
+    prof_fold(96.0 * k * (double)nd);
     int32_t rc = d->cols.init(k, cptr.data(), nd);
     if (rc) return rc;
     rc = upload_gamma(gamma_pows, &d->d_gamma, stream);
@@ -2250,6 +2357,61 @@ extern "C" int32_t gm_sc_claim(const gm_sc* so, uint64_t* h_claim) {
     GM_REQUIRE(so && h_claim, "null argument");
     Fr c = so->claim();
     memcpy(h_claim, &c, 32);
+    return GM_OK;
+}
+
+// ---- profiler ABI (see ScProf)
+extern "C" int32_t gm_sc_profile(int32_t mode) {
+    GM_REQUIRE(mode >= 0 && mode <= 2, "mode 0 (off), 1 (time the large round kernels) or 2 (+ account every round and fold)");
+    ScProf& p = sc_prof();
+    for (auto& r : p.recs) { p.free_events.push_back(r.e0); p.free_events.push_back(r.e1); }
+    p.recs.clear();
+    p.n_slots = 0;
+    p.small_round_bytes = p.fold_bytes = p.small_rounds = p.folds = 0;
+    p.mode = mode;
+    return GM_OK;
+}
+
+extern "C" int32_t gm_sc_profile_read(gm_sc_profile_row* rows, uint32_t cap, uint32_t* n_rows, double* other_round_bytes,
+                                      double* fold_bytes, void* stream) {
+    GM_REQUIRE(n_rows, "null argument");
+    ScProf& p = sc_prof();
+    GM_HIP(hipStreamSynchronize(as_stream(stream)));
+    std::vector<gm_sc_profile_row> acc;
+    std::vector<int> cls_of;
+    for (auto& r : p.recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        const uint64_t pairs = r.h_cells ? (uint64_t)(*r.h_cells >> 1) : r.pairs;
+        size_t j = 0;
+        for (; j < cls_of.size(); j++) if (cls_of[j] == r.cls) break;
+        if (j == cls_of.size()) {
+            cls_of.push_back(r.cls);
+            gm_sc_profile_row row;
+            memset(&row, 0, sizeof(row));
+            snprintf(row.kernel, sizeof(row.kernel), "%s", sc_class_name(r.cls));
+            row.k_cols = (uint32_t)r.k;
+            acc.push_back(row);
+        }
+        gm_sc_profile_row& row = acc[j];
+        row.launches++;
+        row.total_ms += ms;
+        row.pairs += (double)pairs;
+        row.alg_bytes += (64.0 * r.k + ((r.cls & 3) == 2 ? 0.0 : ((r.cls & 3) == 3 ? 0.0 : 32.0))) * (double)pairs;
+        row.fr_mul += (double)r.fr_mul_per_pair * (double)pairs;
+        if (ms > row.max_ms) row.max_ms = ms;
+    }
+    *n_rows = (uint32_t)acc.size();
+    if (rows) {
+        GM_REQUIRE(acc.size() <= cap, "row buffer too small (%zu classes)", acc.size());
+        for (size_t j = 0; j < acc.size(); j++) rows[j] = acc[j];
+    }
+    if (other_round_bytes) *other_round_bytes = p.small_round_bytes;
+    if (fold_bytes) *fold_bytes = p.fold_bytes;
+    for (auto& r : p.recs) { p.free_events.push_back(r.e0); p.free_events.push_back(r.e1); }
+    p.recs.clear();
+    p.n_slots = 0;
+    p.small_round_bytes = p.fold_bytes = p.small_rounds = p.folds = 0;
     return GM_OK;
 }
 

@@ -56,3 +56,76 @@ class Comm:
                 return 9
         self._cb = ffi.ALL_GATHER_CB(_ag)  # keep the thunk alive
         self.c = ffi.GmComm(None, rank, world, self._cb)
+
+
+class RcclComm:
+    """The library's own RCCL communicator (gm_comm_rccl_*, csrc/rccl_comm.hip): ncclAllGather / ncclBroadcast inside
+    libgkrmsm_hip.so, no Python on the data path.  torch.distributed (any backend) is only the side channel that carries the
+    128-byte ncclUniqueId from rank 0 to the other ranks at start-up; pass `dist=None` with `unique_id=` to use another one."""
+
+    def __init__(self, dist, rank, world, unique_id=None, bcast_device=None):
+        import ctypes as C
+        import torch
+        from . import ffi, harness
+        L = ffi.lib()
+        self.L, self.rank, self.world = L, rank, world
+        if unique_id is None:
+            idb = np.zeros(128, dtype=np.uint8)
+            if rank == 0:
+                ffi.check(L.gm_comm_rccl_unique_id(idb.ctypes.data))
+            if world > 1:
+                t = torch.from_numpy(idb)
+                if bcast_device is not None:
+                    t = t.to(bcast_device)
+                dist.broadcast(t, src=0)
+                idb = t.cpu().numpy().copy()
+            unique_id = idb
+        self.unique_id = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        self.h = C.c_void_p()
+        ffi.check(L.gm_comm_rccl_create(self.unique_id.ctypes.data, rank, world, C.byref(self.h), harness.cur_stream()))
+        self.c = ffi.GmComm()
+        ffi.check(L.gm_comm_rccl_as_comm(self.h, C.byref(self.c)))
+
+    def close(self):
+        if self.h:
+            self.L.gm_comm_rccl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def calls(self):
+        import ctypes as C
+        n, b = C.c_uint64(), C.c_uint64()
+        self.L.gm_comm_rccl_stats(self.h, C.byref(n), C.byref(b))
+        return n.value
+
+    def all_gather_dev(self, d_send_ptr, d_recv, nbytes):
+        """d_send_ptr: raw device pointer (int / c_void_p) of nbytes; d_recv: tensor of world * nbytes bytes"""
+        import ctypes as C
+        from . import ffi, harness
+        ffi.check(self.L.gm_comm_rccl_all_gather_dev(self.h, d_send_ptr, C.c_void_p(d_recv.data_ptr()), nbytes, harness.cur_stream()))
+
+    def broadcast_dev(self, tensor, root=0):
+        import ctypes as C
+        from . import ffi, harness
+        ffi.check(self.L.gm_comm_rccl_broadcast_dev(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size(), root,
+                                                    harness.cur_stream()))
+
+    def gather_window_points(self, plan):
+        """all ranks' window points of a window-sharded gm_msm_plan -> numpy uint64 (ncols, y_size, 4), window order"""
+        import ctypes as C
+        import torch
+        from . import ffi
+        p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        ffi.check(self.L.gm_msm_window_points(plan.h, C.byref(p), C.byref(nc), C.byref(cl)))
+        ncols, wpr = nc.value, cl.value
+        nbytes = ncols * wpr * 32
+        recv = torch.empty(self.world * ncols * wpr * 4, dtype=torch.int64, device="cuda")
+        self.all_gather_dev(p, recv, nbytes)
+        raw = recv.cpu().numpy().view(np.uint64).reshape(self.world, ncols, wpr, 4)
+        return np.ascontiguousarray(np.transpose(raw, (1, 0, 2, 3)).reshape(ncols, self.world * wpr, 4))

@@ -66,6 +66,11 @@ class GmFragment(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class GmScProfileRow(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_uint32), ("k_cols", C.c_uint32), ("total_ms", C.c_double),
+                ("max_ms", C.c_double), ("pairs", C.c_double), ("alg_bytes", C.c_double), ("fr_mul", C.c_double)]
+
+
 class GmComm(C.Structure):
     """gm_comm: rank / world and one host-buffer all-gather"""
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", ALL_GATHER_CB)]
@@ -81,6 +86,8 @@ _SIGS = {
     "gm_free": (C.c_int32, [vp]),
     "gm_release_cached_memory": (C.c_int32, []),
     "gm_set_wait_timeout_ms": (C.c_int32, [C.c_uint32]),
+    "gm_sc_profile": (C.c_int32, [C.c_int32]),
+    "gm_sc_profile_read": (C.c_int32, [C.POINTER(GmScProfileRow), C.c_uint32, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "gm_memcpy_h2d": (C.c_int32, [vp, vp, C.c_size_t, vp]),
     "gm_memcpy_d2h": (C.c_int32, [vp, vp, C.c_size_t, vp]),
     "gm_memcpy_d2d": (C.c_int32, [vp, vp, C.c_size_t, vp]),
@@ -115,6 +122,13 @@ _SIGS = {
     "gm_pip_witness_create": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(vp), vp]),
     "gm_pip_witness_create_sharded": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(GmComm), C.POINTER(vp), vp]),
     "gm_comm_sum_fr": (C.c_int32, [C.POINTER(GmComm), vp, C.c_uint32]),
+    "gm_comm_rccl_unique_id": (C.c_int32, [vp]),
+    "gm_comm_rccl_create": (C.c_int32, [vp, C.c_uint32, C.c_uint32, C.POINTER(vp), vp]),
+    "gm_comm_rccl_destroy": (C.c_int32, [vp]),
+    "gm_comm_rccl_as_comm": (C.c_int32, [vp, C.POINTER(GmComm)]),
+    "gm_comm_rccl_all_gather_dev": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),
+    "gm_comm_rccl_broadcast_dev": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
+    "gm_comm_rccl_stats": (C.c_int32, [vp, u64p, u64p]),
     "gm_pip_witness_destroy": (C.c_int32, [vp]),
     "gm_pip_witness_outputs": (C.c_int32, [vp, vp, u32p, u64p, vp]),
     "gm_pip_witness_bytes": (C.c_uint64, [vp]),

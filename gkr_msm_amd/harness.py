@@ -822,3 +822,17 @@ class GkrWitness:
                                       C.byref(rounds)))
         return dict(msgs=codec.from_mont_limbs(msgs[: nm.value]), point=codec.from_mont_limbs(fpt[: npt.value]),
                     evs=codec.from_mont_limbs(fev[: nev.value]), tape_used=used.value, rounds=rounds.value)
+
+
+def sc_profile(mode):
+    ffi.check(ffi.lib().gm_sc_profile(mode))
+
+
+def sc_profile_read():
+    """-> (rows [dict], other_round_bytes, fold_bytes) of the sumcheck round kernels since the last read"""
+    rows = (ffi.GmScProfileRow * 64)()
+    n, orb, fb = C.c_uint32(), C.c_double(), C.c_double()
+    ffi.check(ffi.lib().gm_sc_profile_read(rows, 64, C.byref(n), C.byref(orb), C.byref(fb), cur_stream()))
+    out = [dict(kernel=r.kernel.decode(), launches=r.launches, k_cols=r.k_cols, total_ms=r.total_ms, max_ms=r.max_ms, pairs=r.pairs,
+                alg_bytes=r.alg_bytes, fr_mul=r.fr_mul) for r in rows[: n.value]]
+    return out, orb.value, fb.value

@@ -166,6 +166,27 @@ int32_t gm_sc_final_evals(gm_sc* so, uint64_t* h_evals, uint32_t* n_evals);
 int32_t gm_sc_claim(const gm_sc* so, uint64_t* h_claim);
 int32_t gm_sc_destroy(gm_sc* so);
 
+/* Measurement: the large (non-split) round kernels of the sumcheck objects created on the calling thread are
+ * bracketed with HIP events on their launch stream.  mode 0 = off, 1 = time those launches (cheap: two event records per large
+ * round; exact pair counts of sparse rounds come back by a 4-byte asynchronous copy), 2 = additionally account the
+ * algorithmic bytes of every other round kernel and of every fold.  gm_sc_profile_read synchronises `stream`, returns one row
+ * per kernel class (since the last read / mode change) and the two byte totals, and resets the records.
+ * Algorithmic bytes: a round kernel reads both cells of every pair of its k input columns (64 k bytes per pair, + 32 for the eq
+ * weight of the eq-factored objects); a fold moves 96 bytes per output cell and column. */
+typedef struct gm_sc_profile_row {
+    char kernel[64];     /* e.g. "k_round_deg2_lean<PROJ_L1,vecvec>" */
+    uint32_t launches;
+    uint32_t k_cols;
+    double total_ms;     /* sum of the launches' durations (HIP events) */
+    double max_ms;
+    double pairs;        /* pairs processed over all launches */
+    double alg_bytes;    /* algorithmic bytes read over all launches */
+    double fr_mul;       /* field multiplications over all launches */
+} gm_sc_profile_row;
+int32_t gm_sc_profile(int32_t mode);
+int32_t gm_sc_profile_read(gm_sc_profile_row* rows, uint32_t cap, uint32_t* n_rows, double* other_round_bytes, double* fold_bytes,
+                           void* stream);
+
 /* ---------------------------------------------------------------- Pippenger MSM (a11, a12, a14)
  * The reference's bucketed MSM over Bandersnatch:
  *   digits + bucket scatter      PushForwardState::new      pushforward/pushforward.rs:351-361, 401-429
@@ -320,8 +341,9 @@ int32_t gm_merlin_unread(const gm_merlin* t, uint64_t* n);
 /* ---------------------------------------------------------------- multi-GPU seam
  * One process per GPU.  The path shards by MSM window: rank g owns windows [g*y_size/G, (g+1)*y_size/G), i.e. the bucket
  * rows (y << d_logsize | digit) of its windows -- MSM, witness build, round sums and folds of the bintree GKR are all local to
- * those rows.  The exchange steps are tiny and go through ONE caller-provided collective on host buffers (the harness
- * backs it with torch.distributed: RCCL on GPUs, gloo in the CPU tests; the Rust shim can back it with anything):
+ * those rows.  The exchange steps are tiny and go through ONE collective on host buffers, either the library's own RCCL
+ * backing (gm_comm_rccl_*, below) or a caller-provided one (the CPU tests use torch.distributed over gloo; a Rust shim can
+ * back it with anything):
  *   - per sumcheck round: all-gather of the 2-3 partial round sums (<= 96 bytes per rank), added mod p by every rank;
  *   - once per proof: all-gather of the bucket sums (3 * 2^(y_logsize + d_logsize) field elements in total), after which the
  *     bucket-reduction (triangle) GKR runs replicated, and of one element per column when a dense layer's local
@@ -335,6 +357,26 @@ typedef struct gm_comm {
 } gm_comm;
 /* host-only self-test of a gm_comm (no GPU): sums the field elements h_vals[0..n) of all ranks in place (Montgomery) */
 int32_t gm_comm_sum_fr(const gm_comm* comm, uint64_t* h_vals, uint32_t n);
+
+/* Native backing of the seam: RCCL over xGMI, one communicator per process (= per GPU).  RCCL is bound at run time (dlopen;
+ * a copy already in the process, e.g. PyTorch's, is reused), so single-GPU callers never load it.
+ *   gm_comm_rccl_unique_id       ncclGetUniqueId on one rank; the caller carries the 128 bytes to the others
+ *   gm_comm_rccl_create          ncclCommInitRank on the current device (collective: every rank calls it)
+ *   gm_comm_rccl_as_comm         a gm_comm for gm_pip_witness_create_sharded whose all_gather is ncclAllGather on a device
+ *                                staging buffer on the communicator's stream (payloads <= 64 KiB go through pinned memory)
+ *   gm_comm_rccl_all_gather_dev  device buffers, asynchronous on `stream`: the window points of a window-sharded MSM
+ *                                (gm_msm_window_points: 3 (d_logsize + 1) * windows_per_rank elements per rank)
+ *   gm_comm_rccl_broadcast_dev   operand replication: points / scalars from `root` to every rank (the one link-bound step)
+ * Nothing is REDUCED by RCCL: field and curve additions are not RCCL operations, every rank adds the gathered parts itself. */
+#define GM_RCCL_UNIQUE_ID_BYTES 128
+typedef struct gm_rccl gm_rccl;
+int32_t gm_comm_rccl_unique_id(uint8_t* out_id128);
+int32_t gm_comm_rccl_create(const uint8_t* id128, uint32_t rank, uint32_t world, gm_rccl** out, void* stream);
+int32_t gm_comm_rccl_destroy(gm_rccl* r);
+int32_t gm_comm_rccl_as_comm(gm_rccl* r, gm_comm* out);
+int32_t gm_comm_rccl_all_gather_dev(gm_rccl* r, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream);
+int32_t gm_comm_rccl_broadcast_dev(gm_rccl* r, void* d_buf, uint64_t bytes, uint32_t root, void* stream);
+int32_t gm_comm_rccl_stats(const gm_rccl* r, uint64_t* host_all_gathers, uint64_t* bytes_per_rank_total);
 
 /* ---------------------------------------------------------------- "prove image part" (a10, a11)
  * Host-side driver over the kernels, mirroring PippengerWG::new (pippenger.rs:37-70, without the BLS12-381 G1

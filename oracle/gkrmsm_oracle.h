@@ -79,6 +79,8 @@ void or_msm_combine(const or_fr* window_cols, uint32_t d_logsize, uint32_t n_win
 extern "C" {
 #endif
 typedef struct or_pip_witness or_pip_witness;
+/* CPU-baseline variant switch: 0 = fair (all loops threaded), 1 = reference-faithful (serial where the reference is serial) */
+void or_set_reference_faithful(int on);
 or_pip_witness* or_pip_witness_create(const or_fr* points_xy, const uint64_t* scalars, uint32_t x_logsize,
                                       uint32_t d_logsize, uint32_t y_size, uint32_t y_logsize, int threads);
 void or_pip_witness_destroy(or_pip_witness* w);

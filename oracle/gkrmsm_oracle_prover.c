@@ -9,6 +9,14 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+
+/* CPU-baseline variants.  0 = "fair": every data-parallel loop is threaded.  1 = "reference-faithful":
+ * the loops the reference runs serially stay serial -- the round sums of DenseDeg2SumcheckObjectSO (dense_eq.rs:121-139) and of
+ * VecVecDeg2SumcheckObjectSO (vecvec_eq.rs:320-361), and vecvec_map_split (vecvec.rs:579-594; dense algfn_map_split,
+ * dense.rs:130-135, is serial in both) -- everything the reference hands to rayon stays threaded.  Results are identical. */
+static int g_faithful = 0;
+void or_set_reference_faithful(int on) { g_faithful = on ? 1 : 0; }
+
 #endif
 
 #include "gkrmsm_oracle.h"
@@ -121,7 +129,7 @@ static vvset* vv_map_split(const or_fn* f, const vvset* in, int bundle) {
             o->row_pad[bundle_col(oc, h, bundle)] = rp[oc];
             o->col_pad[bundle_col(oc, h, bundle)] = cp[oc];
         }
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) if (!g_faithful)
     for (uint32_t r = 0; r < in->nrows; r++) {
         or_fr x[64], y[64];
         uint32_t half = in->len[r] / 2, plen = half + (half & 1);
@@ -323,7 +331,7 @@ static void dense_deg2_prove(tape_t* tr, const or_fn* f, uint32_t nv, claims_t* 
         uint64_t half = 1ULL << (nv - rd - 1);
         const or_fr* eq = eqs + (half - 1);
         or_fr s1 = ZERO, s2 = ZERO;
-#pragma omp parallel
+#pragma omp parallel if (!g_faithful)
         {
             or_fr l1 = ZERO, l2 = ZERO;
 #pragma omp for schedule(static) nowait
@@ -430,7 +438,7 @@ static void vecvec_deg2_prove(tape_t* tr, const or_fn* f, uint32_t nv, claims_t*
         const or_fr* eq = seq[nseq - bound];
         const or_fr* px = pre[nseq - bound];
         or_fr s1 = ZERO, s2 = ZERO;
-#pragma omp parallel
+#pragma omp parallel if (!g_faithful)
         {
             or_fr l1 = ZERO, l2 = ZERO;
 #pragma omp for schedule(dynamic, 8) nowait
