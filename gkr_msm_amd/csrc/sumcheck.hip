@@ -15,6 +15,7 @@
 // registers and folds with the plain formula: every round polynomial, folded polynomial and final evaluation
 // is the same canonical field element as in the reference (sums in a field do not depend on their order).
 #include <atomic>
+#include <immintrin.h>
 #include <chrono>
 
 #include "internal.hpp"
@@ -375,116 +376,302 @@ __global__ void __launch_bounds__(64) k_gather_finals(ColPtrs cols, int k, Fr* _
     if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// ------------------------------------------------------------------------------------------ persistent tail rounds
-// Rounds of at most 256 pairs (the last 9 of every dense stage: ~40 % of all rounds of a proof) cost three dispatches each
-// (round kernel, gate, fold), 33 us of which a few are arithmetic.  One launch runs ALL of them: block (segment, point)
-// keeps its segment's input pairs in registers, and per round (i) evaluates the layer function, reduces over the block and
-// writes its partial sum + a sequence word straight into pinned host memory (the host adds the <= 64 partials), (ii) waits
-// for the challenge -- block 0 polls the host's ticket and relays it through device memory, so only one wave crosses PCIe --
-// (iii) folds its own inputs and regroups the pairs through LDS.  No inter-block data dependency, hence no grid barrier.
-// Waits are bounded; on timeout the block flags `status` and leaves.  After the last fold the (segment, 0) blocks write the
-// final evaluations of their input columns.
-struct TailArgs {
-    const Fr* eq[10];          // eq table of tail round r (offset applied)
-    Fr* h_part;                // pinned: partial sum of block y
-    uint32_t* h_seq;           // pinned: sequence word of block y (= ticket0 + r after round r)
-    Fr* h_finals;              // pinned: final evaluation of column c
-    uint32_t* h_fin_seq;       // pinned: per segment, = ticket0 + nrounds when its finals are written
-    const Fr* h_t;             // pinned: challenge slots, round r in slot r & 3
-    const uint32_t* h_ticket;  // pinned: host publishes ticket0 + r with t_r
+// ------------------------------------------------------------------------------------------ persistent stage kernel
+// Small rounds are latency-bound: as separate dispatches a round costs a round kernel (21-29 us), a gate (5-9 us) and a fold
+// (5-8 us).  ONE launch of k_stage runs every small round of a layer instead:
+//   * the "thin" rounds of a VecVec sumcheck -- the rounds left once every row is down to 0 or 2 cells (rows halve every round
+//     and are re-padded to even length, vecvec.rs:420-441, so the last ~7 of the 19 sparse rounds of a bucket-sum layer work on
+//     one pair per row): thread = row, the pair lives in registers, a fold re-pads in registers;
+//   * bind_into_dense (vecvec_eq.rs:157-175): row -> one dense element, regrouped into pairs through LDS;
+//   * the whole dense stage (13 rounds at config B) -- or all rounds of a dense object that starts small (triangle layers).
+// Grid: x = 2 * segment + evaluation point, y = slice of 256 rows / dense elements.  Per round a block (i) evaluates its
+// segment of the layer function on its pairs, reduces over the block and writes its partial sum + a sequence word straight
+// into pinned host memory (the host adds the partials and does the O(1) scalar tail: from12, transcript, challenge),
+// (ii) waits for the challenge -- block (0, 0) polls the host's ticket and relays it through device memory, so one wave
+// crosses PCIe -- (iii) folds its own inputs and regroups the pairs through LDS.  Slices never exchange data until each is
+// down to one element; then every slice hands its element to slice 0 through device memory (release / acquire around a
+// counter) and slice 0 finishes alone.  All blocks are co-resident (<= 512 blocks of 256 threads), so waiting is safe; every
+// wait is bounded (gm_set_wait_timeout_ms): on timeout a block flags `status` and leaves.
+// Coherent 32-byte accesses as two 16-byte instructions.  Relaxed atomic dword accesses would do, but the compiler drains the
+// memory pipeline (s_waitcnt vmcnt(0)) after every one of them: eight dependent round trips per field element (measured: 6.6 us
+// to publish two elements).  sc1 = device-coherent (another CU / XCD wrote or will read the bytes), sc0 sc1 = system-coherent
+// (pinned host memory).  Stores are left in flight: drain with coh_drain() before raising the flag / counter.
+typedef uint32_t gm_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void coh_store_dev(Fr* p, const Fr& v) {
+    const gm_u4 lo = {v.l[0], v.l[1], v.l[2], v.l[3]}, hi = {v.l[4], v.l[5], v.l[6], v.l[7]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ void coh_store_sys(Fr* p, const Fr& v) {
+    const gm_u4 lo = {v.l[0], v.l[1], v.l[2], v.l[3]}, hi = {v.l[4], v.l[5], v.l[6], v.l[7]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" ::"v"(p), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ void coh_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ Fr coh_load_dev(const Fr* p) {
+    gm_u4 lo, hi;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi) : "v"(p) : "memory");
+    Fr r;
+    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w; r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ Fr coh_load_sys(const Fr* p) {
+    gm_u4 lo, hi;
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi) : "v"(p) : "memory");
+    Fr r;
+    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w; r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+    return r;
+}
+
+// Self-validating messages between the stage kernel and the host (and between its blocks): 16-byte chunks of 12 data bytes +
+// the 4-byte sequence number of the round.  Every chunk is one store instruction and is validated on its own, so the writer
+// needs no ordering between stores (no drain, no separate flag) and the reader gets data and flag in ONE round trip.
+__device__ __forceinline__ void chunk_store_sys(uint32_t* p, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t seq) {
+    const gm_u4 v = {a0, a1, a2, seq};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void chunk_store_dev(uint32_t* p, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t seq) {
+    const gm_u4 v = {a0, a1, a2, seq};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// a field element as three chunks (12 + 12 + 8 bytes) at p[0..12)
+__device__ __forceinline__ void fr_chunks_store_sys(uint32_t* p, const Fr& v, uint32_t seq) {
+    chunk_store_sys(p, v.l[0], v.l[1], v.l[2], seq);
+    chunk_store_sys(p + 4, v.l[3], v.l[4], v.l[5], seq);
+    chunk_store_sys(p + 8, v.l[6], v.l[7], 0u, seq);
+}
+__device__ __forceinline__ void fr_chunks_store_dev(uint32_t* p, const Fr& v, uint32_t seq) {
+    chunk_store_dev(p, v.l[0], v.l[1], v.l[2], seq);
+    chunk_store_dev(p + 4, v.l[3], v.l[4], v.l[5], seq);
+    chunk_store_dev(p + 8, v.l[6], v.l[7], 0u, seq);
+}
+// load the three chunks of a field element; 1: every chunk carries `want`, 2: every chunk carries `alt`, 0: neither (yet)
+template <bool SYS>
+__device__ __forceinline__ int fr_chunks_load(const uint32_t* p, Fr* out, uint32_t want, uint32_t alt) {
+    gm_u4 c0, c1, c2;
+    if (SYS)
+        asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
+                     "global_load_dwordx4 %2, %3, off offset:32 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(c0), "=&v"(c1), "=&v"(c2) : "v"(p) : "memory");
+    else
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+                     "global_load_dwordx4 %2, %3, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(c0), "=&v"(c1), "=&v"(c2) : "v"(p) : "memory");
+    out->l[0] = c0.x; out->l[1] = c0.y; out->l[2] = c0.z; out->l[3] = c1.x; out->l[4] = c1.y; out->l[5] = c1.z; out->l[6] = c2.x; out->l[7] = c2.y;
+    if (c0.w == want && c1.w == want && c2.w == want) return 1;
+    if (c0.w == alt && c1.w == alt && c2.w == alt) return 2;
+    return 0;
+}
+
+#define STAGE_MAX_BLOCKS 512
+#define STAGE_MAX_SLICES 64
+#define STAGE_MAX_ROUNDS 16
+struct PadCols {
+    Fr v[16];
+};
+struct StageArgs {
+    uint32_t nrows;                    // thin phase: stored rows (each of 0 or 2 cells); 0 = no thin phase
+    uint32_t n_elems;                  // dense elements (a power of two): 2^col_logsize, or the dense object's current length
+    int n_thin, n_dense;               // rounds of each phase
+    const uint32_t* off;               // thin: row offsets
+    const Fr* row_coef;                // thin: eq(point[0..col_logsize], row)
+    const Fr* thin_eq[12];             // thin round q: entry 0 of that round's level of the row eq sequence
+    const Fr* eq[STAGE_MAX_ROUNDS];    // dense round q: eq table indexed by the global pair index
+    PadCols row_pad, col_pad;          // thin only
+    uint32_t* h_rep;                   // pinned: the round's report at 36 (round & 1) words: sum at point 1, at point 2, tail weight,
+                                       // each as three self-validating chunks (see fr_chunks_store_sys)
+    Fr* d_part;                        // device: 2 partial sums per block (2b: the round sum, 2b+1: the tail weight)
+    uint32_t* d_round_cnt;             // device: one arrival counter per round (zeroed before the launch)
+    Fr* h_finals;                      // pinned: final evaluation of column c
+    uint32_t* h_fin_seq;               // pinned: per segment, = ticket0 + nrounds when its finals are written
+    const uint32_t* h_tkt;             // pinned: the host publishes t_r as three chunks tagged ticket0 + r at 12 (r & 1) words
     uint32_t* h_status;
-    uint32_t* d_relay;         // device: [0] relayed ticket, [8..16) relayed challenge (32 bytes)
+    uint32_t* d_relay;                 // device: the relayed challenge of round r as three chunks at 12 (r & 1) words
+    Fr* d_xbuf;                        // device: hand-over of the slices' last elements, [gridDim.x][6][STAGE_MAX_SLICES]
+    uint32_t* d_merge;                 // device: one arrival counter per blockIdx.x (zeroed before the launch)
     uint32_t ticket0;
-    int nrounds;
-    uint32_t npairs0;
-    uint64_t timeout_ticks;    // bound of every wait (100 MHz wall clock)
+    uint64_t timeout_ticks;
+    uint64_t* d_dbg;                   // development aid: phase time stamps (nullptr normally)
 };
 
-__global__ void __launch_bounds__(256) k_tail_rounds(SegPlan sp, ColPtrs cols, const Fr* __restrict__ gp, TailArgs a) {
+// sum_{o in segment} gamma^o f_o(v) for one pair at evaluation point h
+__device__ __forceinline__ Fr stage_eval(const Seg& g, const Fr* p0, const Fr* p1, const Fr* __restrict__ gp, int h) {
+    Fr v[6], o[4];
+#pragma unroll
+    for (int q = 0; q < 6; q++) v[q] = h ? fr_sub(fr_dbl(p1[q]), p0[q]) : p1[q];
+    prim_exec(g.prim, v, o);
+    Fr A = fr_zero();
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q < g.n_out) {
+            const int oc = g.out0 + q;
+            A = fr_add(A, oc == 0 ? o[q] : fr_mul(fr_load(gp + oc), o[q]));
+        }
+    return A;
+}
+
+__global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const Fr* __restrict__ gp, StageArgs a) {
     __shared__ Fr xch[6][256];
-    __shared__ Fr red[4];
+    __shared__ Fr red[4][2];
     __shared__ Fr ts;
     __shared__ int ok;
+    __shared__ uint32_t is_last;
     const int sgi = blockIdx.x >> 1, h = blockIdx.x & 1;
     const Seg g = sp.seg[sgi];
+    const uint32_t slice = blockIdx.y, nsl = gridDim.y;
     const uint32_t i = threadIdx.x, lane = i & 63, wave = i >> 6;
-    uint32_t np = a.npairs0;
+    const uint32_t blk = slice * gridDim.x + blockIdx.x;
     Fr p0[6], p1[6];
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-        p0[q] = fr_zero(); p1[q] = fr_zero();
-        if (q < g.n_in && i < np) {
-            p0[q] = fr_load(cols.p[g.in[q]] + 2 * i);
-            p1[q] = fr_load(cols.p[g.in[q]] + 2 * i + 1);
-        }
-    }
-    for (int r = 0; r < a.nrounds; r++) {
-        Fr acc = fr_zero();
-        if (i < np) {
-            Fr v[6], o[4];
-#pragma unroll
-            for (int q = 0; q < 6; q++) v[q] = h ? fr_sub(fr_dbl(p1[q]), p0[q]) : p1[q];
-            prim_exec(g.prim, v, o);
-            Fr A = fr_zero();
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (q < g.n_out) {
-                    const int oc = g.out0 + q;
-                    A = fr_add(A, oc == 0 ? o[q] : fr_mul(fr_load(gp + oc), o[q]));
-                }
-            acc = fr_mul(A, fr_load(a.eq[r] + i));
-        }
-        const Fr w = wave_sum(acc);
-        if (lane == 0) red[wave] = w;
+    for (int q = 0; q < 6; q++) { p0[q] = fr_zero(); p1[q] = fr_zero(); }
+    uint32_t round = 0;   // rounds done by this launch so far: the ticket of round r is ticket0 + r
+    bool thin = a.n_thin > 0;   // true while the thin rounds run (reports then carry the tail weight)
+    // development aid (GM_STAGE_DEBUG=1): wall-clock stamps (100 MHz) of the phases of every round, blocks 0 and 1
+#define STAGE_STAMP(k_) do { if (a.d_dbg && i == 0 && blk < 2) a.d_dbg[((size_t)blk * 32 + round) * 8 + (k_)] = wall_clock64(); } while (0)
+
+    // Sum (s0, s1) over all reporting blocks and hand the round's sums to the host, then wait for that round's challenge;
+    // false = give up.  Blocks publish their partial in device memory; the block that arrives last (agent-scope release /
+    // acquire around the round's own counter) adds them up per evaluation point and writes ONE report to pinned host memory:
+    // with up to 192 blocks, per-block reports cost ~45 us per round in PCIe write transactions alone.
+    auto exchange = [&](Fr s0, Fr s1, bool with_w, uint32_t nrep) -> bool {
+        STAGE_STAMP(1);
+        const Fr w0 = wave_sum(s0);
+        Fr w1 = fr_zero();
+        if (with_w) w1 = wave_sum(s1);
+        if (lane == 0) { red[wave][0] = w0; red[wave][1] = w1; }
         __syncthreads();
+        const uint32_t want = a.ticket0 + round;
+        STAGE_STAMP(2);
         if (i == 0) {
-            const Fr tot = fr_add(fr_add(red[0], red[1]), fr_add(red[2], red[3]));
-#pragma unroll
-            for (int l = 0; l < 8; l++) __hip_atomic_store(&a.h_part[blockIdx.x].l[l], tot.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __threadfence_system();
-            __hip_atomic_store(a.h_seq + blockIdx.x, a.ticket0 + (uint32_t)r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            // the challenge
-            const uint32_t want = a.ticket0 + (uint32_t)r;
+            const Fr t0 = fr_add(fr_add(red[0][0], red[1][0]), fr_add(red[2][0], red[3][0]));
+            const Fr t1 = fr_add(fr_add(red[0][1], red[1][1]), fr_add(red[2][1], red[3][1]));
+            // hand-off without cache-wide fences: device-coherent (sc1) stores, drained, then the counter; the reader uses
+            // device-coherent loads (a release / acquire pair would write back and invalidate the whole L2 every round)
+            coh_store_dev(a.d_part + 2 * blk, t0);
+            if (thin) coh_store_dev(a.d_part + 2 * blk + 1, t1);
+            coh_drain();
+            const uint32_t prev = __hip_atomic_fetch_add(a.d_round_cnt + round, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = (prev == nrep - 1) ? 1u : 0u;
+        }
+        __syncthreads();
+        STAGE_STAMP(3);
+        if (is_last && wave == 0) {
+            // the block that arrived last adds the partials up per evaluation point (one wave: nrep <= 512) and reports
+            Fr r0 = fr_zero(), r1 = fr_zero(), rw = fr_zero();   // sums at point 1, at point 2, tail weight
+            for (uint32_t b2 = lane; b2 < nrep; b2 += 64) {
+                const Fr v = coh_load_dev(a.d_part + 2 * b2);
+                if ((b2 % gridDim.x) & 1) r1 = fr_add(r1, v); else r0 = fr_add(r0, v);
+                if (thin && (b2 % gridDim.x) == 0) rw = fr_add(rw, coh_load_dev(a.d_part + 2 * b2 + 1));
+            }
+            r0 = wave_sum(r0);
+            r1 = wave_sum(r1);
+            if (thin) rw = wave_sum(rw);
+            if (lane == 0) {
+                // report slot of this round: a slot is rewritten two rounds later, after the host has read it
+                uint32_t* dst = a.h_rep + 36 * (round & 1);
+                fr_chunks_store_sys(dst, r0, want);
+                fr_chunks_store_sys(dst + 12, r1, want);
+                fr_chunks_store_sys(dst + 24, rw, want);
+            }
+        }
+        STAGE_STAMP(4);
+        if (i == 0) {
             int good = 0;
             Fr t = fr_zero();
-            if (blockIdx.x == 0) {
-                const uint64_t t_begin = wall_clock64();
+            const uint64_t t_begin = wall_clock64();
+            if (blk == 0) {
+                const uint32_t* src = a.h_tkt + 12 * (round & 1);
                 for (uint32_t it = 0;; it++) {   // polling over PCIe until the bound: a slow (interpreted, traced) transcript is fine
                     if ((it & 255u) == 255u && wall_clock64() - t_begin > a.timeout_ticks) break;
-                    const uint32_t f = __hip_atomic_load(a.h_ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if ((int32_t)(f - want) >= 0) { good = 1; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (good) {
-#pragma unroll
-                    for (int l = 0; l < 8; l++) t.l[l] = __hip_atomic_load(&a.h_t[r & 3].l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    // slot r & 1 of the relay: a block still reading t_(r-1) is never overwritten (t_(r+1) needs every block's round-r+1 sum)
-#pragma unroll
-                    for (int l = 0; l < 8; l++) __hip_atomic_store(a.d_relay + 8 + 8 * (r & 1) + l, t.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(a.d_relay, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    __hip_atomic_store(a.h_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(a.d_relay, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // let the others go
-                }
-            } else {
-                const uint64_t t_begin = wall_clock64();
-                for (uint32_t it = 0;; it++) {   // outlasts block 0's wait (4x); block 0 releases the others when it gives up
-                    if ((it & 1023u) == 1023u && wall_clock64() - t_begin > 4 * a.timeout_ticks) break;
-                    const uint32_t f = __hip_atomic_load(a.d_relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    if (f == 0xffffffffu) break;
-                    if ((int32_t)(f - want) >= 0) { good = 1; break; }
+                    if (fr_chunks_load<true>(src, &t, want, a.ticket0 + 0x4000u)) { good = 1; break; }   // ticket0 + 0x4000: the host lets every wait through
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (good) {
-#pragma unroll
-                    for (int l = 0; l < 8; l++) t.l[l] = __hip_atomic_load(a.d_relay + 8 + 8 * (r & 1) + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // slot round & 1 of the relay: a block still reading t_(r-1) is never overwritten (t_(r+1) needs every block's round-r+1 sum)
+                    fr_chunks_store_dev(a.d_relay + 12 * (round & 1), t, want);
+                } else {
+                    __hip_atomic_store(a.h_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    fr_chunks_store_dev(a.d_relay + 12 * (round & 1), t, 0xffffffffu);   // let the others go
+                }
+            } else {
+                const uint32_t* src = a.d_relay + 12 * (round & 1);
+                for (uint32_t it = 0;; it++) {   // outlasts block 0's wait (4x); block 0 releases the others when it gives up
+                    if ((it & 1023u) == 1023u && wall_clock64() - t_begin > 4 * a.timeout_ticks) break;
+                    const int f = fr_chunks_load<false>(src, &t, want, 0xffffffffu);
+                    if (f == 2) break;
+                    if (f == 1) { good = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
             }
             ts = t;
             ok = good;
         }
         __syncthreads();
-        if (!ok) return;
+        STAGE_STAMP(5);
+        return ok != 0;
+    };
+
+    uint32_t np;   // pairs this block holds in the dense phase
+    // ------------------------------------------------------------------ thin phase: thread = row
+    if (a.n_thin > 0) {
+        const uint32_t r = slice * 256 + i;
+        bool have = false;
+        Fr coef = fr_zero();
+        if (r < a.nrows) {
+            const uint32_t c0 = a.off[r];
+            have = a.off[r + 1] != c0;
+            coef = fr_load(a.row_coef + r);
+            if (have) {
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if (q < g.n_in) { p0[q] = fr_load(cols.p[g.in[q]] + c0); p1[q] = fr_load(cols.p[g.in[q]] + c0 + 1); }
+            }
+        }
+        for (int tr = 0; tr < a.n_thin; tr++, round++) {
+            STAGE_STAMP(0);
+            const Fr e0 = fr_load(a.thin_eq[tr]);
+            Fr acc = fr_zero(), accw = fr_zero();
+            if (have) acc = fr_mul(stage_eval(g, p0, p1, gp, h), fr_mul(e0, coef));
+            // the tail weight W = sum_r coef[r] (1 - sum_{idx < seg_r} eq[idx]), get_trailing_sum (vecvec.rs:144-146): once per slice
+            if (blockIdx.x == 0 && r < a.nrows) accw = have ? fr_mul(coef, fr_sub(fr_one(), e0)) : coef;
+            if (!exchange(acc, accw, blockIdx.x == 0, nsl * gridDim.x)) return;
+            if (have) {   // bind_21 on a row of one pair: [p0 + t (p1 - p0), row_pad]
+                const Fr t = ts;
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if (q < g.n_in) { p0[q] = fr_add(p0[q], fr_mul(t, fr_sub(p1[q], p0[q]))); p1[q] = a.row_pad.v[g.in[q]]; }
+            }
+        }
+        thin = false;
+        // bind_into_dense: the last fold above left the row's value in p0; absent cells are row_pad, absent rows col_pad
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (q < g.n_in) xch[q][i] = have ? p0[q] : (r < a.nrows ? a.row_pad.v[g.in[q]] : a.col_pad.v[g.in[q]]);
+        __syncthreads();
+        np = (a.n_elems < 256 ? a.n_elems : 256u) >> 1;
+        if (i < np) {
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                if (q < g.n_in) { p0[q] = xch[q][2 * i]; p1[q] = xch[q][2 * i + 1]; }
+        }
+        __syncthreads();
+    } else {
+        np = (a.n_elems < 256 ? a.n_elems : 256u) >> 1;
+        if (i < np) {
+            const uint64_t gi = (uint64_t)slice * np + i;
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                if (q < g.n_in) { p0[q] = fr_load(cols.p[g.in[q]] + 2 * gi); p1[q] = fr_load(cols.p[g.in[q]] + 2 * gi + 1); }
+        }
+    }
+    // ------------------------------------------------------------------ dense phase: thread = pair
+    uint32_t my_slice = slice;   // 0 after the slices have merged
+    bool merged = false;
+    for (int dr = 0; dr < a.n_dense; dr++, round++) {
+        STAGE_STAMP(0);
+        Fr acc = fr_zero();
+        if (i < np) acc = fr_mul(stage_eval(g, p0, p1, gp, h), fr_load(a.eq[dr] + (uint64_t)my_slice * np + i));
+        if (!exchange(acc, fr_zero(), false, (merged || nsl == 1) ? gridDim.x : nsl * gridDim.x)) return;
         const Fr t = ts;
         if (i < np) {
 #pragma unroll
@@ -492,23 +679,61 @@ __global__ void __launch_bounds__(256) k_tail_rounds(SegPlan sp, ColPtrs cols, c
                 if (q < g.n_in) xch[q][i] = fr_add(p0[q], fr_mul(t, fr_sub(p1[q], p0[q])));
         }
         __syncthreads();
-        np >>= 1;
-        if (i < np) {
+        if (np > 1) {
+            np >>= 1;
+            if (i < np) {
 #pragma unroll
-            for (int q = 0; q < 6; q++)
-                if (q < g.n_in) { p0[q] = xch[q][2 * i]; p1[q] = xch[q][2 * i + 1]; }
+                for (int q = 0; q < 6; q++)
+                    if (q < g.n_in) { p0[q] = xch[q][2 * i]; p1[q] = xch[q][2 * i + 1]; }
+            }
+            __syncthreads();
+        } else if (dr + 1 < a.n_dense) {
+            // one element per slice left: hand it to slice 0 (device memory, release / acquire around the arrival counter)
+            Fr* xb = a.d_xbuf + (size_t)blockIdx.x * 6 * STAGE_MAX_SLICES;
+            if (i < (uint32_t)g.n_in) {
+                coh_store_dev(xb + (size_t)i * STAGE_MAX_SLICES + slice, xch[i][0]);
+            }
+            coh_drain();
+            __syncthreads();
+            if (i == 0) __hip_atomic_fetch_add(a.d_merge + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (slice != 0) return;
+            if (i == 0) {
+                int good = 0;
+                const uint64_t t_begin = wall_clock64();
+                for (uint32_t it = 0;; it++) {
+                    if ((it & 1023u) == 1023u && wall_clock64() - t_begin > 4 * a.timeout_ticks) break;
+                    if (__hip_atomic_load(a.d_merge + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nsl) { good = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!good) __hip_atomic_store(a.h_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = good;
+            }
+            __syncthreads();
+            if (!ok) return;
+            my_slice = 0;
+            merged = true;
+            np = nsl >> 1;
+            if (i < np) {
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if (q < g.n_in) {
+                        // handed-over bytes: system-coherent loads (another CU wrote them)
+                        const Fr* src = xb + (size_t)q * STAGE_MAX_SLICES + 2 * i;
+                        p0[q] = coh_load_dev(src);
+                        p1[q] = coh_load_dev(src + 1);
+                    }
+            }
+            __syncthreads();
         }
     }
-    // finals: the single element left of every input column of this segment
+    // finals: the single element left of every input column of this segment (the blocks that ran the last round hold it)
     if (h == 0) {
         if (i < (uint32_t)g.n_in) {
-            const Fr v = xch[i][0];
-#pragma unroll
-            for (int l = 0; l < 8; l++) __hip_atomic_store(&a.h_finals[g.in[i]].l[l], v.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            coh_store_sys(a.h_finals + g.in[i], xch[i][0]);
         }
-        __threadfence_system();
+        coh_drain();
         __syncthreads();
-        if (i == 0) __hip_atomic_store(a.h_fin_seq + sgi, a.ticket0 + (uint32_t)a.nrounds, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (i == 0) __hip_atomic_store(a.h_fin_seq + sgi, a.ticket0 + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -750,9 +975,6 @@ __global__ void __launch_bounds__(SC_THREADS) k_prefix_sums_levels(const Fr* __r
 
 // VecVec fold: out row = pad2(len/2) cells, cell p < len/2 = p0 + t (p1 - p0), the extra cell = row pad
 // (bind_21, vecvec.rs:420-441); blockIdx.y = column
-struct PadCols {
-    Fr v[16];
-};
 __global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut out, const uint32_t* __restrict__ off_in,
                                                          const uint32_t* __restrict__ off_out, uint32_t nrows, Fr t,
                                                          PadCols pad, const Fr* __restrict__ d_t, int ncols) {
@@ -994,18 +1216,16 @@ static int32_t gather_finals(const Fr* const* cur, int k, hipStream_t s, std::ve
     return GM_OK;
 }
 
-// pinned staging of k_tail_rounds: one per host thread, kept for the life of the process
+// pinned staging of k_stage: one per host thread, kept for the life of the process
 struct TailStage {
     char* base = nullptr;
-    Fr* part() const { return reinterpret_cast<Fr*>(base); }                          // 64 partial sums
-    Fr* finals() const { return reinterpret_cast<Fr*>(base) + 64; }                   // GM_MAX_COLS finals
-    Fr* t() const { return reinterpret_cast<Fr*>(base) + 64 + GM_MAX_COLS; }          // 4 challenge slots
-    uint32_t* seq() const { return reinterpret_cast<uint32_t*>(t() + 4); }            // 64 words
-    uint32_t* fin_seq() const { return seq() + 64; }                                  // GM_MAX_SEGS words
-    uint32_t* ticket() const { return fin_seq() + GM_MAX_SEGS; }
-    uint32_t* status() const { return ticket() + 16; }
+    uint32_t* rep() const { return reinterpret_cast<uint32_t*>(base); }            // 2 report slots of 36 words (3 elements x 3 chunks)
+    uint32_t* tkt() const { return rep() + 128; }                                  // 2 challenge slots of 12 words (3 chunks)
+    Fr* finals() const { return reinterpret_cast<Fr*>(base + 1024); }              // GM_MAX_COLS finals
+    uint32_t* fin_seq() const { return reinterpret_cast<uint32_t*>(finals() + GM_MAX_COLS); }   // GM_MAX_SEGS words
+    uint32_t* status() const { return fin_seq() + GM_MAX_SEGS; }
     uint32_t counter = 0;
-    static constexpr size_t BYTES = (64 + GM_MAX_COLS + 4) * sizeof(Fr) + (64 + GM_MAX_SEGS + 32) * 4;
+    static constexpr size_t BYTES = 1024 + GM_MAX_COLS * sizeof(Fr) + (GM_MAX_SEGS + 32) * 4;
 };
 static int32_t tail_stage(TailStage** out) {
     static thread_local TailStage st;
@@ -1016,7 +1236,176 @@ static int32_t tail_stage(TailStage** out) {
     *out = &st;
     return GM_OK;
 }
-static constexpr uint32_t TAIL_MAX_PAIRS = 256;
+
+static bool stage_enabled() {
+    static const bool v = [] { const char* e = getenv("GM_SC_NO_TAIL"); return !(e && e[0] == '1'); }();
+    return v;
+}
+static bool spin_for(volatile uint32_t* slot, uint32_t want) {
+    for (int spin = 0; spin < 400000; spin++) {
+        if (*slot == want) return true;
+        __builtin_ia32_pause();
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::steady_clock::now() - t0 < wait_timeout_host() + std::chrono::milliseconds(200))
+        for (int spin = 0; spin < 10000; spin++) {
+            if (*slot == want) return true;
+            __builtin_ia32_pause();
+        }
+    return false;
+}
+
+// One launch of k_stage seen from the host.  A VecVec object that enters its thin rounds creates it; the dense object it hands
+// over to (bind_into_dense) keeps using the same launch.
+struct StageRun {
+    TailStage* st = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t ticket0 = 0;
+    int n_thin = 0, n_dense = 0, nseg = 0;
+    int published = 0;                    // rounds whose challenge the host has published
+    uint32_t gx = 0, nsl = 1;
+    int merge_after = 0;                  // dense rounds 0..merge_after report from every slice, later ones from slice 0 only
+    DevBuf xbuf, dpart, state, dbg;
+    static bool debug() {
+        static const bool v = [] { const char* e = getenv("GM_STAGE_DEBUG"); return e && e[0] == '1'; }();
+        return v;
+    }
+    void dump_debug() {
+        if (!dbg.p) return;
+        std::vector<uint64_t> h(2 * 32 * 8);
+        if (hipMemcpy(h.data(), dbg.p, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+        fprintf(stderr, "[k_stage %ux%u thin %d dense %d] per round, us since the round's start: block 0 | block 1\n", gx, nsl, n_thin, n_dense);
+        for (int r = 0; r < total(); r++) {
+            fprintf(stderr, "  r%02d", r);
+            for (int b = 0; b < 2; b++) {
+                const uint64_t* e = &h[((size_t)b * 32 + r) * 8];
+                const uint64_t nxt = (r + 1 < total()) ? h[((size_t)b * 32 + r + 1) * 8] : e[5];
+                fprintf(stderr, "  eval %5.1f red %5.1f pub %5.1f last %5.1f wait %5.1f | next-start %5.1f", (e[1] - e[0]) / 100.0,
+                        (e[2] - e[1]) / 100.0, (e[3] - e[2]) / 100.0, (e[4] - e[3]) / 100.0, (e[5] - e[4]) / 100.0, (nxt - e[0]) / 100.0);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+    int total() const { return n_thin + n_dense; }
+    // geometry for `n_elems` dense elements; false = does not fit one launch
+    static bool fits(int nseg_, uint64_t n_elems, int n_thin_, int n_dense_) {
+        const uint64_t nsl_ = n_elems <= 256 ? 1 : n_elems / 256;
+        return nseg_ >= 1 && nseg_ <= GM_MAX_SEGS && n_elems >= 2 && nsl_ <= STAGE_MAX_SLICES && 2ull * nseg_ * nsl_ <= STAGE_MAX_BLOCKS &&
+               n_thin_ <= 12 && n_dense_ >= 1 && n_dense_ <= STAGE_MAX_ROUNDS;
+    }
+    // a: geometry, data pointers, eq pointers and pads filled by the caller
+    int32_t launch(const SegPlan& sp, const ColPtrs& cp, const Fr* d_gamma, StageArgs a, hipStream_t s) {
+        int32_t rc = tail_stage(&st);
+        if (rc) return rc;
+        stream = s;
+        n_thin = a.n_thin; n_dense = a.n_dense; nseg = sp.nseg;
+        gx = 2u * (uint32_t)sp.nseg;
+        nsl = a.n_elems <= 256 ? 1 : a.n_elems / 256;
+        const uint32_t np0 = (a.n_elems < 256 ? a.n_elems : 256u) >> 1;
+        merge_after = 0;
+        while ((1u << merge_after) < np0) merge_after++;
+        // tickets are exact-match sequence numbers, unique per host thread: ticket0 + r for round r; ticket0 + 0x4000 releases
+        // every wait of the launch (abort).  Launches are spaced 0x8000 apart.
+        st->counter += 0x8000u;
+        if (st->counter == 0 || st->counter > 0xffff0000u) st->counter = 0x8000u;
+        ticket0 = st->counter;
+        if (nsl > 1) {
+            rc = xbuf.alloc((size_t)gx * 6 * STAGE_MAX_SLICES * sizeof(Fr));
+            if (rc) return rc;
+        }
+        rc = dpart.alloc((size_t)2 * gx * nsl * sizeof(Fr));
+        if (rc) return rc;
+        // small device state, zeroed by ONE fill: [0, 128) relay, [128, 256) one arrival counter per round, [256, ..) one merge
+        // counter per blockIdx.x
+        rc = state.alloc(256 + (size_t)gx * 4);
+        if (rc) return rc;
+        GM_HIP(hipMemsetAsync(state.p, 0, 256 + (size_t)gx * 4, s));
+        a.h_rep = st->rep(); a.h_finals = st->finals(); a.h_fin_seq = st->fin_seq();
+        a.h_tkt = st->tkt(); a.h_status = st->status();
+        a.d_relay = reinterpret_cast<uint32_t*>(state.p);
+        a.d_round_cnt = reinterpret_cast<uint32_t*>(state.p) + 32;
+        a.d_merge = reinterpret_cast<uint32_t*>(state.p) + 64;
+        a.d_part = dpart.fr();
+        a.d_xbuf = xbuf.fr();
+        if (debug()) {
+            rc = dbg.alloc(2 * 32 * 8 * 8);
+            if (rc) return rc;
+            GM_HIP(hipMemsetAsync(dbg.p, 0, 2 * 32 * 8 * 8, s));
+            a.d_dbg = reinterpret_cast<uint64_t*>(dbg.p);
+        }
+        a.ticket0 = ticket0;
+        a.timeout_ticks = wait_timeout_ticks();
+        // the staging outlives this launch (one per host thread): a timeout flagged by an earlier launch must not fail this one
+        *reinterpret_cast<volatile uint32_t*>(st->status()) = 0;
+        hipLaunchKernelGGL(k_stage, dim3(gx, nsl), dim3(256), 0, s, sp, cp, d_gamma, a);
+        GM_LAUNCH_CHECK();
+        published = 0;
+        return GM_OK;
+    }
+    // round r of the launch: wait for the reporting blocks and add their partials up: s[h] = sum over the (segment, h) blocks,
+    // w = the tail weight (thin rounds)
+    // one field element from three self-validating chunks; false while any chunk still carries another sequence number
+    static bool read_chunks(const volatile uint32_t* p, uint32_t want, Fr* out) {
+        if (p[3] != want || p[7] != want || p[11] != want) return false;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        out->l[0] = p[0]; out->l[1] = p[1]; out->l[2] = p[2]; out->l[3] = p[4]; out->l[4] = p[5]; out->l[5] = p[6]; out->l[6] = p[8]; out->l[7] = p[9];
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return p[3] == want && p[7] == want && p[11] == want;
+    }
+    int32_t sums(int r, Fr* s1, Fr* s2, Fr* w) {
+        const uint32_t want = ticket0 + (uint32_t)r;
+        const volatile uint32_t* rep = st->rep() + 36 * (r & 1);
+        Fr v[3];
+        auto all = [&] { return read_chunks(rep, want, &v[0]) && read_chunks(rep + 12, want, &v[1]) && read_chunks(rep + 24, want, &v[2]); };
+        bool seen = false;
+        for (int spin = 0; spin < 400000 && !seen; spin++) {
+            seen = all();
+            if (!seen) __builtin_ia32_pause();
+        }
+        if (!seen) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!seen && std::chrono::steady_clock::now() - t0 < wait_timeout_host() + std::chrono::milliseconds(200))
+                for (int spin = 0; spin < 10000 && !seen; spin++) seen = all();
+        }
+        if (*reinterpret_cast<volatile uint32_t*>(st->status())) {
+            *reinterpret_cast<volatile uint32_t*>(st->status()) = 0;
+            return set_err(GM_ERR_STATE, "the stage kernel timed out waiting for a challenge (gm_set_wait_timeout_ms)");
+        }
+        if (!seen) return set_err(GM_ERR_STATE, "stage round result did not arrive in time (gm_set_wait_timeout_ms)");
+        *s1 = v[0];
+        *s2 = v[1];
+        if (w) *w = v[2];
+        return GM_OK;
+    }
+    static void write_chunks(volatile uint32_t* p, const Fr& t, uint32_t tag) {
+        // each chunk is one aligned 16-byte store (the device validates every chunk on its own)
+        alignas(16) uint32_t c[12] = {t.l[0], t.l[1], t.l[2], tag, t.l[3], t.l[4], t.l[5], tag, t.l[6], t.l[7], 0u, tag};
+        for (int j = 0; j < 3; j++) {
+            const __m128i vv = _mm_load_si128(reinterpret_cast<const __m128i*>(c + 4 * j));
+            _mm_store_si128(reinterpret_cast<__m128i*>(const_cast<uint32_t*>(p) + 4 * j), vv);
+        }
+    }
+    void publish(int r, const Fr& t) {
+        write_chunks(st->tkt() + 12 * (r & 1), t, ticket0 + (uint32_t)r);
+        published = r + 1;
+    }
+    int32_t finals(int ncols, std::vector<Fr>* out) {
+        const uint32_t want = ticket0 + (uint32_t)total();
+        for (int sg = 0; sg < nseg; sg++)
+            if (!spin_for(st->fin_seq() + sg, want)) return set_err(GM_ERR_STATE, "stage final evaluations did not arrive in time (gm_set_wait_timeout_ms)");
+        std::atomic_thread_fence(std::memory_order_acquire);
+        out->assign(st->finals(), st->finals() + ncols);
+        if (debug()) { (void)hipStreamSynchronize(stream); dump_debug(); }
+        return GM_OK;
+    }
+    ~StageRun() {
+        if (st && published < total()) {   // never leave waiting blocks behind: the release tag lets every wait of this launch through
+            write_chunks(st->tkt(), fr_zero(), ticket0 + 0x4000u);
+            write_chunks(st->tkt() + 12, fr_zero(), ticket0 + 0x4000u);
+            (void)hipStreamSynchronize(stream);
+        }
+    }
+};
 
 // grid for a round: x over pairs (grid-stride beyond the cap), y = sub-units in split mode
 static uint64_t sc_split_max_pairs() {
@@ -1540,40 +1929,27 @@ struct ScDenseDeg2 : gm_sc {
         prof_small_round(64.0 * cols.k * (double)npairs);
         return GM_OK;
     }
-    // ---- persistent tail (see k_tail_rounds): rounds [tail_r0, num_vars) run inside one launch
+    // ---- persistent stage (see k_stage): rounds [tail_r0, num_vars) run inside one launch
     bool tail_active = false;
-    uint32_t tail_r0 = 0, tail_ticket0 = 0;
-    TailStage* tail = nullptr;
-    static bool tail_enabled() {
-        static const bool v = [] { const char* e = getenv("GM_SC_NO_TAIL"); return !(e && e[0] == '1'); }();
-        return v;
+    uint32_t tail_r0 = 0;
+    std::shared_ptr<StageRun> stage;
+    int stage_round() const { return stage->n_thin + (int)(round_idx - tail_r0); }
+    bool stage_fits(uint32_t r0, uint64_t npairs0) const {
+        return StageRun::fits(sp.nseg, 2 * npairs0, 0, (int)(num_vars - r0));
     }
     // cp: the columns as they are at round r0 (npairs0 pairs); everything before it in the stream has been enqueued
     int32_t launch_tail(const ColPtrs& cp, uint32_t r0, uint64_t npairs0) {
-        int32_t rc = tail_stage(&tail);
-        if (rc) return rc;
-        TailArgs a;
+        StageArgs a;
         memset(&a, 0, sizeof(a));
         const int nr = (int)(num_vars - r0);
-        if (nr < 1 || nr > 10 || (1ull << (nr - 1)) != npairs0) return set_err(GM_ERR_STATE, "tail rounds: inconsistent shape");
+        if (nr < 1 || nr > STAGE_MAX_ROUNDS || (1ull << (nr - 1)) != npairs0) return set_err(GM_ERR_STATE, "stage rounds: inconsistent shape");
         const uint64_t g0 = glob_off >> (r0 - round_idx);   // glob_off at round r0
         for (int q = 0; q < nr; q++) a.eq[q] = eq_level(num_vars - 1 - (r0 + q)) + (g0 >> (q + 1));
-        if (tail->counter > 0x7fff0000u) {   // tickets compare as signed differences: restart well before the wrap
-            tail->counter = 0;               // (no launch of this thread is waiting: objects run one after the other)
-            *reinterpret_cast<volatile uint32_t*>(tail->ticket()) = 0;
-        }
-        tail->counter += (uint32_t)nr + 2;
-        tail_ticket0 = tail->counter - (uint32_t)nr - 1;
-        a.h_part = tail->part(); a.h_seq = tail->seq(); a.h_finals = tail->finals(); a.h_fin_seq = tail->fin_seq();
-        a.h_t = tail->t(); a.h_ticket = tail->ticket(); a.h_status = tail->status();
-        a.d_relay = reinterpret_cast<uint32_t*>(static_cast<char*>(rs.counter.p) + 128);
-        a.ticket0 = tail_ticket0; a.nrounds = nr; a.npairs0 = (uint32_t)npairs0;
-        a.timeout_ticks = wait_timeout_ticks();
-        // the stage outlives this object (one per host thread): a timeout flagged by an earlier launch must not fail this one
-        *reinterpret_cast<volatile uint32_t*>(tail->status()) = 0;
-        GM_HIP(hipMemsetAsync(a.d_relay, 0, 96, stream));
-        hipLaunchKernelGGL(k_tail_rounds, dim3(2 * sp.nseg), dim3(256), 0, stream, sp, cp, d_gamma.fr(), a);
-        GM_LAUNCH_CHECK();
+        a.n_elems = (uint32_t)(2 * npairs0);
+        a.n_dense = nr;
+        stage.reset(new StageRun());
+        int32_t rc = stage->launch(sp, cp, d_gamma.fr(), a, stream);
+        if (rc) return rc;
         for (int q = 0; q < nr; q++) {   // rounds and folds that happen inside the launch
             prof_small_round(64.0 * cols.k * (double)(npairs0 >> q));
             prof_fold(96.0 * cols.k * (double)(npairs0 >> q));
@@ -1582,47 +1958,20 @@ struct ScDenseDeg2 : gm_sc {
         tail_r0 = r0;
         return GM_OK;
     }
-    static bool spin_for(volatile uint32_t* slot, uint32_t want) {
-        for (int spin = 0; spin < 400000; spin++) {
-            if (*slot == want) return true;
-            __builtin_ia32_pause();
-        }
-        const auto t0 = std::chrono::steady_clock::now();
-        while (std::chrono::steady_clock::now() - t0 < wait_timeout_host() + std::chrono::milliseconds(200))
-            for (int spin = 0; spin < 10000; spin++) {
-                if (*slot == want) return true;
-                __builtin_ia32_pause();
-            }
-        return false;
+    // the dense stage of a VecVec object whose k_stage launch is already running (bind_into_dense inside the kernel)
+    void adopt_stage(const std::shared_ptr<StageRun>& run) {
+        stage = run;
+        tail_active = true;
+        tail_r0 = 0;
+        k_enq = num_vars;
     }
-    int32_t tail_round_sums(Fr* s1, Fr* s2) {
-        const uint32_t want = tail_ticket0 + (round_idx - tail_r0);
-        const int ny = 2 * sp.nseg;
-        for (int y = 0; y < ny; y++)
-            if (!spin_for(tail->seq() + y, want)) return set_err(GM_ERR_STATE, "tail round result did not arrive in time (gm_set_wait_timeout_ms)");
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (*reinterpret_cast<volatile uint32_t*>(tail->status())) {
-            *reinterpret_cast<volatile uint32_t*>(tail->status()) = 0;
-            return set_err(GM_ERR_STATE, "the tail kernel timed out waiting for a challenge (gm_set_wait_timeout_ms)");
-        }
-        *s1 = fr_zero(); *s2 = fr_zero();
-        for (int y = 0; y < ny; y++) {
-            const Fr v = tail->part()[y];
-            if (y & 1) *s2 = fr_add(*s2, v); else *s1 = fr_add(*s1, v);
-        }
-        return GM_OK;
-    }
-    void tail_publish(const Fr& t) {
-        const uint32_t r = round_idx - tail_r0;
-        tail->t()[r & 3] = t;
-        std::atomic_thread_fence(std::memory_order_release);
-        *reinterpret_cast<volatile uint32_t*>(tail->ticket()) = tail_ticket0 + r;
-    }
+    int32_t tail_round_sums(Fr* s1, Fr* s2) { return stage->sums(stage_round(), s1, s2, nullptr); }
+    void tail_publish(const Fr& t) { stage->publish(stage_round(), t); }
 
     int32_t unipoly_pipelined(std::vector<Fr>* coeffs, uint64_t npairs, const Fr* eq_cur, const ColPtrs& cp) {
         const uint32_t r = round_idx;
-        const bool tail_ok = tail_enabled() && sp.nseg <= 32 && (rs.own_pinned || pinned_exclusive());
-        if (!tail_active && tail_ok && npairs <= TAIL_MAX_PAIRS && k_enq <= r) {
+        const bool tail_ok = stage_enabled() && sp.nseg <= 32 && (rs.own_pinned || pinned_exclusive());
+        if (!tail_active && tail_ok && stage_fits(r, npairs) && k_enq <= r) {
             int32_t rc = launch_tail(cp, r, npairs);   // the object starts small: everything runs in the tail
             if (rc) return rc;
             k_enq = num_vars;
@@ -1660,7 +2009,7 @@ struct ScDenseDeg2 : gm_sc {
             prof_fold(96.0 * cols.k * (double)n_out);
             GM_LAUNCH_CHECK();
             fold_pending = true;
-            if (tail_ok && (npairs >> 1) <= TAIL_MAX_PAIRS) {   // everything after this fold runs in one launch
+            if (tail_ok && stage_fits(r + 1, npairs >> 1)) {   // everything after this fold runs in one launch
                 int32_t rc = launch_tail(cn, r + 1, npairs >> 1);
                 if (rc) return rc;
                 k_enq = num_vars;
@@ -1686,13 +2035,10 @@ struct ScDenseDeg2 : gm_sc {
         return GM_OK;
     }
     ~ScDenseDeg2() override {
-        const bool tail_waiting = tail_active && round_idx < num_vars;
-        if (fold_pending) rs.publish(round_idx, fr_zero(), fold_ticket);  // never leave a waiting kernel behind
-        if (tail_waiting) {   // a ticket past every round of this launch lets all its waits through
-            std::atomic_thread_fence(std::memory_order_release);
-            *reinterpret_cast<volatile uint32_t*>(tail->ticket()) = tail_ticket0 + (num_vars - tail_r0);
+        if (fold_pending) {   // never leave a waiting kernel behind (a gate here; the stage launch releases its own waiters)
+            rs.publish(round_idx, fr_zero(), fold_ticket);
+            (void)hipStreamSynchronize(stream);
         }
-        if (fold_pending || tail_waiting) (void)hipStreamSynchronize(stream);
     }
 
     int32_t bind(const Fr& t) override {
@@ -1739,12 +2085,7 @@ struct ScDenseDeg2 : gm_sc {
     int32_t final_evals(std::vector<Fr>* out) override {
         if (tail_active) {
             if (round_idx != num_vars) return set_err(GM_ERR_STATE, "final_evals before the last round");
-            const uint32_t want = tail_ticket0 + (num_vars - tail_r0);
-            for (int sg = 0; sg < sp.nseg; sg++)
-                if (!spin_for(tail->fin_seq() + sg, want)) return set_err(GM_ERR_STATE, "tail final evaluations did not arrive in time (gm_set_wait_timeout_ms)");
-            std::atomic_thread_fence(std::memory_order_acquire);
-            out->assign(tail->finals(), tail->finals() + cols.k);
-            return GM_OK;
+            return stage->finals(cols.k, out);
         }
         return gather_finals(cols.cur.data(), cols.k, stream, out);
     }
