@@ -482,8 +482,8 @@ struct StageArgs {
                                        // each as three self-validating chunks (see fr_chunks_store_sys)
     Fr* d_part;                        // device: 2 partial sums per block (2b: the round sum, 2b+1: the tail weight)
     uint32_t* d_round_cnt;             // device: one arrival counter per round (zeroed before the launch)
-    Fr* h_finals;                      // pinned: final evaluation of column c
-    uint32_t* h_fin_seq;               // pinned: per segment, = ticket0 + nrounds when its finals are written
+    Fr* h_finals;                      // pinned: what is left of column c after the last round, 32 slots per column
+    uint32_t* h_fin_seq;               // pinned: word [segment][slice] = ticket0 + rounds once that block's part is written
     const uint32_t* h_tkt;             // pinned: the host publishes t_r as three chunks tagged ticket0 + r at 12 (r & 1) words
     uint32_t* h_status;
     uint32_t* d_relay;                 // device: the relayed challenge of round r as three chunks at 12 (r & 1) words
@@ -556,7 +556,9 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
         __syncthreads();
         STAGE_STAMP(3);
         if (is_last && wave == 0) {
-            // the block that arrived last adds the partials up per evaluation point (one wave: nrep <= 512) and reports
+            // the block that arrived last adds the partials up per evaluation point (one wave: nrep <= 512) and reports;
+            // it also leaves the round's counter at zero for the next launch (the state buffer is never memset)
+            if (lane == 0) __hip_atomic_store(a.d_round_cnt + round, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             Fr r0 = fr_zero(), r1 = fr_zero(), rw = fr_zero();   // sums at point 1, at point 2, tail weight
             for (uint32_t b2 = lane; b2 < nrep; b2 += 64) {
                 const Fr v = coh_load_dev(a.d_part + 2 * b2);
@@ -667,6 +669,7 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
     // ------------------------------------------------------------------ dense phase: thread = pair
     uint32_t my_slice = slice;   // 0 after the slices have merged
     bool merged = false;
+    uint32_t n_left = np;        // elements this block holds after the last fold of the launch
     for (int dr = 0; dr < a.n_dense; dr++, round++) {
         STAGE_STAMP(0);
         Fr acc = fr_zero();
@@ -679,6 +682,8 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
                 if (q < g.n_in) xch[q][i] = fr_add(p0[q], fr_mul(t, fr_sub(p1[q], p0[q])));
         }
         __syncthreads();
+        n_left = np;
+        if (dr + 1 == a.n_dense) break;   // the folded elements stay in xch[q][0 .. n_left): exported below
         if (np > 1) {
             np >>= 1;
             if (i < np) {
@@ -687,7 +692,7 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
                     if (q < g.n_in) { p0[q] = xch[q][2 * i]; p1[q] = xch[q][2 * i + 1]; }
             }
             __syncthreads();
-        } else if (dr + 1 < a.n_dense) {
+        } else {
             // one element per slice left: hand it to slice 0 (device memory, release / acquire around the arrival counter)
             Fr* xb = a.d_xbuf + (size_t)blockIdx.x * 6 * STAGE_MAX_SLICES;
             if (i < (uint32_t)g.n_in) {
@@ -706,6 +711,7 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (!good) __hip_atomic_store(a.h_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else __hip_atomic_store(a.d_merge + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
                 ok = good;
             }
             __syncthreads();
@@ -726,14 +732,17 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
             __syncthreads();
         }
     }
-    // finals: the single element left of every input column of this segment (the blocks that ran the last round hold it)
+    // What is left of every input column of this segment goes to pinned host memory: the single final evaluation when the launch
+    // ran every round, or the last <= 32 elements per column when the host finishes the sumcheck itself (rounds of <= 16 pairs
+    // take the host a few microseconds each; here each costs a full round trip).  Element e of column c at h_finals[c * 32 + e].
     if (h == 0) {
-        if (i < (uint32_t)g.n_in) {
-            coh_store_sys(a.h_finals + g.in[i], xch[i][0]);
+        for (uint32_t e = i; e < n_left * (uint32_t)g.n_in; e += 256) {
+            const uint32_t q = e / n_left, j = e % n_left;
+            coh_store_sys(a.h_finals + (size_t)g.in[q] * 32 + (size_t)my_slice * n_left + j, xch[q][j]);
         }
         coh_drain();
         __syncthreads();
-        if (i == 0) __hip_atomic_store(a.h_fin_seq + sgi, a.ticket0 + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (i == 0) __hip_atomic_store(a.h_fin_seq + (size_t)sgi * STAGE_MAX_SLICES + my_slice, a.ticket0 + round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1221,11 +1230,15 @@ struct TailStage {
     char* base = nullptr;
     uint32_t* rep() const { return reinterpret_cast<uint32_t*>(base); }            // 2 report slots of 36 words (3 elements x 3 chunks)
     uint32_t* tkt() const { return rep() + 128; }                                  // 2 challenge slots of 12 words (3 chunks)
-    Fr* finals() const { return reinterpret_cast<Fr*>(base + 1024); }              // GM_MAX_COLS finals
-    uint32_t* fin_seq() const { return reinterpret_cast<uint32_t*>(finals() + GM_MAX_COLS); }   // GM_MAX_SEGS words
-    uint32_t* status() const { return fin_seq() + GM_MAX_SEGS; }
+    uint32_t* status() const { return rep() + 192; }
+    Fr* finals() const { return reinterpret_cast<Fr*>(base + 1024); }              // 32 slots per column: what the launch leaves of it
+    uint32_t* fin_seq() const { return reinterpret_cast<uint32_t*>(finals() + 32 * GM_MAX_COLS); }   // [segment][slice]
     uint32_t counter = 0;
-    static constexpr size_t BYTES = 1024 + GM_MAX_COLS * sizeof(Fr) + (GM_MAX_SEGS + 32) * 4;
+    // device state of the launches of this host thread (never memset: the kernel leaves its counters at zero, tags are unique)
+    uint32_t* d_state = nullptr;
+    bool d_state_dirty = true;
+    static constexpr size_t BYTES = 1024 + 32 * GM_MAX_COLS * sizeof(Fr) + (size_t)GM_MAX_SEGS * STAGE_MAX_SLICES * 4;
+    static constexpr size_t STATE_BYTES = 256 + 2 * GM_MAX_SEGS * 4;
 };
 static int32_t tail_stage(TailStage** out) {
     static thread_local TailStage st;
@@ -1255,17 +1268,30 @@ static bool spin_for(volatile uint32_t* slot, uint32_t want) {
     return false;
 }
 
+// The last rounds of a dense stage are a handful of pairs: a round trip through the device costs ~20 us each, the host does
+// them in a few microseconds.  How many trailing rounds the host takes: as many as fit ~600 field multiplications in total
+// (per pair: two evaluations of the layer function + the gamma combination), at most 5, and at least one round stays on the device.
+static int stage_host_rounds(const SegPlan& sp, int n_dense) {
+    static const int cap = [] { const char* e = getenv("GM_SC_HOST_ROUNDS"); return e ? atoi(e) : 5; }();
+    int mul_per_pair = 0;
+    for (int sg = 0; sg < sp.nseg; sg++) mul_per_pair += 2 * (6 + sp.seg[sg].n_out);
+    int h = 0;
+    while (h < cap && h + 1 < n_dense && mul_per_pair * ((2 << h) - 1) <= 600) h++;
+    return h;
+}
+
 // One launch of k_stage seen from the host.  A VecVec object that enters its thin rounds creates it; the dense object it hands
 // over to (bind_into_dense) keeps using the same launch.
 struct StageRun {
     TailStage* st = nullptr;
     hipStream_t stream = nullptr;
     uint32_t ticket0 = 0;
-    int n_thin = 0, n_dense = 0, nseg = 0;
+    int n_thin = 0, n_dense = 0, nseg = 0;   // n_dense: dense rounds that run on the device
+    uint32_t n_elems0 = 0;                // dense elements at the start of the dense phase
     int published = 0;                    // rounds whose challenge the host has published
     uint32_t gx = 0, nsl = 1;
     int merge_after = 0;                  // dense rounds 0..merge_after report from every slice, later ones from slice 0 only
-    DevBuf xbuf, dpart, state, dbg;
+    DevBuf xbuf, dpart, dbg;
     static bool debug() {
         static const bool v = [] { const char* e = getenv("GM_STAGE_DEBUG"); return e && e[0] == '1'; }();
         return v;
@@ -1299,6 +1325,7 @@ struct StageRun {
         if (rc) return rc;
         stream = s;
         n_thin = a.n_thin; n_dense = a.n_dense; nseg = sp.nseg;
+        n_elems0 = a.n_elems;
         gx = 2u * (uint32_t)sp.nseg;
         nsl = a.n_elems <= 256 ? 1 : a.n_elems / 256;
         const uint32_t np0 = (a.n_elems < 256 ? a.n_elems : 256u) >> 1;
@@ -1315,16 +1342,23 @@ struct StageRun {
         }
         rc = dpart.alloc((size_t)2 * gx * nsl * sizeof(Fr));
         if (rc) return rc;
-        // small device state, zeroed by ONE fill: [0, 128) relay, [128, 256) one arrival counter per round, [256, ..) one merge
-        // counter per blockIdx.x
-        rc = state.alloc(256 + (size_t)gx * 4);
-        if (rc) return rc;
-        GM_HIP(hipMemsetAsync(state.p, 0, 256 + (size_t)gx * 4, s));
+        // small device state: [0, 128) relay, [128, 256) one arrival counter per round, [256, ..) one merge counter per
+        // blockIdx.x.  It belongs to the host thread and is zeroed once: a launch leaves its counters at zero, relay tags are unique.
+        // A launch that was aborted (time-out, failing transcript) may leave counters behind: the next launch zeroes again.
+        if (!st->d_state) {
+            GM_HIP(hipMalloc((void**)&st->d_state, TailStage::STATE_BYTES));
+            st->d_state_dirty = true;
+        }
+        if (st->d_state_dirty) {
+            GM_HIP(hipMemsetAsync(st->d_state, 0, TailStage::STATE_BYTES, s));
+            st->d_state_dirty = false;
+        }
+        void* state_p = st->d_state;
         a.h_rep = st->rep(); a.h_finals = st->finals(); a.h_fin_seq = st->fin_seq();
         a.h_tkt = st->tkt(); a.h_status = st->status();
-        a.d_relay = reinterpret_cast<uint32_t*>(state.p);
-        a.d_round_cnt = reinterpret_cast<uint32_t*>(state.p) + 32;
-        a.d_merge = reinterpret_cast<uint32_t*>(state.p) + 64;
+        a.d_relay = reinterpret_cast<uint32_t*>(state_p);
+        a.d_round_cnt = reinterpret_cast<uint32_t*>(state_p) + 32;
+        a.d_merge = reinterpret_cast<uint32_t*>(state_p) + 64;
         a.d_part = dpart.fr();
         a.d_xbuf = xbuf.fr();
         if (debug()) {
@@ -1369,9 +1403,13 @@ struct StageRun {
         }
         if (*reinterpret_cast<volatile uint32_t*>(st->status())) {
             *reinterpret_cast<volatile uint32_t*>(st->status()) = 0;
+            st->d_state_dirty = true;
             return set_err(GM_ERR_STATE, "the stage kernel timed out waiting for a challenge (gm_set_wait_timeout_ms)");
         }
-        if (!seen) return set_err(GM_ERR_STATE, "stage round result did not arrive in time (gm_set_wait_timeout_ms)");
+        if (!seen) {
+            st->d_state_dirty = true;
+            return set_err(GM_ERR_STATE, "stage round result did not arrive in time (gm_set_wait_timeout_ms)");
+        }
         *s1 = v[0];
         *s2 = v[1];
         if (w) *w = v[2];
@@ -1389,17 +1427,29 @@ struct StageRun {
         write_chunks(st->tkt() + 12 * (r & 1), t, ticket0 + (uint32_t)r);
         published = r + 1;
     }
-    int32_t finals(int ncols, std::vector<Fr>* out) {
+    // elements per column the launch leaves behind (1 = the final evaluations) and the slices that hold them
+    uint32_t left_per_col() const { return n_elems0 >> n_dense; }
+    // what the launch left of every column: cols[c][0 .. left_per_col())
+    int32_t collect(int ncols, std::vector<std::vector<Fr>>* cols) {
         const uint32_t want = ticket0 + (uint32_t)total();
+        const bool merged = nsl > 1 && n_dense - 1 > merge_after;
+        const uint32_t slices = (nsl > 1 && !merged) ? nsl : 1;
         for (int sg = 0; sg < nseg; sg++)
-            if (!spin_for(st->fin_seq() + sg, want)) return set_err(GM_ERR_STATE, "stage final evaluations did not arrive in time (gm_set_wait_timeout_ms)");
+            for (uint32_t sl = 0; sl < slices; sl++)
+                if (!spin_for(st->fin_seq() + (size_t)sg * STAGE_MAX_SLICES + sl, want)) {
+                    st->d_state_dirty = true;
+                    return set_err(GM_ERR_STATE, "stage results did not arrive in time (gm_set_wait_timeout_ms)");
+                }
         std::atomic_thread_fence(std::memory_order_acquire);
-        out->assign(st->finals(), st->finals() + ncols);
+        const uint32_t n = left_per_col();
+        cols->assign(ncols, std::vector<Fr>());
+        for (int c = 0; c < ncols; c++) (*cols)[c].assign(st->finals() + (size_t)c * 32, st->finals() + (size_t)c * 32 + n);
         if (debug()) { (void)hipStreamSynchronize(stream); dump_debug(); }
         return GM_OK;
     }
     ~StageRun() {
         if (st && published < total()) {   // never leave waiting blocks behind: the release tag lets every wait of this launch through
+            st->d_state_dirty = true;
             write_chunks(st->tkt(), fr_zero(), ticket0 + 0x4000u);
             write_chunks(st->tkt() + 12, fr_zero(), ticket0 + 0x4000u);
             (void)hipStreamSynchronize(stream);
@@ -1828,7 +1878,8 @@ struct ScDenseDeg2 : gm_sc {
     std::vector<std::unique_ptr<DevBuf>> owned;
 
     Fr claim() const override { return claim_; }
-    const Fr* eq_level(uint32_t i) const { return d_eq.fr() + ((1ull << i) - 1); }
+    const Fr* eq_ext = nullptr;   // levels built by someone else (the VecVec object's row_eq_coefs scratch), packed like d_eq
+    const Fr* eq_level(uint32_t i) const { return (eq_ext ? eq_ext : d_eq.fr()) + ((1ull << i) - 1); }
 
     int32_t gather_cols() {
         const int k = cols.k;
@@ -1946,7 +1997,9 @@ struct ScDenseDeg2 : gm_sc {
         const uint64_t g0 = glob_off >> (r0 - round_idx);   // glob_off at round r0
         for (int q = 0; q < nr; q++) a.eq[q] = eq_level(num_vars - 1 - (r0 + q)) + (g0 >> (q + 1));
         a.n_elems = (uint32_t)(2 * npairs0);
-        a.n_dense = nr;
+        const int hr = stage_host_rounds(sp, nr);
+        a.n_dense = nr - hr;
+        host_r0 = r0 + (uint32_t)(nr - hr);
         stage.reset(new StageRun());
         int32_t rc = stage->launch(sp, cp, d_gamma.fr(), a, stream);
         if (rc) return rc;
@@ -1963,10 +2016,68 @@ struct ScDenseDeg2 : gm_sc {
         stage = run;
         tail_active = true;
         tail_r0 = 0;
+        host_r0 = (uint32_t)run->n_dense;
         k_enq = num_vars;
     }
-    int32_t tail_round_sums(Fr* s1, Fr* s2) { return stage->sums(stage_round(), s1, s2, nullptr); }
-    void tail_publish(const Fr& t) { stage->publish(stage_round(), t); }
+    // ---- the last rounds on the host (see stage_host_rounds): rounds [host_r0, num_vars) over the elements the launch left
+    uint32_t host_r0 = 0xffffffffu;
+    std::vector<std::vector<Fr>> hcols;
+    bool host_round() const { return tail_active && round_idx >= host_r0; }
+    int32_t host_collect() {
+        if (!hcols.empty()) return GM_OK;
+        return stage->collect(cols.k, &hcols);
+    }
+    int32_t host_round_sums(Fr* s1, Fr* s2) {
+        int32_t rc = host_collect();
+        if (rc) return rc;
+        const size_t np = hcols[0].size() / 2;
+        if (np < 1 || (np << 1) != hcols[0].size() || (size_t)1 << (point.size() - 1) != np)
+            return set_err(GM_ERR_STATE, "host rounds: %zu elements left for %zu variables", hcols[0].size(), point.size());
+        // eq(point[0 .. n-1), .): point[0] is the most significant variable (utils.rs:222-250)
+        std::vector<Fr> eq(1, fr_one()), nx;
+        for (size_t v = 0; v + 1 < point.size(); v++) {
+            nx.resize(2 * eq.size());
+            for (size_t j = 0; j < eq.size(); j++) {
+                const Fr m = fr_mul(point[v], eq[j]);
+                nx[2 * j] = fr_sub(eq[j], m);
+                nx[2 * j + 1] = m;
+            }
+            eq.swap(nx);
+        }
+        Fr in1[GM_MAX_COLS], in2[GM_MAX_COLS], o1[GM_MAX_COLS], o2[GM_MAX_COLS];
+        *s1 = fr_zero(); *s2 = fr_zero();
+        for (size_t i = 0; i < np; i++) {
+            for (int c = 0; c < cols.k; c++) {
+                in1[c] = hcols[c][2 * i + 1];
+                in2[c] = fr_sub(fr_dbl(in1[c]), hcols[c][2 * i]);
+            }
+            seg_plan_exec_host(sp, in1, o1);
+            seg_plan_exec_host(sp, in2, o2);
+            Fr a1 = o1[0], a2 = o2[0];
+            for (int o = 1; o < sp.n_outs; o++) {
+                a1 = fr_add(a1, fr_mul(gamma_pows[o], o1[o]));
+                a2 = fr_add(a2, fr_mul(gamma_pows[o], o2[o]));
+            }
+            *s1 = fr_add(*s1, fr_mul(eq[i], a1));
+            *s2 = fr_add(*s2, fr_mul(eq[i], a2));
+        }
+        return GM_OK;
+    }
+    void host_fold(const Fr& t) {
+        for (auto& col : hcols) {
+            const size_t n = col.size() / 2;
+            for (size_t i = 0; i < n; i++) col[i] = fr_add(col[2 * i], fr_mul(t, fr_sub(col[2 * i + 1], col[2 * i])));
+            col.resize(n);
+        }
+    }
+    int32_t tail_round_sums(Fr* s1, Fr* s2) {
+        if (host_round()) return host_round_sums(s1, s2);
+        return stage->sums(stage_round(), s1, s2, nullptr);
+    }
+    void tail_publish(const Fr& t) {
+        if (host_round()) host_fold(t);
+        else stage->publish(stage_round(), t);
+    }
 
     int32_t unipoly_pipelined(std::vector<Fr>* coeffs, uint64_t npairs, const Fr* eq_cur, const ColPtrs& cp) {
         const uint32_t r = round_idx;
@@ -2085,7 +2196,14 @@ struct ScDenseDeg2 : gm_sc {
     int32_t final_evals(std::vector<Fr>* out) override {
         if (tail_active) {
             if (round_idx != num_vars) return set_err(GM_ERR_STATE, "final_evals before the last round");
-            return stage->finals(cols.k, out);
+            int32_t rc = host_collect();   // one element per column is left (after the device's or the host's last fold)
+            if (rc) return rc;
+            out->resize(cols.k);
+            for (int c = 0; c < cols.k; c++) {
+                if (hcols[c].size() != 1) return set_err(GM_ERR_STATE, "final_evals: %zu elements left", hcols[c].size());
+                (*out)[c] = hcols[c][0];
+            }
+            return GM_OK;
         }
         return gather_finals(cols.cur.data(), cols.k, stream, out);
     }
@@ -2128,6 +2246,16 @@ struct ScVecVecDeg2 : gm_sc {
         if (dense2) return dense2->unipoly(coeffs);
         if (dense) return dense->unipoly(coeffs);
         if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (vecvec_eq.rs:305-307)");
+        Fr acc[4];
+        if (!stage_active && k_enq <= already_bound && cur_max_len == 2 && stage_ok()) {
+            // every row is down to one pair: this round, the rest of the sparse stage and the whole dense stage run in one launch
+            int32_t rc = launch_stage(cur.data(), off_cur, already_bound);
+            if (rc) return rc;
+        }
+        if (stage_active) {
+            int32_t rc = stage->sums((int)(already_bound - stage_r0), &acc[0], &acc[1], &acc[2]);
+            if (rc) return rc;
+        } else {
         const bool split_now = cells_bound / 2 + 1 <= SC_SPLIT_MAX_PAIRS;
         const bool piped = split_now && !sh.comm && ScDenseDeg2::pipeline_enabled() &&
                            (rs.own_pinned || pinned_exclusive() || k_enq > already_bound);
@@ -2162,11 +2290,19 @@ struct ScVecVecDeg2 : gm_sc {
             GM_LAUNCH_CHECK();
             prof_fold(96.0 * k * (double)(cells_bound / 2));
             fold_pending = true;
-            int32_t rc = launch_sparse_round(nx_cur.data(), nx_off, nx_bound, already_bound + 1);
-            if (rc) return rc;
-            k_enq = already_bound + 2;
+            const uint32_t half = cur_max_len / 2, next_max = half + (half & 1);
+            if (next_max == 2 && stage_ok()) {   // the fold leaves one pair per row: everything after it runs in one launch
+                int32_t rc = launch_stage(nx_cur.data(), nx_off, already_bound + 1);
+                if (rc) return rc;
+                stage_active = false;   // this round still reports through its own kernel; bind() switches over
+                stage_armed = true;
+                k_enq = 0x7fffffffu;
+            } else {
+                int32_t rc = launch_sparse_round(nx_cur.data(), nx_off, nx_bound, already_bound + 1);
+                if (rc) return rc;
+                k_enq = already_bound + 2;
+            }
         }
-        Fr acc[4];
         int32_t rc = rs.finish_seq(k_seq[already_bound & 63], 3, stream, acc, !fold_pending);
         if (rc) return rc;
         if (rs.ticket_word()[1]) {
@@ -2176,6 +2312,7 @@ struct ScVecVecDeg2 : gm_sc {
         if (sh.comm) {
             rc = shard_sum_fr(sh, acc, 3);
             if (rc) return rc;
+        }
         }
         const Fr* w = acc + 2;
         // pads: f(row_pad..) weighted by W, f(col_pad..) by the coefficient tail (vecvec_eq.rs:309-315, 345-371)
@@ -2201,6 +2338,50 @@ struct ScVecVecDeg2 : gm_sc {
     }
 
     uint64_t cells_bound = 0;  // upper bound of off_cur[nrows]
+    uint32_t cur_max_len = 0;  // longest stored row now (halves, re-padded to even, with every sparse bind)
+
+    // ---- persistent stage (k_stage): the thin sparse rounds + bind_into_dense + the whole dense stage in one launch
+    std::shared_ptr<StageRun> stage;
+    bool stage_active = false, stage_armed = false;
+    uint32_t stage_r0 = 0;     // already_bound of the launch's first round
+    bool stage_ok() const {
+        if (!stage_enabled() || sh.comm || !pinned_exclusive() || k > 16 || col_logsize < 1 || nrows > (1u << col_logsize)) return false;
+        for (uint32_t i = 0; i < col_logsize; i++)
+            if (fr_eq(point[i], fr_one())) return false;   // the dense stage would need the generic object (from12 divides by 1 - q)
+        return true;
+    }
+    int32_t launch_stage(const Fr* const* cols_now, const uint32_t* off, uint32_t ab0) {
+        const int n_thin = (int)(n_row_vars0 - ab0);
+        if (n_thin < 1 || !StageRun::fits(sp.nseg, 1ull << col_logsize, n_thin, (int)col_logsize))
+            return set_err(GM_ERR_STATE, "stage launch: shape does not fit (%d thin rounds, %u dense)", n_thin, col_logsize);
+        StageArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nrows = nrows;
+        a.n_elems = 1u << col_logsize;
+        a.n_thin = n_thin;
+        a.n_dense = (int)col_logsize - stage_host_rounds(sp, (int)col_logsize);   // the host finishes the last few rounds
+        a.off = off;
+        a.row_coef = d_row_coef.fr() + row_base;
+        for (int tr = 0; tr < n_thin; tr++) a.thin_eq[tr] = d_eq_seq.fr() + eq_level_off[eq_level_len.size() - 1 - (ab0 + tr)];
+        // the dense stage's eq tables are the lower levels of row_eq_coefs = eq(point[0..col_logsize]), kept in the scratch half
+        const Fr* levels = d_row_coef.fr() + ((size_t)1 << col_logsize);
+        for (int dr = 0; dr < a.n_dense; dr++) a.eq[dr] = levels + ((1ull << (col_logsize - 1 - dr)) - 1);
+        for (int i = 0; i < k; i++) { a.row_pad.v[i] = row_pad[i]; a.col_pad.v[i] = col_pad[i]; }
+        ColPtrs cp;
+        for (int i = 0; i < k; i++) cp.p[i] = cols_now[i];
+        stage.reset(new StageRun());
+        int32_t rc = stage->launch(sp, cp, d_gamma.fr(), a, stream);
+        if (rc) return rc;
+        for (int tr = 0; tr < n_thin; tr++) { prof_small_round(64.0 * k * (double)nrows); prof_fold(96.0 * k * (double)nrows); }
+        for (uint32_t dr = 0; dr < col_logsize; dr++) {
+            prof_small_round(64.0 * k * (double)(1ull << (col_logsize - 1 - dr)));
+            prof_fold(96.0 * k * (double)(1ull << (col_logsize - 1 - dr)));
+        }
+        stage_active = true;
+        stage_r0 = ab0;
+        k_enq = 0x7fffffffu;
+        return GM_OK;
+    }
 
     // ---- pre-enqueued small sparse rounds (same scheme as ScDenseDeg2's, see k_fold_gate); rounds are indexed by already_bound
     uint32_t k_enq = 0;
@@ -2255,6 +2436,35 @@ struct ScVecVecDeg2 : gm_sc {
         if (dense2) return dense2->bind(t);
         if (dense) return dense->bind(t);
         if (!has_cached) return set_err(GM_ERR_STATE, "bind before unipoly (vecvec_eq.rs:299 unwrap)");
+        if (stage_active) {   // the fold happens inside the stage kernel
+            stage->publish((int)(already_bound - stage_r0), t);
+            const Fr mult_next = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));
+            const Fr claim_next = evaluate_univar(cached, t);
+            has_cached = false;
+            if ((uint32_t)binding_var_idx > col_logsize) {   // sparse bind (vecvec_eq.rs:295-300)
+                multiplier = mult_next;
+                claim_ = claim_next;
+                row_logsize--;
+                binding_var_idx--;
+                already_bound++;
+                return GM_OK;
+            }
+            // bind_into_dense (vecvec_eq.rs:157-190): the launch goes on with the dense stage; the host side is the eq-factored object
+            std::unique_ptr<ScDenseDeg2> d(new ScDenseDeg2());
+            d->stream = stream;
+            d->sp = sp;
+            d->num_vars = col_logsize;
+            d->loc_vars = col_logsize;
+            d->gamma_pows = gamma_pows;
+            d->point.assign(point.begin(), point.begin() + col_logsize);
+            d->multiplier = mult_next;
+            d->claim_ = claim_next;
+            d->cols.k = k;
+            d->cols.cur.assign(k, nullptr);
+            d->adopt_stage(stage);
+            dense2 = std::move(d);
+            return GM_OK;
+        }
         if ((uint32_t)binding_var_idx > col_logsize) {
             // sparse bind (vecvec_eq.rs:295-300)
             if (fold_pending) {  // the fold is already in the stream: hand it the challenge
@@ -2265,6 +2475,8 @@ struct ScVecVecDeg2 : gm_sc {
                 cur_is_a = nx_to_a;
                 started = true;
                 cells_bound = nx_bound;
+                { const uint32_t half = cur_max_len / 2; cur_max_len = half + (half & 1); }
+                if (stage_armed) { stage_armed = false; stage_active = true; }   // the stage kernel is behind this fold in the stream
                 row_logsize--;
                 multiplier = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));
                 binding_var_idx--;
@@ -2295,6 +2507,7 @@ struct ScVecVecDeg2 : gm_sc {
             cur_is_a = to_a;
             started = true;
             cells_bound = new_bound;
+            { const uint32_t half = cur_max_len / 2; cur_max_len = half + (half & 1); }
             row_logsize--;
             multiplier = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));
             binding_var_idx--;
@@ -2419,12 +2632,8 @@ int32_t ScVecVecDeg2::bind_into_dense_deg2(const Fr& t) {
     if (rc) return rc;
     rc = upload_gamma(gamma_pows, &d->d_gamma, stream);
     if (rc) return rc;
-    rc = d->d_eq.alloc(((size_t)1 << col_logsize) * sizeof(Fr));
-    if (rc) return rc;
-    std::vector<Fr*> lv(col_logsize);
-    for (uint32_t i = 0; i < col_logsize; i++) lv[i] = d->d_eq.fr() + ((1ull << i) - 1);
-    rc = launch_eq_sequence(fr_one(), d->point.data(), col_logsize - 1, lv.data(), stream);
-    if (rc) return rc;
+    // eq_poly_sequence(point[0..col_logsize - 1]) = the lower levels of row_eq_coefs, already in the scratch half of d_row_coef
+    d->eq_ext = d_row_coef.fr() + ((size_t)1 << col_logsize);
     rc = d->rs.init(stream);
     if (rc) return rc;
     has_cached = false;
@@ -2515,6 +2724,7 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
     so->row_pad = polys->row_pad;
     so->col_pad = polys->col_pad;
     so->cells_bound = polys->total;
+    so->cur_max_len = polys->max_row_len + (polys->max_row_len & 1);
     so->sh = current_shard();
     so->row_base = polys->row_base;
     if (so->sh.comm) {
