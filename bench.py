@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--no-sumcheck", action="store_true")
     ap.add_argument("--cpu-sumcheck-xlog", type=int, default=20, help="CPU prover sample (config B itself by default: ~25 s)")
     ap.add_argument("--cpu-faithful-xlog", type=int, default=17, help="sample of the 'reference-faithful' CPU variant (serial round loops)")
-    ap.add_argument("--gen1-log-points", type=int, default=18, help="gen-1 gkr_msm_prove size (0 = skip)")
+    ap.add_argument("--gen1-log-points", type=int, default=20, help="gen-1 gkr_msm_prove size (0 = skip)")
     ap.add_argument("--cpu-gen1-log-points", type=int, default=12)
     ap.add_argument("--g1-log-points", type=int, default=21, help="BLS12-381 G1 MSM size (KZG commit shape; 0 = skip)")
     ap.add_argument("--cpu-g1-log-points", type=int, default=19)
@@ -441,19 +441,40 @@ def main():
         # first call: the library's device-memory pool grows by the trace (the driver hands out recycled HBM at ~40 GiB/s);
         # steady state = the second call, as for a prover that proves more than once
         try:
+            # the column commitments gkr_msm_prove writes first (gkr_msm_simple.rs:117-151): 2^7 bit columns through binary_msm
+            # (gamma = 4, the reference bench's value) + the point column; the CommitmentKey (bases, binary tables) is setup
+            lcols, gamma = 7, 4
+            col_size = 1 << (lp + lb - lcols)
+            d_cbases = harness.g1_gen_points(col_size, 0x434B)
+            d_ctables = harness.g1_prepare_bases(d_cbases, col_size, gamma)
+            hb = np.zeros((1 << lcols, 12), dtype=np.uint64)
+            hp = np.zeros(12, dtype=np.uint64)
+
+            def commit():
+                ffi.check(L.gm_gkr_msm_commit(C.c_void_p(d_pts_g.data_ptr()), C.c_void_p(d_bits.data_ptr()), lp, lb, lcols,
+                                              C.c_void_p(d_cbases.data_ptr()), C.c_void_p(d_ctables.data_ptr()), gamma, hb.ctypes.data,
+                                              hp.ctypes.data, harness.cur_stream()))
+            commit()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             harness.gkr_msm_prove(d_pts_g, d_bits, lp, lb, g_tape, msgs_cap=1 << 16)
             g_cold = time.perf_counter() - t1
             torch.cuda.synchronize()
             t1 = time.perf_counter()
+            commit()
+            torch.cuda.synchronize()
+            c_dt = time.perf_counter() - t1
+            t1 = time.perf_counter()
             g1 = harness.gkr_msm_prove(d_pts_g, d_bits, lp, lb, g_tape, msgs_cap=1 << 16)
             g_dt = time.perf_counter() - t1
-            out["gen1"] = {"workload": "gkr_msm_prove log_num_points=%d log_num_scalar_bits=%d (witness + prover)" % (lp, lb),
-                           "total_ms": round(g_dt * 1e3, 2), "first_call_ms_incl_allocation": round(g_cold * 1e3, 2),
+            out["gen1"] = {"workload": "gkr_msm_prove log_num_points=%d log_num_scalar_bits=%d: column commitments (2^%d bit columns, "
+                                       "binary_msm gamma=%d, + the point column) + witness + prover" % (lp, lb, lcols, gamma),
+                           "total_ms": round((g_dt + c_dt) * 1e3, 2), "commit_ms": round(c_dt * 1e3, 2), "gkr_ms": round(g_dt * 1e3, 2),
+                           "first_call_ms_incl_allocation": round(g_cold * 1e3, 2),
                            "witness_ms": round(g1["witness_ms"], 2), "rounds": g1["rounds"],
                            "rounds_per_sec": round(g1["rounds"] / max(g_dt - g1["witness_ms"] * 1e-3, 1e-9), 1),
-                           "points_per_sec": round((1 << lp) / g_dt, 1)}
+                           "points_per_sec": round((1 << lp) / (g_dt + c_dt), 1)}
+            del d_cbases, d_ctables
         except Exception as e:
             out["gen1"] = {"error": repr(e)[:300]}
         del d_bits

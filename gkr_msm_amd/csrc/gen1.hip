@@ -18,6 +18,8 @@ using namespace gm;
 
 extern "C" {
 struct gm_sc;
+int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, const uint64_t* const* d_cols, const uint64_t* h_point,
+                                const uint64_t* h_gamma, const uint64_t* h_claims, gm_sc** out, void* stream);
 int32_t gm_sc_dense_create(int32_t kind, const gm_fn* f, uint32_t num_vars, const uint64_t* const* d_cols,
                            const uint64_t* h_gamma, const uint64_t* h_claim, gm_sc** out, void* stream);
 int32_t gm_sc_unipoly(gm_sc* so, uint64_t* h_coeffs, uint32_t* n_coeffs);
@@ -116,16 +118,23 @@ static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_
     GM_HIP(hipEventCreate(&e0));
     GM_HIP(hipEventCreate(&e1));
     GM_HIP(hipEventRecord(e0, s));
-    // base layer + witness (trace[i] = input of layer i)
+    // base layer + witness.  trace[i] = input of layer i, kept only where the prover needs it:
+    //   * Split layers prove without polynomial data (SplitProver::round folds claims, split.rs:66-82): nothing is kept;
+    //   * the base polynomials (bit, px, py) are the 2^lb-fold expansion of the inputs: they are rebuilt from the points and bits
+    //     right before the first layer is proven (the last step of the reverse pass) instead of sitting in HBM throughout;
+    //   * every entry is released as soon as its layer is proven.
+    // At log_num_points = 20, 2^8 bits this is 96 GiB of trace at its peak instead of 160 GiB (and a 26 GiB workspace
+    // instead of 48): BASELINE.json configs[2] fits one MI355X with room to spare.
     std::vector<Cols> trace(layers.size());
     Cols cur;
     TRY(alloc_cols(3, n0, &cur));
     hipLaunchKernelGGL(k_gen1_base, dim3(ceil_div(n0, 256)), dim3(256), 0, s, reinterpret_cast<const Fr*>(d_points_xy),
                        d_scalar_bits, lb, n0, cur.c[0]->fr(), cur.c[1]->fr(), cur.c[2]->fr());
     GM_LAUNCH_CHECK();
+    size_t arena_need = 0;
     for (size_t li = 0; li < layers.size(); li++) {
         const L1& L = layers[li];
-        trace[li] = cur;
+        if (L.is_map && li > 0) trace[li] = cur;
         GmFn g;
         SegPlan sp;
         Cols nxt;
@@ -138,6 +147,9 @@ static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_
             TRY(alloc_cols(sp.n_outs, cur.len, &nxt));
             for (auto& c : nxt.c) co.push_back(c->fr());
             TRY(launch_dense_map(sp, ci.data(), co.data(), cur.len, s));
+            // workspace of this layer's sumcheck object: fold buffers of 1/2 and 1/4 of every column, the eq levels (2^nv), slack
+            const size_t need = (size_t)sp.n_ins * (cur.len / 2 + cur.len / 4 + 8) * sizeof(Fr) + (size_t)cur.len * sizeof(Fr);
+            if (need > arena_need) arena_need = need;
         } else {
             gm_fn idn = prim(GM_FN_ID);
             idn.count[0] = L.n_split;
@@ -147,7 +159,7 @@ static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_
             for (auto& c : nxt.c) co.push_back(c->fr());
             TRY(launch_dense_map_split(sp, ci.data(), co.data(), cur.len, 0, (uint32_t)L.n_split, s));
         }
-        cur = nxt;
+        cur = nxt;   // the previous columns go back to the pool here unless the trace holds them (stream order keeps reuse safe)
     }
     GM_HIP(hipEventRecord(e1, s));
     // output polys (3 x 2^lb): transcript + claim
@@ -199,8 +211,9 @@ static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_
     }
 
     // workspace for the sumcheck objects of one layer at a time
+    cur = Cols();   // the output columns are on the host now
     Arena arena;
-    TRY(arena.init((size_t)(n0 * 32) * 6 + ((size_t)32 << 20)));
+    TRY(arena.init(arena_need + ((size_t)64 << 20)));
     Fr* pinned = nullptr;
     GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
     memset(pinned, 0, 16 * sizeof(Fr));
@@ -240,10 +253,23 @@ static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_
         // divides by 1 - point_j; if a coordinate equals 1 (probability 2^-255) the generic object is used instead.
         bool coord_is_one = false;
         for (const Fr& c : point) coord_is_one = coord_is_one || fr_eq(c, fr_one());
+        if (li == 0) {   // the base polynomials, rebuilt from the inputs (outside the layer workspace)
+            ArenaScope none(nullptr);
+            TRY(alloc_cols(3, n0, &trace[0]));
+            hipLaunchKernelGGL(k_gen1_base, dim3(ceil_div(n0, 256)), dim3(256), 0, s, reinterpret_cast<const Fr*>(d_points_xy),
+                               d_scalar_bits, lb, n0, trace[0].c[0]->fr(), trace[0].c[1]->fr(), trace[0].c[2]->fr());
+            GM_LAUNCH_CHECK();
+        }
         std::vector<const uint64_t*> cols;
         for (int i = 0; i < sp.n_ins; i++) cols.push_back(reinterpret_cast<const uint64_t*>(trace[li].c[i]->p));
         ScHolder h;
         DevBuf eqbuf;
+        Arena big;   // the generic object (a claim coordinate equal to 1: probability 2^-255) needs a larger workspace
+        std::unique_ptr<ArenaScope> big_scope;
+        if (coord_is_one || sp.deg != 2) {
+            TRY(big.init((size_t)(sp.n_ins + 4) * ((size_t)1 << nv) * sizeof(Fr) + ((size_t)64 << 20)));
+            big_scope.reset(new ArenaScope(&big));
+        }
         if (!coord_is_one && sp.deg == 2) {
             TRY(gm_sc_dense_deg2_create(&L.f, nv, cols.data(), reinterpret_cast<const uint64_t*>(point.data()),
                                         reinterpret_cast<const uint64_t*>(&c0), reinterpret_cast<const uint64_t*>(evs.data()),
@@ -277,6 +303,9 @@ static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_
         evs.assign(fe, fe + sp.n_ins);             // final_evaluations[0..num_i]
         emit(evs.data(), evs.size());
         point = rs;
+        if (h.so) { gm_sc_destroy(h.so); h.so = nullptr; }   // before its workspace goes
+        big_scope.reset();
+        trace[li] = Cols();                        // this layer's input is not needed again: back to the pool
     }
     if (n_msgs) *n_msgs = msgs.size();
     if (h_msgs) {

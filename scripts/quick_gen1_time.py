@@ -1,4 +1,4 @@
-"""Quick timing of the gen-1 prover gkr_msm_prove at a given size (development aid)."""
+"""Quick timing of the gen-1 prover gkr_msm_prove at a given size (development aid): time, device memory in use."""
 import ctypes as C
 import os
 import sys
@@ -18,10 +18,11 @@ ffi.check(L.gm_gen_points(C.c_void_p(d_pts.data_ptr()), 1 << lp, 0x474b524d534d,
 rng = np.random.default_rng(11)
 d_bits = torch.from_numpy(rng.integers(0, 2, size=(1 << (lp + lb)), dtype=np.uint8)).cuda()
 tape = [int.from_bytes(rng.bytes(64), "little") % codec.P for _ in range(6000)]
-for it in range(2):
+for it in range(3):
     torch.cuda.synchronize()
     t = time.time()
     r = H.gkr_msm_prove(d_pts, d_bits, lp, lb, tape, msgs_cap=1 << 16)
     dt = time.time() - t
-    print("gkr_msm_prove lp=%d lb=%d: %.1f ms total, witness %.1f ms, %d rounds" % (lp, lb, dt * 1e3, r["witness_ms"], r["rounds"]),
-          flush=True)
+    free, total = torch.cuda.mem_get_info()
+    print("gkr_msm_prove 2^%d x 2^%d: %.1f ms (witness %.1f ms), %d rounds; device memory in use (pool incl.) %.1f GiB" % (
+        lp, lb, dt * 1e3, r["witness_ms"], r["rounds"], (total - free) / 2**30), flush=True)
