@@ -43,11 +43,12 @@ SEED = 0x474B524D534D      # "GKRMSM"
 
 # HBM traffic per launch of the dominant kernels at config B from the committed PMC passes (profiles/r02/*_pmc_hbm.csv:
 # (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction); None for any other shape
-PMC_TRAFFIC_MSM_B = 5741469043
-PMC_TRAFFIC_SC_B = {}      # kernel name -> bytes per launch (filled from profiles/r02/prover_pmc_hbm.csv)
+PMC_TRAFFIC_MSM_B = None
+PMC_TRAFFIC_SC_B = {}      # kernel name -> bytes per launch (profiles/r02/prover_pmc_per_launch.json, written by scripts/summarise_profiles.py)
 try:
     with open(os.path.join(ROOT, "profiles", "r02", "prover_pmc_per_launch.json")) as _f:
         PMC_TRAFFIC_SC_B = json.load(_f)
+    PMC_TRAFFIC_MSM_B = PMC_TRAFFIC_SC_B.get("k_add_level0")
 except Exception:
     pass
 

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 outputs of scripts/collect_profiles.sh (gpurun_out/<dir>) into the committed summaries under
+profiles/<round>/: kernel statistics, HBM traffic per launch (two PMC passes; FETCH_SIZE doubled per the gfx950 note in
+MI355X_MICROARCH.md) and the per-launch traffic table bench.py reads for `sumcheck.roofline.traffic`.
+
+usage: summarise_profiles.py gpurun_out/r02_prof profiles/r02"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(src, pattern))
+    return f[0] if f else None
+
+
+def key(n):
+    return n.split("(")[0].replace("void ", "").replace("gm::", "")
+
+
+def pmc(path, name):
+    acc = collections.defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == name:
+                acc[key(row["Kernel_Name"])].append(float(row["Counter_Value"]) * 1024)
+    return acc
+
+
+def durations(path):
+    acc = collections.defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            acc[key(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e9)
+    return acc
+
+
+for tag in ("bench", "msm", "prover"):
+    ks = one("%s_kt/*/*kernel_stats.csv" % tag)
+    if ks:
+        shutil.copy(ks, os.path.join(dst, "%s_kernel_stats.csv" % ("msm_only" if tag == "msm" else tag)))
+for f in ("bench_profiled_run.json", "msm_only_profiled_run.json"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+
+per_launch = {}
+for tag in ("msm", "prover"):
+    ff, wf, kt = one("%s_FETCH_SIZE/*/*counter_collection.csv" % tag), one("%s_WRITE_SIZE/*/*counter_collection.csv" % tag), one("%s_kt/*/*kernel_trace.csv" % tag)
+    if not (ff and wf):
+        continue
+    fetch, write = pmc(ff, "FETCH_SIZE"), pmc(wf, "WRITE_SIZE")
+    dur = durations(kt) if kt else {}
+    rows = []
+    for k in fetch:
+        fb, wb = sum(fetch[k]), sum(write.get(k, [0.0]))
+        n = len(fetch[k])
+        secs = sum(dur.get(k, [])) * (n / max(len(dur.get(k, [])), 1)) if dur.get(k) else 0.0
+        rows.append((2 * fb + wb, k, n, fb / n, wb / n, (fb + wb) / n, (2 * fb + wb) / n, secs))
+    with open(os.path.join(dst, "%s_pmc_hbm.csv" % ("msm_bench" if tag == "msm" else "prover")), "w") as out:
+        out.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes per launch = counter (KB) * 1024, mean over the launches\n")
+        out.write("# of that kernel; hbm_bytes_fetch_x2 applies the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads; gathers are\n")
+        out.write("# uncalibrated, so the raw sum is listed too).  avg_GB_per_s = corrected bytes / kernel time of a --kernel-trace run of the same command.\n")
+        out.write("kernel,launches,FETCH_SIZE_bytes_per_launch,WRITE_SIZE_bytes_per_launch,hbm_bytes_raw_per_launch,hbm_bytes_fetch_x2_per_launch,avg_GB_per_s\n")
+        for tot, k, n, f1, w1, raw, cor, secs in sorted(rows, reverse=True):
+            if tot < 1e7:
+                continue
+            out.write("%s,%d,%d,%d,%d,%d,%s\n" % (k, n, f1, w1, raw, cor, ("%.0f" % (tot / secs / 1e9)) if secs > 0 else ""))
+            per_launch[k] = int(cor)
+
+# kernel names as bench.py prints them (k_round_deg2_lean<PROJ_L1,vecvec> ...) from the template arguments rocprof shows
+PRIM = {1: "AFF_L1", 2: "AFF_L2", 3: "AFF_L3", 4: "PROJ_L1", 5: "PROJ_L2", 6: "PROJ_L3", 10: "PT_BIT_CHOICE", 100: "AFF_L1+BITCHECK",
+        11: "ADD_INVERSES", 12: "LOGUP_LAYER"}
+table = {}
+for k, v in per_launch.items():
+    if k.startswith("k_round_deg2_lean<"):
+        a, b = k[len("k_round_deg2_lean<"):-1].split(",")
+        # only the LARGE launches are what bench.py times; the PMC mean is over all launches of the kernel, which are the same set
+        table["k_round_deg2_lean<%s,%s>" % (PRIM.get(int(a), a), "vecvec" if b.strip() == "true" else "dense")] = v
+    elif k == "k_add_level0":
+        table["k_add_level0"] = v
+with open(os.path.join(dst, "prover_pmc_per_launch.json"), "w") as f:
+    json.dump(table, f, indent=1, sort_keys=True)
+print("wrote", sorted(os.listdir(dst)))
