@@ -2221,7 +2221,9 @@ struct ScVecVecDeg2 : gm_sc {
     std::vector<std::unique_ptr<DevBuf>> bufA, bufB;
     bool cur_is_a = false, started = false;
     const uint32_t* off_cur = nullptr;
-    DevBuf off_all;  // row layouts of all sparse rounds: table l at off_all + l * (nrows + 1), table 0 = the input layout
+    DevBuf off_all;  // row layouts of all sparse rounds: table l at off_tab + l * (nrows + 1), table 0 = the input layout
+    const uint32_t* off_tab = nullptr;          // = off_all, or the shape's own table of layouts (gm_vv::off_levels)
+    std::shared_ptr<DevBuf> off_keep;
     uint32_t cap_a = 0, cap_b = 0;
     std::vector<Fr> row_pad, col_pad, gamma_pows, point;
     int binding_var_idx = 0;
@@ -2256,8 +2258,9 @@ struct ScVecVecDeg2 : gm_sc {
             int32_t rc = stage->sums((int)(already_bound - stage_r0), &acc[0], &acc[1], &acc[2]);
             if (rc) return rc;
         } else {
-        const bool split_now = cells_bound / 2 + 1 <= SC_SPLIT_MAX_PAIRS;
-        const bool piped = split_now && !sh.comm && ScDenseDeg2::pipeline_enabled() &&
+        // every sparse round (large ones too: the fold and the next round kernel are then already in the stream when the
+        // challenge arrives, ~8 us of launch latency per round) enqueues its fold behind a gate and the next round's kernel
+        const bool piped = !sh.comm && ScDenseDeg2::pipeline_enabled() &&
                            (rs.own_pinned || pinned_exclusive() || k_enq > already_bound);
         if (k_enq <= already_bound) {
             int32_t rc = launch_sparse_round(cur.data(), off_cur, cells_bound, already_bound);
@@ -2265,10 +2268,10 @@ struct ScVecVecDeg2 : gm_sc {
             k_enq = already_bound + 1;
         }
         if (piped && !fold_pending && k_enq == already_bound + 1 && (uint32_t)binding_var_idx > col_logsize &&
-            already_bound + 1 < n_off_tables && (cells_bound / 2 + nrows) / 2 + 1 <= SC_SPLIT_MAX_PAIRS && k <= 16) {
+            already_bound + 1 < n_off_tables && k <= 16) {
             // enqueue the fold of this round (behind a gate that waits for t) and the next round's kernel now
             nx_to_a = !started || !cur_is_a;
-            nx_off = reinterpret_cast<const uint32_t*>(off_all.p) + (uint64_t)(already_bound + 1) * (nrows + 1);
+            nx_off = off_tab + (uint64_t)(already_bound + 1) * (nrows + 1);
             nx_bound = cells_bound / 2 + nrows;
             ColPtrs ci;
             ColPtrsMut co;
@@ -2487,7 +2490,7 @@ struct ScVecVecDeg2 : gm_sc {
             }
             const bool to_a = !started || !cur_is_a;
             if (already_bound + 1 >= n_off_tables) return set_err(GM_ERR_STATE, "more sparse binds than row variables");
-            const uint32_t* off_next = reinterpret_cast<const uint32_t*>(off_all.p) + (uint64_t)(already_bound + 1) * (nrows + 1);
+            const uint32_t* off_next = off_tab + (uint64_t)(already_bound + 1) * (nrows + 1);
             const uint64_t new_bound = cells_bound / 2 + nrows;
             ColPtrs ci;
             ColPtrsMut co;
@@ -2746,10 +2749,18 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
     for (uint32_t i = 0; i < polys->k; i++) so->cur.push_back(polys->cols[i]->fr());
     so->off_cur = reinterpret_cast<const uint32_t*>(polys->off->p);
     so->n_off_tables = polys->row_logsize + 1;
-    rc = so->off_all.alloc((size_t)so->n_off_tables * (so->nrows + 1) * 4);
-    if (rc) return rc;
-    rc = launch_offsets_all_from_off(so->off_cur, reinterpret_cast<uint32_t*>(so->off_all.p), so->nrows, so->n_off_tables, s);
-    if (rc) return rc;
+    if (polys->off_levels && polys->off_level + polys->row_logsize <= polys->n_off_levels) {
+        // the layouts of the row_logsize sparse rounds (tables 0 .. row_logsize - 1) are in the shape's table already
+        so->off_tab = reinterpret_cast<const uint32_t*>(polys->off_levels->p) + (size_t)polys->off_level * (so->nrows + 1);
+        so->off_keep = polys->off_levels;
+        so->n_off_tables = polys->row_logsize;
+    } else {
+        rc = so->off_all.alloc((size_t)so->n_off_tables * (so->nrows + 1) * 4);
+        if (rc) return rc;
+        rc = launch_offsets_all_from_off(so->off_cur, reinterpret_cast<uint32_t*>(so->off_all.p), so->nrows, so->n_off_tables, s);
+        if (rc) return rc;
+        so->off_tab = reinterpret_cast<const uint32_t*>(so->off_all.p);
+    }
     for (uint32_t i = 0; i < polys->k; i++) {
         so->bufA.emplace_back(new DevBuf());
         so->bufB.emplace_back(new DevBuf());

@@ -192,6 +192,15 @@ static void pads_through(const SegPlan& sp, const gm_vv* in, std::vector<Fr>* rp
 
 namespace gm {
 
+// a non-owning DevBuf over part of another allocation (the holder keeps the allocation alive through off_levels)
+static std::shared_ptr<DevBuf> off_view(const std::shared_ptr<DevBuf>& base, uint32_t level, uint32_t nrows) {
+    std::shared_ptr<DevBuf> v(new DevBuf());
+    v->p = static_cast<char*>(base->p) + (size_t)level * (nrows + 1) * 4;
+    v->bytes = (size_t)(nrows + 1) * 4;
+    v->owned = false;
+    return v;
+}
+
 int32_t vv_map(const SegPlan& sp, const gm_vv* in, gm_vv** out, hipStream_t s) {
     // exec reads args[0..n_ins): extra trailing polys are ignored, as in the reference
     // (bintree level 0 maps affine l1 over the 6-poly GlueSplit output, bintree_add.rs:213-215)
@@ -201,6 +210,7 @@ int32_t vv_map(const SegPlan& sp, const gm_vv* in, gm_vv** out, hipStream_t s) {
     o->max_row_len = in->max_row_len;
     o->row_base = in->row_base; o->sharded = in->sharded;
     o->off = in->off;  // shared shape
+    o->share_levels(in, 0);
     int32_t rc = o->alloc_cols(sp.n_outs, in->total);
     if (rc) return rc;
     pads_through(sp, in, &o->row_pad, &o->col_pad);
@@ -226,17 +236,25 @@ int32_t vv_map_split(const SegPlan& sp, const gm_vv* in, uint32_t bundle, gm_vv*
     o->nrows = in->nrows; o->row_logsize = in->row_logsize - 1; o->col_logsize = in->col_logsize;
     o->max_row_len = pad2(in->max_row_len / 2);
     o->row_base = in->row_base; o->sharded = in->sharded;
-    o->off.reset(new DevBuf());
-    int32_t rc = o->off->alloc((size_t)(in->nrows + 1) * 4);
-    if (rc) return rc;
-    const uint32_t* off_in = reinterpret_cast<const uint32_t*>(in->off->p);
-    uint32_t* off_out = reinterpret_cast<uint32_t*>(o->off->p);
-    rc = launch_offsets_next(off_in, off_out, in->nrows, s);
-    if (rc) return rc;
-    // upper bound on the new total without a sync: total/2 + one pad per row; exact value read back
+    int32_t rc = GM_OK;
     uint32_t tot = 0;
-    GM_HIP(hipMemcpyAsync(&tot, off_out + in->nrows, 4, hipMemcpyDeviceToHost, s));
-    GM_HIP(hipStreamSynchronize(s));
+    if (in->off_levels && in->off_level + 1 < in->n_off_levels) {
+        // the next layout is already in the table: no launch, no read-back
+        o->share_levels(in, 1);
+        o->off = off_view(in->off_levels, o->off_level, in->nrows);
+        tot = (*in->level_totals)[o->off_level];
+    } else {
+        o->off.reset(new DevBuf());
+        rc = o->off->alloc((size_t)(in->nrows + 1) * 4);
+        if (rc) return rc;
+        const uint32_t* off_in = reinterpret_cast<const uint32_t*>(in->off->p);
+        uint32_t* off_out = reinterpret_cast<uint32_t*>(o->off->p);
+        rc = launch_offsets_next(off_in, off_out, in->nrows, s);
+        if (rc) return rc;
+        // upper bound on the new total without a sync: total/2 + one pad per row; exact value read back
+        GM_HIP(hipMemcpyAsync(&tot, off_out + in->nrows, 4, hipMemcpyDeviceToHost, s));
+        GM_HIP(hipStreamSynchronize(s));
+    }
     rc = o->alloc_cols(2 * sp.n_outs, tot);
     if (rc) return rc;
     std::vector<Fr> rp, cp;
@@ -255,8 +273,8 @@ int32_t vv_map_split(const SegPlan& sp, const gm_vv* in, uint32_t bundle, gm_vv*
     for (int i = 0; i < sp.n_ins; i++) ci.p[i] = in->cols[i]->fr();
     for (int i = 0; i < 2 * sp.n_outs; i++) co.p[i] = o->cols[i]->fr();
     if (tot) {
-        hipLaunchKernelGGL(k_vv_map_split, dim3(ceil_div(tot, 256)), dim3(256), 0, s, sp, ci, co, off_in, off_out,
-                           in->nrows, bundle, pv);
+        hipLaunchKernelGGL(k_vv_map_split, dim3(ceil_div(tot, 256)), dim3(256), 0, s, sp, ci, co,
+                           reinterpret_cast<const uint32_t*>(in->off->p), reinterpret_cast<const uint32_t*>(o->off->p), in->nrows, bundle, pv);
         GM_LAUNCH_CHECK();
     }
     *out = o.release();
@@ -368,13 +386,22 @@ int32_t gm::vv_from_msm(const gm_msm_plan* p, const uint64_t* d_points_xy, uint3
     v->nrows = p->nrows; v->row_logsize = p->x_log; v->col_logsize = y_logsize + p->d_log;
     v->row_base = p->y0 << p->d_log;
     v->sharded = partial;
-    v->off.reset(new DevBuf());
-    int32_t rc = v->off->alloc((size_t)(p->nrows + 1) * 4);
+    // the plan holds the row layouts of all x_logsize levels (k_offsets_all_levels): keep a copy with the image, so that the
+    // witness builder's splits and every layer's sumcheck object take their layouts from it
+    const size_t lvl_words = (size_t)p->nrows + 1, tab_bytes = (size_t)p->x_log * lvl_words * 4;
+    v->off_levels.reset(new DevBuf());
+    int32_t rc = v->off_levels->alloc(tab_bytes);
     if (rc) return rc;
-    GM_HIP(hipMemcpyAsync(v->off->p, p->off[0], (size_t)(p->nrows + 1) * 4, hipMemcpyDeviceToDevice, s));
-    std::vector<uint32_t> off(p->nrows + 1);
-    GM_HIP(hipMemcpyAsync(off.data(), p->off[0], (size_t)(p->nrows + 1) * 4, hipMemcpyDeviceToHost, s));
+    GM_HIP(hipMemcpyAsync(v->off_levels->p, p->off[0], tab_bytes, hipMemcpyDeviceToDevice, s));
+    v->n_off_levels = p->x_log;
+    v->off_level = 0;
+    v->off = off_view(v->off_levels, 0, p->nrows);
+    std::vector<uint32_t> tab((size_t)p->x_log * lvl_words);
+    GM_HIP(hipMemcpyAsync(tab.data(), p->off[0], tab_bytes, hipMemcpyDeviceToHost, s));
     GM_HIP(hipStreamSynchronize(s));
+    v->level_totals.reset(new std::vector<uint32_t>(p->x_log));
+    for (uint32_t l = 0; l < p->x_log; l++) (*v->level_totals)[l] = tab[(size_t)l * lvl_words + p->nrows];
+    const uint32_t* off = tab.data();
     uint32_t mx = 0;
     for (uint32_t r = 0; r < p->nrows; r++) mx = (off[r + 1] - off[r] > mx) ? off[r + 1] - off[r] : mx;
     v->max_row_len = mx;
@@ -431,6 +458,7 @@ extern "C" int32_t gm_vv_slice(const gm_vv* in, uint32_t first, uint32_t count, 
     gm_vv* v = new gm_vv();
     v->k = count; v->nrows = in->nrows; v->total = in->total; v->row_logsize = in->row_logsize;
     v->col_logsize = in->col_logsize; v->max_row_len = in->max_row_len; v->off = in->off; v->row_base = in->row_base; v->sharded = in->sharded;
+    v->share_levels(in, 0);
     for (uint32_t i = 0; i < count; i++) {
         v->cols.push_back(in->cols[first + i]);
         v->row_pad.push_back(in->row_pad[first + i]);

@@ -16,6 +16,17 @@ struct gm_vv {
     bool sharded = false;      // this handle is one rank's slice of the rows (dense conversions then produce the slice only)
     uint32_t row_base = 0;     // sharded: global index of stored row 0 (this handle holds rows row_base .. row_base + nrows)
     std::shared_ptr<gm::DevBuf> off;                // u32[nrows + 1]
+    // Every row layout this shape goes through (rows halve and are re-padded to even length with each split / sparse fold:
+    // vecvec.rs:420-441, 579-594): level l at l * (nrows + 1) words, `off` = level off_level.  Present for the bucket image
+    // (the MSM plan computes all x_logsize layouts in one launch); splits and sumcheck objects then take their layouts from
+    // here instead of recomputing them per layer.
+    std::shared_ptr<gm::DevBuf> off_levels;
+    uint32_t off_level = 0, n_off_levels = 0;
+    std::shared_ptr<std::vector<uint32_t>> level_totals;   // host copy: cells per level
+    void share_levels(const gm_vv* in, uint32_t level_shift) {
+        off_levels = in->off_levels; n_off_levels = in->n_off_levels; level_totals = in->level_totals;
+        off_level = in->off_level + level_shift;
+    }
     std::vector<std::shared_ptr<gm::DevBuf>> cols;  // k arrays of `total` elements
     std::vector<gm::Fr> row_pad, col_pad;
     int32_t alloc_cols(uint32_t k_, uint64_t total_);
