@@ -143,16 +143,22 @@ struct EqSmallArgs {
     uint32_t nlev;  // levels 1..nlev are computed here
 };
 __global__ void __launch_bounds__(1024) k_eq_small(EqSmallArgs a) {
-    if (threadIdx.x == 0) fr_store(a.level[0], a.mult);
+    // Levels of up to 1024 entries ping-pong through LDS (a level is read back right after it is written: through global memory
+    // that costs an L2 round trip per level, ~1 us of the ~1.8 us a level takes); every level is also stored to its global array.
+    __shared__ Fr buf[2][1024];
+    if (threadIdx.x == 0) { fr_store(a.level[0], a.mult); buf[0][0] = a.mult; }
     __syncthreads();
     for (uint32_t i = 1; i <= a.nlev; i++) {
         const uint32_t np = 1u << (i - 1);
         const Fr r = a.pt[i - 1];
+        const bool src_lds = np <= 1024, dst_lds = 2 * np <= 1024;
         for (uint32_t j = threadIdx.x; j < np; j += blockDim.x) {
-            const Fr w = fr_load(a.level[i - 1] + j);
+            const Fr w = src_lds ? buf[(i - 1) & 1][j] : fr_load(a.level[i - 1] + j);
             const Fr m = fr_mul(r, w);
-            fr_store(a.level[i] + 2 * j, fr_sub(w, m));
+            const Fr lo = fr_sub(w, m);
+            fr_store(a.level[i] + 2 * j, lo);
             fr_store(a.level[i] + 2 * j + 1, m);
+            if (dst_lds) { buf[i & 1][2 * j] = lo; buf[i & 1][2 * j + 1] = m; }
         }
         __syncthreads();  // same workgroup: the stores above are visible to the loads of the next level
     }

@@ -16,6 +16,7 @@
 //
 // The Fiat-Shamir transcript (merlin) stays with the caller: challenges are taken from a tape
 // the caller provides, prover messages are returned in order.
+#include <chrono>
 #include <memory>
 #include <vector>
 
@@ -203,14 +204,36 @@ struct Tape {
     }
 };
 
+// GM_PROVE_TIMING=2: where the host's wall time of the layer provers goes (development aid)
+struct LayerClock {
+    double create = 0, unipoly = 0, bind = 0, finals = 0, other = 0;
+    uint64_t layers = 0, rounds = 0;
+    static bool on() {
+        static const bool v = [] { const char* e = getenv("GM_PROVE_TIMING"); return e && e[0] == '2'; }();
+        return v;
+    }
+    static LayerClock& get() { static thread_local LayerClock c; return c; }
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void dump(const char* who) {
+        if (!on()) return;
+        fprintf(stderr, "[gm %s] %llu layers, %llu rounds: create %.1f ms, unipoly (wait for sums) %.1f ms, bind %.1f ms, finals %.1f ms\n", who,
+                (unsigned long long)layers, (unsigned long long)rounds, create / 1e3, unipoly / 1e3, bind / 1e3, finals / 1e3);
+        *this = LayerClock();
+    }
+};
+
 // GenericSumcheckProtocol::prove (sumcheck.rs:101-123)
 int32_t generic_sumcheck_prove(Tape* tr, gm_sc* so, uint32_t num_rounds, uint32_t degree, std::vector<Fr>* point,
                                std::vector<Fr>* final_evals) {
     std::vector<Fr> r;
+    const bool clk = LayerClock::on();
+    LayerClock& lc = LayerClock::get();
     for (uint32_t rd = 0; rd < num_rounds; rd++) {
         Fr coeffs[8];
         uint32_t nc = 0;
+        const double t0 = clk ? LayerClock::now() : 0;
         TRY(gm_sc_unipoly(so, reinterpret_cast<uint64_t*>(coeffs), &nc));
+        if (clk) { lc.unipoly += LayerClock::now() - t0; lc.rounds++; }
         if (nc != degree + 1) return set_err(GM_ERR_STATE, "round polynomial has %u coefficients, expected %u", nc, degree + 1);
         std::vector<Fr> msg;  // compress_coefficients: drop the linear term (sumcheck.rs:27-31)
         msg.push_back(coeffs[0]);
@@ -219,13 +242,17 @@ int32_t generic_sumcheck_prove(Tape* tr, gm_sc* so, uint32_t num_rounds, uint32_
         Fr x;
         TRY(tr->challenge(&x));
         r.push_back(x);
+        const double t1 = clk ? LayerClock::now() : 0;
         TRY(gm_sc_bind(so, reinterpret_cast<const uint64_t*>(&x)));
+        if (clk) lc.bind += LayerClock::now() - t1;
         tr->rounds++;
     }
     point->assign(r.rbegin(), r.rend());
     Fr ev[GM_MAX_COLS + 1];
     uint32_t ne = 0;
+    const double t2 = clk ? LayerClock::now() : 0;
     TRY(gm_sc_final_evals(so, reinterpret_cast<uint64_t*>(ev), &ne));
+    if (clk) lc.finals += LayerClock::now() - t2;
     final_evals->assign(ev, ev + ne);
     return GM_OK;
 }
@@ -242,9 +269,11 @@ int32_t dense_deg2_prove(Tape* tr, const gm_fn& f, uint32_t num_vars, Claims* cl
     TRY(tr->challenge(&gamma));
     ScHolder h;
     auto ptrs = adv.col_ptrs();
+    const double t0 = LayerClock::on() ? LayerClock::now() : 0;
     TRY(gm_sc_dense_deg2_create(&f, num_vars, ptrs.data(), reinterpret_cast<const uint64_t*>(claims->point.data()),
                                 reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(claims->evs.data()),
                                 &h.so, s));
+    if (LayerClock::on()) { LayerClock::get().create += LayerClock::now() - t0; LayerClock::get().layers++; }
     std::vector<Fr> pt, evs;
     TRY(generic_sumcheck_prove(tr, h.so, num_vars, 3, &pt, &evs));
     tr->write_scalars(evs);
@@ -259,9 +288,11 @@ int32_t vecvec_deg2_prove(Tape* tr, const gm_fn& f, uint32_t num_vars, Claims* c
     Fr gamma;
     TRY(tr->challenge(&gamma));
     ScHolder h;
+    const double t0 = LayerClock::on() ? LayerClock::now() : 0;
     TRY(gm_sc_vecvec_deg2_create(&f, adv.vv->v, reinterpret_cast<const uint64_t*>(claims->point.data()),
                                  reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(claims->evs.data()),
                                  &h.so, s));
+    if (LayerClock::on()) { LayerClock::get().create += LayerClock::now() - t0; LayerClock::get().layers++; }
     std::vector<Fr> pt, evs;
     TRY(generic_sumcheck_prove(tr, h.so, num_vars, 3, &pt, &evs));
     evs.pop_back();  // the eq column (vecvec_eq.rs:451)
@@ -596,7 +627,12 @@ static int32_t prove_image_part(const gm_pip_witness* w, const uint64_t* h_claim
     memcpy(c.point.data(), h_claim_point, 32 * (size_t)multirow);
     c.evs.resize(3 * (bucket + 1));
     memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
+    const double t_all = LayerClock::on() ? LayerClock::now() : 0;
     TRY(image_part_core(w, &tr, &c));
+    if (LayerClock::on()) {
+        fprintf(stderr, "[gm image part] total %.1f ms\n", (LayerClock::now() - t_all) / 1e3);
+        LayerClock::get().dump("image part");
+    }
     if (n_msgs) *n_msgs = msgs.size();
     if (h_msgs) {
         GM_REQUIRE(msgs.size() <= msgs_cap, "message buffer too small: %zu > %llu", msgs.size(), (unsigned long long)msgs_cap);

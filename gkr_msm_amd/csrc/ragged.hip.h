@@ -19,6 +19,21 @@ __device__ __forceinline__ uint32_t find_row(const uint32_t* __restrict__ off, u
     return lo;
 }
 
+// Row lookup through a coarse table: coarse[c] = row of cell c << GM_COARSE_SHIFT (clamped to the last cell), so the row of
+// cell j lies in [coarse[j >> S], coarse[(j >> S) + 1]]: a search over the rows that intersect one 2^S-cell block.
+#define GM_COARSE_SHIFT 8
+__device__ __forceinline__ uint32_t find_row_coarse(const uint32_t* __restrict__ off, uint32_t nrows, const uint32_t* __restrict__ coarse,
+                                                    uint32_t j) {
+    const uint32_t c = j >> GM_COARSE_SHIFT;
+    uint32_t lo = coarse[c], hi = coarse[c + 1] + 1;  // off[lo] <= j < off[hi]
+    if (hi > nrows) hi = nrows;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // Block-cooperative row lookup for a block whose threads own consecutive cells [j0, j0 + blockDim.x): two lanes
 // bracket the block's row range with a full binary search, every thread then searches only inside that bracket
 // (usually one or two rows).  This replaces log2(nrows) dependent global loads per thread by ~1.

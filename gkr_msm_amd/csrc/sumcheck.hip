@@ -271,6 +271,7 @@ struct VVArgs {
     uint32_t nrows;
     const Fr* row_coef;
     const Fr* eq_prefix;
+    const uint32_t* coarse;   // row of cell c << GM_COARSE_SHIFT for every c (gm_vv::coarse), or nullptr: full binary search
 };
 
 template <bool VECVEC, bool SPLIT>
@@ -829,7 +830,9 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
         Fr w;
         if (VECVEC) {
             const uint32_t cell0 = (uint32_t)(2 * i);
-            const uint32_t r = find_row(vv.off, vv.nrows, cell0);
+            // 13 dependent loads of a full binary search per pair stall the few resident waves; the coarse table brackets the
+            // row to the rows that intersect one 256-cell block (one or two for long rows)
+            const uint32_t r = vv.coarse ? find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0) : find_row(vv.off, vv.nrows, cell0);
             w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
         } else {
             w = fr_load(eq + i);
@@ -1923,7 +1926,7 @@ struct ScDenseDeg2 : gm_sc {
         for (int i = 0; i < cols.k; i++) cp.p[i] = cols.cur[i];
         const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
         const dim3 grid = round_grid(npairs, split ? 2 * sp.nseg : 1);
-        const VVArgs none{nullptr, 0, nullptr, nullptr};
+        const VVArgs none{nullptr, 0, nullptr, nullptr, nullptr};
         const int lean = (!split && cols.k <= 6) ? lean_prim_of(sp) : 0;
         // results of pre-enqueued kernels land in the pinned staging: it must be this object's alone for the duration
         if (split && !sh.comm && pipeline_enabled() && (rs.own_pinned || pinned_exclusive() || k_enq > round_idx))
@@ -1972,7 +1975,7 @@ struct ScDenseDeg2 : gm_sc {
     }
     int32_t launch_small_round(const ColPtrs& cp, const Fr* eq, uint64_t npairs, uint32_t round) {
         const dim3 grid = round_grid(npairs, 2 * sp.nseg);
-        const VVArgs none{nullptr, 0, nullptr, nullptr};
+        const VVArgs none{nullptr, 0, nullptr, nullptr, nullptr};
         const FinishCtx fc = rs.ctx();
         hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq, d_gamma.fr(), npairs, none, fc);
         GM_LAUNCH_CHECK();
@@ -2224,6 +2227,16 @@ struct ScVecVecDeg2 : gm_sc {
     DevBuf off_all;  // row layouts of all sparse rounds: table l at off_tab + l * (nrows + 1), table 0 = the input layout
     const uint32_t* off_tab = nullptr;          // = off_all, or the shape's own table of layouts (gm_vv::off_levels)
     std::shared_ptr<DevBuf> off_keep;
+    // coarse row tables of the shape's layouts (gm_vv::coarse): table of layout l at coarse_base + coarse_off[l0 + l]
+    std::shared_ptr<DevBuf> coarse_keep;
+    std::shared_ptr<std::vector<uint64_t>> coarse_off;
+    uint32_t coarse_l0 = 0;
+    const uint32_t* coarse_for(const uint32_t* off) const {
+        if (!coarse_keep || !off_tab || off < off_tab) return nullptr;
+        const uint64_t l = (uint64_t)(off - off_tab) / (nrows + 1);
+        if ((uint64_t)(off - off_tab) % (nrows + 1) != 0 || coarse_l0 + l >= coarse_off->size()) return nullptr;
+        return reinterpret_cast<const uint32_t*>(coarse_keep->p) + (*coarse_off)[coarse_l0 + l];
+    }
     uint32_t cap_a = 0, cap_b = 0;
     std::vector<Fr> row_pad, col_pad, gamma_pows, point;
     int binding_var_idx = 0;
@@ -2406,7 +2419,7 @@ struct ScVecVecDeg2 : gm_sc {
         const bool split = bound_pairs <= SC_SPLIT_MAX_PAIRS;
         const uint64_t gx = bound_pairs > nrows ? bound_pairs : nrows;  // the tail-weight loop runs over rows
         const dim3 grid = round_grid(gx, split ? 2 * sp.nseg : 1);
-        const VVArgs va{off, nrows, d_row_coef.fr() + row_base, eq_pre};
+        const VVArgs va{off, nrows, d_row_coef.fr() + row_base, eq_pre, coarse_for(off)};
         const int lean = (!split && k <= 6) ? lean_prim_of(sp) : 0;
         const FinishCtx fc = rs.ctx();
         if (lean) {
@@ -2754,6 +2767,9 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         so->off_tab = reinterpret_cast<const uint32_t*>(polys->off_levels->p) + (size_t)polys->off_level * (so->nrows + 1);
         so->off_keep = polys->off_levels;
         so->n_off_tables = polys->row_logsize;
+        so->coarse_keep = polys->coarse;
+        so->coarse_off = polys->coarse_off;
+        so->coarse_l0 = polys->off_level;
     } else {
         rc = so->off_all.alloc((size_t)so->n_off_tables * (so->nrows + 1) * 4);
         if (rc) return rc;

@@ -192,6 +192,24 @@ static void pads_through(const SegPlan& sp, const gm_vv* in, std::vector<Fr>* rp
 
 namespace gm {
 
+// coarse row tables of all levels in one launch: blockIdx.y = level; entry c = row of cell min(c << S, cells - 1)
+__global__ void __launch_bounds__(256) k_coarse_rows(const uint32_t* __restrict__ off_levels, uint32_t nrows, const uint64_t* __restrict__ tab_off,
+                                                     uint32_t* __restrict__ coarse) {
+    const uint32_t lvl = blockIdx.y;
+    const uint32_t* off = off_levels + (size_t)lvl * (nrows + 1);
+    const uint32_t cells = off[nrows];
+    const uint32_t n = (cells >> GM_COARSE_SHIFT) + 2;
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    uint32_t j = c << GM_COARSE_SHIFT;
+    uint32_t r = nrows ? nrows - 1 : 0;
+    if (cells) {
+        if (j >= cells) j = cells - 1;
+        r = find_row(off, nrows, j);
+    }
+    coarse[tab_off[lvl] + c] = r;
+}
+
 // a non-owning DevBuf over part of another allocation (the holder keeps the allocation alive through off_levels)
 static std::shared_ptr<DevBuf> off_view(const std::shared_ptr<DevBuf>& base, uint32_t level, uint32_t nrows) {
     std::shared_ptr<DevBuf> v(new DevBuf());
@@ -402,6 +420,29 @@ int32_t gm::vv_from_msm(const gm_msm_plan* p, const uint64_t* d_points_xy, uint3
     v->level_totals.reset(new std::vector<uint32_t>(p->x_log));
     for (uint32_t l = 0; l < p->x_log; l++) (*v->level_totals)[l] = tab[(size_t)l * lvl_words + p->nrows];
     const uint32_t* off = tab.data();
+    {   // coarse row tables of every level (the large VecVec round kernels bracket their row search with them)
+        v->coarse_off.reset(new std::vector<uint64_t>(p->x_log));
+        uint64_t words = 0;
+        uint32_t max_entries = 1;
+        for (uint32_t l = 0; l < p->x_log; l++) {
+            (*v->coarse_off)[l] = words;
+            const uint32_t n = ((*v->level_totals)[l] >> GM_COARSE_SHIFT) + 2;
+            words += n;
+            if (n > max_entries) max_entries = n;
+        }
+        v->coarse.reset(new DevBuf());
+        rc = v->coarse->alloc(words * 4);
+        if (rc) return rc;
+        DevBuf d_tab_off;
+        rc = d_tab_off.alloc((size_t)p->x_log * 8);
+        if (rc) return rc;
+        GM_HIP(hipMemcpyAsync(d_tab_off.p, v->coarse_off->data(), (size_t)p->x_log * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_coarse_rows, dim3(ceil_div(max_entries, 256), p->x_log), dim3(256), 0, s,
+                           reinterpret_cast<const uint32_t*>(v->off_levels->p), p->nrows, reinterpret_cast<const uint64_t*>(d_tab_off.p),
+                           reinterpret_cast<uint32_t*>(v->coarse->p));
+        GM_LAUNCH_CHECK();
+        GM_HIP(hipStreamSynchronize(s));   // d_tab_off goes out of scope
+    }
     uint32_t mx = 0;
     for (uint32_t r = 0; r < p->nrows; r++) mx = (off[r + 1] - off[r] > mx) ? off[r + 1] - off[r] : mx;
     v->max_row_len = mx;

@@ -23,8 +23,12 @@ struct gm_vv {
     std::shared_ptr<gm::DevBuf> off_levels;
     uint32_t off_level = 0, n_off_levels = 0;
     std::shared_ptr<std::vector<uint32_t>> level_totals;   // host copy: cells per level
+    // coarse row tables of every level (find_row_coarse, ragged.hip.h): level l at word coarse_off[l], (cells >> 8) + 2 entries
+    std::shared_ptr<gm::DevBuf> coarse;
+    std::shared_ptr<std::vector<uint64_t>> coarse_off;
     void share_levels(const gm_vv* in, uint32_t level_shift) {
         off_levels = in->off_levels; n_off_levels = in->n_off_levels; level_totals = in->level_totals;
+        coarse = in->coarse; coarse_off = in->coarse_off;
         off_level = in->off_level + level_shift;
     }
     std::vector<std::shared_ptr<gm::DevBuf>> cols;  // k arrays of `total` elements

@@ -1,5 +1,6 @@
 """Harness plumbing (tests / bench): torch tensors as device memory for the C ABI."""
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -365,11 +366,13 @@ class PipWitness:
         fpt = np.zeros((64, 4), dtype=np.uint64)
         fev = np.zeros((8, 4), dtype=np.uint64)
         nm, used, rounds, npt = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        t0 = time.perf_counter()
         ffi.check(self.L.gm_pip_prove_image_part(self.h, cp.ctypes.data, ce.ctypes.data, tp.ctypes.data, len(tape),
                                                  msgs.ctypes.data, msgs_cap, C.byref(nm), fpt.ctypes.data,
                                                  C.byref(npt), fev.ctypes.data, C.byref(used), C.byref(rounds)))
+        call_s = time.perf_counter() - t0   # the library call alone (the conversions below are Python big-int plumbing)
         return dict(msgs=codec.from_mont_limbs(msgs[: nm.value]), point=codec.from_mont_limbs(fpt[: npt.value]),
-                    evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value, rounds=rounds.value)
+                    evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value, rounds=rounds.value, call_s=call_s)
 
 
 def pushforward_prove(plan, d_points, y_logsize, claim_point, claim_evs, tape, msgs_cap=1 << 16):
@@ -384,13 +387,15 @@ def pushforward_prove(plan, d_points, y_logsize, claim_point, claim_evs, tape, m
     cpt, cev = np.zeros((max(x, 1), 4), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64)
     dpt, dev = np.zeros((max(d, 1), 4), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64)
     nm, used, rounds = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    t0 = time.perf_counter()
     ffi.check(L.gm_pushforward_prove(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, cp.ctypes.data, ce.ctypes.data,
                                      tp.ctypes.data, len(tape), msgs.ctypes.data, msgs_cap, C.byref(nm), g.ctypes.data,
                                      mp.ctypes.data, me.ctypes.data, cpt.ctypes.data, cev.ctypes.data, dpt.ctypes.data,
                                      dev.ctypes.data, C.byref(used), C.byref(rounds), cur_stream()))
+    call_s = time.perf_counter() - t0
     f = codec.from_mont_limbs
     return dict(msgs=f(msgs[: nm.value]), gamma=f(g)[0], matrix=(f(mp), f(me)), ac_c=(f(cpt[:x]), f(cev)), ac_d=(f(dpt[:d]), f(dev)),
-                tape_used=used.value, rounds=rounds.value)
+                tape_used=used.value, rounds=rounds.value, call_s=call_s)
 
 
 def multiopen_prove(cols, nvars, points, evs, tape, msgs_cap=4096):
@@ -551,14 +556,16 @@ def gkr_msm_prove(d_points, d_bits_u8, log_num_points, log_num_scalar_bits, tape
     fpt = np.zeros((64, 4), dtype=np.uint64)
     fev = np.zeros((8, 4), dtype=np.uint64)
     nm, used, rounds, npt, wms = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_double()
+    t0 = time.perf_counter()
     ffi.check(L.gm_gkr_msm_prove(C.c_void_p(d_points.data_ptr()), C.c_void_p(d_bits_u8.data_ptr()), log_num_points,
                                  log_num_scalar_bits, tp.ctypes.data, len(tape), msgs.ctypes.data, msgs_cap, C.byref(nm),
                                  outp.ctypes.data, fpt.ctypes.data, C.byref(npt), fev.ctypes.data, C.byref(used),
                                  C.byref(rounds), C.byref(wms), cur_stream()))
+    call_s = time.perf_counter() - t0
     return dict(msgs=codec.from_mont_limbs(msgs[: nm.value]), output=[codec.from_mont_limbs(outp[c * nout:(c + 1) * nout])
                                                                         for c in range(3)],
                 point=codec.from_mont_limbs(fpt[: npt.value]), evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value,
-                rounds=rounds.value, witness_ms=wms.value)
+                rounds=rounds.value, witness_ms=wms.value, call_s=call_s)
 
 
 # ------------------------------------------------------------------ BLS12-381 G1 (include/gkrmsm.h, G1 section)
