@@ -151,7 +151,10 @@ def main():
                 rcomm = None
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
-    transport = "none" if world == 1 else ("rccl-native (ncclAllGather / ncclBroadcast inside libgkrmsm_hip.so)" if rcomm is not None
+    if world == 1 and os.environ.get("GM_BENCH_RCCL_WORLD1") == "1":
+        # rehearsal of the native-communicator code path on one GPU: a world-1 ncclAllGather / ncclBroadcast per step
+        rcomm = gdist.RcclComm(None, 0, 1)
+    transport = ("none" if rcomm is None else "rccl-native, world 1 (rehearsal)") if world == 1 else ("rccl-native (ncclAllGather / ncclBroadcast inside libgkrmsm_hip.so)" if rcomm is not None
                                             else "torch.distributed/%s callback" % backend)
 
     L = ffi.lib()
@@ -222,46 +225,54 @@ def main():
         ffi.check(L.gm_msm_profile(plan.h, 1))
         dom_ms = []
         prof = (C.c_float * 7)()
-        if world == 1:
-            # Software pipeline over two plans on two streams: while the GPU runs step i, the host reads back and recombines the
-            # window points of step i - 1 (27 KB D2H + ~270 host curve operations, ~0.2 ms that would otherwise idle the GPU).
-            # Every step still produces its final group element inside the timed region.
-            plan_b = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
-            plans = [plan, plan_b]
-            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-            for pl, st in zip(plans, streams):
-                with torch.cuda.stream(st):
-                    pl.run(d_pts, d_sc)
-                    pl.window_points_raw()
-            ffi.check(L.gm_msm_profile(plan_b.h, 1))
+        # Software pipeline over two plans on two streams: while the GPU runs step i, the host reads back and recombines the
+        # window points of step i - 1 (27 KB D2H + ~270 host curve operations, ~0.2 ms that would otherwise idle the GPU; with
+        # N ranks also the all-gather of the window points, enqueued on the step's own stream).  Every step still produces its
+        # final group element inside the timed region, on every rank.
+        plan_b = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
+        plans = [plan, plan_b]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        recv = [torch.empty(world * ncols * wpr * 4, dtype=torch.int64, device="cuda") for _ in range(2)] if rcomm is not None else None
 
-            def finish(j):
-                with torch.cuda.stream(streams[j & 1]):
-                    raw_ = plans[j & 1].window_points_raw()          # waits for step j's kernels only
-                    ffi.check(L.gm_msm_profile_read(plans[j & 1].h, prof, 7))
-                dom_ms.append(prof[4])
-                return harness.combine_host(raw_, d_log), raw_
-            sync_all()
-            t0 = time.perf_counter()
-            for j in range(steps):
-                with torch.cuda.stream(streams[j & 1]):
-                    plans[j & 1].run(d_pts, d_sc)
-                if j > 0:
-                    result, raw = finish(j - 1)
-            result, raw = finish(steps - 1)
-            sync_all()
-            dt = time.perf_counter() - t0
-            plan_b.close()
-            del plan_b
-        else:
-            sync_all()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                result, raw = step()
-                ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
-                dom_ms.append(prof[4])
-            sync_all()
-            dt = max_over_ranks(time.perf_counter() - t0)
+        def launch(j):
+            with torch.cuda.stream(streams[j & 1]):
+                plans[j & 1].run(d_pts, d_sc)
+                if rcomm is not None:
+                    p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
+                    ffi.check(L.gm_msm_window_points(plans[j & 1].h, C.byref(p), C.byref(nc), C.byref(cl)))
+                    rcomm.all_gather_dev(p, recv[j & 1], ncols * wpr * 32)      # ncclAllGather, asynchronous on this stream
+
+        def finish(j):
+            with torch.cuda.stream(streams[j & 1]):
+                if rcomm is not None:
+                    g = recv[j & 1].cpu().numpy().view(np.uint64).reshape(world, ncols, wpr, 4)   # waits for step j's stream only
+                    raw_ = np.ascontiguousarray(np.transpose(g, (1, 0, 2, 3)).reshape(ncols, world * wpr, 4))
+                elif world > 1:
+                    p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
+                    ffi.check(L.gm_msm_window_points(plans[j & 1].h, C.byref(p), C.byref(nc), C.byref(cl)))
+                    mine = torch.empty((ncols, wpr, 4), dtype=torch.int64, device="cuda")
+                    ffi.check(L.gm_memcpy_d2d(C.c_void_p(mine.data_ptr()), p, ncols * wpr * 32, harness.cur_stream()))
+                    raw_ = gdist.gather_window_points(dist, mine.to(xdev), world)
+                else:
+                    raw_ = plans[j & 1].window_points_raw()
+                ffi.check(L.gm_msm_profile_read(plans[j & 1].h, prof, 7))
+            dom_ms.append(prof[4])
+            return harness.combine_host(raw_, d_log), raw_
+        for j in range(2):
+            launch(j)
+            finish(j)
+        ffi.check(L.gm_msm_profile(plan_b.h, 1))
+        sync_all()
+        t0 = time.perf_counter()
+        for j in range(steps):
+            launch(j)
+            if j > 0:
+                result, raw = finish(j - 1)
+        result, raw = finish(steps - 1)
+        sync_all()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        plan_b.close()
+        del plan_b, recv
         # stage breakdown (one extra, untimed pass)
         ffi.check(L.gm_msm_profile(plan.h, 2))
         step()
@@ -287,6 +298,15 @@ def main():
                         "avg_launch_ms": round(dom, 4), "algorithmic_bytes_per_launch": alg_bytes, "fr_mul_per_launch": fr_mul0,
                         "fr_mul_per_s": round(fr_mul0 / (dom * 1e-3), 1),
                         "valu_frac_of_measured_ceiling": round(fr_mul0 / (dom * 1e-3) / FR_MUL_CEILING, 3)}
+            # In the timed loop the kernel shares the chip with the late, latency-bound levels of the previous step (other
+            # stream): that overlap shortens the step and lengthens this launch.  The same launch with the chip to itself
+            # (the untimed stage-breakdown pass below):
+            alone = stages["add_level0"]
+            if alone > 0:
+                roofline["unoverlapped"] = {"launch_ms": alone, "achieved": round(alg_bytes / (alone * 1e-3) / 1e9, 1),
+                                            "frac": round(alg_bytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "fr_mul_per_s": round(fr_mul0 / (alone * 1e-3), 1),
+                                            "valu_frac_of_measured_ceiling": round(fr_mul0 / (alone * 1e-3) / FR_MUL_CEILING, 3)}
         res = {"x_logsize": x_log, "value": round(n * steps / dt, 1), "ms_per_step": round(ms_per_step, 4), "roofline": roofline,
                "stage_ms": stages, "result_x": hex(result[0]),
                # SURVEY 8(d)'s whole-MSM unit: 96 B of compulsory HBM traffic per point (64 B point + 32 B scalar)
