@@ -229,50 +229,56 @@ def main():
         # window points of step i - 1 (27 KB D2H + ~270 host curve operations, ~0.2 ms that would otherwise idle the GPU; with
         # N ranks also the all-gather of the window points, enqueued on the step's own stream).  Every step still produces its
         # final group element inside the timed region, on every rank.
-        plan_b = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
-        plans = [plan, plan_b]
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        recv = [torch.empty(world * ncols * wpr * 4, dtype=torch.int64, device="cuda") for _ in range(2)] if rcomm is not None else None
+        # Depth: 2 steps in flight when a step is milliseconds of large kernels; 4 when a rank's share is small (x_logsize 20 over
+        # 8 ranks: ~25 launches of 10-200 us, a 0.93 ms dependency chain for 0.5 ms of work -- measured on one GPU with
+        # scripts/quick_rank_share_time.py: 0.97 ms unpipelined, 0.66 ms at depth 2, 0.55 ms at depth 4).
+        depth = 4 if (world > 1 and wpr * n <= (1 << 24)) else 2
+        plans = [plan] + [harness.MsmPlan(x_log, d_log, y_size, y0, y1) for _ in range(depth - 1)]
+        streams = [torch.cuda.Stream() for _ in range(depth)]
+        recv = [torch.empty(world * ncols * wpr * 4, dtype=torch.int64, device="cuda") for _ in range(depth)] if rcomm is not None else None
 
         def launch(j):
-            with torch.cuda.stream(streams[j & 1]):
-                plans[j & 1].run(d_pts, d_sc)
+            with torch.cuda.stream(streams[j % depth]):
+                plans[j % depth].run(d_pts, d_sc)
                 if rcomm is not None:
                     p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
-                    ffi.check(L.gm_msm_window_points(plans[j & 1].h, C.byref(p), C.byref(nc), C.byref(cl)))
-                    rcomm.all_gather_dev(p, recv[j & 1], ncols * wpr * 32)      # ncclAllGather, asynchronous on this stream
+                    ffi.check(L.gm_msm_window_points(plans[j % depth].h, C.byref(p), C.byref(nc), C.byref(cl)))
+                    rcomm.all_gather_dev(p, recv[j % depth], ncols * wpr * 32)      # ncclAllGather, asynchronous on this stream
 
         def finish(j):
-            with torch.cuda.stream(streams[j & 1]):
+            with torch.cuda.stream(streams[j % depth]):
                 if rcomm is not None:
-                    g = recv[j & 1].cpu().numpy().view(np.uint64).reshape(world, ncols, wpr, 4)   # waits for step j's stream only
+                    g = recv[j % depth].cpu().numpy().view(np.uint64).reshape(world, ncols, wpr, 4)   # waits for step j's stream only
                     raw_ = np.ascontiguousarray(np.transpose(g, (1, 0, 2, 3)).reshape(ncols, world * wpr, 4))
                 elif world > 1:
                     p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
-                    ffi.check(L.gm_msm_window_points(plans[j & 1].h, C.byref(p), C.byref(nc), C.byref(cl)))
+                    ffi.check(L.gm_msm_window_points(plans[j % depth].h, C.byref(p), C.byref(nc), C.byref(cl)))
                     mine = torch.empty((ncols, wpr, 4), dtype=torch.int64, device="cuda")
                     ffi.check(L.gm_memcpy_d2d(C.c_void_p(mine.data_ptr()), p, ncols * wpr * 32, harness.cur_stream()))
                     raw_ = gdist.gather_window_points(dist, mine.to(xdev), world)
                 else:
-                    raw_ = plans[j & 1].window_points_raw()
-                ffi.check(L.gm_msm_profile_read(plans[j & 1].h, prof, 7))
+                    raw_ = plans[j % depth].window_points_raw()
+                ffi.check(L.gm_msm_profile_read(plans[j % depth].h, prof, 7))
             dom_ms.append(prof[4])
             return harness.combine_host(raw_, d_log), raw_
-        for j in range(2):
+        for j in range(depth):
             launch(j)
             finish(j)
-        ffi.check(L.gm_msm_profile(plan_b.h, 1))
+        for pl in plans[1:]:
+            ffi.check(L.gm_msm_profile(pl.h, 1))
         sync_all()
         t0 = time.perf_counter()
         for j in range(steps):
             launch(j)
-            if j > 0:
-                result, raw = finish(j - 1)
-        result, raw = finish(steps - 1)
+            if j >= depth - 1:
+                result, raw = finish(j - depth + 1)
+        for j in range(max(steps - depth + 1, 0), steps):
+            result, raw = finish(j)
         sync_all()
         dt = max_over_ranks(time.perf_counter() - t0)
-        plan_b.close()
-        del plan_b, recv
+        for pl in plans[1:]:
+            pl.close()
+        del plans, recv
         # stage breakdown (one extra, untimed pass)
         ffi.check(L.gm_msm_profile(plan.h, 2))
         step()

@@ -41,3 +41,31 @@ ffi.check(L.gm_msm_profile(plan.h, 2))
 plan.run(d_pts, d_sc); plan.window_points_raw()
 ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
 print(dict(zip(["digits", "histogram", "chunk_scan_offsets", "scatter", "add_level0", "add_levels_ge1", "triangle"], [round(float(v), 4) for v in prof])))
+
+# pipelined over `depth` plans / streams, as bench.py's timed loop (without the all-gather)
+for depth in (2, 3, 4):
+    plans = [plan] + [harness.MsmPlan(x_log, d_log, y_size, y0, y1) for _ in range(depth - 1)]
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    for pl, st in zip(plans, streams):
+        ffi.check(L.gm_msm_profile(pl.h, 0))
+        with torch.cuda.stream(st):
+            pl.run(d_pts, d_sc); pl.window_points_raw()
+    torch.cuda.synchronize()
+
+    def finish(j):
+        with torch.cuda.stream(streams[j % depth]):
+            return harness.combine_host(plans[j % depth].window_points_raw(), d_log)
+    steps = 40
+    t = time.perf_counter()
+    for j in range(steps):
+        with torch.cuda.stream(streams[j % depth]):
+            plans[j % depth].run(d_pts, d_sc)
+        if j >= depth - 1:
+            res = finish(j - depth + 1)
+    for j in range(steps - depth + 1, steps):
+        res = finish(j)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps
+    print("pipelined depth %d: %.3f ms per step incl. host combine -> %.1f M points/s" % (depth, dt * 1e3, n / dt / 1e6))
+    for pl in plans[1:]:
+        pl.close()
