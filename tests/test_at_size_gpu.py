@@ -10,10 +10,18 @@ OpenMP on the host cores):
   configs[2]  gen-1 gkr_msm_prove at the largest size of the reference's own bench grid (benches/gkr_msm_simple.rs:97-107:
               log_num_points 13..17 exclusive, 256-bit scalars) -> every transcript message
 
+  configs[3]  x_logsize=24, nbits=256 MSM sharded by windows over 8 GPUs -> ONE rank's share at full size on one GPU (4 of the
+              32 windows over all 2^24 points: ranks 0 and 5), bit-exact against the oracle run on the same digits
+  configs[4]  x_logsize=24 prover sharded 8 ways -> DRY RUN of one rank's share at full size (memory and time of every kernel at
+              that shape; the other ranks' partial sums are absent, so the transcript is not a real proof's)
+  configs[1] sharded: the image-part prover of config B with its bucket rows split over 4 ranks (4 processes sharing the one GPU,
+              gloo): every message equal to the unsharded proof, which the first test pins to the oracle
+
 The x = 20 prover check needs ~30 s of CPU and ~20 GiB of host memory for the oracle's witness trace; when the host has less
 than 40 GiB available the prover leg (only) drops to x_logsize = 18 and says so."""
 import ctypes as C
 import os
+import sys
 import time
 
 import numpy as np
@@ -189,4 +197,190 @@ def test_gen1_at_the_reference_bench_size():
     assert codec.from_mont_limbs(c["point"]) == g["point"] and codec.from_mont_limbs(c["evs"]) == g["evs"]
     print("[at-size] gen-1 gkr_msm_prove 2^%d points x 2^%d bits: %d rounds, %d messages bit-exact vs the C oracle (%.1f s on the CPU)" % (
         lp, lb, g["rounds"], len(g["msgs"]), cpu_s))
+    torch.cuda.empty_cache()
+
+
+def test_config_d_one_ranks_share_of_the_window_sharded_msm():
+    """BASELINE.json configs[3] (x_logsize=24, nbits=256, windows sharded 8 ways: pushforward.rs:401 is the unit of sharding):
+    the share of rank 0 and of rank 5 -- 4 windows over all 2^24 points, twice the cells of config B -- at full size.  The
+    oracle computes the same four windows from the scalars shifted down to them (digit k of `s >> 8 y0` is digit y0 + k of s)."""
+    from gkr_msm_amd import dist as gdist
+    x_log, d_log, nbits, world = 24, 8, 256, 8
+    if avail_gib() < 24:
+        x_log = 22
+        print("[at-size] host has %.0f GiB available: config D share runs at x_logsize=22" % avail_gib())
+    y_size = nbits // d_log
+    d_pts, d_sc, sc = device_inputs(x_log, nbits, 0xD0D0)
+    pts_host = H.to_host(d_pts).reshape(-1, 8)
+    for rank in (0, 5):
+        y0, y1 = gdist.window_range(rank, world, y_size)
+        assert y1 - y0 == 4
+        plan = H.MsmPlan(x_log, d_log, y_size, y0, y1)
+        plan.run(d_pts, d_sc)
+        raw = plan.window_points_raw()
+        # the scalars shifted right by 8 * y0 bits, cut to the 32 bits of this rank's windows
+        bit0 = d_log * y0
+        limb, sh = bit0 // 64, bit0 % 64
+        assert sh + 32 <= 64
+        sub = np.zeros_like(sc)
+        sub[:, 0] = (sc[:, limb] >> np.uint64(sh)) & np.uint64(0xFFFFFFFF)
+        t0 = time.perf_counter()
+        ref = O.msm(pts_host, sub, x_log, d_log, y1 - y0, threads=host_threads(), want_aux=True)
+        cpu_s = time.perf_counter() - t0
+        px, py, pz, nb = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        ffi.check(plan.L.gm_msm_bucket_sums(plan.h, C.byref(px), C.byref(py), C.byref(pz), C.byref(nb)))
+        assert nb.value == (y1 - y0) << d_log
+        for p, k in ((px, "bx"), (py, "by"), (pz, "bz")):
+            assert np.array_equal(H.read_dev(p, nb.value * 32).reshape(-1, 4), ref[k]), "bucket sums " + k
+        assert np.array_equal(raw, ref["window_cols"]), "window points of rank %d" % rank
+        print("[at-size] config D share of rank %d (windows %d..%d, x_logsize %d): bucket sums + window points bit-exact (%.1f s on the CPU)" % (
+            rank, y0, y1 - 1, x_log, cpu_s))
+        plan.close()
+    del d_pts, d_sc
+    ffi.lib().gm_release_cached_memory()
+    torch.cuda.empty_cache()
+
+
+def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
+    """one rank of the at-size sharded proof: operands from gm_gen_points / numpy (identical on every rank), the unsharded
+    proof as the reference (pinned to the oracle by test_config_b_msm_and_image_part_at_full_size)"""
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for d in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+            if d not in sys.path:
+                sys.path.insert(0, d)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from gkr_msm_amd import dist as gd
+        y_size = (nbits + d_log - 1) // d_log
+        y_log = (y_size - 1).bit_length()
+        d_pts, d_sc, sc = device_inputs(x_log, nbits, 0x474B524D534D)
+        pr = np.random.default_rng(7)
+        r_pt = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(y_log)]
+        tape = [int.from_bytes(pr.bytes(16), "little") for _ in range(4000)]
+
+        def ev(poly):
+            cur = list(poly)
+            for f in reversed(r_pt):
+                cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
+            return cur[0]
+        plan = H.MsmPlan(x_log, d_log, y_size)
+        plan.run(d_pts, d_sc)
+        w = H.PipWitness(plan, d_pts, y_log)
+        outs, bs = w.outputs()
+        evs = [ev(o) for o in outs]
+        ref = w.prove_image_part(r_pt, evs, tape)
+        w.close()
+        plan.close()
+        ffi.lib().gm_release_cached_memory()
+        y0, y1 = gd.window_range(rank, world, y_size)
+        comm = gd.Comm(dist, rank, world)
+        plan_s = H.MsmPlan(x_log, d_log, y_size, y0, y1)
+        plan_s.run(d_pts, d_sc)
+        ws = H.PipWitness(plan_s, d_pts, y_log, comm=comm)
+        outs_s, bs_s = ws.outputs()
+        t0 = time.perf_counter()
+        got = ws.prove_image_part(r_pt, evs, tape)
+        dt = time.perf_counter() - t0
+        ok = (outs_s == outs and bs_s == bs and got["msgs"] == ref["msgs"] and got["point"] == ref["point"] and
+              got["evs"] == ref["evs"] and got["rounds"] == ref["rounds"] and got["tape_used"] == ref["tape_used"])
+        q.put((rank, ok, "%d exchanges, %.2f s" % (comm.calls, dt), got["rounds"]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # report instead of hanging the parent
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc(), 0))
+
+
+def test_config_b_image_part_sharded_over_four_ranks():
+    """the sharded prover (gm_pip_witness_create_sharded: bucket rows = windows split over the ranks, one small all-gather per
+    round) at config B's full size, world 4 on the one GPU"""
+    import torch.multiprocessing as mp
+    world, x_log, d_log, nbits = 4, 20, 8, 256
+    if avail_gib() < 64:
+        x_log = 17
+    ffi.lib().gm_release_cached_memory()
+    torch.cuda.empty_cache()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, x_log, d_log, nbits, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=600))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert len(res) == world
+    for rank, ok, info, rounds in sorted(res):
+        assert ok, "rank %d: %s" % (rank, info)
+    print("[at-size] config B image-part prover sharded over %d ranks (x_logsize %d): %d rounds, %s per rank, equal to the unsharded proof" % (
+        world, x_log, res[0][3], res[0][2]))
+
+
+def test_config_e_dry_run_of_one_ranks_share_of_the_sharded_prover():
+    """BASELINE.json configs[4] (x_logsize=24, bucket rows sharded 8 ways): rank 3's share -- the witness of 4 windows over 2^24
+    points (twice config B's cells) and all sumcheck rounds over it -- at full size on one GPU.  A DRY RUN: the all-gather
+    callback returns only this rank's slot (the seven other ranks do not exist here), so the round sums and challenges are not
+    those of a real proof; what is checked is that the share fits and runs (every kernel at the shape the 8-GPU run launches),
+    that its bucket sums are the window-sharded MSM's (pinned by the config D test above), and how long it takes."""
+    from gkr_msm_amd import dist as gdist
+    x_log, d_log, nbits, world, rank = 24, 8, 256, 8, 3
+    if avail_gib() < 24:
+        x_log = 20
+    y_size = nbits // d_log
+    y_log = (y_size - 1).bit_length()
+    d_pts, d_sc, sc = device_inputs(x_log, nbits, 0xE0E0)
+    y0, y1 = gdist.window_range(rank, world, y_size)
+    plan = H.MsmPlan(x_log, d_log, y_size, y0, y1)
+    plan.run(d_pts, d_sc)
+
+    class LoopbackComm:
+        def __init__(self):
+            self.calls = 0
+
+            def _ag(ctx, buf, nbytes):
+                self.calls += 1     # own slot is already in place; the other slots keep whatever the library put there
+                return 0
+            self._cb = ffi.ALL_GATHER_CB(_ag)
+            self.c = ffi.GmComm(None, rank, world, self._cb)
+    comm = LoopbackComm()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    w = H.PipWitness(plan, d_pts, y_log, comm=comm)
+    torch.cuda.synchronize()
+    t_wit = time.perf_counter() - t0
+    # this rank's rows of the bucket-sum columns = the bucket sums of its MSM plan
+    bs_ptrs = (C.c_void_p * 3)()
+    out_ptrs = (C.c_void_p * (3 * (d_log + 1)))()
+    n_, ln_ = C.c_uint32(), C.c_uint64()
+    ffi.check(w.L.gm_pip_witness_outputs(w.h, out_ptrs, C.byref(n_), C.byref(ln_), bs_ptrs))
+    px, py, pz, nb = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    ffi.check(plan.L.gm_msm_bucket_sums(plan.h, C.byref(px), C.byref(py), C.byref(pz), C.byref(nb)))
+    rows0 = y0 << d_log
+    for k, p in enumerate((px, py, pz)):
+        mine = H.read_dev(p, nb.value * 32).reshape(-1, 4)
+        full = H.read_dev(bs_ptrs[k], (1 << (y_log + d_log)) * 32).reshape(-1, 4)
+        assert np.array_equal(full[rows0:rows0 + nb.value], mine), "bucket-sum rows of this rank"
+    pr = np.random.default_rng(5)
+    r_pt = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(y_log)]
+    r_evs = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(3 * (d_log + 1))]
+    tape = [int.from_bytes(pr.bytes(16), "little") for _ in range(6000)]
+    g = w.prove_image_part(r_pt, r_evs, tape)
+    free, total = torch.cuda.mem_get_info()
+    assert g["rounds"] >= 1518 and len(g["msgs"]) > 3 * g["rounds"] and comm.calls > 1000
+    print("[at-size] config E dry run, rank %d of %d at x_logsize %d: witness %.0f ms, %d rounds in %.0f ms (%.0f rounds/s), %d exchanges, "
+          "%.1f GiB of HBM in use" % (rank, world, x_log, t_wit * 1e3, g["rounds"], g["call_s"] * 1e3, g["rounds"] / g["call_s"],
+                                      comm.calls, (total - free) / 2 ** 30))
+    w.close()
+    plan.close()
+    del d_pts, d_sc
+    ffi.lib().gm_release_cached_memory()
     torch.cuda.empty_cache()
