@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "msm_plan.hpp"
 #include "ragged.hip.h"
+#include "fr9.hip.h"
 
 namespace gm {
 
@@ -71,6 +72,65 @@ __device__ __forceinline__ Point3 proj_add(const Point3& p, const Point3& g) {
     Point3 r;
     r.x = fr_mul(m, X); r.y = fr_mul(q, Y); r.z = fr_mul(m, q);
     return r;
+}
+
+// The same two compositions in the 9 x 29-bit form (fr9.hip.h): this is what the level kernels run.  Identical field values --
+// the results are canonicalised when stored -- with 205-instruction products, carry-free sums and no conditional subtraction
+// inside the formula.  Bounds per line: L = limb bound, S = value / p bound (2^261 / p = 70.66).
+struct Point9 {
+    Fr9 x, y, z;
+};
+
+// inputs: loaded values (L 2^29, S 32) or the identity's constants
+__device__ __forceinline__ Point9 aff_add9(const Fr9& x1, const Fr9& y1, const Fr9& x2, const Fr9& y2) {
+    const Fr9 A = fr9_mul(x1, x2), B = fr9_mul(y1, y2);                      // L 2^29, S 15.5
+    const Fr9 C = fr9_mul(fr9_add(x1, y1), fr9_add(x2, y2));                 // operands L 2^30, S 64 -> S 59
+    const Fr9 s = fr9_sub2_32(C, A, B);                                      // x1y2 + x2y1: L 2^31, S 91
+    const Fr9 t = fr9_norm(fr9_add(B, fr9_mul5(A)));                         // y1y2 - a x1x2, a = -5: S 93, top limb < 2^29.4
+    const Fr9 dxy = fr9_mul(fr9_mul(A, B), fr9_coeff_d());                   // S 4.4 -> S 1.07
+    const Fr9 m = fr9_norm(fr9_sub8(fr9_one(), dxy));                        // S 9
+    const Fr9 q = fr9_add(fr9_one(), dxy);                                   // L 2^30, S 2.07
+    Point9 r;
+    r.x = fr9_mul(m, s);                                                     // 2^29 x 2^31; S 12.6
+    r.y = fr9_mul(q, t);                                                     // 2^30 x 2^29.4; S 3.7
+    r.z = fr9_mul(m, q);                                                     // S 1.3
+    return r;
+}
+
+// inputs: loaded coordinates (L 2^29, S 32)
+__device__ __forceinline__ Point9 proj_add9(const Point9& p, const Point9& g) {
+    const Fr9 A = fr9_mul(p.x, g.x), B = fr9_mul(p.y, g.y), zz = fr9_mul(p.z, g.z);   // S 15.5
+    const Fr9 C = fr9_mul(fr9_add(p.x, p.y), fr9_add(g.x, g.y));                       // S 59
+    const Fr9 s = fr9_sub2_32(C, A, B);                                                // L 2^31, S 91
+    const Fr9 t = fr9_add(B, fr9_mul5(A));                                             // L 6 2^29, S 93
+    const Fr9 X = fr9_mul(s, zz);                                                      // 2^31 x 2^29; S 21
+    const Fr9 Y = fr9_mul(t, zz);                                                      // 54 2^58 + 9 2^58 + 2^36 < 2^64; S 21.4
+    const Fr9 z2 = fr9_sqr(zz);                                                        // S 4.4
+    const Fr9 dxy = fr9_mul(fr9_mul(A, B), fr9_coeff_d());                             // S 1.07
+    const Fr9 m = fr9_norm(fr9_sub8(z2, dxy));                                         // S 12.4
+    const Fr9 q = fr9_add(z2, dxy);                                                    // L 2^30, S 5.5
+    Point9 r;
+    r.x = fr9_mul(m, X);                                                               // S 4.7
+    r.y = fr9_mul(q, Y);                                                               // S 2.7
+    r.z = fr9_mul(m, q);                                                               // S 2
+    return r;
+}
+
+__device__ __forceinline__ Point9 pt9_load(const Fr* x, const Fr* y, const Fr* z, uint64_t i) {
+    Point9 p;
+    p.x = fr9_load(x + i); p.y = fr9_load(y + i); p.z = fr9_load(z + i);
+    return p;
+}
+__device__ __forceinline__ void pt9_store(Fr* x, Fr* y, Fr* z, uint64_t i, const Point9& p) {
+    fr9_store(x + i, p.x); fr9_store(y + i, p.y); fr9_store(z + i, p.z);
+}
+__device__ __forceinline__ Point9 pt9_identity() {
+    Point9 p;
+    p.x = fr9_zero(); p.y = fr9_one(); p.z = fr9_one();
+    return p;
+}
+__device__ __forceinline__ void pt_store(Fr* x, Fr* y, Fr* z, uint64_t i, const Point3& p) {
+    fr_store(x + i, p.x); fr_store(y + i, p.y); fr_store(z + i, p.z);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -254,25 +314,21 @@ __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* _
     if (j >= total) return;
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
-    Point3 res;
     if (p < half) {
         const uint32_t i0 = cells[(uint64_t)in0 + 2 * p], i1 = cells[(uint64_t)in0 + 2 * p + 1];
-        Fr x1 = fr_load(points_xy + 2ull * i0), y1 = fr_load(points_xy + 2ull * i0 + 1);
-        Fr x2, y2;
+        const Fr9 x1 = fr9_load(points_xy + 2ull * i0), y1 = fr9_load(points_xy + 2ull * i0 + 1);
+        Fr9 x2, y2;
         if (i1 != PAD_IDX) {
-            x2 = fr_load(points_xy + 2ull * i1);
-            y2 = fr_load(points_xy + 2ull * i1 + 1);
+            x2 = fr9_load(points_xy + 2ull * i1);
+            y2 = fr9_load(points_xy + 2ull * i1 + 1);
         } else {
-            x2 = fr_zero();
-            y2 = fr_one();
+            x2 = fr9_zero();
+            y2 = fr9_one();
         }
-        res = aff_add(x1, y1, x2, y2);
+        pt9_store(ox, oy, oz, j, aff_add9(x1, y1, x2, y2));
     } else {
-        res = pt_identity();  // f(row_pad): l3(l2(l1(0,1,0,1))) = (0,1,1)
+        pt_store(ox, oy, oz, j, pt_identity());  // f(row_pad): l3(l2(l1(0,1,0,1))) = (0,1,1)
     }
-    fr_store(ox + j, res.x);
-    fr_store(oy + j, res.y);
-    fr_store(oz + j, res.z);
 }
 
 // bintree level >= 1
@@ -285,19 +341,12 @@ __global__ void __launch_bounds__(128) k_add_level(const Fr* __restrict__ ix, co
     if (j >= total) return;
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
-    Point3 res;
     if (p < half) {
         const uint64_t a = (uint64_t)in0 + 2 * p;
-        Point3 P, Q;
-        P.x = fr_load(ix + a); P.y = fr_load(iy + a); P.z = fr_load(iz + a);
-        Q.x = fr_load(ix + a + 1); Q.y = fr_load(iy + a + 1); Q.z = fr_load(iz + a + 1);
-        res = proj_add(P, Q);
+        pt9_store(ox, oy, oz, j, proj_add9(pt9_load(ix, iy, iz, a), pt9_load(ix, iy, iz, a + 1)));
     } else {
-        res = pt_identity();
+        pt_store(ox, oy, oz, j, pt_identity());
     }
-    fr_store(ox + j, res.x);
-    fr_store(oy + j, res.y);
-    fr_store(oz + j, res.z);
 }
 
 // Offsets of every level in one launch: level 0 from the bucket populations, level l+1 from level l.
