@@ -6,7 +6,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <unordered_map>
 
@@ -49,11 +51,19 @@ inline int32_t set_err(int32_t code, const char* fmt, ...) {
 // gm_release_cached_memory() hands them back.  Same-stream reuse is safe by stream order, as with any caching allocator;
 // callers that share buffers across streams must synchronise before destroying handles (they already must for hipFree).  Blocks below 1 MiB are cached in power-of-two classes.
 // Idle blocks are keyed by the device that was current when they were allocated (gm_set_device): a block is only ever reused on its own GPU.
+// They are also keyed by the host thread that freed them: two host threads that prove concurrently (each on its own stream) never
+// hand each other a block whose last kernels may still be running on the other's stream.
 struct DevPool {
     std::mutex mu;
     struct Block { size_t bytes; int dev; };
     std::unordered_map<void*, Block> live;
-    std::multimap<std::pair<int, size_t>, void*> idle;   // keyed by (device, size class): a block never crosses devices
+    typedef std::tuple<int, int, size_t> Key;   // (device, host thread, size class)
+    std::multimap<Key, void*> idle;
+    static int thread_key() {
+        static std::atomic<int> next{0};
+        static thread_local int k = next.fetch_add(1);
+        return k;
+    }
     size_t idle_bytes = 0;
     uint64_t n_driver_allocs = 0, driver_alloc_bytes = 0;  // pool misses (diagnostics)
     static constexpr size_t SMALL = (size_t)1 << 20;
@@ -75,7 +85,7 @@ struct DevPool {
         (void)hipGetDevice(&dev);
         {
             std::lock_guard<std::mutex> g(mu);
-            auto it = idle.find({dev, b});
+            auto it = idle.find(Key{dev, thread_key(), b});
             if (it != idle.end()) {
                 *out = it->second;
                 live[it->second] = Block{b, dev};
@@ -103,7 +113,7 @@ struct DevPool {
             std::lock_guard<std::mutex> g(mu);
             auto it = live.find(p);
             if (it != live.end()) {
-                idle.insert({{it->second.dev, it->second.bytes}, p});
+                idle.insert({Key{it->second.dev, thread_key(), it->second.bytes}, p});
                 idle_bytes += it->second.bytes;
                 live.erase(it);
                 return;
@@ -112,7 +122,7 @@ struct DevPool {
         (void)hipFree(p);
     }
     void release() {
-        std::multimap<std::pair<int, size_t>, void*> take;
+        std::multimap<Key, void*> take;
         {
             std::lock_guard<std::mutex> g(mu);
             take.swap(idle);

@@ -17,6 +17,7 @@
 #include <atomic>
 #include <immintrin.h>
 #include <chrono>
+#include <condition_variable>
 
 #include "internal.hpp"
 #include "ragged.hip.h"
@@ -1283,9 +1284,44 @@ static int stage_host_rounds(const SegPlan& sp, int n_dense) {
     return h;
 }
 
+// Co-residency budget of k_stage.  Its blocks wait for each other, so all of them must be resident at once: the budget is what
+// the device can hold (occupancy of k_stage x compute units, queried once per device), a launch larger than that is not made
+// (StageRun::fits), and host threads that prove concurrently on one device share it -- a launch waits until the blocks of the
+// launches in flight plus its own fit (two 512-block launches from two threads would otherwise each hold part of the chip and
+// spin until their time-outs).
+struct StageSlots {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t capacity[16] = {0}, in_flight[16] = {0};
+    static StageSlots& get() { static StageSlots s; return s; }
+    static int device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < 16) ? d : 0; }
+    uint32_t cap(int dev) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!capacity[dev]) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stage, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
+            (void)hipGetLastError();
+            capacity[dev] = (uint32_t)per_cu * (uint32_t)cus;
+        }
+        return capacity[dev];
+    }
+    bool acquire(int dev, uint32_t n) {
+        const uint32_t c = cap(dev);
+        std::unique_lock<std::mutex> g(mu);
+        return cv.wait_for(g, wait_timeout_host(), [&] { return in_flight[dev] + n <= c; }) ? (in_flight[dev] += n, true) : false;
+    }
+    void release(int dev, uint32_t n) {
+        { std::lock_guard<std::mutex> g(mu); in_flight[dev] -= n; }
+        cv.notify_all();
+    }
+};
+
 // One launch of k_stage seen from the host.  A VecVec object that enters its thin rounds creates it; the dense object it hands
 // over to (bind_into_dense) keeps using the same launch.
 struct StageRun {
+    int slot_dev = 0;
+    uint32_t slots_held = 0;
     TailStage* st = nullptr;
     hipStream_t stream = nullptr;
     uint32_t ticket0 = 0;
@@ -1320,6 +1356,7 @@ struct StageRun {
     static bool fits(int nseg_, uint64_t n_elems, int n_thin_, int n_dense_) {
         const uint64_t nsl_ = n_elems <= 256 ? 1 : n_elems / 256;
         return nseg_ >= 1 && nseg_ <= GM_MAX_SEGS && n_elems >= 2 && nsl_ <= STAGE_MAX_SLICES && 2ull * nseg_ * nsl_ <= STAGE_MAX_BLOCKS &&
+               2ull * nseg_ * nsl_ <= StageSlots::get().cap(StageSlots::device()) &&
                n_thin_ <= 12 && n_dense_ >= 1 && n_dense_ <= STAGE_MAX_ROUNDS;
     }
     // a: geometry, data pointers, eq pointers and pads filled by the caller
@@ -1374,6 +1411,10 @@ struct StageRun {
         a.timeout_ticks = wait_timeout_ticks();
         // the staging outlives this launch (one per host thread): a timeout flagged by an earlier launch must not fail this one
         *reinterpret_cast<volatile uint32_t*>(st->status()) = 0;
+        slot_dev = StageSlots::device();
+        if (!StageSlots::get().acquire(slot_dev, gx * nsl))
+            return set_err(GM_ERR_STATE, "stage launch: the device stayed full of other threads' stage kernels (gm_set_wait_timeout_ms)");
+        slots_held = gx * nsl;
         hipLaunchKernelGGL(k_stage, dim3(gx, nsl), dim3(256), 0, s, sp, cp, d_gamma, a);
         GM_LAUNCH_CHECK();
         published = 0;
@@ -1448,6 +1489,8 @@ struct StageRun {
         cols->assign(ncols, std::vector<Fr>());
         for (int c = 0; c < ncols; c++) (*cols)[c].assign(st->finals() + (size_t)c * 32, st->finals() + (size_t)c * 32 + n);
         if (debug()) { (void)hipStreamSynchronize(stream); dump_debug(); }
+        // the finals are written after a block's last wait: the launch no longer needs its share of the device
+        if (slots_held) { StageSlots::get().release(slot_dev, slots_held); slots_held = 0; }
         return GM_OK;
     }
     ~StageRun() {
@@ -1457,6 +1500,8 @@ struct StageRun {
             write_chunks(st->tkt() + 12, fr_zero(), ticket0 + 0x4000u);
             (void)hipStreamSynchronize(stream);
         }
+        // every block is past its last wait (the finals were collected, or the release tag let them through)
+        if (slots_held) StageSlots::get().release(slot_dev, slots_held);
     }
 };
 

@@ -31,7 +31,13 @@ extern "C" {
 #define GM_ERR_STATE 4     /* call order violated (e.g. bind before unipoly: vecvec_eq.rs:305-307) */
 #define GM_ERR_VERIFY 5    /* the verifier rejected the proof (an assert! in the reference's verify functions) */
 
-/* ---------------------------------------------------------------- runtime */
+/* ---------------------------------------------------------------- runtime
+ * Threads.  Handles are not shared between host threads while a call on them is in progress, but different threads may work
+ * on different handles at the same time (a proving service: one thread = one stream + one plan / witness; rayon workers in
+ * the reference play the same role).  Everything the library keeps between calls is per thread (pinned staging, the host
+ * tables, the last error) or behind a lock (the device-memory cache, which hands a freed block only to the thread that
+ * freed it; the co-residency budget of the persistent round kernel).  A thread must outlive the handles it created.
+ * bench.py's `sumcheck.concurrent_provers` and tests/test_prover_gpu.py::test_provers_on_concurrent_host_threads use this. */
 const char* gm_last_error(void);
 const char* gm_version(void);
 int32_t gm_device_count(int32_t* out_count);

@@ -126,6 +126,51 @@ __global__ void k_mov(uint64_t* out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+__global__ void k_shr64(uint64_t* out, uint32_t seed) {
+    uint64_t acc[CHAINS];
+    for (int c = 0; c < CHAINS; c++) acc[c] = ((uint64_t)(c + threadIdx.x + seed) << 40) | 12345;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(acc[c]));
+    }
+    uint64_t s = 0;
+    for (int c = 0; c < CHAINS; c++) s += acc[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_alignbit(uint64_t* out, uint32_t seed) {
+    uint32_t acc[CHAINS];
+    uint32_t b = seed * 3 + 1;
+    for (int c = 0; c < CHAINS; c++) acc[c] = c + threadIdx.x + seed;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(acc[c]) : "v"(b));
+    }
+    uint64_t s = 0;
+    for (int c = 0; c < CHAINS; c++) s += acc[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_and(uint64_t* out, uint32_t seed) {
+    uint32_t acc[CHAINS];
+    for (int c = 0; c < CHAINS; c++) acc[c] = c + threadIdx.x + seed;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(acc[c]));
+    }
+    uint64_t s = 0;
+    for (int c = 0; c < CHAINS; c++) s += acc[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// dependent chain of multiply-adds (one accumulator): what the compiler pads with s_nop
+__global__ void k_mad64_dep(uint64_t* out, uint32_t seed) {
+    uint64_t acc = threadIdx.x;
+    uint32_t a = seed + threadIdx.x, b = seed * 3 + 1;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\ts_nop 0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 template <typename K>
 static void run(const char* name, K k, int ops_per_iter, uint64_t* d_out) {
     const int blocks = 256 * 8, threads = 256;  // 8 blocks of 4 waves per CU = 8 waves / SIMD
@@ -157,5 +202,9 @@ int main() {
     run("fma_f64", k_fma64, CHAINS, d_out);
     run("fma_f32", k_fma32, CHAINS, d_out);
     run("mov_b32", k_mov, 2 * CHAINS, d_out);
+    run("lshrrev_b64", k_shr64, CHAINS, d_out);
+    run("alignbit_b32", k_alignbit, CHAINS, d_out);
+    run("and_b32 lit", k_and, CHAINS, d_out);
+    run("mad64 dep+nop", k_mad64_dep, CHAINS, d_out);
     return 0;
 }

@@ -185,3 +185,59 @@ def test_a_timed_out_wait_does_not_poison_later_proofs():
         again = w.prove_image_part(claims[0], claims[1], tape)
         assert again["msgs"] == ref["msgs"] and again["evs"] == ref["evs"]
     assert timeouts, "no wait timed out: the bound is not honoured"
+
+
+def test_provers_on_concurrent_host_threads():
+    """four host threads, each with its own stream, plan and witness (two shapes, so that large and small stage kernels meet on
+    the device), prove at the same time: every proof equals the one the same thread made alone, which equals the oracle's for
+    that shape (include/gkrmsm.h "Threads"; the reference's provers run under rayon in the same way)"""
+    import threading
+    import torch
+    shapes = [(9, 8, 64), (8, 4, 32), (9, 8, 64), (7, 6, 128)]
+    ref = {}
+    for x_log, d_log, nbits in set(shapes):
+        y_size = (nbits + d_log - 1) // d_log
+        y_log = PL.log2_exact(y_size)
+        n = 1 << x_log
+        pts = F.random_points(n, 7 + x_log)
+        sc = F.random_scalars(n, nbits, 70 + d_log)
+        image, digits, counter, wg = G.pippenger_witness(pts, sc, y_size, y_log, d_log, x_log)
+        out = G.pippenger_dense_output(wg, y_log, d_log)
+        rng = F.SplitMix64(99)
+        r = [rng.next_fr() for _ in range(y_log)]
+        claims = G.pippenger_claims(out, r)
+        tape = [rng.next_bits(128) for _ in range(4000)]
+        tr = TapeTranscript(tape)
+        G.prove_image_part(tr, y_log, d_log, x_log, claims, wg)
+        ref[(x_log, d_log, nbits)] = dict(pts=codec.points_to_mont(pts), sc=codec.ints_to_limbs(sc), claims=claims, tape=tape,
+                                          msgs=[v for m in tr.msgs for v in m], y_size=y_size, y_log=y_log)
+    bar = threading.Barrier(len(shapes))
+    errors = []
+
+    def prover(k):
+        try:
+            x_log, d_log, nbits = shapes[k]
+            c = ref[shapes[k]]
+            with torch.cuda.stream(torch.cuda.Stream()):
+                d_pts, d_sc = H.to_dev(c["pts"]), H.to_dev(c["sc"])
+                plan = H.MsmPlan(x_log, d_log, c["y_size"])
+                plan.run(d_pts, d_sc)
+                w = H.PipWitness(plan, d_pts, c["y_log"])
+                bar.wait(timeout=120)
+                for _ in range(6):
+                    res = w.prove_image_part(c["claims"][0], c["claims"][1], c["tape"])
+                    assert res["msgs"] == c["msgs"], "thread %d: proof differs from the oracle's" % k
+                w.close()
+                plan.close()
+        except Exception as e:  # noqa: BLE001 - reported to the test thread
+            errors.append("thread %d: %r" % (k, e))
+            try:
+                bar.abort()
+            except Exception:
+                pass
+    ths = [threading.Thread(target=prover, args=(k,)) for k in range(len(shapes))]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=300)
+    assert not errors, errors
