@@ -25,11 +25,11 @@
 #include <thread>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
 
 #include "common.hpp"
 #include "internal.hpp"
 #include "g1.hip.h"
+#include "sort.hip.h"
 #include "msm_plan.hpp"
 
 namespace gm {
@@ -58,17 +58,63 @@ __global__ void __launch_bounds__(256) k_g1_lower_bound(const uint32_t* __restri
     }
 }
 
-// lens[r] = ceil(len0[r] / 2^shift), lens[nkeys] = 0
-__global__ void __launch_bounds__(256) k_g1_level_lens(const uint32_t* __restrict__ off0, uint32_t nkeys, uint32_t shift,
-                                                        uint32_t* __restrict__ lens) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > nkeys) return;
-    uint32_t v = 0;
-    if (r < nkeys) {
-        const uint32_t len = off0[r + 1] - off0[r];
-        v = (len + (1u << shift) - 1) >> shift;
+// Row layouts of all the levels of the tree in two launches: level l (blockIdx.y = l - 1) has rows of ceil(len0 / 2^l) cells;
+// its offsets are the exclusive scan of those lengths over the nkeys rows (+ the total at row nkeys).  Same tile scheme as
+// exclusive_scan_u32 (sort.hip.h), the lengths computed on the fly from the level-0 offsets.
+__global__ void __launch_bounds__(1024) k_g1_levels_scan_tiles(const uint32_t* __restrict__ off0, uint32_t nkeys, uint32_t* __restrict__ off_all,
+                                                                size_t ostride, uint32_t* __restrict__ tile_tot) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, shift = blockIdx.y + 1;
+    const uint32_t n = nkeys + 1;
+    uint32_t* dst = off_all + (size_t)shift * ostride;
+    const uint32_t r0 = blockIdx.x * SCAN_TILE + tid * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t sum = 0;
+    uint32_t prev = (r0 < n) ? off0[r0] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_ITEMS; k++) {
+        uint32_t len = 0;
+        if (r0 + k < nkeys) { const uint32_t nx = off0[r0 + k + 1]; len = nx - prev; prev = nx; }
+        v[k] = (len + (1u << shift) - 1) >> shift;
+        sum += v[k];
     }
-    lens[r] = v;
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if ((int)lane >= d) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < 16; w++) { const uint32_t t = wave_tot[w]; tot += t; if (w < wave) base += t; }
+    uint32_t run = base + inc - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_ITEMS; k++) {
+        if (r0 + k < n) dst[r0 + k] = run;
+        run += v[k];
+    }
+    if (tid == 0) tile_tot[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(1024) k_g1_levels_scan_fix(uint32_t nkeys, uint32_t* __restrict__ off_all, size_t ostride,
+                                                              const uint32_t* __restrict__ tile_tot) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    if (b == 0) return;
+    const uint32_t* tt = tile_tot + (size_t)blockIdx.y * gridDim.x;
+    uint32_t part = 0;
+    for (uint32_t i = tid; i < b; i += 1024) part += tt[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+    if (lane == 0) wave_tot[wave] = part;
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t w = 0; w < 16; w++) off += wave_tot[w];
+    uint32_t* dst = off_all + (size_t)(blockIdx.y + 1) * ostride;
+    const uint32_t r0 = b * SCAN_TILE + tid * SCAN_ITEMS;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_ITEMS; k++)
+        if (r0 + k <= nkeys) dst[r0 + k] += off;
 }
 
 __device__ __forceinline__ uint32_t g1_find_row(const uint32_t* __restrict__ off, uint32_t nrows, uint32_t j) {
@@ -400,10 +446,7 @@ static uint32_t bit_len(uint32_t v) {
 
 // bytes of scratch the engine needs for ntasks tasks over nkeys rows (besides the caller's task arrays)
 static int32_t g1_engine_layout(uint64_t ntasks, uint32_t nkeys, G1Layout* L) {
-    size_t st = 0, sc = 0;
-    uint32_t* np = nullptr;
-    GM_HIP(rocprim::radix_sort_pairs(nullptr, st, np, np, np, np, ntasks, 0, bit_len(nkeys)));
-    GM_HIP(rocprim::exclusive_scan(nullptr, sc, np, np, 0u, (size_t)nkeys + 1));
+    const size_t st = radix_sort_tmp_bytes(ntasks), sc = 33 * scan_tmp_bytes((size_t)nkeys + 1);   // tile totals of every level
     L->sort_tmp = st;
     L->scan_tmp = sc;
     L->total = al(st) + al(sc) + 2 * al(ntasks * 4) + 35 * al(((size_t)nkeys + 1) * 4) + al(64) +
@@ -420,24 +463,22 @@ static int32_t g1_sum_by_key(G1Scratch& ws, const G1Aff* src_aff, const G1Jac* s
     G1Layout L;
     int32_t rc = g1_engine_layout(ntasks ? ntasks : 1, nkeys, &L);
     if (rc) return rc;
-    void* sort_tmp = ws.carve(L.sort_tmp);
-    void* scan_tmp = ws.carve(L.scan_tmp);
+    uint32_t* sort_tmp = (uint32_t*)ws.carve(L.sort_tmp);
+    uint32_t* scan_tmp = (uint32_t*)ws.carve(L.scan_tmp);
     uint32_t* keys_s = (uint32_t*)ws.carve((ntasks + 1) * 4);
     uint32_t* idx_s = (uint32_t*)ws.carve((ntasks + 1) * 4);
     const size_t orow = (size_t)nkeys + 1;
     uint32_t* off_all = (uint32_t*)ws.carve(33 * al(orow * 4));  // level l at off_all + l * ostride
     const size_t ostride = al(orow * 4) / 4;
-    uint32_t* lens = (uint32_t*)ws.carve(orow * 4);
+    (void)ws.carve(orow * 4);   // (reserved)
     uint32_t* d_max = (uint32_t*)ws.carve(64);
     G1Jac* bufA = (G1Jac*)ws.carve((ntasks / 2 + nkeys + 1) * sizeof(G1Jac));
     G1Jac* bufB = (G1Jac*)ws.carve((ntasks / 4 + nkeys + 1) * sizeof(G1Jac));
     if (ws.used > ws.cap) return set_err(GM_ERR_STATE, "G1 scratch under-reserved (%zu > %zu)", ws.used, ws.cap);
 
     GM_HIP(hipMemsetAsync(d_max, 0, 4, s));
-    if (ntasks) {
-        size_t st = L.sort_tmp;
-        GM_HIP(rocprim::radix_sort_pairs(sort_tmp, st, keys, keys_s, idx, idx_s, ntasks, 0, bit_len(nkeys), s));
-    }
+    // stable sort of the tasks by key (sort.hip.h): the sorted arrays end up in the caller's or in the scratch buffers
+    GM_HIP(radix_sort_pairs_u32(keys, idx, keys_s, idx_s, ntasks, bit_len(nkeys), sort_tmp, &keys_s, &idx_s, s));
     hipLaunchKernelGGL(k_g1_lower_bound, dim3(ceil_div(orow, 256)), dim3(256), 0, s, keys_s, ntasks, nkeys, off_all, d_max);
     GM_LAUNCH_CHECK();
     uint32_t max_len = 0;
@@ -446,11 +487,14 @@ static int32_t g1_sum_by_key(G1Scratch& ws, const G1Aff* src_aff, const G1Jac* s
     uint32_t nlev = 0;
     while ((1u << nlev) < max_len) nlev++;
     GM_REQUIRE(nlev <= 32, "row too long");
-    for (uint32_t l = 1; l <= nlev; l++) {
-        hipLaunchKernelGGL(k_g1_level_lens, dim3(ceil_div(orow, 256)), dim3(256), 0, s, off_all, nkeys, l, lens);
+    if (nlev) {
+        const uint32_t ntiles = ceil_div(orow, SCAN_TILE);
+        hipLaunchKernelGGL(k_g1_levels_scan_tiles, dim3(ntiles, nlev), dim3(1024), 0, s, off_all, nkeys, off_all, ostride, scan_tmp);
         GM_LAUNCH_CHECK();
-        size_t sc = L.scan_tmp;
-        GM_HIP(rocprim::exclusive_scan(scan_tmp, sc, lens, off_all + l * ostride, 0u, orow, rocprim::plus<uint32_t>(), s));
+        if (ntiles > 1) {
+            hipLaunchKernelGGL(k_g1_levels_scan_fix, dim3(ntiles, nlev), dim3(1024), 0, s, nkeys, off_all, ostride, scan_tmp);
+            GM_LAUNCH_CHECK();
+        }
     }
     const G1SrcAff sa{src_aff, idx_s};
     const G1SrcJac sj{src_jac, idx_s};
