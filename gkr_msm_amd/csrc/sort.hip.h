@@ -1,39 +1,35 @@
 // Stable radix sort of (key, value) u32 pairs and a plain exclusive scan, for the G1 "sum by key" engine (g1.hip): the
-// histogram / chunk-scan / ballot-ranked scatter scheme of the bucket sort in msm.hip, run once per RS_BITS-bit digit (LSD).
-// Digits are narrow on purpose: a wave then appends to 2^RS_BITS output runs only, and the lines it is filling stay in L2 until
-// they are full (with 8-bit digits every resident wave keeps 256 partial lines open and the scatter writes 4 bytes per line).
-// One wave walks one chunk of RS_CHUNK items in order, so equal keys keep their input order: the association order of the
-// point sums below -- and with it every intermediate Jacobian representative -- is a function of the input alone.
+// histogram / scan / ballot-ranked scatter scheme of the bucket sort in msm.hip, run once per 8-bit digit (LSD).
+// A workgroup owns a tile of RS_TILE consecutive items.  Its four waves rank their quarter of the tile in input order (equal
+// digits found with 8 ballots per 64 items), the tile is regrouped by digit in LDS, and written out digit by digit: items of one
+// digit leave as one run of consecutive words (16 items on average), so the scatter writes whole cache lines instead of 4 bytes
+// per line.  Equal keys keep their input order: the association order of the point sums that follow -- and with it every
+// intermediate Jacobian representative -- is a function of the input alone.
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
 namespace gm {
 
-static constexpr uint32_t RS_CHUNK = 4096;  // items per wave
-static constexpr uint32_t RS_WAVES = 4;     // waves per workgroup
-#ifndef GM_RS_BITS
-#define GM_RS_BITS 5
-#endif
-static constexpr uint32_t RS_BITS = GM_RS_BITS, RS_BINS = 1u << RS_BITS;
+static constexpr uint32_t RS_WAVES = 4;                    // waves per workgroup
+static constexpr uint32_t RS_PER_WAVE = 1024;              // items one wave ranks (16 steps of 64)
+static constexpr uint32_t RS_TILE = RS_WAVES * RS_PER_WAVE;
+static constexpr uint32_t RS_BITS = 8, RS_BINS = 1u << RS_BITS;
 
-// hist[d * nchunks + c] = number of items of chunk c whose digit is d
-__global__ void __launch_bounds__(64 * RS_WAVES) k_rs_hist(const uint32_t* __restrict__ keys, uint64_t n, uint32_t shift, uint32_t nchunks,
+// hist[d * ntiles + t] = number of items of tile t whose digit is d
+__global__ void __launch_bounds__(64 * RS_WAVES) k_rs_hist(const uint32_t* __restrict__ keys, uint64_t n, uint32_t shift, uint32_t ntiles,
                                                           uint32_t* __restrict__ hist) {
-    __shared__ uint32_t cnt_all[RS_WAVES][RS_BINS];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* cnt = cnt_all[wave];
-    const uint64_t c = (uint64_t)blockIdx.x * RS_WAVES + wave;
-    if (c >= nchunks) return;  // whole wave; only wave-level barriers below
-    for (uint32_t i = lane; i < RS_BINS; i += 64) cnt[i] = 0;
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t x0 = c * RS_CHUNK;
-    for (uint32_t i = lane; i < RS_CHUNK; i += 64) {
+    __shared__ uint32_t cnt[RS_BINS];
+    const uint32_t tid = threadIdx.x;
+    cnt[tid] = 0;
+    __syncthreads();
+    const uint64_t x0 = (uint64_t)blockIdx.x * RS_TILE;
+    for (uint32_t i = tid; i < RS_TILE; i += 64 * RS_WAVES) {
         const uint64_t x = x0 + i;
         if (x < n) atomicAdd(&cnt[(keys[x] >> shift) & (RS_BINS - 1)], 1u);
     }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < RS_BINS; i += 64) hist[(uint64_t)i * nchunks + c] = cnt[i];
+    __syncthreads();
+    hist[(uint64_t)tid * ntiles + blockIdx.x] = cnt[tid];
 }
 
 // exclusive scan of `n` counters in place (+ the total at v[n] when with_total); one 1024-thread workgroup
@@ -139,24 +135,33 @@ static inline void exclusive_scan_u32(const uint32_t* src, uint32_t* dst, uint64
 }
 static inline size_t scan_tmp_bytes(uint64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(uint32_t); }
 
-// scatter of one digit pass; base[d * nchunks + c] = first output slot of (digit d, chunk c)
+// scatter of one digit pass; base[d * ntiles + t] = first output slot of (digit d, tile t)
 __global__ void __launch_bounds__(64 * RS_WAVES) k_rs_scatter(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t n,
-                                                             uint32_t shift, uint32_t nchunks, const uint32_t* __restrict__ base) {
-    __shared__ uint32_t cnt_all[RS_WAVES][RS_BINS];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* cnt = cnt_all[wave];
-    const uint64_t c = (uint64_t)blockIdx.x * RS_WAVES + wave;
-    if (c >= nchunks) return;
-    for (uint32_t i = lane; i < RS_BINS; i += 64) cnt[i] = base[(uint64_t)i * nchunks + c];
+                                                             uint32_t shift, uint32_t ntiles, const uint32_t* __restrict__ base) {
+    __shared__ uint32_t cnt[RS_WAVES][RS_BINS];   // per wave: running count of every digit, then its first slot in the tile
+    __shared__ uint32_t dig_start[RS_BINS + 1];   // first slot of every digit in the regrouped tile
+    __shared__ uint32_t gbase[RS_BINS];
+    __shared__ uint32_t st_key[RS_TILE], st_val[RS_TILE];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr uint32_t STEPS = RS_PER_WAVE / 64;
+    for (uint32_t i = lane; i < RS_BINS; i += 64) cnt[wave][i] = 0;
+    gbase[tid] = base[(uint64_t)tid * ntiles + blockIdx.x];
     __builtin_amdgcn_wave_barrier();
     const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const uint64_t x0 = c * RS_CHUNK;
-    for (uint32_t i = 0; i < RS_CHUNK; i += 64) {
-        const uint64_t x = x0 + i + lane;
+    const uint64_t x0 = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)wave * RS_PER_WAVE;
+    uint32_t k[STEPS], v[STEPS], rank[STEPS];
+#pragma unroll
+    for (uint32_t st = 0; st < STEPS; st++) {
+        const uint64_t x = x0 + st * 64 + lane;
         const bool valid = x < n;
-        const uint32_t k = valid ? keys[x] : 0u;
-        const uint32_t dg = (k >> shift) & (RS_BINS - 1);
+        k[st] = valid ? keys[x] : 0xffffffffu;
+        v[st] = valid ? vals[x] : 0u;
+    }
+#pragma unroll
+    for (uint32_t st = 0; st < STEPS; st++) {
+        const bool valid = x0 + st * 64 + lane < n;
+        const uint32_t dg = (k[st] >> shift) & (RS_BINS - 1);
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (uint32_t b = 0; b < RS_BITS; b++) {
@@ -164,21 +169,60 @@ __global__ void __launch_bounds__(64 * RS_WAVES) k_rs_scatter(const uint32_t* __
             peers &= ((dg >> b) & 1u) ? m : ~m;
         }
         const uint32_t before = __popcll(peers & lane_lt);
-        const uint32_t pos = cnt[dg] + before;
+        const uint32_t pos = cnt[wave][dg] + before;
         __builtin_amdgcn_wave_barrier();
-        if (valid && (peers >> lane) == 1ull) cnt[dg] = pos + 1;   // the highest peer lane publishes the new count
+        if (valid && (peers >> lane) == 1ull) cnt[wave][dg] = pos + 1;   // the highest peer lane publishes the new count
         __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            keys_out[pos] = k;
-            vals_out[pos] = vals[x];
+        rank[st] = valid ? pos : 0xffffffffu;
+    }
+    __syncthreads();
+    // thread d: slots of digit d in the regrouped tile, wave after wave (stable), after all smaller digits
+    {
+        uint32_t c[RS_WAVES], tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < RS_WAVES; w++) { c[w] = cnt[w][tid]; tot += c[w]; }
+        // exclusive scan of tot over the 256 digits: wave scan + the four wave totals
+        uint32_t inc = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d, 64);
+            if ((int)lane >= d) inc += t;
         }
+        __shared__ uint32_t wtot[RS_WAVES];
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - tot;
+        for (uint32_t w = 0; w < wave; w++) run += wtot[w];
+        dig_start[tid] = run;
+        if (tid == RS_BINS - 1) dig_start[RS_BINS] = run + tot;
+#pragma unroll
+        for (uint32_t w = 0; w < RS_WAVES; w++) { cnt[w][tid] = run; run += c[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t st = 0; st < STEPS; st++) {
+        if (rank[st] != 0xffffffffu) {
+            const uint32_t dg = (k[st] >> shift) & (RS_BINS - 1);
+            const uint32_t p = cnt[wave][dg] + rank[st];
+            st_key[p] = k[st];
+            st_val[p] = v[st];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = dig_start[RS_BINS];
+    for (uint32_t p = tid; p < total; p += 64 * RS_WAVES) {
+        const uint32_t key = st_key[p];
+        const uint32_t dg = (key >> shift) & (RS_BINS - 1);
+        const uint32_t pos = gbase[dg] + (p - dig_start[dg]);
+        keys_out[pos] = key;
+        vals_out[pos] = st_val[p];
     }
 }
 
 // bytes of histogram scratch for n items
 static inline size_t radix_sort_tmp_bytes(uint64_t n) {
-    const uint64_t nchunks = (n + RS_CHUNK - 1) / RS_CHUNK;
-    const uint64_t entries = (uint64_t)RS_BINS * (nchunks ? nchunks : 1) + 1;
+    const uint64_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+    const uint64_t entries = (uint64_t)RS_BINS * (ntiles ? ntiles : 1) + 1;
     return (size_t)entries * sizeof(uint32_t) + scan_tmp_bytes(entries);
 }
 
@@ -188,12 +232,11 @@ static inline hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a
                                               uint32_t bits, uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t s) {
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
     if (n) {
-        const uint32_t nchunks = (uint32_t)((n + RS_CHUNK - 1) / RS_CHUNK);
-        const unsigned blocks = (nchunks + RS_WAVES - 1) / RS_WAVES;
+        const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
         for (uint32_t shift = 0; shift < (bits ? bits : 1); shift += RS_BITS) {
-            hipLaunchKernelGGL(k_rs_hist, dim3(blocks), dim3(64 * RS_WAVES), 0, s, ki, n, shift, nchunks, tmp);
-            exclusive_scan_u32(tmp, tmp, (uint64_t)RS_BINS * nchunks, 0, tmp + (uint64_t)RS_BINS * nchunks + 1, s);
-            hipLaunchKernelGGL(k_rs_scatter, dim3(blocks), dim3(64 * RS_WAVES), 0, s, ki, vi, ko, vo, n, shift, nchunks, tmp);
+            hipLaunchKernelGGL(k_rs_hist, dim3(ntiles), dim3(64 * RS_WAVES), 0, s, ki, n, shift, ntiles, tmp);
+            exclusive_scan_u32(tmp, tmp, (uint64_t)RS_BINS * ntiles, 0, tmp + (uint64_t)RS_BINS * ntiles + 1, s);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles), dim3(64 * RS_WAVES), 0, s, ki, vi, ko, vo, n, shift, ntiles, tmp);
             uint32_t* t;
             t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;
