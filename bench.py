@@ -37,7 +37,8 @@ from gkr_msm_amd import codec, ffi, harness  # noqa: E402
 from gkr_msm_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FR_MUL_CEILING = 115e9     # measured: scripts/ubench/instr_rate.hip, 302-instruction multiplier, all 256 CUs
+FR_MUL_CEILING = 115e9     # measured: scripts/ubench/fr_mul_asm_test.hip, the 302-instruction 8 x 32-bit multiplier the sumcheck kernels use, all 256 CUs
+FR9_MUL_CEILING = 150e9    # measured: scripts/ubench/fr9_mul_test.hip, the 205-instruction 9 x 29-bit multiplier the MSM level kernels use
 P = codec.P
 SEED = 0x474B524D534D      # "GKRMSM"
 
@@ -304,7 +305,7 @@ def main():
                         "traffic": PMC_TRAFFIC_MSM_B if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None,
                         "avg_launch_ms": round(dom, 4), "algorithmic_bytes_per_launch": alg_bytes, "fr_mul_per_launch": fr_mul0,
                         "fr_mul_per_s": round(fr_mul0 / (dom * 1e-3), 1),
-                        "valu_frac_of_measured_ceiling": round(fr_mul0 / (dom * 1e-3) / FR_MUL_CEILING, 3)}
+                        "valu_frac_of_measured_ceiling": round(fr_mul0 / (dom * 1e-3) / FR9_MUL_CEILING, 3)}
             # In the timed loop the kernel shares the chip with the late, latency-bound levels of the previous step (other
             # stream): that overlap shortens the step and lengthens this launch.  The same launch with the chip to itself
             # (the untimed stage-breakdown pass below):
@@ -313,7 +314,7 @@ def main():
                 roofline["unoverlapped"] = {"launch_ms": alone, "achieved": round(alg_bytes / (alone * 1e-3) / 1e9, 1),
                                             "frac": round(alg_bytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                             "fr_mul_per_s": round(fr_mul0 / (alone * 1e-3), 1),
-                                            "valu_frac_of_measured_ceiling": round(fr_mul0 / (alone * 1e-3) / FR_MUL_CEILING, 3)}
+                                            "valu_frac_of_measured_ceiling": round(fr_mul0 / (alone * 1e-3) / FR9_MUL_CEILING, 3)}
         res = {"x_logsize": x_log, "value": round(n * steps / dt, 1), "ms_per_step": round(ms_per_step, 4), "roofline": roofline,
                "stage_ms": stages, "result_x": hex(result[0]),
                # SURVEY 8(d)'s whole-MSM unit: 96 B of compulsory HBM traffic per point (64 B point + 32 B scalar)
@@ -321,7 +322,7 @@ def main():
                              "frac_of_hbm_peak": round(96 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "fr_mul_per_step_per_gpu": fr_mul_step,
                              "fr_mul_per_s_per_gpu": round(fr_mul_step / (ms_per_step * 1e-3), 1),
-                             "valu_frac_of_measured_ceiling": round(fr_mul_step / (ms_per_step * 1e-3) / FR_MUL_CEILING, 3),
+                             "valu_frac_of_measured_ceiling": round(fr_mul_step / (ms_per_step * 1e-3) / FR9_MUL_CEILING, 3),
                              "bound": "integer VALU (8-12 Fr multiplications per bucket add; MFMA not applicable)"}}
         if bcast_ms is not None:
             res["operand_broadcast_ms"] = round(bcast_ms, 2)
