@@ -241,6 +241,52 @@ __device__ __forceinline__ Fr9 fr9_sub2_32(const Fr9& a, const Fr9& b, const Fr9
     return r;
 }
 
+// ---- the unshifted view: the limbs of X itself (value x 2^256 mod p, "domain 256").  A product of a domain-d value and a
+// domain-e value is a domain-(d + e - 261) value, so formulas whose terms are homogeneous in their inputs can work on raw loads
+// (S = 1, no conversion at all) and fix the domain once, with a constant, at the very end.  L = 2^29, S = 1.
+__device__ __forceinline__ Fr9 fr9_from_raw(const Fr& x) {
+    Fr9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int s = 29 * i, w = s >> 5, off = s & 31;
+        const uint32_t lo = x.l[w], hi = (w + 1 < 8) ? x.l[w + 1] : 0u;
+        r.l[i] = (off ? __builtin_amdgcn_alignbit(hi, lo, off) : lo) & M29;
+    }
+    return r;
+}
+__device__ __forceinline__ Fr9 fr9_load_raw(const Fr* p) { return fr9_from_raw(fr_load(p)); }
+// normalised limbs (< 2^29, top limb what is left), value < 2 p, already in domain 256  ->  canonical 8 x 32
+__device__ __forceinline__ Fr fr9_to_raw(const Fr9& z) {
+    Fr w;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int s = 32 * j, i0 = s / 29, o0 = s % 29;
+        uint32_t v = z.l[i0] >> o0;
+        int have = 29 - o0;
+        if (i0 + 1 < 9) { v |= z.l[i0 + 1] << have; have += 29; }
+        if (have < 32 && i0 + 2 < 9) v |= z.l[i0 + 2] << have;
+        w.l[j] = v;
+    }
+    return fr_reduce_once(w);
+}
+// constants as raw limbs
+__device__ __forceinline__ Fr9 fr9_const(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6,
+                                         uint32_t a7, uint32_t a8) {
+    Fr9 r;
+    r.l[0] = a0; r.l[1] = a1; r.l[2] = a2; r.l[3] = a3; r.l[4] = a4; r.l[5] = a5; r.l[6] = a6; r.l[7] = a7; r.l[8] = a8;
+    return r;
+}
+// 2^256 mod p (the field's one in domain 256), 2^271 mod p, 2^276 mod p
+__device__ __forceinline__ Fr9 fr9_one256() {
+    return fr9_const(0x1ffffffeu, 0x0000000fu, 0x00d20080u, 0x096ff400u, 0x04ff5588u, 0x07f7f65eu, 0x15be6631u, 0x0b3598a0u, 0x001824b1u);
+}
+__device__ __forceinline__ Fr9 fr9_two271() {
+    return fr9_const(0x1ffee558u, 0x0008d53fu, 0x0f2eaa00u, 0x0220139fu, 0x05e4224eu, 0x100eb2eau, 0x00c2a845u, 0x12a69488u, 0x0021b895u);
+}
+__device__ __forceinline__ Fr9 fr9_two276() {
+    return fr9_const(0x1fdcaaf7u, 0x011aa847u, 0x09864240u, 0x0e7a3defu, 0x13014aa7u, 0x15b231edu, 0x1a2dd48du, 0x1743bfd3u, 0x0023b7d0u);
+}
+
 __device__ __forceinline__ Fr9 fr9_zero() {
     Fr9 r;
 #pragma unroll

@@ -21,6 +21,7 @@
 
 #include "internal.hpp"
 #include "ragged.hip.h"
+#include "fr9.hip.h"
 #include "vecvec.hpp"
 
 namespace gm {
@@ -853,6 +854,110 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
     block_reduce_finish<NACC>(acc, fc);
 }
 
+// ---- the same large rounds in the 9 x 29-bit form (fr9.hip.h).  Inputs are loaded raw (the limbs of the stored value: domain
+// 256, S = 1 -- no conversion); every term of these layer functions is a product of exactly two inputs, so all of them land in
+// domain 251, the gamma powers are loaded in domain 261 (shifted loads: g x term stays in 251), the weight brings the
+// accumulators to domain 241 (VecVec: eq x coef) or 246 (dense), and ONE multiplication by 2^276 / 2^271 per thread at the end
+// returns to the stored form.  Same field values as k_round_deg2_lean, bit for bit (the sums are canonicalised before the block
+// reduction).  Bounds per line: L = limb bound, S = value / p (2^261 / p = 70.66).
+// Measured at config B (bench.py, ms per proof over the large launches, 9 x 29 vs 8 x 32): AFF_L3 3.01 vs 3.26, PROJ_L2 5.10 vs
+// 5.26, PROJ_L3 4.98 vs 5.12 -- but PROJ_L1 8.02 vs 6.35 and AFF_L1+BITCHECK 6.63 vs 5.24: six inputs of nine registers each
+// push those two to 256 VGPRs (one wave per SIMD).  The form is therefore used for the three- and four-input primitives only;
+// GM_LEAN_FR9=all forces it everywhere (tests), GM_LEAN_FR9=0 nowhere.
+__host__ __device__ constexpr bool lean9_has(int prim) {
+    return prim == FN_PROJ_L1 || prim == FN_PROJ_L2 || prim == FN_PROJ_L3 || prim == FN_AFF_L1 || prim == LEAN_AFF_L1_BC || prim == FN_AFF_L3;
+}
+__host__ __device__ constexpr bool lean9_pays(int prim) { return prim == FN_PROJ_L2 || prim == FN_PROJ_L3 || prim == FN_AFF_L3; }
+// v[q]: L 2^29, S <= 10, domain 256.  Result: domain 251, L <= 5 2^29, S <= 30.
+template <int PRIM>
+__device__ __forceinline__ Fr9 lean_gamma_eval9(const Fr9* v, const Fr* __restrict__ g) {
+    if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
+        Fr9 A = fr9_mul(v[0], v[3]);                                                      // S 2.42
+        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v[2], v[1])));                    // g: S 32; product S 2.1
+        const Fr9 t = fr9_add(fr9_mul(v[1], v[3]), fr9_mul5(fr9_mul(v[0], v[2])));        // - a = 5: L 6 2^29, S 14.5
+        A = fr9_add(A, fr9_mul(fr9_load(g + 2), t));                                      // 2^29 x 6 2^29; S 7.6
+        if (PRIM == LEAN_AFF_L1_BC) {
+            // b^2 - b = b (b - 1): (b - 1 + 8 p) normalised has S 18, the product S 3.5, times gamma S 2.6
+            const Fr9 b4 = fr9_mul(v[4], fr9_norm(fr9_sub8(v[4], fr9_one256())));
+            A = fr9_add(A, fr9_mul(fr9_load(g + 3), b4));
+            const Fr9 b5 = fr9_mul(v[5], fr9_norm(fr9_sub8(v[5], fr9_one256())));
+            A = fr9_add(A, fr9_mul(fr9_load(g + 4), b5));
+        }
+        return A;
+    } else if (PRIM == FN_AFF_L3 || PRIM == FN_PROJ_L3) {
+        const Fr9 dxy = fr9_mul(v[PRIM == FN_AFF_L3 ? 2 : 3], fr9_coeff_d());            // d in domain 261: dxy in 256, S 1.14
+        const Fr9 base = PRIM == FN_AFF_L3 ? fr9_one256() : v[2];
+        const Fr9 m = fr9_norm(fr9_sub8(base, dxy));                                      // S 18
+        const Fr9 q = fr9_add(base, dxy);                                                 // L 2^30, S 11.2
+        Fr9 A = fr9_mul(m, v[0]);                                                         // S 3.5
+        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(q, v[1])));                       // 2^30 x 2^29; S 2.6 -> 2.2
+        return fr9_add(A, fr9_mul(fr9_load(g + 2), fr9_mul(m, q)));                       // S 3.9 -> 2.8
+    } else if (PRIM == FN_PROJ_L1) {
+        Fr9 A = fr9_mul(v[0], v[4]);
+        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v[3], v[1])));
+        const Fr9 t = fr9_add(fr9_mul(v[1], v[4]), fr9_mul5(fr9_mul(v[0], v[3])));        // L 6 2^29, S 14.5
+        A = fr9_add(A, fr9_mul(fr9_load(g + 2), t));
+        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(v[2], v[5])));                 // L 4 2^29, S 14.2
+    } else {  // FN_PROJ_L2
+        Fr9 A = fr9_mul(fr9_add(v[0], v[1]), v[3]);                                       // 2^30 x 2^29; S 3.8
+        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v[2], v[3])));
+        A = fr9_add(A, fr9_mul(fr9_load(g + 2), fr9_sqr(v[3])));
+        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(v[0], v[1])));                 // L 4 2^29, S 10.1
+    }
+}
+
+template <int PRIM, bool VECVEC>
+__global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean9(LeanCols cols, const Fr* __restrict__ eq, const Fr* __restrict__ gp,
+                                                                  uint64_t npairs_dense, VVArgs vv, FinishCtx fc) {
+    constexpr int NACC = VECVEC ? 3 : 2;
+    constexpr int NI = lean_n_in(PRIM);
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    if (VECVEC) {
+        for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
+            const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+        }
+    }
+    Fr9 a0 = fr9_zero(), a1 = fr9_zero();   // domain 241 (VecVec) / 246 (dense); normalised, S grows by <= 1.5 per pair
+    uint32_t it = 0;
+    const uint64_t npairs = VECVEC ? (uint64_t)(vv.off[vv.nrows] >> 1) : npairs_dense;
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS, it++) {
+        Fr9 w;
+        if (VECVEC) {
+            const uint32_t cell0 = (uint32_t)(2 * i);
+            const uint32_t r = vv.coarse ? find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0) : find_row(vv.off, vv.nrows, cell0);
+            w = fr9_mul(fr9_load_raw(eq + ((cell0 - vv.off[r]) >> 1)), fr9_load_raw(vv.row_coef + r));   // domain 251, S 1.02
+        } else {
+            w = fr9_load_raw(eq + i);                                                                      // domain 256, S 1
+        }
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            Fr9 v[NI];
+#pragma unroll
+            for (int q = 0; q < NI; q++) {
+                const Fr9 p1 = fr9_load_raw(cols.p[q] + 2 * i + 1);
+                if (h) {
+                    const Fr9 p0 = fr9_load_raw(cols.p[q] + 2 * i);
+                    v[q] = fr9_norm(fr9_sub8(fr9_add(p1, p1), p0));     // 2 p1 - p0 + 8 p: S 10
+                } else {
+                    v[q] = p1;
+                }
+            }
+            const Fr9 t = fr9_mul(lean_gamma_eval9<PRIM>(v, gp), w);    // L <= 5 2^29 x 2^29; S <= 30 x 1.02 / 70.66 + 1 = 1.5
+            if (h == 0) a0 = fr9_norm(fr9_add(a0, t)); else a1 = fr9_norm(fr9_add(a1, t));
+        }
+        if ((it & 15u) == 15u) {   // S <= 16 x 3 + 2: back below 2 (times one in domain 261 keeps the domain)
+            a0 = fr9_mul(a0, fr9_one());
+            a1 = fr9_mul(a1, fr9_one());
+        }
+    }
+    // back to the stored form: domain 241 / 246 times 2^276 / 2^271 (domain-free integers) = domain 256; S <= 50 / 70.66 + 1 < 2
+    const Fr9 K = VECVEC ? fr9_two276() : fr9_two271();
+    acc[0] = fr9_to_raw(fr9_mul(a0, K));
+    acc[1] = fr9_to_raw(fr9_mul(a1, K));
+    block_reduce_finish<NACC>(acc, fc);
+}
+
 // generic degree-3 round of F = eq * GammaWrapper(f) (same contract as k_round_generic<3, false>, kind 0); cols.p[NI] = eq
 template <int PRIM>
 __global__ void __launch_bounds__(SC_THREADS) k_round_generic3_lean(LeanCols cols, const Fr* __restrict__ gp, uint64_t npairs,
@@ -1545,6 +1650,18 @@ static int32_t launch_deg2_lean(int prim, dim3 grid, hipStream_t s, const LeanCo
                                 const VVArgs& va, const FinishCtx& fc) {
 #define GM_LEAN_CASE(P)                                                                                                  \
     case P: hipLaunchKernelGGL((k_round_deg2_lean<P, VECVEC>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, npairs, va, fc); break;
+    static const int use9 = [] { const char* e = getenv("GM_LEAN_FR9"); return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1)); }();
+    if (use9 && lean9_has(prim) && (use9 == 2 || lean9_pays(prim))) {
+#define GM_LEAN9_CASE(P)                                                                                                 \
+    case P: hipLaunchKernelGGL((k_round_deg2_lean9<P, VECVEC>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, npairs, va, fc); break;
+        switch (prim) {
+            GM_LEAN9_CASE(FN_AFF_L1) GM_LEAN9_CASE(FN_AFF_L3) GM_LEAN9_CASE(FN_PROJ_L1) GM_LEAN9_CASE(FN_PROJ_L2)
+            GM_LEAN9_CASE(FN_PROJ_L3) GM_LEAN9_CASE(LEAN_AFF_L1_BC)
+        }
+#undef GM_LEAN9_CASE
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
     switch (prim) {
         GM_LEAN_CASE(FN_AFF_L1) GM_LEAN_CASE(FN_AFF_L2) GM_LEAN_CASE(FN_AFF_L3) GM_LEAN_CASE(FN_PROJ_L1)
         GM_LEAN_CASE(FN_PROJ_L2) GM_LEAN_CASE(FN_PROJ_L3) GM_LEAN_CASE(FN_PT_BIT_CHOICE) GM_LEAN_CASE(LEAN_AFF_L1_BC)
