@@ -860,49 +860,75 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
 // accumulators to domain 241 (VecVec: eq x coef) or 246 (dense), and ONE multiplication by 2^276 / 2^271 per thread at the end
 // returns to the stored form.  Same field values as k_round_deg2_lean, bit for bit (the sums are canonicalised before the block
 // reduction).  Bounds per line: L = limb bound, S = value / p (2^261 / p = 70.66).
-// Measured at config B (bench.py, ms per proof over the large launches, 9 x 29 vs 8 x 32): AFF_L3 3.01 vs 3.26, PROJ_L2 5.10 vs
-// 5.26, PROJ_L3 4.98 vs 5.12 -- but PROJ_L1 8.02 vs 6.35 and AFF_L1+BITCHECK 6.63 vs 5.24: six inputs of nine registers each
-// push those two to 256 VGPRs (one wave per SIMD).  The form is therefore used for the three- and four-input primitives only;
-// GM_LEAN_FR9=all forces it everywhere (tests), GM_LEAN_FR9=0 nowhere.
+// Measured at config B (bench.py, ms per proof over the large launches, 9 x 29 vs 8 x 32): PROJ_L1 6.03 vs 6.25, PROJ_L2 5.10 vs
+// 5.22, PROJ_L3 4.65 vs 5.12, AFF_L1+BITCHECK 4.42 vs 5.13, AFF_L3 2.88 vs 3.26; gen-1 at 2^20 points: 353 vs 368 ms.
+// GM_LEAN_FR9=0 switches the form off (A/B measurements).
 __host__ __device__ constexpr bool lean9_has(int prim) {
     return prim == FN_PROJ_L1 || prim == FN_PROJ_L2 || prim == FN_PROJ_L3 || prim == FN_AFF_L1 || prim == LEAN_AFF_L1_BC || prim == FN_AFF_L3;
 }
-__host__ __device__ constexpr bool lean9_pays(int prim) { return prim == FN_PROJ_L2 || prim == FN_PROJ_L3 || prim == FN_AFF_L3; }
-// v[q]: L 2^29, S <= 10, domain 256.  Result: domain 251, L <= 5 2^29, S <= 30.
-template <int PRIM>
-__device__ __forceinline__ Fr9 lean_gamma_eval9(const Fr9* v, const Fr* __restrict__ g) {
+// ld(q): input q at the evaluation point -- L 2^29, S <= 10, domain 256; loaded (and, at the second point, formed from the pair)
+// when the formula first needs it, in an order that keeps at most three inputs live: nine registers per value is what pushed the
+// six-input primitives to 256 VGPRs when all inputs were loaded up front.  Result: domain 251, L <= 5 2^29, S <= 30.
+template <int PRIM, typename LD>
+__device__ __forceinline__ Fr9 lean_gamma_eval9(const LD& ld, const Fr* __restrict__ g) {
     if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
-        Fr9 A = fr9_mul(v[0], v[3]);                                                      // S 2.42
-        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v[2], v[1])));                    // g: S 32; product S 2.1
-        const Fr9 t = fr9_add(fr9_mul(v[1], v[3]), fr9_mul5(fr9_mul(v[0], v[2])));        // - a = 5: L 6 2^29, S 14.5
+        // v0 v3 + g1 v2 v1 + g2 (v1 v3 + 5 v0 v2) [+ g3 (v4^2 - v4) + g4 (v5^2 - v5)]
+        Fr9 A, t;
+        {
+            const Fr9 v3 = ld(3), v2 = ld(2);
+            {
+                const Fr9 v0 = ld(0);
+                A = fr9_mul(v0, v3);                                                      // S 2.42
+                t = fr9_mul5(fr9_mul(v0, v2));                                            // - a = 5: L 5 2^29, S 12.1
+            }
+            const Fr9 v1 = ld(1);
+            t = fr9_add(t, fr9_mul(v1, v3));                                              // L 6 2^29, S 14.5
+            A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v2, v1)));                    // g: S 32; product S 2.1
+        }
         A = fr9_add(A, fr9_mul(fr9_load(g + 2), t));                                      // 2^29 x 6 2^29; S 7.6
         if (PRIM == LEAN_AFF_L1_BC) {
             // b^2 - b = b (b - 1): (b - 1 + 8 p) normalised has S 18, the product S 3.5, times gamma S 2.6
-            const Fr9 b4 = fr9_mul(v[4], fr9_norm(fr9_sub8(v[4], fr9_one256())));
-            A = fr9_add(A, fr9_mul(fr9_load(g + 3), b4));
-            const Fr9 b5 = fr9_mul(v[5], fr9_norm(fr9_sub8(v[5], fr9_one256())));
-            A = fr9_add(A, fr9_mul(fr9_load(g + 4), b5));
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const Fr9 b = ld(4 + k);
+                A = fr9_add(A, fr9_mul(fr9_load(g + 3 + k), fr9_mul(b, fr9_norm(fr9_sub8(b, fr9_one256())))));
+            }
         }
         return A;
     } else if (PRIM == FN_AFF_L3 || PRIM == FN_PROJ_L3) {
-        const Fr9 dxy = fr9_mul(v[PRIM == FN_AFF_L3 ? 2 : 3], fr9_coeff_d());            // d in domain 261: dxy in 256, S 1.14
-        const Fr9 base = PRIM == FN_AFF_L3 ? fr9_one256() : v[2];
+        const Fr9 dxy = fr9_mul(ld(PRIM == FN_AFF_L3 ? 2 : 3), fr9_coeff_d());           // d in domain 261: dxy in 256, S 1.14
+        const Fr9 base = PRIM == FN_AFF_L3 ? fr9_one256() : ld(2);
         const Fr9 m = fr9_norm(fr9_sub8(base, dxy));                                      // S 18
         const Fr9 q = fr9_add(base, dxy);                                                 // L 2^30, S 11.2
-        Fr9 A = fr9_mul(m, v[0]);                                                         // S 3.5
-        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(q, v[1])));                       // 2^30 x 2^29; S 2.6 -> 2.2
+        Fr9 A = fr9_mul(m, ld(0));                                                        // S 3.5
+        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(q, ld(1))));                      // 2^30 x 2^29; S 2.6 -> 2.2
         return fr9_add(A, fr9_mul(fr9_load(g + 2), fr9_mul(m, q)));                       // S 3.9 -> 2.8
     } else if (PRIM == FN_PROJ_L1) {
-        Fr9 A = fr9_mul(v[0], v[4]);
-        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v[3], v[1])));
-        const Fr9 t = fr9_add(fr9_mul(v[1], v[4]), fr9_mul5(fr9_mul(v[0], v[3])));        // L 6 2^29, S 14.5
+        // v0 v4 + g1 v3 v1 + g2 (v1 v4 + 5 v0 v3) + g3 v2 v5
+        Fr9 A, t;
+        {
+            const Fr9 v3 = ld(3), v4 = ld(4);
+            {
+                const Fr9 v0 = ld(0);
+                A = fr9_mul(v0, v4);
+                t = fr9_mul5(fr9_mul(v0, v3));
+            }
+            const Fr9 v1 = ld(1);
+            t = fr9_add(t, fr9_mul(v1, v4));                                              // L 6 2^29, S 14.5
+            A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v3, v1)));
+        }
         A = fr9_add(A, fr9_mul(fr9_load(g + 2), t));
-        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(v[2], v[5])));                 // L 4 2^29, S 14.2
-    } else {  // FN_PROJ_L2
-        Fr9 A = fr9_mul(fr9_add(v[0], v[1]), v[3]);                                       // 2^30 x 2^29; S 3.8
-        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v[2], v[3])));
-        A = fr9_add(A, fr9_mul(fr9_load(g + 2), fr9_sqr(v[3])));
-        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(v[0], v[1])));                 // L 4 2^29, S 10.1
+        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(ld(2), ld(5))));               // L 4 2^29, S 14.2
+    } else {  // FN_PROJ_L2: (v0 + v1) v3 + g1 v2 v3 + g2 v3^2 + g3 v0 v1
+        Fr9 A;
+        const Fr9 v0 = ld(0), v1 = ld(1);
+        {
+            const Fr9 v3 = ld(3);
+            A = fr9_mul(fr9_add(v0, v1), v3);                                             // 2^30 x 2^29; S 3.8
+            A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(ld(2), v3)));
+            A = fr9_add(A, fr9_mul(fr9_load(g + 2), fr9_sqr(v3)));
+        }
+        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(v0, v1)));                     // L 4 2^29, S 10.1
     }
 }
 
@@ -910,7 +936,6 @@ template <int PRIM, bool VECVEC>
 __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean9(LeanCols cols, const Fr* __restrict__ eq, const Fr* __restrict__ gp,
                                                                   uint64_t npairs_dense, VVArgs vv, FinishCtx fc) {
     constexpr int NACC = VECVEC ? 3 : 2;
-    constexpr int NI = lean_n_in(PRIM);
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
     if (VECVEC) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
@@ -932,18 +957,13 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean9(LeanCols cols, 
         }
 #pragma unroll 1
         for (int h = 0; h < 2; h++) {
-            Fr9 v[NI];
-#pragma unroll
-            for (int q = 0; q < NI; q++) {
+            auto ld = [&](int q) -> Fr9 {
                 const Fr9 p1 = fr9_load_raw(cols.p[q] + 2 * i + 1);
-                if (h) {
-                    const Fr9 p0 = fr9_load_raw(cols.p[q] + 2 * i);
-                    v[q] = fr9_norm(fr9_sub8(fr9_add(p1, p1), p0));     // 2 p1 - p0 + 8 p: S 10
-                } else {
-                    v[q] = p1;
-                }
-            }
-            const Fr9 t = fr9_mul(lean_gamma_eval9<PRIM>(v, gp), w);    // L <= 5 2^29 x 2^29; S <= 30 x 1.02 / 70.66 + 1 = 1.5
+                if (!h) return p1;
+                const Fr9 p0 = fr9_load_raw(cols.p[q] + 2 * i);
+                return fr9_norm(fr9_sub8(fr9_add(p1, p1), p0));         // 2 p1 - p0 + 8 p: S 10
+            };
+            const Fr9 t = fr9_mul(lean_gamma_eval9<PRIM>(ld, gp), w);   // L <= 5 2^29 x 2^29; S <= 30 x 1.02 / 70.66 + 1 = 1.5
             if (h == 0) a0 = fr9_norm(fr9_add(a0, t)); else a1 = fr9_norm(fr9_add(a1, t));
         }
         if ((it & 15u) == 15u) {   // S <= 16 x 3 + 2: back below 2 (times one in domain 261 keeps the domain)
@@ -1650,8 +1670,8 @@ static int32_t launch_deg2_lean(int prim, dim3 grid, hipStream_t s, const LeanCo
                                 const VVArgs& va, const FinishCtx& fc) {
 #define GM_LEAN_CASE(P)                                                                                                  \
     case P: hipLaunchKernelGGL((k_round_deg2_lean<P, VECVEC>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, npairs, va, fc); break;
-    static const int use9 = [] { const char* e = getenv("GM_LEAN_FR9"); return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1)); }();
-    if (use9 && lean9_has(prim) && (use9 == 2 || lean9_pays(prim))) {
+    static const bool use9 = [] { const char* e = getenv("GM_LEAN_FR9"); return !(e && e[0] == '0'); }();
+    if (use9 && lean9_has(prim)) {
 #define GM_LEAN9_CASE(P)                                                                                                 \
     case P: hipLaunchKernelGGL((k_round_deg2_lean9<P, VECVEC>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, npairs, va, fc); break;
         switch (prim) {

@@ -83,6 +83,7 @@ int main() {
         printf("9x29 x2  : %.3f ms  %.1f G mul/s\n", ms, muls / ms / 1e6);
     }
     hipMemcpy(h1, o1, 4096 * 32, hipMemcpyDeviceToHost); hipMemcpy(h2, o2, 4096 * 32, hipMemcpyDeviceToHost);
-    printf("chain results equal: %s\n", memcmp(h1, h2, 4096 * 32) ? "NO" : "yes");
-    return bad != 0 || bad3 != 0;
+    const int chain_bad = memcmp(h1, h2, 4096 * 32) != 0;
+    printf("chain results equal: %s\n", chain_bad ? "NO" : "yes");
+    return bad != 0 || bad3 != 0 || chain_bad;
 }
