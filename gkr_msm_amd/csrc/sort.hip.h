@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64 * RS_WAVES) k_rs_scatter(const uint32_t* __
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr uint32_t STEPS = RS_PER_WAVE / 64;
     for (uint32_t i = lane; i < RS_BINS; i += 64) cnt[wave][i] = 0;
-    gbase[tid] = base[(uint64_t)tid * ntiles + blockIdx.x];
+    if (base) gbase[tid] = base[(uint64_t)tid * ntiles + blockIdx.x];
     __builtin_amdgcn_wave_barrier();
     const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const uint64_t x0 = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)wave * RS_PER_WAVE;
@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(64 * RS_WAVES) k_rs_scatter(const uint32_t* __
         uint32_t run = inc - tot;
         for (uint32_t w = 0; w < wave; w++) run += wtot[w];
         dig_start[tid] = run;
+        if (!base) gbase[tid] = run;   // a single tile is its own histogram: slot of digit d = its slot in the regrouped tile
         if (tid == RS_BINS - 1) dig_start[RS_BINS] = run + tot;
 #pragma unroll
         for (uint32_t w = 0; w < RS_WAVES; w++) { cnt[w][tid] = run; run += c[w]; }
@@ -234,9 +235,12 @@ static inline hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a
     if (n) {
         const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
         for (uint32_t shift = 0; shift < (bits ? bits : 1); shift += RS_BITS) {
-            hipLaunchKernelGGL(k_rs_hist, dim3(ntiles), dim3(64 * RS_WAVES), 0, s, ki, n, shift, ntiles, tmp);
-            exclusive_scan_u32(tmp, tmp, (uint64_t)RS_BINS * ntiles, 0, tmp + (uint64_t)RS_BINS * ntiles + 1, s);
-            hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles), dim3(64 * RS_WAVES), 0, s, ki, vi, ko, vo, n, shift, ntiles, tmp);
+            if (ntiles > 1) {
+                hipLaunchKernelGGL(k_rs_hist, dim3(ntiles), dim3(64 * RS_WAVES), 0, s, ki, n, shift, ntiles, tmp);
+                exclusive_scan_u32(tmp, tmp, (uint64_t)RS_BINS * ntiles, 0, tmp + (uint64_t)RS_BINS * ntiles + 1, s);
+            }
+            hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles), dim3(64 * RS_WAVES), 0, s, ki, vi, ko, vo, n, shift, ntiles,
+                               ntiles > 1 ? (const uint32_t*)tmp : (const uint32_t*)nullptr);
             uint32_t* t;
             t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;
