@@ -79,6 +79,71 @@ inline void seg_plan_exec_host(const SegPlan& sp, const Fr* in, Fr* out) {
     }
 }
 
+// ---- term split (the persistent stage kernel, sumcheck.hip).  The gamma-combined layer function sum_o gamma^o f_o(v) of a
+// twisted-Edwards layer is a sum of a few products, and any partition of the products over workgroups gives the same round sums
+// (the cross-block reduction adds them up, exactly).  A "part" is a pseudo-segment that evaluates one share of a segment's
+// products from the inputs those products need: a lone wave needs ~0.6 us per dependent multiplication, so cutting a segment's
+// chain of 9 multiplications (and 6 folds per round) into parts of 2-3 (and 2-3 folds) is what shortens a small round.
+// Part segments: prim = FN_P_*, in[] = the inputs the part reads (indices into the plan's columns), out0 = the out0 of the
+// segment they come from (gamma index base), n_out unused.
+enum {
+    FN_P_PROJ_L1_A = 64,  // v0 (G0 v4 + 5 G2 v3)            in: v0, v3, v4
+    FN_P_PROJ_L1_B = 65,  // v1 (G1 v3 + G2 v4)              in: v1, v3, v4
+    FN_P_PROJ_L1_C = 66,  // G3 v2 v5                        in: v2, v5
+    FN_P_PROJ_L2_A = 67,  // G0 (v0 + v1) v3 + G3 v0 v1      in: v0, v1, v3
+    FN_P_PROJ_L2_B = 68,  // v3 (G1 v2 + G2 v3)              in: v2, v3
+    FN_P_PROJ_L3_A = 69,  // G0 m v0                         in: v0, v2, v3      (m = v2 - d v3, q = v2 + d v3)
+    FN_P_PROJ_L3_B = 70,  // G1 q v1                         in: v1, v2, v3
+    FN_P_PROJ_L3_C = 71,  // G2 m q                          in: v2, v3
+    FN_P_AFF_L1_A = 72,   // v0 (G0 v3 + 5 G2 v2)            in: v0, v2, v3
+    FN_P_AFF_L1_B = 73,   // v1 (G1 v2 + G2 v3)              in: v1, v2, v3
+    FN_P_AFF_L3_A = 74,   // G0 m v0                         in: v0, v2          (m = 1 - d v2, q = 1 + d v2)
+    FN_P_AFF_L3_B = 75,   // G1 q v1                         in: v1, v2
+    FN_P_AFF_L3_C = 76,   // G2 m q                          in: v2
+};
+GM_HD bool prim_is_part(int prim) { return prim >= 64; }
+
+// the plan with every splittable segment replaced by its parts; false (and *out untouched) when nothing splits or it does not fit
+inline bool seg_plan_split_terms(const SegPlan& sp, SegPlan* out) {
+    struct PartDef { int prim, n_in, in[3]; };
+    static const PartDef P_L1[3] = {{FN_P_PROJ_L1_A, 3, {0, 3, 4}}, {FN_P_PROJ_L1_B, 3, {1, 3, 4}}, {FN_P_PROJ_L1_C, 2, {2, 5, 0}}};
+    static const PartDef P_L2[2] = {{FN_P_PROJ_L2_A, 3, {0, 1, 3}}, {FN_P_PROJ_L2_B, 2, {2, 3, 0}}};
+    static const PartDef P_L3[3] = {{FN_P_PROJ_L3_A, 3, {0, 2, 3}}, {FN_P_PROJ_L3_B, 3, {1, 2, 3}}, {FN_P_PROJ_L3_C, 2, {2, 3, 0}}};
+    static const PartDef A_L1[2] = {{FN_P_AFF_L1_A, 3, {0, 2, 3}}, {FN_P_AFF_L1_B, 3, {1, 2, 3}}};
+    static const PartDef A_L3[3] = {{FN_P_AFF_L3_A, 2, {0, 2, 0}}, {FN_P_AFF_L3_B, 2, {1, 2, 0}}, {FN_P_AFF_L3_C, 1, {2, 0, 0}}};
+    SegPlan r = sp;
+    r.nseg = 0;
+    bool any = false;
+    for (int s = 0; s < sp.nseg; s++) {
+        const Seg& g = sp.seg[s];
+        const PartDef* pd = nullptr;
+        int np = 0;
+        switch (g.prim) {
+            case FN_PROJ_L1: pd = P_L1; np = 3; break;
+            case FN_PROJ_L2: pd = P_L2; np = 2; break;
+            case FN_PROJ_L3: pd = P_L3; np = 3; break;
+            case FN_AFF_L1: pd = A_L1; np = 2; break;
+            case FN_AFF_L3: pd = A_L3; np = 3; break;
+            default: break;
+        }
+        if (!pd) {
+            if (r.nseg >= GM_MAX_SEGS) return false;
+            r.seg[r.nseg++] = g;
+            continue;
+        }
+        for (int k = 0; k < np; k++) {
+            if (r.nseg >= GM_MAX_SEGS) return false;
+            Seg& o = r.seg[r.nseg++];
+            o.prim = (int8_t)pd[k].prim; o.n_in = (int8_t)pd[k].n_in; o.n_out = 0; o.out0 = g.out0;
+            for (int q = 0; q < 6; q++) o.in[q] = q < pd[k].n_in ? g.in[pd[k].in[q]] : 0;
+        }
+        any = true;
+    }
+    if (!any) return false;
+    *out = r;
+    return true;
+}
+
 struct ColPtrs {
     const Fr* p[GM_MAX_COLS];
 };

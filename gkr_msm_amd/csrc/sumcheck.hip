@@ -497,11 +497,42 @@ struct StageArgs {
     uint64_t* d_dbg;                   // development aid: phase time stamps (nullptr normally)
 };
 
+// one part of a split segment (segfn.hip.h): its share of sum_o gamma^o f_o; G(k, x) = gamma^(out0 + k) x
+__device__ __forceinline__ Fr stage_part_eval(int prim, int out0, const Fr* v, const Fr* __restrict__ gp) {
+    auto G = [&](int k, const Fr& x) -> Fr { return out0 + k == 0 ? x : fr_mul(fr_load(gp + out0 + k), x); };
+    auto x5 = [](const Fr& x) -> Fr { return fr_add(fr_dbl(fr_dbl(x)), x); };   // -a x, a = -5
+    switch (prim) {
+        case FN_P_PROJ_L1_A: return fr_mul(v[0], fr_add(G(0, v[2]), x5(G(2, v[1]))));          // v0, v3, v4
+        case FN_P_PROJ_L1_B: return fr_mul(v[0], fr_add(G(1, v[1]), G(2, v[2])));              // v1, v3, v4
+        case FN_P_PROJ_L1_C: return G(3, fr_mul(v[0], v[1]));                                  // v2, v5
+        case FN_P_PROJ_L2_A: return fr_add(G(0, fr_mul(fr_add(v[0], v[1]), v[2])), G(3, fr_mul(v[0], v[1])));   // v0, v1, v3
+        case FN_P_PROJ_L2_B: return fr_mul(v[1], fr_add(G(1, v[0]), G(2, v[1])));              // v2, v3
+        case FN_P_PROJ_L3_A: return G(0, fr_mul(fr_sub(v[1], fr_mul_by_d(v[2])), v[0]));       // v0, v2, v3
+        case FN_P_PROJ_L3_B: return G(1, fr_mul(fr_add(v[1], fr_mul_by_d(v[2])), v[0]));       // v1, v2, v3
+        case FN_P_PROJ_L3_C: {                                                                 // v2, v3
+            const Fr dxy = fr_mul_by_d(v[1]);
+            return G(2, fr_mul(fr_sub(v[0], dxy), fr_add(v[0], dxy)));
+        }
+        case FN_P_AFF_L1_A: return fr_mul(v[0], fr_add(G(0, v[2]), x5(G(2, v[1]))));           // v0, v2, v3
+        case FN_P_AFF_L1_B: return fr_mul(v[0], fr_add(G(1, v[1]), G(2, v[2])));               // v1, v2, v3
+        case FN_P_AFF_L3_A: return G(0, fr_mul(fr_sub(fr_one(), fr_mul_by_d(v[1])), v[0]));    // v0, v2
+        case FN_P_AFF_L3_B: return G(1, fr_mul(fr_add(fr_one(), fr_mul_by_d(v[1])), v[0]));    // v1, v2
+        default: {                                                                             // FN_P_AFF_L3_C: v2
+            const Fr dxy = fr_mul_by_d(v[0]);
+            return G(2, fr_mul(fr_sub(fr_one(), dxy), fr_add(fr_one(), dxy)));
+        }
+    }
+}
+
 // sum_{o in segment} gamma^o f_o(v) for one pair at evaluation point h
 __device__ __forceinline__ Fr stage_eval(const Seg& g, const Fr* p0, const Fr* p1, const Fr* __restrict__ gp, int h) {
     Fr v[6], o[4];
 #pragma unroll
-    for (int q = 0; q < 6; q++) v[q] = h ? fr_sub(fr_dbl(p1[q]), p0[q]) : p1[q];
+    for (int q = 0; q < 6; q++) {
+        v[q] = p1[q];
+        if (h && q < g.n_in) v[q] = fr_sub(fr_dbl(p1[q]), p0[q]);   // a lone wave: skip the inputs the segment does not have
+    }
+    if (prim_is_part(g.prim)) return stage_part_eval(g.prim, g.out0, v, gp);
     prim_exec(g.prim, v, o);
     Fr A = fr_zero();
 #pragma unroll
@@ -516,6 +547,7 @@ __device__ __forceinline__ Fr stage_eval(const Seg& g, const Fr* p0, const Fr* p
 __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const Fr* __restrict__ gp, StageArgs a) {
     __shared__ Fr xch[6][256];
     __shared__ Fr red[4][2];
+    __shared__ Fr red3[4][3];
     __shared__ Fr ts;
     __shared__ int ok;
     __shared__ uint32_t is_last;
@@ -558,12 +590,13 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
         }
         __syncthreads();
         STAGE_STAMP(3);
-        if (is_last && wave == 0) {
-            // the block that arrived last adds the partials up per evaluation point (one wave: nrep <= 512) and reports;
-            // it also leaves the round's counter at zero for the next launch (the state buffer is never memset)
-            if (lane == 0) __hip_atomic_store(a.d_round_cnt + round, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (is_last) {
+            // the block that arrived last adds the partials up per evaluation point and reports; all four waves load (one or two
+            // partials per thread: the loads of a lane are dependent round trips), then wave sums and one pass over the wave totals.
+            // It also leaves the round's counter at zero for the next launch (the state buffer is never memset).
+            if (i == 0) __hip_atomic_store(a.d_round_cnt + round, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             Fr r0 = fr_zero(), r1 = fr_zero(), rw = fr_zero();   // sums at point 1, at point 2, tail weight
-            for (uint32_t b2 = lane; b2 < nrep; b2 += 64) {
+            for (uint32_t b2 = i; b2 < nrep; b2 += 256) {
                 const Fr v = coh_load_dev(a.d_part + 2 * b2);
                 if ((b2 % gridDim.x) & 1) r1 = fr_add(r1, v); else r0 = fr_add(r0, v);
                 if (thin && (b2 % gridDim.x) == 0) rw = fr_add(rw, coh_load_dev(a.d_part + 2 * b2 + 1));
@@ -571,7 +604,12 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
             r0 = wave_sum(r0);
             r1 = wave_sum(r1);
             if (thin) rw = wave_sum(rw);
-            if (lane == 0) {
+            if (lane == 0) { red3[wave][0] = r0; red3[wave][1] = r1; red3[wave][2] = rw; }
+            __syncthreads();   // is_last is uniform over the block
+            if (i == 0) {
+                r0 = fr_add(fr_add(red3[0][0], red3[1][0]), fr_add(red3[2][0], red3[3][0]));
+                r1 = fr_add(fr_add(red3[0][1], red3[1][1]), fr_add(red3[2][1], red3[3][1]));
+                if (thin) rw = fr_add(fr_add(red3[0][2], red3[1][2]), fr_add(red3[2][2], red3[3][2]));
                 // report slot of this round: a slot is rewritten two rounds later, after the host has read it
                 uint32_t* dst = a.h_rep + 36 * (round & 1);
                 fr_chunks_store_sys(dst, r0, want);
@@ -1485,7 +1523,13 @@ struct StageRun {
                n_thin_ <= 12 && n_dense_ >= 1 && n_dense_ <= STAGE_MAX_ROUNDS;
     }
     // a: geometry, data pointers, eq pointers and pads filled by the caller
-    int32_t launch(const SegPlan& sp, const ColPtrs& cp, const Fr* d_gamma, StageArgs a, hipStream_t s) {
+    int32_t launch(const SegPlan& sp_in, const ColPtrs& cp, const Fr* d_gamma, StageArgs a, hipStream_t s) {
+        // term split (segfn.hip.h): more, shorter evaluation chains per round when the wider grid still fits the device
+        static const bool no_split = [] { const char* e = getenv("GM_STAGE_SPLIT"); return e && e[0] == '0'; }();
+        SegPlan sp_split;
+        const bool split = !no_split && seg_plan_split_terms(sp_in, &sp_split) &&
+                           fits(sp_split.nseg, a.n_elems, a.n_thin > 0 ? a.n_thin : 0, a.n_dense);
+        const SegPlan& sp = split ? sp_split : sp_in;
         int32_t rc = tail_stage(&st);
         if (rc) return rc;
         stream = s;
