@@ -299,7 +299,10 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2(SegPlan sp, ColPtrs c
             // small (split) launches are latency bound: bracket the block's rows once instead of log2(nrows) dependent
             // loads per thread; large launches hide that latency behind other waves and must not pay the barriers
             uint32_t r;
-            if (SPLIT && (uint64_t)gridDim.x * SC_THREADS >= npairs) {  // single pass (block-uniform condition)
+            if (SPLIT && vv.coarse) {  // the coarse table brackets the row in one load (block-uniform condition)
+                if (!valid) continue;
+                r = find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0);
+            } else if (SPLIT && (uint64_t)gridDim.x * SC_THREADS >= npairs) {  // single pass (block-uniform condition)
                 r = find_row_span(vv.off, vv.nrows, cell0, valid, (uint32_t)(2 * base), (uint32_t)(2 * last_pair));
                 if (!valid) continue;
             } else {
