@@ -148,6 +148,37 @@ static inline std::chrono::milliseconds wait_timeout_host() { return std::chrono
 // ------------------------------------------------------------------------------------------ kernels
 #define SC_THREADS 256
 
+// Coherent 32-byte accesses as two 16-byte instructions: sc1 = device-coherent (another CU / XCD wrote or will read the bytes),
+// sc0 sc1 = system-coherent (pinned host memory).  They replace release / acquire fences around hand-offs: on gfx950 an agent- or
+// system-scope release writes the whole L2 back (buffer_wbl2) and an acquire invalidates it -- after a fold has left megabytes of
+// dirty lines that is microseconds per round.  Stores are left in flight: drain with coh_drain() before raising a flag / counter.
+typedef uint32_t gm_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void coh_store_dev(Fr* p, const Fr& v) {
+    const gm_u4 lo = {v.l[0], v.l[1], v.l[2], v.l[3]}, hi = {v.l[4], v.l[5], v.l[6], v.l[7]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ void coh_store_sys(Fr* p, const Fr& v) {
+    const gm_u4 lo = {v.l[0], v.l[1], v.l[2], v.l[3]}, hi = {v.l[4], v.l[5], v.l[6], v.l[7]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" ::"v"(p), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ void coh_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ Fr coh_load_dev(const Fr* p) {
+    gm_u4 lo, hi;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi) : "v"(p) : "memory");
+    Fr r;
+    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w; r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ Fr coh_load_sys(const Fr* p) {
+    gm_u4 lo, hi;
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi) : "v"(p) : "memory");
+    Fr r;
+    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w; r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+    return r;
+}
+
 // Block-wide sum of NACC field elements per thread, then the cross-block sum inside the same launch:
 // every block publishes its partial, the block that arrives last (agent-scope release / acquire around one
 // device counter) adds the partials up and writes the NACC results straight into pinned host memory, so a round is
@@ -198,19 +229,13 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
     const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
     {
         const Fr tot = block_sum<NACC>(acc, red);
-        if (threadIdx.x < NACC) fr_store(fc.partial + (uint64_t)bid * NACC + threadIdx.x, tot);
+        // hand-off without cache-wide fences (see the coherent helpers above): write-through stores, drained, then the counter
+        if (threadIdx.x < NACC) { coh_store_dev(fc.partial + (uint64_t)bid * NACC + threadIdx.x, tot); coh_drain(); }
     }
-    __syncthreads();  // all partial stores of this block are issued (and waited for below) before the counter moves
+    __syncthreads();  // all partial stores of this block have completed before the counter moves
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t prev = atomicAdd(fc.counter, 1u);
-        const uint32_t last = (prev == nblk - 1) ? 1u : 0u;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        is_last = last;
+        const uint32_t prev = __hip_atomic_fetch_add(fc.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == nblk - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (!is_last) return;
@@ -218,18 +243,17 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
 #pragma unroll
     for (int a = 0; a < NACC; a++) {
         Fr s = fr_zero();
-        for (uint32_t b2 = threadIdx.x; b2 < nblk; b2 += SC_THREADS) s = fr_add(s, fr_load(fc.partial + (uint64_t)b2 * NACC + a));
+        for (uint32_t b2 = threadIdx.x; b2 < nblk; b2 += SC_THREADS) s = fr_add(s, coh_load_dev(fc.partial + (uint64_t)b2 * NACC + a));
         s2[a] = s;
     }
     {
         const Fr tot = block_sum<NACC>(s2, red);
-        if (threadIdx.x < NACC) fr_store(fc.out + threadIdx.x, tot);
+        if (threadIdx.x < NACC) { coh_store_sys(fc.out + threadIdx.x, tot); coh_drain(); }
     }
-    __syncthreads();
+    __syncthreads();  // the results have reached host memory before the sequence word is written
     if (threadIdx.x == 0) {
-        *fc.counter = 0;
-        __threadfence_system();
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(fc.out + 7), fc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fc.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(fc.out + 7), fc.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -402,33 +426,6 @@ __global__ void __launch_bounds__(64) k_gather_finals(ColPtrs cols, int k, Fr* _
 // memory pipeline (s_waitcnt vmcnt(0)) after every one of them: eight dependent round trips per field element (measured: 6.6 us
 // to publish two elements).  sc1 = device-coherent (another CU / XCD wrote or will read the bytes), sc0 sc1 = system-coherent
 // (pinned host memory).  Stores are left in flight: drain with coh_drain() before raising the flag / counter.
-typedef uint32_t gm_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void coh_store_dev(Fr* p, const Fr& v) {
-    const gm_u4 lo = {v.l[0], v.l[1], v.l[2], v.l[3]}, hi = {v.l[4], v.l[5], v.l[6], v.l[7]};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(lo), "v"(hi) : "memory");
-}
-__device__ __forceinline__ void coh_store_sys(Fr* p, const Fr& v) {
-    const gm_u4 lo = {v.l[0], v.l[1], v.l[2], v.l[3]}, hi = {v.l[4], v.l[5], v.l[6], v.l[7]};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" ::"v"(p), "v"(lo), "v"(hi) : "memory");
-}
-__device__ __forceinline__ void coh_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ Fr coh_load_dev(const Fr* p) {
-    gm_u4 lo, hi;
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(lo), "=&v"(hi) : "v"(p) : "memory");
-    Fr r;
-    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w; r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
-    return r;
-}
-__device__ __forceinline__ Fr coh_load_sys(const Fr* p) {
-    gm_u4 lo, hi;
-    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(lo), "=&v"(hi) : "v"(p) : "memory");
-    Fr r;
-    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w; r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
-    return r;
-}
-
 // Self-validating messages between the stage kernel and the host (and between its blocks): 16-byte chunks of 12 data bytes +
 // the 4-byte sequence number of the round.  Every chunk is one store instruction and is validated on its own, so the writer
 // needs no ordering between stores (no drain, no separate flag) and the reader gets data and flag in ONE round trip.
