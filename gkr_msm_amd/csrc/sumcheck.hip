@@ -371,12 +371,11 @@ __global__ void __launch_bounds__(64) k_fold_gate(const Fr* __restrict__ t_slot,
     const uint64_t t_begin = wall_clock64();
     for (uint32_t it = 0;; it++) {
         if ((it & 255u) == 255u && wall_clock64() - t_begin > timeout_ticks) break;
-        const uint32_t f = __hip_atomic_load(ticket_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // no acquire (it would invalidate the caches on every poll): the host stores t, then the ticket (x86 store order), and both
+        // are read straight from host memory, the challenge after the ticket has been seen, as two 16-byte loads (one round trip)
+        const uint32_t f = __hip_atomic_load(ticket_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int32_t)(f - ticket) >= 0) {
-            Fr t;
-#pragma unroll
-            for (int l = 0; l < 8; l++) t.l[l] = __hip_atomic_load(&t_slot->l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            *d_t = t;
+            *d_t = coh_load_sys(t_slot);
             return;
         }
         __builtin_amdgcn_s_sleep(4);
@@ -396,14 +395,10 @@ __global__ void __launch_bounds__(256) k_dense_fold_dev(ColPtrs in, ColPtrsMut o
 // Final evaluations of a finished sumcheck: element 0 of every column, gathered by one wave straight into pinned host
 // memory, then a sequence number the host polls (k separate 32-byte copies cost ~20 us each).
 __global__ void __launch_bounds__(64) k_gather_finals(ColPtrs cols, int k, Fr* __restrict__ h_out, uint32_t* __restrict__ h_seq, uint32_t seq) {
-    for (int i = threadIdx.x; i < k; i += 64) {
-        const Fr v = fr_load(cols.p[i]);
-#pragma unroll
-        for (int l = 0; l < 8; l++) __hip_atomic_store(&h_out[i].l[l], v.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = threadIdx.x; i < k; i += 64) coh_store_sys(h_out + i, fr_load(cols.p[i]));
+    coh_drain();       // the values have reached host memory ...
+    __syncthreads();   // ... for every lane, before the sequence word is written (no cache-wide fence)
+    if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------ persistent stage kernel
