@@ -463,9 +463,11 @@ def main():
                         bar.wait()
                         wk.close()
                         pl.close()
+                except threading.BrokenBarrierError:
+                    box["ok"] = False
                 except Exception as e:
                     box["ok"] = False
-                    box["error"] = repr(e)[:200]
+                    box.setdefault("error", repr(e)[:300])
                     bar.abort()
             ths = [threading.Thread(target=prover_thread, args=(k,)) for k in range(T)]
             for th in ths:

@@ -1446,7 +1446,10 @@ static int stage_host_rounds(const SegPlan& sp, int n_dense) {
 // the device can hold (occupancy of k_stage x compute units, queried once per device), a launch larger than that is not made
 // (StageRun::fits), and host threads that prove concurrently on one device share it -- a launch waits until the blocks of the
 // launches in flight plus its own fit (two 512-block launches from two threads would otherwise each hold part of the chip and
-// spin until their time-outs).
+// spin until their time-outs).  A thread may WAIT for its share only while none of its own kernels is waiting for it (a
+// pre-enqueued fold's gate spins on a CU until this thread publishes the challenge: waiting then could keep the holder's blocks
+// from ever becoming resident -- a cycle); launches made while such a gate is in the stream only TRY, and the layer goes on with
+// ordinary round kernels when the device is busy.
 struct StageSlots {
     std::mutex mu;
     std::condition_variable cv;
@@ -1469,17 +1472,27 @@ struct StageSlots {
         std::unique_lock<std::mutex> g(mu);
         return cv.wait_for(g, wait_timeout_host(), [&] { return in_flight[dev] + n <= c; }) ? (in_flight[dev] += n, true) : false;
     }
+    bool try_acquire(int dev, uint32_t n) {
+        const uint32_t c = cap(dev);
+        std::lock_guard<std::mutex> g(mu);
+        if (in_flight[dev] + n > c) return false;
+        in_flight[dev] += n;
+        return true;
+    }
     void release(int dev, uint32_t n) {
         { std::lock_guard<std::mutex> g(mu); in_flight[dev] -= n; }
         cv.notify_all();
     }
 };
+// StageRun::launch could not get its share of the device without waiting (internal; never leaves the library)
+#define GM_STAGE_BUSY 1000
 
 // One launch of k_stage seen from the host.  A VecVec object that enters its thin rounds creates it; the dense object it hands
 // over to (bind_into_dense) keeps using the same launch.
 struct StageRun {
     int slot_dev = 0;
     uint32_t slots_held = 0;
+    bool launched = false;   // the kernel is (or was) in the stream: only then are there waits to release
     TailStage* st = nullptr;
     hipStream_t stream = nullptr;
     uint32_t ticket0 = 0;
@@ -1518,7 +1531,7 @@ struct StageRun {
                n_thin_ <= 12 && n_dense_ >= 1 && n_dense_ <= STAGE_MAX_ROUNDS;
     }
     // a: geometry, data pointers, eq pointers and pads filled by the caller
-    int32_t launch(const SegPlan& sp_in, const ColPtrs& cp, const Fr* d_gamma, StageArgs a, hipStream_t s) {
+    int32_t launch(const SegPlan& sp_in, const ColPtrs& cp, const Fr* d_gamma, StageArgs a, hipStream_t s, bool may_wait = true) {
         // term split (segfn.hip.h): more, shorter evaluation chains per round when the wider grid still fits the device
         static const bool no_split = [] { const char* e = getenv("GM_STAGE_SPLIT"); return e && e[0] == '0'; }();
         SegPlan sp_split;
@@ -1576,11 +1589,17 @@ struct StageRun {
         // the staging outlives this launch (one per host thread): a timeout flagged by an earlier launch must not fail this one
         *reinterpret_cast<volatile uint32_t*>(st->status()) = 0;
         slot_dev = StageSlots::device();
-        if (!StageSlots::get().acquire(slot_dev, gx * nsl))
-            return set_err(GM_ERR_STATE, "stage launch: the device stayed full of other threads' stage kernels (gm_set_wait_timeout_ms)");
+        if (!may_wait) {
+            // GM_STAGE_FORCE_BUSY=1 (tests): every launch that may only try finds the device busy
+            static const bool force_busy = [] { const char* e = getenv("GM_STAGE_FORCE_BUSY"); return e && e[0] == '1'; }();
+            if (force_busy || !StageSlots::get().try_acquire(slot_dev, gx * nsl)) return GM_STAGE_BUSY;
+        } else if (!StageSlots::get().acquire(slot_dev, gx * nsl))
+            return set_err(GM_ERR_STATE, "stage launch: the device stayed full of other threads' stage kernels (%u blocks wanted, %u in flight, "
+                           "capacity %u; gm_set_wait_timeout_ms)", gx * nsl, StageSlots::get().in_flight[slot_dev], StageSlots::get().cap(slot_dev));
         slots_held = gx * nsl;
         hipLaunchKernelGGL(k_stage, dim3(gx, nsl), dim3(256), 0, s, sp, cp, d_gamma, a);
         GM_LAUNCH_CHECK();
+        launched = true;
         published = 0;
         return GM_OK;
     }
@@ -1658,7 +1677,7 @@ struct StageRun {
         return GM_OK;
     }
     ~StageRun() {
-        if (st && published < total()) {   // never leave waiting blocks behind: the release tag lets every wait of this launch through
+        if (launched && st && published < total()) {   // never leave waiting blocks behind: the release tag lets every wait of this launch through
             st->d_state_dirty = true;
             write_chunks(st->tkt(), fr_zero(), ticket0 + 0x4000u);
             write_chunks(st->tkt() + 12, fr_zero(), ticket0 + 0x4000u);
@@ -2213,7 +2232,7 @@ struct ScDenseDeg2 : gm_sc {
         return StageRun::fits(sp.nseg, 2 * npairs0, 0, (int)(num_vars - r0));
     }
     // cp: the columns as they are at round r0 (npairs0 pairs); everything before it in the stream has been enqueued
-    int32_t launch_tail(const ColPtrs& cp, uint32_t r0, uint64_t npairs0) {
+    int32_t launch_tail(const ColPtrs& cp, uint32_t r0, uint64_t npairs0, bool may_wait = true) {
         StageArgs a;
         memset(&a, 0, sizeof(a));
         const int nr = (int)(num_vars - r0);
@@ -2223,10 +2242,10 @@ struct ScDenseDeg2 : gm_sc {
         a.n_elems = (uint32_t)(2 * npairs0);
         const int hr = stage_host_rounds(sp, nr);
         a.n_dense = nr - hr;
-        host_r0 = r0 + (uint32_t)(nr - hr);
         stage.reset(new StageRun());
-        int32_t rc = stage->launch(sp, cp, d_gamma.fr(), a, stream);
-        if (rc) return rc;
+        int32_t rc = stage->launch(sp, cp, d_gamma.fr(), a, stream, may_wait);
+        if (rc) { stage.reset(); return rc; }
+        host_r0 = r0 + (uint32_t)(nr - hr);
         for (int q = 0; q < nr; q++) {   // rounds and folds that happen inside the launch
             prof_small_round(64.0 * cols.k * (double)(npairs0 >> q));
             prof_fold(96.0 * cols.k * (double)(npairs0 >> q));
@@ -2344,9 +2363,14 @@ struct ScDenseDeg2 : gm_sc {
             prof_fold(96.0 * cols.k * (double)n_out);
             GM_LAUNCH_CHECK();
             fold_pending = true;
+            bool staged = false;
             if (tail_ok && stage_fits(r + 1, npairs >> 1)) {   // everything after this fold runs in one launch
-                int32_t rc = launch_tail(cn, r + 1, npairs >> 1);
-                if (rc) return rc;
+                // this round's gate is in the stream, waiting for this thread: try only (StageSlots)
+                int32_t rc = launch_tail(cn, r + 1, npairs >> 1, false);
+                if (rc && rc != GM_STAGE_BUSY) return rc;
+                staged = rc == GM_OK;
+            }
+            if (staged) {
                 k_enq = num_vars;
             } else {
                 const Fr* eq_next = eq_level(num_vars - 2 - r) + (glob_off >> 2);
@@ -2528,9 +2552,14 @@ struct ScVecVecDeg2 : gm_sc {
             prof_fold(96.0 * k * (double)(cells_bound / 2));
             fold_pending = true;
             const uint32_t half = cur_max_len / 2, next_max = half + (half & 1);
+            bool staged = false;
             if (next_max == 2 && stage_ok()) {   // the fold leaves one pair per row: everything after it runs in one launch
-                int32_t rc = launch_stage(nx_cur.data(), nx_off, already_bound + 1);
-                if (rc) return rc;
+                // this round's gate is in the stream, waiting for this thread: try only (StageSlots)
+                int32_t rc = launch_stage(nx_cur.data(), nx_off, already_bound + 1, false);
+                if (rc && rc != GM_STAGE_BUSY) return rc;
+                staged = rc == GM_OK;
+            }
+            if (staged) {
                 stage_active = false;   // this round still reports through its own kernel; bind() switches over
                 stage_armed = true;
                 k_enq = 0x7fffffffu;
@@ -2587,7 +2616,7 @@ struct ScVecVecDeg2 : gm_sc {
             if (fr_eq(point[i], fr_one())) return false;   // the dense stage would need the generic object (from12 divides by 1 - q)
         return true;
     }
-    int32_t launch_stage(const Fr* const* cols_now, const uint32_t* off, uint32_t ab0) {
+    int32_t launch_stage(const Fr* const* cols_now, const uint32_t* off, uint32_t ab0, bool may_wait = true) {
         const int n_thin = (int)(n_row_vars0 - ab0);
         if (n_thin < 1 || !StageRun::fits(sp.nseg, 1ull << col_logsize, n_thin, (int)col_logsize))
             return set_err(GM_ERR_STATE, "stage launch: shape does not fit (%d thin rounds, %u dense)", n_thin, col_logsize);
@@ -2607,8 +2636,8 @@ struct ScVecVecDeg2 : gm_sc {
         ColPtrs cp;
         for (int i = 0; i < k; i++) cp.p[i] = cols_now[i];
         stage.reset(new StageRun());
-        int32_t rc = stage->launch(sp, cp, d_gamma.fr(), a, stream);
-        if (rc) return rc;
+        int32_t rc = stage->launch(sp, cp, d_gamma.fr(), a, stream, may_wait);
+        if (rc) { stage.reset(); return rc; }
         for (int tr = 0; tr < n_thin; tr++) { prof_small_round(64.0 * k * (double)nrows); prof_fold(96.0 * k * (double)nrows); }
         for (uint32_t dr = 0; dr < col_logsize; dr++) {
             prof_small_round(64.0 * k * (double)(1ull << (col_logsize - 1 - dr)));
@@ -3132,6 +3161,16 @@ extern "C" int32_t gm_sc_unipoly(gm_sc* so, uint64_t* h_coeffs, uint32_t* n_coef
     if (rc) return rc;
     memcpy(h_coeffs, c.data(), c.size() * sizeof(Fr));
     if (n_coeffs) *n_coeffs = (uint32_t)c.size();
+    return GM_OK;
+}
+
+// diagnostics: blocks of the persistent round kernel the calling process has in flight on the current device, and the budget
+extern "C" int32_t gm_stage_slots(uint32_t* in_flight, uint32_t* capacity) {
+    const int dev = StageSlots::device();
+    const uint32_t c = StageSlots::get().cap(dev);
+    std::lock_guard<std::mutex> g(StageSlots::get().mu);
+    if (in_flight) *in_flight = StageSlots::get().in_flight[dev];
+    if (capacity) *capacity = c;
     return GM_OK;
 }
 

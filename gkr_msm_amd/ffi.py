@@ -86,6 +86,7 @@ _SIGS = {
     "gm_free": (C.c_int32, [vp]),
     "gm_release_cached_memory": (C.c_int32, []),
     "gm_set_wait_timeout_ms": (C.c_int32, [C.c_uint32]),
+    "gm_stage_slots": (C.c_int32, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gm_sc_profile": (C.c_int32, [C.c_int32]),
     "gm_sc_profile_read": (C.c_int32, [C.POINTER(GmScProfileRow), C.c_uint32, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "gm_memcpy_h2d": (C.c_int32, [vp, vp, C.c_size_t, vp]),

@@ -54,6 +54,9 @@ int32_t gm_release_cached_memory(void);
  * `ms` milliseconds (default 20000; 0 restores the default) the waiting kernel flags a status word and leaves, and the call in
  * progress returns GM_ERR_STATE -- a caller whose transcript dies never wedges the GPU.  Process-wide; affects later launches. */
 int32_t gm_set_wait_timeout_ms(uint32_t ms);
+/* Diagnostics of the co-residency budget the persistent round kernel's launches share ("Threads" above): workgroups this process
+ * has in flight on the current device and the budget (occupancy x compute units).  0 in flight whenever no proof is running. */
+int32_t gm_stage_slots(uint32_t* in_flight, uint32_t* capacity);
 int32_t gm_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
 int32_t gm_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 int32_t gm_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream); /* asynchronous */

@@ -241,3 +241,17 @@ def test_provers_on_concurrent_host_threads():
     for th in ths:
         th.join(timeout=300)
     assert not errors, errors
+
+
+def test_stage_launch_denied_falls_back_to_ordinary_rounds():
+    """a stage launch that may only TRY for its share of the device (one of this thread's own gates is waiting in the stream) and
+    finds it busy leaves the layer on ordinary round kernels: GM_STAGE_FORCE_BUSY=1 makes every such launch find the device busy
+    (read once per process, hence the child process); the proofs must still equal the oracle's"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GM_STAGE_FORCE_BUSY="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_prover_gpu.py"), "-x", "-q", "-k",
+                          "matches_oracle and (9-8-64 or 7-6-128 or 5-3-16)"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "3 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
