@@ -519,16 +519,41 @@ __device__ __forceinline__ Fr stage_part_eval(int prim, int out0, const Fr* v, c
     }
 }
 
+// the primitives with at most three inputs (the narrow instance of the stage kernel: the wide arms of prim_exec would only cost it
+// registers); outputs as prim_exec
+__device__ __forceinline__ void prim_exec3(int id, const Fr* a, Fr* o) {
+    switch (id) {
+        case FN_AFF_L2: aff_l2(a, o); break;
+        case FN_AFF_L3: aff_l3(a, o); break;
+        case FN_ID: o[0] = a[0]; break;
+        case FN_BITCHECK: o[0] = fr_sub(fr_sqr(a[0]), a[0]); break;
+        case FN_PT_BIT_CHOICE: {
+            o[0] = fr_mul(a[0], a[1]);
+            o[1] = fr_add(fr_mul(a[0], fr_sub(a[2], fr_one())), fr_one());
+        } break;
+        case FN_ADD_INVERSES: {
+            o[0] = fr_add(a[0], a[1]);
+            o[1] = fr_mul(a[0], a[1]);
+        } break;
+        default: break;
+    }
+}
+__host__ __device__ constexpr bool prim_fits3(int prim) {
+    return prim >= 64 || prim == FN_AFF_L2 || prim == FN_AFF_L3 || prim == FN_ID || prim == FN_BITCHECK || prim == FN_PT_BIT_CHOICE ||
+           prim == FN_ADD_INVERSES;
+}
+
 // sum_{o in segment} gamma^o f_o(v) for one pair at evaluation point h
+template <int MAXIN>
 __device__ __forceinline__ Fr stage_eval(const Seg& g, const Fr* p0, const Fr* p1, const Fr* __restrict__ gp, int h) {
-    Fr v[6], o[4];
+    Fr v[MAXIN], o[4];
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
+    for (int q = 0; q < MAXIN; q++) {
         v[q] = p1[q];
         if (h && q < g.n_in) v[q] = fr_sub(fr_dbl(p1[q]), p0[q]);   // a lone wave: skip the inputs the segment does not have
     }
     if (prim_is_part(g.prim)) return stage_part_eval(g.prim, g.out0, v, gp);
-    prim_exec(g.prim, v, o);
+    if (MAXIN == 3) prim_exec3(g.prim, v, o); else prim_exec(g.prim, v, o);
     Fr A = fr_zero();
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -539,8 +564,11 @@ __device__ __forceinline__ Fr stage_eval(const Seg& g, const Fr* p0, const Fr* p
     return A;
 }
 
+// MAXIN = inputs a segment may have: 6 (any plan) or 3 (every segment of the plan is a part or a narrow primitive -- all the
+// split twisted-Edwards layers): the narrow instance keeps half the state in registers and in LDS.
+template <int MAXIN>
 __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const Fr* __restrict__ gp, StageArgs a) {
-    __shared__ Fr xch[6][256];
+    __shared__ Fr xch[MAXIN][256];
     __shared__ Fr red[4][2];
     __shared__ Fr red3[4][3];
     __shared__ Fr ts;
@@ -551,9 +579,9 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
     const uint32_t slice = blockIdx.y, nsl = gridDim.y;
     const uint32_t i = threadIdx.x, lane = i & 63, wave = i >> 6;
     const uint32_t blk = slice * gridDim.x + blockIdx.x;
-    Fr p0[6], p1[6];
+    Fr p0[MAXIN], p1[MAXIN];
 #pragma unroll
-    for (int q = 0; q < 6; q++) { p0[q] = fr_zero(); p1[q] = fr_zero(); }
+    for (int q = 0; q < MAXIN; q++) { p0[q] = fr_zero(); p1[q] = fr_zero(); }
     uint32_t round = 0;   // rounds done by this launch so far: the ticket of round r is ticket0 + r
     bool thin = a.n_thin > 0;   // true while the thin rounds run (reports then carry the tail weight)
     // development aid (GM_STAGE_DEBUG=1): wall-clock stamps (100 MHz) of the phases of every round, blocks 0 and 1
@@ -661,7 +689,7 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
             coef = fr_load(a.row_coef + r);
             if (have) {
 #pragma unroll
-                for (int q = 0; q < 6; q++)
+                for (int q = 0; q < MAXIN; q++)
                     if (q < g.n_in) { p0[q] = fr_load(cols.p[g.in[q]] + c0); p1[q] = fr_load(cols.p[g.in[q]] + c0 + 1); }
             }
         }
@@ -669,27 +697,27 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
             STAGE_STAMP(0);
             const Fr e0 = fr_load(a.thin_eq[tr]);
             Fr acc = fr_zero(), accw = fr_zero();
-            if (have) acc = fr_mul(stage_eval(g, p0, p1, gp, h), fr_mul(e0, coef));
+            if (have) acc = fr_mul(stage_eval<MAXIN>(g, p0, p1, gp, h), fr_mul(e0, coef));
             // the tail weight W = sum_r coef[r] (1 - sum_{idx < seg_r} eq[idx]), get_trailing_sum (vecvec.rs:144-146): once per slice
             if (blockIdx.x == 0 && r < a.nrows) accw = have ? fr_mul(coef, fr_sub(fr_one(), e0)) : coef;
             if (!exchange(acc, accw, blockIdx.x == 0, nsl * gridDim.x)) return;
             if (have) {   // bind_21 on a row of one pair: [p0 + t (p1 - p0), row_pad]
                 const Fr t = ts;
 #pragma unroll
-                for (int q = 0; q < 6; q++)
+                for (int q = 0; q < MAXIN; q++)
                     if (q < g.n_in) { p0[q] = fr_add(p0[q], fr_mul(t, fr_sub(p1[q], p0[q]))); p1[q] = a.row_pad.v[g.in[q]]; }
             }
         }
         thin = false;
         // bind_into_dense: the last fold above left the row's value in p0; absent cells are row_pad, absent rows col_pad
 #pragma unroll
-        for (int q = 0; q < 6; q++)
+        for (int q = 0; q < MAXIN; q++)
             if (q < g.n_in) xch[q][i] = have ? p0[q] : (r < a.nrows ? a.row_pad.v[g.in[q]] : a.col_pad.v[g.in[q]]);
         __syncthreads();
         np = (a.n_elems < 256 ? a.n_elems : 256u) >> 1;
         if (i < np) {
 #pragma unroll
-            for (int q = 0; q < 6; q++)
+            for (int q = 0; q < MAXIN; q++)
                 if (q < g.n_in) { p0[q] = xch[q][2 * i]; p1[q] = xch[q][2 * i + 1]; }
         }
         __syncthreads();
@@ -698,7 +726,7 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
         if (i < np) {
             const uint64_t gi = (uint64_t)slice * np + i;
 #pragma unroll
-            for (int q = 0; q < 6; q++)
+            for (int q = 0; q < MAXIN; q++)
                 if (q < g.n_in) { p0[q] = fr_load(cols.p[g.in[q]] + 2 * gi); p1[q] = fr_load(cols.p[g.in[q]] + 2 * gi + 1); }
         }
     }
@@ -709,12 +737,12 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
     for (int dr = 0; dr < a.n_dense; dr++, round++) {
         STAGE_STAMP(0);
         Fr acc = fr_zero();
-        if (i < np) acc = fr_mul(stage_eval(g, p0, p1, gp, h), fr_load(a.eq[dr] + (uint64_t)my_slice * np + i));
+        if (i < np) acc = fr_mul(stage_eval<MAXIN>(g, p0, p1, gp, h), fr_load(a.eq[dr] + (uint64_t)my_slice * np + i));
         if (!exchange(acc, fr_zero(), false, (merged || nsl == 1) ? gridDim.x : nsl * gridDim.x)) return;
         const Fr t = ts;
         if (i < np) {
 #pragma unroll
-            for (int q = 0; q < 6; q++)
+            for (int q = 0; q < MAXIN; q++)
                 if (q < g.n_in) xch[q][i] = fr_add(p0[q], fr_mul(t, fr_sub(p1[q], p0[q])));
         }
         __syncthreads();
@@ -724,7 +752,7 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
             np >>= 1;
             if (i < np) {
 #pragma unroll
-                for (int q = 0; q < 6; q++)
+                for (int q = 0; q < MAXIN; q++)
                     if (q < g.n_in) { p0[q] = xch[q][2 * i]; p1[q] = xch[q][2 * i + 1]; }
             }
             __syncthreads();
@@ -757,7 +785,7 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
             np = nsl >> 1;
             if (i < np) {
 #pragma unroll
-                for (int q = 0; q < 6; q++)
+                for (int q = 0; q < MAXIN; q++)
                     if (q < g.n_in) {
                         // handed-over bytes: system-coherent loads (another CU wrote them)
                         const Fr* src = xb + (size_t)q * STAGE_MAX_SLICES + 2 * i;
@@ -1453,20 +1481,26 @@ static int stage_host_rounds(const SegPlan& sp, int n_dense) {
 struct StageSlots {
     std::mutex mu;
     std::condition_variable cv;
-    uint32_t capacity[16] = {0}, in_flight[16] = {0};
+    // budget in units of 1 / (pw pn) of a compute unit, pw / pn = workgroups of the wide / narrow instance a CU holds: a wide
+    // workgroup costs pn units, a narrow one pw, the device has CUs * pw * pn
+    uint32_t capacity[16] = {0}, in_flight[16] = {0}, cost_wide[16] = {0}, cost_narrow[16] = {0};
     static StageSlots& get() { static StageSlots s; return s; }
     static int device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < 16) ? d : 0; }
     uint32_t cap(int dev) {
         std::lock_guard<std::mutex> g(mu);
         if (!capacity[dev]) {
-            int per_cu = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stage, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+            int pw = 0, pn = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_stage<6>, 256, 0) != hipSuccess || pw < 1) pw = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pn, k_stage<3>, 256, 0) != hipSuccess || pn < 1) pn = 1;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
             (void)hipGetLastError();
-            capacity[dev] = (uint32_t)per_cu * (uint32_t)cus;
+            cost_wide[dev] = (uint32_t)pn;
+            cost_narrow[dev] = (uint32_t)pw;
+            capacity[dev] = (uint32_t)cus * (uint32_t)pw * (uint32_t)pn;
         }
         return capacity[dev];
     }
+    uint32_t cost(int dev, uint32_t blocks, bool narrow) { (void)cap(dev); return blocks * (narrow ? cost_narrow[dev] : cost_wide[dev]); }
     bool acquire(int dev, uint32_t n) {
         const uint32_t c = cap(dev);
         std::unique_lock<std::mutex> g(mu);
@@ -1484,6 +1518,12 @@ struct StageSlots {
         cv.notify_all();
     }
 };
+// every segment of the plan is a part or a narrow primitive: the narrow instance of the stage kernel serves it
+static bool stage_plan_is_narrow(const SegPlan& sp) {
+    for (int s = 0; s < sp.nseg; s++)
+        if (sp.seg[s].n_in > 3 || !prim_fits3(sp.seg[s].prim)) return false;
+    return true;
+}
 // StageRun::launch could not get its share of the device without waiting (internal; never leaves the library)
 #define GM_STAGE_BUSY 1000
 
@@ -1527,7 +1567,7 @@ struct StageRun {
     static bool fits(int nseg_, uint64_t n_elems, int n_thin_, int n_dense_) {
         const uint64_t nsl_ = n_elems <= 256 ? 1 : n_elems / 256;
         return nseg_ >= 1 && nseg_ <= GM_MAX_SEGS && n_elems >= 2 && nsl_ <= STAGE_MAX_SLICES && 2ull * nseg_ * nsl_ <= STAGE_MAX_BLOCKS &&
-               2ull * nseg_ * nsl_ <= StageSlots::get().cap(StageSlots::device()) &&
+               StageSlots::get().cost(StageSlots::device(), (uint32_t)(2ull * nseg_ * nsl_), false) <= StageSlots::get().cap(StageSlots::device()) &&
                n_thin_ <= 12 && n_dense_ >= 1 && n_dense_ <= STAGE_MAX_ROUNDS;
     }
     // a: geometry, data pointers, eq pointers and pads filled by the caller
@@ -1589,15 +1629,18 @@ struct StageRun {
         // the staging outlives this launch (one per host thread): a timeout flagged by an earlier launch must not fail this one
         *reinterpret_cast<volatile uint32_t*>(st->status()) = 0;
         slot_dev = StageSlots::device();
+        const bool narrow = stage_plan_is_narrow(sp);
+        const uint32_t want = StageSlots::get().cost(slot_dev, gx * nsl, narrow);
         if (!may_wait) {
             // GM_STAGE_FORCE_BUSY=1 (tests): every launch that may only try finds the device busy
             static const bool force_busy = [] { const char* e = getenv("GM_STAGE_FORCE_BUSY"); return e && e[0] == '1'; }();
-            if (force_busy || !StageSlots::get().try_acquire(slot_dev, gx * nsl)) return GM_STAGE_BUSY;
-        } else if (!StageSlots::get().acquire(slot_dev, gx * nsl))
-            return set_err(GM_ERR_STATE, "stage launch: the device stayed full of other threads' stage kernels (%u blocks wanted, %u in flight, "
-                           "capacity %u; gm_set_wait_timeout_ms)", gx * nsl, StageSlots::get().in_flight[slot_dev], StageSlots::get().cap(slot_dev));
-        slots_held = gx * nsl;
-        hipLaunchKernelGGL(k_stage, dim3(gx, nsl), dim3(256), 0, s, sp, cp, d_gamma, a);
+            if (force_busy || !StageSlots::get().try_acquire(slot_dev, want)) return GM_STAGE_BUSY;
+        } else if (!StageSlots::get().acquire(slot_dev, want))
+            return set_err(GM_ERR_STATE, "stage launch: the device stayed full of other threads' stage kernels (%u units wanted, %u in flight, "
+                           "capacity %u; gm_set_wait_timeout_ms)", want, StageSlots::get().in_flight[slot_dev], StageSlots::get().cap(slot_dev));
+        slots_held = want;
+        if (narrow) hipLaunchKernelGGL(k_stage<3>, dim3(gx, nsl), dim3(256), 0, s, sp, cp, d_gamma, a);
+        else hipLaunchKernelGGL(k_stage<6>, dim3(gx, nsl), dim3(256), 0, s, sp, cp, d_gamma, a);
         GM_LAUNCH_CHECK();
         launched = true;
         published = 0;
