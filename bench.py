@@ -37,8 +37,18 @@ from gkr_msm_amd import codec, ffi, harness  # noqa: E402
 from gkr_msm_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FR_MUL_CEILING = 115e9     # measured: scripts/ubench/fr_mul_asm_test.hip, the 302-instruction 8 x 32-bit multiplier the sumcheck kernels use, all 256 CUs
-FR9_MUL_CEILING = 150e9    # measured: scripts/ubench/fr9_mul_test.hip, the 205-instruction 9 x 29-bit multiplier the MSM level kernels use
+FR_MUL_CEILING = 115e9     # measured: scripts/ubench/fr_mul_asm_test.hip, the 302-instruction 8 x 32-bit multiplier, all 256 CUs
+FR9_MUL_CEILING = 150e9    # measured: scripts/ubench/fr9_mul_test.hip, the 205-instruction 9 x 29-bit multiplier (MSM level kernels, large-round kernels below)
+FR9_ROUND_PRIMS = ("PROJ_L1", "PROJ_L2", "PROJ_L3", "AFF_L1", "AFF_L3")   # large-round kernels that compute in the 9 x 29 form (sumcheck.hip: lean9_has)
+
+
+def round_kernel_ceiling(name):
+    """multiplier ceiling of a large-round kernel by the form it computes in (GM_LEAN_FR9=0 puts all of them on 8 x 32)"""
+    if os.environ.get("GM_LEAN_FR9", "1")[:1] != "0" and name.startswith("k_round_deg2_lean<") and any(
+            name.split("<")[1].startswith(p_) for p_ in FR9_ROUND_PRIMS):
+        return FR9_MUL_CEILING, "9x29"
+    return FR_MUL_CEILING, "8x32"
+
 P = codec.P
 SEED = 0x474B524D534D      # "GKRMSM"
 
@@ -397,7 +407,8 @@ def main():
                              "total_ms_per_proof": round(r_["total_ms"] / reps, 3), "avg_launch_ms": round(r_["total_ms"] / per, 4),
                              "algorithmic_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 4),
                              "fr_mul_per_s": round(r_["fr_mul"] / (r_["total_ms"] * 1e-3), 1),
-                             "valu_frac_of_measured_ceiling": round(r_["fr_mul"] / (r_["total_ms"] * 1e-3) / FR_MUL_CEILING, 3)})
+                             "valu_frac_of_measured_ceiling": round(r_["fr_mul"] / (r_["total_ms"] * 1e-3) / round_kernel_ceiling(r_["kernel"])[0], 3),
+                             "field_form": round_kernel_ceiling(r_["kernel"])[1]})
             dom_r = max(rows, key=lambda r_: r_["total_ms"])
             ach = dom_r["alg_bytes"] / (dom_r["total_ms"] * 1e-3) / 1e9
             out["sumcheck"]["roofline"] = {
@@ -408,7 +419,8 @@ def main():
                 "algorithmic_bytes_per_launch": int(dom_r["alg_bytes"] / dom_r["launches"]),
                 "algorithmic_bytes_per_pair": int(64 * dom_r["k_cols"] + 32), "launches_per_proof": dom_r["launches"] // reps,
                 "fr_mul_per_s": round(dom_r["fr_mul"] / (dom_r["total_ms"] * 1e-3), 1),
-                "valu_frac_of_measured_ceiling": round(dom_r["fr_mul"] / (dom_r["total_ms"] * 1e-3) / FR_MUL_CEILING, 3),
+                "valu_frac_of_measured_ceiling": round(dom_r["fr_mul"] / (dom_r["total_ms"] * 1e-3) / round_kernel_ceiling(dom_r["kernel"])[0], 3),
+                "field_form": round_kernel_ceiling(dom_r["kernel"])[1],
                 "note": "average over the large (> 2^14 pairs) launches of this kernel in the timed proofs, HIP events on the launch stream"}
             out["sumcheck"]["large_round_kernels"] = kern
             big_bytes = sum(r_["alg_bytes"] for r_ in rows2)
