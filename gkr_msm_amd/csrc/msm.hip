@@ -295,6 +295,95 @@ __global__ void k_rank_scatter(const uint16_t* __restrict__ digits, const uint32
     }
 }
 
+// The same ranking with the scatter regrouped: a workgroup of four waves owns four consecutive chunks of ONE window (4096 points),
+// ranks them as above, regroups the tile by digit in LDS and writes every digit's run out contiguously (16 points per bucket on
+// average at config B = one 64-byte line) instead of 4 bytes per line: k_rank_scatter wrote 1.14 GB through L2 for 128 MB of
+// cell indices.  counter[] is written in x order as before.  Needs chunk == 1024, nchunks % 4 == 0, nd <= 1024.
+__global__ void __launch_bounds__(256) k_rank_scatter_tile(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ chunk_base,
+                                                           const uint32_t* __restrict__ off, uint32_t* __restrict__ counter,
+                                                           uint32_t* __restrict__ cells, uint64_t N, uint32_t d_log, uint32_t nchunks) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t nd = 1u << d_log;
+    uint32_t* cnt = lds;                       // [4][nd] running position of every digit, per wave
+    uint32_t* base0 = cnt + 4 * nd;            // [nd] position of the tile's first point of digit d in its row
+    uint32_t* dig_start = base0 + nd;          // [nd + 1] first slot of digit d in the regrouped tile
+    uint32_t* st_val = dig_start + nd + 1;     // [4096]
+    uint16_t* st_dig = reinterpret_cast<uint16_t*>(st_val + 4096);   // [4096]
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;   // = w * nchunks + c; the four tasks of a block share w
+    const uint64_t w = ((uint64_t)blockIdx.x * 4) / nchunks, c = task % nchunks;
+    const uint32_t* base = chunk_base + task * nd;
+    for (uint32_t i = lane; i < nd; i += 64) cnt[wave * nd + i] = base[i];
+    if (wave == 0) for (uint32_t i = lane; i < nd; i += 64) base0[i] = base[i];
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t xs[16], ps[16];
+    uint16_t ds[16];
+#pragma unroll
+    for (uint32_t st = 0; st < 16; st++) {
+        const uint64_t x = c * 1024 + st * 64 + lane;
+        const bool valid = x < N;
+        const uint32_t dg = valid ? digits[w * N + x] : 0u;
+        uint64_t peers = __ballot(valid);
+        for (uint32_t b = 0; b < d_log; b++) {
+            const uint64_t m = __ballot((dg >> b) & 1u);
+            peers &= ((dg >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = __popcll(peers & lane_lt);
+        const uint32_t pos = cnt[wave * nd + dg] + before;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers >> lane) == 1ull) cnt[wave * nd + dg] = pos + 1;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) counter[w * N + x] = pos;
+        xs[st] = valid ? (uint32_t)x : 0xffffffffu;
+        ps[st] = pos;
+        ds[st] = (uint16_t)dg;
+    }
+    __syncthreads();
+    // points of digit d in the tile = where the last wave's counter ended minus where the first one's began
+    uint32_t mine[4], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t d = tid * 4 + k;   // 4 consecutive digits per thread (nd <= 1024)
+        mine[k] = d < nd ? cnt[3 * nd + d] - base0[d] : 0u;
+        sum += mine[k];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t t = __shfl_up(inc, dd, 64);
+        if ((int)lane >= dd) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (uint32_t k = 0; k < wave; k++) run += wave_tot[k];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t d = tid * 4 + k;
+        if (d < nd) dig_start[d] = run;
+        run += mine[k];
+    }
+    if (tid == 255) dig_start[nd] = run;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t st = 0; st < 16; st++) {
+        if (xs[st] != 0xffffffffu) {
+            const uint32_t slot = dig_start[ds[st]] + (ps[st] - base0[ds[st]]);
+            st_val[slot] = xs[st];
+            st_dig[slot] = ds[st];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = dig_start[nd];
+    for (uint32_t p = tid; p < total; p += 256) {
+        const uint32_t dg = st_dig[p];
+        const uint32_t row = (uint32_t)w * nd + dg;
+        cells[(uint64_t)off[row] + base0[dg] + (p - dig_start[dg])] = st_val[p];
+    }
+}
+
 // identity padding of odd rows (vecvec.rs:181-186)
 __global__ void k_pad_cells(const uint32_t* __restrict__ row_len, const uint32_t* __restrict__ off,
                             uint32_t* __restrict__ cells, uint32_t nrows) {
@@ -700,9 +789,15 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     GM_LAUNCH_CHECK();
     STAGE_MARK(3);
     // 3. stable scatter
-    hipLaunchKernelGGL(k_rank_scatter, dim3(ceil_div(ntasks, waves)), dim3(64 * waves),
-                       waves * nd * sizeof(uint32_t), s, p->digits, p->hist, p->off[0], p->counter, p->cells, N,
-                       p->d_log, p->nchunks, p->chunk, ntasks);
+    if (p->chunk == 1024 && p->nchunks % 4 == 0 && nd <= 1024) {
+        const size_t lds = ((size_t)7 * nd + 1 + 4096) * sizeof(uint32_t) + 4096 * sizeof(uint16_t);
+        hipLaunchKernelGGL(k_rank_scatter_tile, dim3((unsigned)(ntasks / 4)), dim3(256), lds, s, p->digits, p->hist, p->off[0], p->counter,
+                           p->cells, N, p->d_log, p->nchunks);
+    } else {
+        hipLaunchKernelGGL(k_rank_scatter, dim3(ceil_div(ntasks, waves)), dim3(64 * waves),
+                           waves * nd * sizeof(uint32_t), s, p->digits, p->hist, p->off[0], p->counter, p->cells, N,
+                           p->d_log, p->nchunks, p->chunk, ntasks);
+    }
     GM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pad_cells, dim3(ceil_div(nrows, 256)), dim3(256), 0, s, p->row_len, p->off[0], p->cells,
                        nrows);
