@@ -393,14 +393,42 @@ __global__ void k_pad_cells(const uint32_t* __restrict__ row_len, const uint32_t
     if (l & 1u) cells[(uint64_t)off[r] + l] = PAD_IDX;
 }
 
+// First row of every 128-cell block of every level's OUTPUT layout, all levels in one launch: the level kernels then bracket
+// their rows with two loads instead of two 13-step binary searches of dependent loads at the head of every workgroup.
+struct BlockRowsArgs {
+    uint32_t nlev;
+    uint32_t first[33];   // first entry of level l in blk_row; first[nlev] = total entries
+};
+__global__ void __launch_bounds__(256) k_block_rows(BlockRowsArgs a, const uint32_t* __restrict__ off_all, uint32_t nrows,
+                                                    uint32_t* __restrict__ blk_row) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.first[a.nlev]) return;
+    uint32_t l = 0;
+    while (l + 1 < a.nlev && e >= a.first[l + 1]) l++;
+    const uint32_t* off = off_all + (uint64_t)(l + 1) * (nrows + 1);   // output layout of level l
+    const uint32_t j = (e - a.first[l]) * 128, total = off[nrows];
+    blk_row[e] = j < total ? find_row(off, nrows, j) : nrows - 1;
+}
+// row of cell j for a thread of block blockIdx.x, from the block-row table of its level
+__device__ __forceinline__ uint32_t find_row_tab(const uint32_t* __restrict__ off, uint32_t nrows, const uint32_t* __restrict__ br, uint32_t j) {
+    uint32_t lo = br[blockIdx.x], hi = br[blockIdx.x + 1] + 1;  // off[lo] <= j < off[hi]
+    if (hi > nrows) hi = nrows;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // bintree level 0: gather affine points by index, add pairs (2p, 2p+1) of every row
 __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* __restrict__ cells,
                              const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
-                             uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz) {
+                             uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz,
+                             const uint32_t* __restrict__ br) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = off_out[nrows];
-    const uint32_t r = find_row_block(off_out, nrows, j, j < total, total);
     if (j >= total) return;
+    const uint32_t r = find_row_tab(off_out, nrows, br, j);
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
     if (p < half) {
@@ -423,11 +451,12 @@ __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* _
 // bintree level >= 1
 __global__ void __launch_bounds__(128) k_add_level(const Fr* __restrict__ ix, const Fr* __restrict__ iy, const Fr* __restrict__ iz,
                             const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
-                            uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz) {
+                            uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz,
+                            const uint32_t* __restrict__ br) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = off_out[nrows];
-    const uint32_t r = find_row_block(off_out, nrows, j, j < total, total);
     if (j >= total) return;
+    const uint32_t r = find_row_tab(off_out, nrows, br, j);
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
     if (p < half) {
@@ -736,6 +765,18 @@ extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, ui
     GM_REQUIRE(cells_in < 0xfffffff0ull, "too many cells for 32-bit offsets");
     p->cap0 = cells_in / 2 + p->nrows + 2;
     p->cap1 = p->cap0 / 2 + p->nrows + 2;
+    {   // block-row tables of the flat levels 0 .. x_logsize - 2 (the last level is the row-owned tail kernel)
+        uint64_t cells = p->cap0;
+        uint32_t tot = 0;
+        p->blk_nlev = p->x_log >= 2 ? p->x_log - 1 : 0;
+        if (p->blk_nlev > 32) p->blk_nlev = 32;
+        for (uint32_t l = 0; l < p->blk_nlev; l++) {
+            p->blk_first[l] = tot;
+            tot += (uint32_t)((cells + 127) / 128) + 1;
+            cells = cells / 2 + p->nrows + 2;
+        }
+        p->blk_first[p->blk_nlev] = tot;
+    }
     int32_t rc = GM_OK;
 #define ALLOC(ptr, n) if ((rc = plan_alloc(p, &(ptr), (n))) != GM_OK) { gm_msm_plan_destroy(p); return rc; }
     ALLOC(p->digits, (uint64_t)p->nwin * p->N);
@@ -744,6 +785,7 @@ extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, ui
     ALLOC(p->row_len, p->nrows);
     // off[0] holds the offsets of ALL levels: level l at off[0] + l * (nrows + 1); level 0 = the image rows
     ALLOC(p->off[0], (uint64_t)(x_logsize + 1) * (p->nrows + 1));
+    ALLOC(p->blk_row, (uint64_t)p->blk_first[p->blk_nlev] + 1);
     ALLOC(p->cells, cells_in + 2);
     for (int c = 0; c < 3; c++) {
         ALLOC(p->lvl[0][c], p->cap0);
@@ -760,7 +802,7 @@ extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, ui
 extern "C" int32_t gm_msm_plan_destroy(gm_msm_plan* p) {
     if (!p) return GM_OK;
     dev_free(p->digits); dev_free(p->counter); dev_free(p->hist); dev_free(p->row_len);
-    dev_free(p->off[0]); dev_free(p->off[1]); dev_free(p->off[2]); dev_free(p->cells);
+    dev_free(p->off[0]); dev_free(p->off[1]); dev_free(p->off[2]); dev_free(p->cells); dev_free(p->blk_row);
     for (int c = 0; c < 3; c++) { dev_free(p->lvl[0][c]); dev_free(p->lvl[1][c]); dev_free(p->bsum[c]); }
     dev_free(p->win_pts);
     dev_free(p->tri_scratch);
@@ -826,6 +868,13 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     GM_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_offsets_levels_par<false>), dim3(p->x_log), dim3(1024), 0, s, p->row_len, p->off[0], nrows);
     GM_LAUNCH_CHECK();
+    if (p->blk_nlev) {
+        BlockRowsArgs ba;
+        ba.nlev = p->blk_nlev;
+        for (uint32_t l = 0; l <= p->blk_nlev; l++) ba.first[l] = p->blk_first[l];
+        hipLaunchKernelGGL(k_block_rows, dim3(ceil_div(p->blk_first[p->blk_nlev], 256)), dim3(256), 0, s, ba, p->off[0], nrows, p->blk_row);
+        GM_LAUNCH_CHECK();
+    }
     STAGE_MARK(3);
     // 3. stable scatter
     if (p->chunk == 1024 && p->nchunks % 4 == 0 && nd <= 1024) {
@@ -853,7 +902,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     } else {
         STAGE_MARK(4);
         hipLaunchKernelGGL(k_add_level0, dim3(ceil_div(cap_out, 128)), dim3(128), 0, s, pts, p->cells, p->off[0],
-                           p->off[0] + stride, nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2]);
+                           p->off[0] + stride, nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2], p->blk_row + p->blk_first[0]);
         GM_LAUNCH_CHECK();
         STAGE_MARK(5);
         // The row-owned tail kernel can take over any number of trailing levels in one launch.  Measured on MI355X
@@ -867,7 +916,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
             hipLaunchKernelGGL(k_add_level, dim3(ceil_div(cells_next, 128)), dim3(128), 0, s, p->lvl[cur_lvl][0],
                                p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[0] + (uint64_t)level * stride,
                                p->off[0] + (uint64_t)(level + 1) * stride, nrows, p->lvl[cur_lvl ^ 1][0],
-                               p->lvl[cur_lvl ^ 1][1], p->lvl[cur_lvl ^ 1][2]);
+                               p->lvl[cur_lvl ^ 1][1], p->lvl[cur_lvl ^ 1][2], p->blk_row + p->blk_first[level]);
             GM_LAUNCH_CHECK();
             cur_lvl ^= 1;
             cells_cur = cells_next;

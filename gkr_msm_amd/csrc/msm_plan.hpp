@@ -15,6 +15,9 @@ struct gm_msm_plan {
     uint32_t* row_len = nullptr;
     uint32_t* off[3] = {nullptr, nullptr, nullptr};  // [0] = image rows (kept), [1],[2] ping-pong over levels
     uint32_t* cells = nullptr;
+    uint32_t* blk_row = nullptr;   // first row of every 128-cell block of every level's output layout (k_block_rows)
+    uint32_t blk_first[33] = {};  // level l's entries start at blk_first[l]; blk_nlev levels
+    uint32_t blk_nlev = 0;
     Fr* lvl[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     Fr* bsum[3] = {nullptr, nullptr, nullptr};
     Fr* win_pts = nullptr;
