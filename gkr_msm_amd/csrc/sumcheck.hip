@@ -1176,12 +1176,19 @@ __global__ void __launch_bounds__(SC_THREADS) k_prefix_sums_levels(const Fr* __r
 // (bind_21, vecvec.rs:420-441); blockIdx.y = column
 __global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut out, const uint32_t* __restrict__ off_in,
                                                          const uint32_t* __restrict__ off_out, uint32_t nrows, Fr t,
-                                                         PadCols pad, const Fr* __restrict__ d_t, int ncols) {
+                                                         PadCols pad, const Fr* __restrict__ d_t, int ncols,
+                                                         const uint32_t* __restrict__ coarse_out) {
     if (d_t) t = fr_load(d_t);  // pre-enqueued fold: the challenge arrives through the gate kernel (k_fold_gate)
     const uint32_t j = blockIdx.x * SC_THREADS + threadIdx.x;
     const uint32_t total = off_out[nrows];
-    const uint32_t r = find_row_block(off_out, nrows, j, j < total, total);
-    if (j >= total) return;
+    uint32_t r;
+    if (coarse_out) {   // the coarse table of the output layout: one load instead of the block's two 13-step searches (small folds are all latency)
+        if (j >= total) return;
+        r = find_row_coarse(off_out, nrows, coarse_out, j);
+    } else {
+        r = find_row_block(off_out, nrows, j, j < total, total);
+        if (j >= total) return;
+    }
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
     // two columns per thread (grid y = ceil(k / 2)): four loads in flight per thread, one row lookup for both
@@ -2590,7 +2597,7 @@ struct ScVecVecDeg2 : gm_sc {
             hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(already_bound), rs.ticket_word(), fold_ticket,
                                rs.ticket_word() + 1, d_t, wait_timeout_ticks());
             hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(nx_bound, SC_THREADS), (k + 1) / 2), dim3(SC_THREADS), 0, stream, ci, co, off_cur,
-                               nx_off, nrows, fr_zero(), pd, (const Fr*)d_t, k);
+                               nx_off, nrows, fr_zero(), pd, (const Fr*)d_t, k, coarse_for(nx_off));
             GM_LAUNCH_CHECK();
             prof_fold(96.0 * k * (double)(cells_bound / 2));
             fold_pending = true;
@@ -2808,7 +2815,7 @@ struct ScVecVecDeg2 : gm_sc {
                 pd.v[i] = row_pad[i];
             }
             hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(new_bound, SC_THREADS), (k + 1) / 2), dim3(SC_THREADS), 0, stream, ci, co,
-                               off_cur, off_next, nrows, t, pd, (const Fr*)nullptr, k);
+                               off_cur, off_next, nrows, t, pd, (const Fr*)nullptr, k, coarse_for(off_next));
             GM_LAUNCH_CHECK();
             prof_fold(96.0 * k * (double)(cells_bound / 2));
             for (int i = 0; i < k; i++) cur[i] = co.p[i];
