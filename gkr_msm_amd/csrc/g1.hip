@@ -126,6 +126,33 @@ __device__ __forceinline__ uint32_t g1_find_row(const uint32_t* __restrict__ off
     return lo;
 }
 
+// First row of every 128-cell block of every level's output layout, all levels in one launch (as msm.hip's k_block_rows): a thread
+// of k_g1_level then brackets its row with two loads instead of an 18-step search of dependent loads -- these kernels run one or
+// two waves per SIMD, nothing hides that latency.
+struct G1BlockRowsArgs {
+    uint32_t nlev;
+    uint32_t first[34];   // first entry of level l + 1 in blk_row; first[nlev] = total entries
+};
+__global__ void __launch_bounds__(256) k_g1_block_rows(G1BlockRowsArgs a, const uint32_t* __restrict__ off_all, size_t ostride,
+                                                       uint32_t nrows, uint32_t* __restrict__ blk_row) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.first[a.nlev]) return;
+    uint32_t l = 0;
+    while (l + 1 < a.nlev && e >= a.first[l + 1]) l++;
+    const uint32_t* off = off_all + (size_t)(l + 1) * ostride;
+    const uint32_t j = (e - a.first[l]) * 128, total = off[nrows];
+    blk_row[e] = j < total ? g1_find_row(off, nrows, j) : nrows - 1;
+}
+__device__ __forceinline__ uint32_t g1_find_row_tab(const uint32_t* __restrict__ off, uint32_t nrows, const uint32_t* __restrict__ br, uint32_t j) {
+    uint32_t lo = br[blockIdx.x], hi = br[blockIdx.x + 1] + 1;  // off[lo] <= j < off[hi]
+    if (hi > nrows) hi = nrows;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // sources of level 0: points addressed through the sorted task indices
 struct G1SrcAff {
     const G1Aff* pts;
@@ -162,10 +189,10 @@ __device__ __forceinline__ G1Jac g1_pair(const G1SrcJac& s, uint32_t c0, bool tw
 template <class Src>
 __global__ void __launch_bounds__(128) k_g1_level(Src src, const uint32_t* __restrict__ off_in,
                                                    const uint32_t* __restrict__ off_out, uint32_t nrows,
-                                                   G1Jac* __restrict__ out) {
+                                                   G1Jac* __restrict__ out, const uint32_t* __restrict__ br) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= off_out[nrows]) return;
-    const uint32_t r = g1_find_row(off_out, nrows, j);
+    const uint32_t r = g1_find_row_tab(off_out, nrows, br, j);
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], len = off_in[r + 1] - in0;
     g1_store(out + j, g1_pair(src, in0 + 2 * p, 2 * p + 1 < len));
@@ -449,7 +476,7 @@ static int32_t g1_engine_layout(uint64_t ntasks, uint32_t nkeys, G1Layout* L) {
     const size_t st = radix_sort_tmp_bytes(ntasks), sc = 33 * scan_tmp_bytes((size_t)nkeys + 1);   // tile totals of every level
     L->sort_tmp = st;
     L->scan_tmp = sc;
-    L->total = al(st) + al(sc) + 2 * al(ntasks * 4) + 35 * al(((size_t)nkeys + 1) * 4) + al(64) +
+    L->total = al(st) + al(sc) + 2 * al(ntasks * 4) + 35 * al(((size_t)nkeys + 1) * 4) + al(64) + al((ntasks / 64 + (size_t)34 * (nkeys / 32 + 3) + 64) * 4) +
                al((ntasks / 2 + nkeys + 1) * sizeof(G1Jac)) + al((ntasks / 4 + nkeys + 1) * sizeof(G1Jac)) + 4096;
     return GM_OK;
 }
@@ -474,6 +501,7 @@ static int32_t g1_sum_by_key(G1Scratch& ws, const G1Aff* src_aff, const G1Jac* s
     uint32_t* d_max = (uint32_t*)ws.carve(64);
     G1Jac* bufA = (G1Jac*)ws.carve((ntasks / 2 + nkeys + 1) * sizeof(G1Jac));
     G1Jac* bufB = (G1Jac*)ws.carve((ntasks / 4 + nkeys + 1) * sizeof(G1Jac));
+    uint32_t* blk_row = (uint32_t*)ws.carve((ntasks / 64 + (size_t)34 * (nkeys / 32 + 3) + 64) * 4);
     if (ws.used > ws.cap) return set_err(GM_ERR_STATE, "G1 scratch under-reserved (%zu > %zu)", ws.used, ws.cap);
 
     GM_HIP(hipMemsetAsync(d_max, 0, 4, s));
@@ -506,15 +534,29 @@ static int32_t g1_sum_by_key(G1Scratch& ws, const G1Aff* src_aff, const G1Jac* s
     }
     // level 1 from the sources; cells of level l never exceed ntasks / 2^l + nkeys
     uint64_t bound = ntasks / 2 + nkeys;
-    if (src_aff) hipLaunchKernelGGL((k_g1_level<G1SrcAff>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sa, off_all, off_all + ostride, nkeys, bufA);
-    else hipLaunchKernelGGL((k_g1_level<G1SrcJac>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sj, off_all, off_all + ostride, nkeys, bufA);
+    G1BlockRowsArgs ba;
+    ba.nlev = nlev;
+    {
+        uint64_t b = bound;
+        uint32_t tot = 0;
+        for (uint32_t l = 0; l < nlev; l++) {
+            ba.first[l] = tot;
+            tot += (uint32_t)((b + 127) / 128) + 1;
+            b = b / 2 + nkeys;
+        }
+        ba.first[nlev] = tot;
+        hipLaunchKernelGGL(k_g1_block_rows, dim3(ceil_div(tot, 256)), dim3(256), 0, s, ba, off_all, ostride, nkeys, blk_row);
+        GM_LAUNCH_CHECK();
+    }
+    if (src_aff) hipLaunchKernelGGL((k_g1_level<G1SrcAff>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sa, off_all, off_all + ostride, nkeys, bufA, blk_row + ba.first[0]);
+    else hipLaunchKernelGGL((k_g1_level<G1SrcJac>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sj, off_all, off_all + ostride, nkeys, bufA, blk_row + ba.first[0]);
     GM_LAUNCH_CHECK();
     G1Jac *cur = bufA, *nxt = bufB;
     for (uint32_t l = 2; l <= nlev; l++) {
         bound = bound / 2 + nkeys;
         const G1SrcJac sl{cur, nullptr};
         hipLaunchKernelGGL((k_g1_level<G1SrcJac>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sl, off_all + (l - 1) * ostride,
-                           off_all + l * ostride, nkeys, nxt);
+                           off_all + l * ostride, nkeys, nxt, blk_row + ba.first[l - 1]);
         GM_LAUNCH_CHECK();
         G1Jac* t = cur; cur = nxt; nxt = t;
     }
