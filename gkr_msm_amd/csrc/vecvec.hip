@@ -61,10 +61,11 @@ struct PadVals {
 __global__ void __launch_bounds__(256) k_vv_map_split(SegPlan sp, ColPtrs in, ColPtrsMut out,
                                                        const uint32_t* __restrict__ off_in,
                                                        const uint32_t* __restrict__ off_out, uint32_t nrows,
-                                                       uint32_t bundle, PadVals pad) {
+                                                       uint32_t bundle, PadVals pad, const uint32_t* __restrict__ coarse_out) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= off_out[nrows]) return;
-    const uint32_t r = find_row(off_out, nrows, j);
+    // the coarse table of the output layout (gm_vv::coarse) when the shape carries one: one load instead of 13 dependent ones
+    const uint32_t r = coarse_out ? find_row_coarse(off_out, nrows, coarse_out, j) : find_row(off_out, nrows, j);
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half_len = (off_in[r + 1] - in0) >> 1;
     if (p < half_len) {
@@ -292,7 +293,9 @@ int32_t vv_map_split(const SegPlan& sp, const gm_vv* in, uint32_t bundle, gm_vv*
     for (int i = 0; i < 2 * sp.n_outs; i++) co.p[i] = o->cols[i]->fr();
     if (tot) {
         hipLaunchKernelGGL(k_vv_map_split, dim3(ceil_div(tot, 256)), dim3(256), 0, s, sp, ci, co,
-                           reinterpret_cast<const uint32_t*>(in->off->p), reinterpret_cast<const uint32_t*>(o->off->p), in->nrows, bundle, pv);
+                           reinterpret_cast<const uint32_t*>(in->off->p), reinterpret_cast<const uint32_t*>(o->off->p), in->nrows, bundle, pv,
+                           (o->coarse && o->coarse_off && o->off_level < o->coarse_off->size())
+                               ? reinterpret_cast<const uint32_t*>(o->coarse->p) + (*o->coarse_off)[o->off_level] : (const uint32_t*)nullptr);
         GM_LAUNCH_CHECK();
     }
     *out = o.release();
