@@ -164,6 +164,54 @@ __global__ void __launch_bounds__(1024) k_eq_small(EqSmallArgs a) {
     }
 }
 
+// Two independent small sequences in ONE launch, one workgroup each (a VecVec sumcheck object needs eq(point[0..col]) and the
+// padded row sequence: 36 + 13 us back to back as two launches), plus up to 16 scalars stored by workgroup 1 (the scalar levels of
+// the padded sequence: one more launch saved).
+struct EqPairArgs {
+    EqSmallArgs a[2];
+    Fr scal[16];
+    Fr* scal_dst;
+    uint32_t n_scal;
+};
+__global__ void __launch_bounds__(1024) k_eq_small_pair(EqPairArgs q) {
+    __shared__ Fr buf[2][1024];
+    const EqSmallArgs& a = q.a[blockIdx.x];
+    if (blockIdx.x == 1 && threadIdx.x < q.n_scal) fr_store(q.scal_dst + threadIdx.x, q.scal[threadIdx.x]);
+    if (threadIdx.x == 0) { fr_store(a.level[0], a.mult); buf[0][0] = a.mult; }
+    __syncthreads();
+    for (uint32_t i = 1; i <= a.nlev; i++) {
+        const uint32_t np = 1u << (i - 1);
+        const Fr r = a.pt[i - 1];
+        const bool src_lds = np <= 1024, dst_lds = 2 * np <= 1024;
+        for (uint32_t j = threadIdx.x; j < np; j += blockDim.x) {
+            const Fr w = src_lds ? buf[(i - 1) & 1][j] : fr_load(a.level[i - 1] + j);
+            const Fr m = fr_mul(r, w);
+            const Fr lo = fr_sub(w, m);
+            fr_store(a.level[i] + 2 * j, lo);
+            fr_store(a.level[i] + 2 * j + 1, m);
+            if (dst_lds) { buf[i & 1][2 * j] = lo; buf[i & 1][2 * j + 1] = m; }
+        }
+        __syncthreads();
+    }
+}
+// false: does not fit one launch (a sequence longer than EQ_SMALL_LEVELS or too many scalars): use launch_eq_sequence
+bool launch_eq_pair(const Fr& mult0, const Fr* pt0, uint32_t nvars0, Fr* const* levels0, const Fr& mult1, const Fr* pt1, uint32_t nvars1,
+                    Fr* const* levels1, const Fr* scal, uint32_t n_scal, Fr* scal_dst, hipStream_t s) {
+    if (nvars0 > EQ_SMALL_LEVELS || nvars1 > EQ_SMALL_LEVELS || n_scal > 16) return false;
+    EqPairArgs q;
+    q.a[0].mult = mult0; q.a[0].nlev = nvars0;
+    for (uint32_t i = 0; i <= nvars0; i++) q.a[0].level[i] = levels0[i];
+    for (uint32_t i = 0; i < nvars0; i++) q.a[0].pt[i] = pt0[i];
+    q.a[1].mult = mult1; q.a[1].nlev = nvars1;
+    for (uint32_t i = 0; i <= nvars1; i++) q.a[1].level[i] = levels1[i];
+    for (uint32_t i = 0; i < nvars1; i++) q.a[1].pt[i] = pt1[i];
+    for (uint32_t i = 0; i < n_scal; i++) q.scal[i] = scal[i];
+    q.scal_dst = scal_dst;
+    q.n_scal = n_scal;
+    hipLaunchKernelGGL(k_eq_small_pair, dim3(2), dim3(1024), 0, s, q);
+    return hipGetLastError() == hipSuccess;
+}
+
 int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s) {
     const uint32_t small = nvars < EQ_SMALL_LEVELS ? nvars : EQ_SMALL_LEVELS;
     {

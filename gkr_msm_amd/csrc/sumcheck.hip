@@ -3100,6 +3100,7 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
     const uint32_t n_seq_vars = (nvars - 1) - polys->col_logsize;        // row_vars_range().len()
     so->padded_vars = padded;
     // row_eq_coefs = eq(point[0..col_logsize]) and its tail sums
+    std::vector<Fr*> row_lv;
     {
         rc = so->d_row_coef.alloc(((size_t)2 << polys->col_logsize) * sizeof(Fr));
         if (rc) return rc;
@@ -3107,8 +3108,7 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         Fr* scratch = so->d_row_coef.fr() + ((size_t)1 << polys->col_logsize);
         for (uint32_t i = 0; i < polys->col_logsize; i++) lv[i] = scratch + ((1ull << i) - 1);
         lv[polys->col_logsize] = so->d_row_coef.fr();
-        rc = launch_eq_sequence(fr_one(), so->point.data(), polys->col_logsize, lv.data(), s);
-        if (rc) return rc;
+        row_lv = lv;   // launched below, together with the padded row sequence
         // row_eq_coefs_tail_sums[nrows] = sum_{j >= nrows} eq(point[0..col], j) = 1 - eq_sum(point[0..col], nrows)
         so->row_coef_tail.assign(((size_t)1 << polys->col_logsize) + 1, fr_zero());
         so->row_coef_tail[so->nrows] = fr_sub(fr_one(), eq_sum_host(so->point.data(), polys->col_logsize, so->nrows));
@@ -3134,13 +3134,19 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         std::vector<Fr> scal(padded + 1);
         scal[0] = fr_one();
         for (uint32_t i = 1; i <= padded; i++) { acc = fr_mul(acc, fr_sub(fr_one(), pt[i - 1])); scal[i] = acc; }
-        rc = upload_small(scal.data(), scal.size(), so->d_eq_seq.fr(), s);
-        if (rc) return rc;
         std::vector<Fr*> lv(n_seq_vars - padded + 1);
         for (uint32_t i = padded; i <= n_seq_vars; i++) lv[i - padded] = so->d_eq_seq.fr() + so->eq_level_off[i];
-        // levels padded..n_seq_vars are the ordinary doubling levels started from the scalar m
-        rc = launch_eq_sequence(m, pt + padded, n_seq_vars - padded, lv.data(), s);
-        if (rc) return rc;
+        // levels padded..n_seq_vars are the ordinary doubling levels started from the scalar m; both sequences and the scalar levels
+        // in one launch when they fit (they do for every shape with col_logsize, row variables <= 14)
+        if (!launch_eq_pair(fr_one(), so->point.data(), polys->col_logsize, row_lv.data(), m, pt + padded, n_seq_vars - padded, lv.data(),
+                            scal.data(), (uint32_t)scal.size(), so->d_eq_seq.fr(), s)) {
+            rc = launch_eq_sequence(fr_one(), so->point.data(), polys->col_logsize, row_lv.data(), s);
+            if (rc) return rc;
+            rc = upload_small(scal.data(), scal.size(), so->d_eq_seq.fr(), s);
+            if (rc) return rc;
+            rc = launch_eq_sequence(m, pt + padded, n_seq_vars - padded, lv.data(), s);
+            if (rc) return rc;
+        }
         // row_eq_poly_prefix_seq (vecvec.rs:101-109): level l -> len_l + 1 prefix sums, packed at offset off_l + l
         rc = so->d_prefix.alloc((size_t)(tot + n_seq_vars + 2) * sizeof(Fr));
         if (rc) return rc;
