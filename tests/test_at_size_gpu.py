@@ -384,3 +384,12 @@ def test_config_e_dry_run_of_one_ranks_share_of_the_sharded_prover():
     del d_pts, d_sc
     ffi.lib().gm_release_cached_memory()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("x_log,d_log,nbits", [(12, 10, 30), (13, 9, 27), (12, 3, 12), (14, 6, 128), (12, 2, 6)])
+def test_tiled_scatter_and_block_row_tables_at_other_bucket_widths(x_log, d_log, nbits):
+    """the MSM paths that need at least 4096 points (tile-regrouped bucket scatter, block-row tables of the level kernels) at the
+    bucket widths the full-size configs do not cover (d_logsize 2, 3, 6, 9, 10), against the C oracle: digits, counter, bucket
+    populations, bucket sums, window points, final point"""
+    plan, d_pts, d_sc, pts_host, sc = check_msm(x_log, d_log, nbits, 0x7157 + d_log)
+    plan.close()
