@@ -422,6 +422,17 @@ def main():
                 "valu_frac_of_measured_ceiling": round(dom_r["fr_mul"] / (dom_r["total_ms"] * 1e-3) / round_kernel_ceiling(dom_r["kernel"])[0], 3),
                 "field_form": round_kernel_ceiling(dom_r["kernel"])[1],
                 "note": "average over the large (> 2^14 pairs) launches of this kernel in the timed proofs, HIP events on the launch stream"}
+            if dom_r.get("max_ms_pairs", 0) > 0 and dom_r["max_ms"] > 0:
+                # the largest launch on its own (the average above is dominated by the 2^14-2^17-pair launches and their ~15 us of
+                # launch + cross-block reduction each)
+                bpp = dom_r["alg_bytes"] / dom_r["pairs"]
+                mpp = dom_r["fr_mul"] / dom_r["pairs"]
+                lg_b = bpp * dom_r["max_ms_pairs"] / (dom_r["max_ms"] * 1e-3) / 1e9
+                lg_m = mpp * dom_r["max_ms_pairs"] / (dom_r["max_ms"] * 1e-3)
+                out["sumcheck"]["roofline"]["largest_launch"] = {
+                    "pairs": int(dom_r["max_ms_pairs"]), "ms": round(dom_r["max_ms"], 4), "achieved": round(lg_b, 1),
+                    "frac": round(lg_b / HBM_PEAK_GBS, 4), "fr_mul_per_s": round(lg_m, 1),
+                    "valu_frac_of_measured_ceiling": round(lg_m / round_kernel_ceiling(dom_r["kernel"])[0], 3)}
             out["sumcheck"]["large_round_kernels"] = kern
             big_bytes = sum(r_["alg_bytes"] for r_ in rows2)
             tot = big_bytes + other_bytes + fold_bytes

@@ -3293,7 +3293,7 @@ extern "C" int32_t gm_sc_profile_read(gm_sc_profile_row* rows, uint32_t cap, uin
         row.pairs += (double)pairs;
         row.alg_bytes += (64.0 * r.k + ((r.cls & 3) == 2 ? 0.0 : ((r.cls & 3) == 3 ? 0.0 : 32.0))) * (double)pairs;
         row.fr_mul += (double)r.fr_mul_per_pair * (double)pairs;
-        if (ms > row.max_ms) row.max_ms = ms;
+        if (ms > row.max_ms) { row.max_ms = ms; row.max_ms_pairs = (double)pairs; }
     }
     *n_rows = (uint32_t)acc.size();
     if (rows) {

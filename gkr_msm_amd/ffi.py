@@ -68,7 +68,8 @@ class GmFragment(C.Structure):
 
 class GmScProfileRow(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_uint32), ("k_cols", C.c_uint32), ("total_ms", C.c_double),
-                ("max_ms", C.c_double), ("pairs", C.c_double), ("alg_bytes", C.c_double), ("fr_mul", C.c_double)]
+                ("max_ms", C.c_double), ("pairs", C.c_double), ("alg_bytes", C.c_double), ("fr_mul", C.c_double),
+                ("max_ms_pairs", C.c_double)]
 
 
 class GmComm(C.Structure):

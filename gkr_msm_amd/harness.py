@@ -841,5 +841,5 @@ def sc_profile_read():
     n, orb, fb = C.c_uint32(), C.c_double(), C.c_double()
     ffi.check(ffi.lib().gm_sc_profile_read(rows, 64, C.byref(n), C.byref(orb), C.byref(fb), cur_stream()))
     out = [dict(kernel=r.kernel.decode(), launches=r.launches, k_cols=r.k_cols, total_ms=r.total_ms, max_ms=r.max_ms, pairs=r.pairs,
-                alg_bytes=r.alg_bytes, fr_mul=r.fr_mul) for r in rows[: n.value]]
+                alg_bytes=r.alg_bytes, fr_mul=r.fr_mul, max_ms_pairs=r.max_ms_pairs) for r in rows[: n.value]]
     return out, orb.value, fb.value

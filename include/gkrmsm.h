@@ -191,6 +191,7 @@ typedef struct gm_sc_profile_row {
     double pairs;        /* pairs processed over all launches */
     double alg_bytes;    /* algorithmic bytes read over all launches */
     double fr_mul;       /* field multiplications over all launches */
+    double max_ms_pairs; /* pairs of the launch that took max_ms (the largest one: its own roofline figure) */
 } gm_sc_profile_row;
 int32_t gm_sc_profile(int32_t mode);
 int32_t gm_sc_profile_read(gm_sc_profile_row* rows, uint32_t cap, uint32_t* n_rows, double* other_round_bytes, double* fold_bytes,
