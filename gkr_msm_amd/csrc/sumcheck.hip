@@ -994,7 +994,7 @@ __device__ __forceinline__ Fr9 lean_gamma_eval9(const LD& ld, const Fr* __restri
 }
 
 template <int PRIM, bool VECVEC>
-__global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean9(LeanCols cols, const Fr* __restrict__ eq, const Fr* __restrict__ gp,
+__global__ void __launch_bounds__(SC_THREADS, 3) k_round_deg2_lean9(LeanCols cols, const Fr* __restrict__ eq, const Fr* __restrict__ gp,
                                                                   uint64_t npairs_dense, VVArgs vv, FinishCtx fc) {
     constexpr int NACC = VECVEC ? 3 : 2;
     Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
