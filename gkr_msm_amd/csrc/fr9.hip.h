@@ -233,6 +233,17 @@ __device__ __forceinline__ Fr9 fr9_sub8(const Fr9& a, const Fr9& b) {
     for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + fr9_bias8(i) - b.l[i];
     return r;
 }
+// a - b + 64 p: b may be a shifted load (32 X, anything below 63.9 p)
+__device__ __forceinline__ constexpr uint32_t fr9_bias64(int i) {
+    return i == 0 ? 0x40000040u : i == 1 ? 0x5ffffdfeu : i == 2 ? 0x45bfeffdu : i == 3 ? 0x52017ffdu : i == 4 ? 0x40154ef4u
+         : i == 5 ? 0x41013439u : i == 6 ? 0x483339d6u : i == 7 ? 0x594cebe8u : 0x1cfb69d2u;
+}
+__device__ __forceinline__ Fr9 fr9_sub64(const Fr9& a, const Fr9& b) {
+    Fr9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + fr9_bias64(i) - b.l[i];
+    return r;
+}
 // a - b - c + 32 p  (limbs of b + c <= 2^30 - 2: both normalised; top limbs: b + c < 31.9 p)
 __device__ __forceinline__ Fr9 fr9_sub2_32(const Fr9& a, const Fr9& b, const Fr9& c) {
     Fr9 r;
@@ -283,6 +294,11 @@ __device__ __forceinline__ Fr9 fr9_one256() {
 __device__ __forceinline__ Fr9 fr9_two271() {
     return fr9_const(0x1ffee558u, 0x0008d53fu, 0x0f2eaa00u, 0x0220139fu, 0x05e4224eu, 0x100eb2eau, 0x00c2a845u, 0x12a69488u, 0x0021b895u);
 }
+__device__ __forceinline__ Fr9 fr9_two266() {
+    return fr9_const(0x1ffff72bu, 0x000046a7u, 0x1f5f3540u, 0x0ce3021cu, 0x118f3661u, 0x008176cbu, 0x054e487cu, 0x102e8190u, 0x001e092eu);
+}
+// 2^251 (below p): the field's one in domain 251
+__device__ __forceinline__ Fr9 fr9_one251() { return fr9_const(0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0x00080000u); }
 __device__ __forceinline__ Fr9 fr9_two276() {
     return fr9_const(0x1fdcaaf7u, 0x011aa847u, 0x09864240u, 0x0e7a3defu, 0x13014aa7u, 0x15b231edu, 0x1a2dd48du, 0x1743bfd3u, 0x0023b7d0u);
 }

@@ -925,14 +925,42 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
 // 5.22, PROJ_L3 4.65 vs 5.12, AFF_L1+BITCHECK 4.42 vs 5.13, AFF_L3 2.88 vs 3.26; gen-1 at 2^20 points: 353 vs 368 ms.
 // GM_LEAN_FR9=0 switches the form off (A/B measurements).
 __host__ __device__ constexpr bool lean9_has(int prim) {
-    return prim == FN_PROJ_L1 || prim == FN_PROJ_L2 || prim == FN_PROJ_L3 || prim == FN_AFF_L1 || prim == LEAN_AFF_L1_BC || prim == FN_AFF_L3;
+    return prim == FN_PROJ_L1 || prim == FN_PROJ_L2 || prim == FN_PROJ_L3 || prim == FN_AFF_L1 || prim == LEAN_AFF_L1_BC || prim == FN_AFF_L3 ||
+           prim == FN_AFF_L2 || prim == FN_PT_BIT_CHOICE || prim == FN_ADD_INVERSES || prim == FN_LOGUP_LAYER;
 }
+// AFF_L2 and ADD_INVERSES have terms of degree one (a + b): those stay in domain 256, and their product term is brought there by
+// taking ONE factor from a shifted load (domain 261): (g v0) v1s is 261 + 256 - 261 = 256, times 261, minus 261 = 256.  Their
+// accumulators therefore sit five binary places higher than the others'.
+__host__ __device__ constexpr bool lean9_terms_256(int prim) { return prim == FN_AFF_L2 || prim == FN_ADD_INVERSES; }
 // ld(q): input q at the evaluation point -- L 2^29, S <= 10, domain 256; loaded (and, at the second point, formed from the pair)
 // when the formula first needs it, in an order that keeps at most three inputs live: nine registers per value is what pushed the
 // six-input primitives to 256 VGPRs when all inputs were loaded up front.  Result: domain 251, L <= 5 2^29, S <= 30.
-template <int PRIM, typename LD>
-__device__ __forceinline__ Fr9 lean_gamma_eval9(const LD& ld, const Fr* __restrict__ g) {
-    if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
+// lds(q): the same input from shifted loads (domain 261, L 2^29 with a top limb below 2^29.9, S <= 128)
+template <int PRIM, typename LD, typename LDS>
+__device__ __forceinline__ Fr9 lean_gamma_eval9(const LD& ld, const LDS& lds, const Fr* __restrict__ g) {
+    if (PRIM == FN_ADD_INVERSES) {
+        // v0 + v1 + g1 v0 v1, every term in domain 256
+        const Fr9 v0 = ld(0);
+        const Fr9 t = fr9_mul(fr9_mul(fr9_load(g + 1), v0), lds(1));                     // S 5.5, then 5.5 x 128 / 70.66 + 1 = 11
+        return fr9_add(fr9_add(v0, ld(1)), t);                                           // L 3 2^29, S 31
+    } else if (PRIM == FN_AFF_L2) {
+        // v0 + v1 + g1 v2 + g2 v0 v1, every term in domain 256
+        const Fr9 v0 = ld(0);
+        Fr9 A = fr9_mul(fr9_mul(fr9_load(g + 2), v0), lds(1));                           // S 11
+        A = fr9_add(A, fr9_mul(fr9_load(g + 1), ld(2)));                                 // S 5.5
+        return fr9_add(fr9_add(A, v0), ld(1));                                           // L 4 2^29, S 36.5
+    } else if (PRIM == FN_PT_BIT_CHOICE) {
+        // b x + g1 (b (y - 1) + 1): the constant one joins in domain 251
+        const Fr9 b = ld(0);
+        const Fr9 by = fr9_add(fr9_mul(b, fr9_norm(fr9_sub8(ld(2), fr9_one256()))), fr9_one251());   // S 3.5 + 0.06, L 2^30
+        return fr9_add(fr9_mul(b, ld(1)), fr9_mul(fr9_load(g + 1), by));                 // L 2 2^29, S 5.5
+    } else if (PRIM == FN_LOGUP_LAYER) {
+        // a d + b c + g1 b d
+        const Fr9 v1 = ld(1), v3 = ld(3);
+        Fr9 A = fr9_mul(ld(0), v3);
+        A = fr9_add(A, fr9_mul(v1, ld(2)));
+        return fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v1, v3)));                    // L 3 2^29, S 7
+    } else if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
         // v0 v3 + g1 v2 v1 + g2 (v1 v3 + 5 v0 v2) [+ g3 (v4^2 - v4) + g4 (v5^2 - v5)]
         Fr9 A, t;
         {
@@ -1024,7 +1052,13 @@ __global__ void __launch_bounds__(SC_THREADS, 3) k_round_deg2_lean9(LeanCols col
                 const Fr9 p0 = fr9_load_raw(cols.p[q] + 2 * i);
                 return fr9_norm(fr9_sub8(fr9_add(p1, p1), p0));         // 2 p1 - p0 + 8 p: S 10
             };
-            const Fr9 t = fr9_mul(lean_gamma_eval9<PRIM>(ld, gp), w);   // L <= 5 2^29 x 2^29; S <= 30 x 1.02 / 70.66 + 1 = 1.5
+            auto lds = [&](int q) -> Fr9 {
+                const Fr9 p1 = fr9_load(cols.p[q] + 2 * i + 1);         // the limbs of 32 X: domain 261, S 32
+                if (!h) return p1;
+                const Fr9 p0 = fr9_load(cols.p[q] + 2 * i);
+                return fr9_norm(fr9_sub64(fr9_add(p1, p1), p0));        // 2 p1 - p0 + 64 p: S 128, top limb < 2^29.9
+            };
+            const Fr9 t = fr9_mul(lean_gamma_eval9<PRIM>(ld, lds, gp), w);   // L <= 5 2^29 x 2^29; S <= 37 x 1.02 / 70.66 + 1 = 1.6
             if (h == 0) a0 = fr9_norm(fr9_add(a0, t)); else a1 = fr9_norm(fr9_add(a1, t));
         }
         if ((it & 15u) == 15u) {   // S <= 16 x 3 + 2: back below 2 (times one in domain 261 keeps the domain)
@@ -1033,7 +1067,8 @@ __global__ void __launch_bounds__(SC_THREADS, 3) k_round_deg2_lean9(LeanCols col
         }
     }
     // back to the stored form: domain 241 / 246 times 2^276 / 2^271 (domain-free integers) = domain 256; S <= 50 / 70.66 + 1 < 2
-    const Fr9 K = VECVEC ? fr9_two276() : fr9_two271();
+    // (terms in domain 256 -- lean9_terms_256 -- leave the accumulators five places higher: 2^271 / 2^266)
+    const Fr9 K = lean9_terms_256(PRIM) ? (VECVEC ? fr9_two271() : fr9_two266()) : (VECVEC ? fr9_two276() : fr9_two271());
     acc[0] = fr9_to_raw(fr9_mul(a0, K));
     acc[1] = fr9_to_raw(fr9_mul(a1, K));
     block_reduce_finish<NACC>(acc, fc);
@@ -1784,7 +1819,8 @@ static int32_t launch_deg2_lean(int prim, dim3 grid, hipStream_t s, const LeanCo
     case P: hipLaunchKernelGGL((k_round_deg2_lean9<P, VECVEC>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, npairs, va, fc); break;
         switch (prim) {
             GM_LEAN9_CASE(FN_AFF_L1) GM_LEAN9_CASE(FN_AFF_L3) GM_LEAN9_CASE(FN_PROJ_L1) GM_LEAN9_CASE(FN_PROJ_L2)
-            GM_LEAN9_CASE(FN_PROJ_L3) GM_LEAN9_CASE(LEAN_AFF_L1_BC)
+            GM_LEAN9_CASE(FN_PROJ_L3) GM_LEAN9_CASE(LEAN_AFF_L1_BC) GM_LEAN9_CASE(FN_AFF_L2) GM_LEAN9_CASE(FN_PT_BIT_CHOICE)
+            GM_LEAN9_CASE(FN_ADD_INVERSES) GM_LEAN9_CASE(FN_LOGUP_LAYER)
         }
 #undef GM_LEAN9_CASE
         GM_LAUNCH_CHECK();

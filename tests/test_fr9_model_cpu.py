@@ -37,7 +37,8 @@ def bias(k):
     return c
 
 
-BIAS8, BIAS32 = bias(8), bias(32)
+BIAS8, BIAS32, BIAS64 = bias(8), bias(32), bias(64)
+assert BIAS64 == [0x40000040, 0x5ffffdfe, 0x45bfeffd, 0x52017ffd, 0x40154ef4, 0x41013439, 0x483339d6, 0x594cebe8, 0x1cfb69d2]
 # the constants of fr9.hip.h
 assert BIAS8 == [0x40000008, 0x5fffffbe, 0x5cb7fdfd, 0x5a402ffd, 0x4c02a9dc, 0x40202685, 0x49066739, 0x53299d7b, 0x039f6d38]
 assert BIAS32 == [0x40000020, 0x5ffffefe, 0x52dff7fd, 0x4900bffd, 0x500aa779, 0x40809a1b, 0x44199cea, 0x4ca675f3, 0x0e7db4e8]
@@ -225,8 +226,30 @@ def test_msm_formulas_stay_inside_their_bounds_and_give_the_field_values():
 
 
 # ------------------------------------------------------------------------------------------------ large-round kernels (raw form)
-def eval9(prim, ld, g):
-    """lean_gamma_eval9: ld(q) = input q (domain 256, normalised, S <= 10); g[o] = gamma^o loaded shifted (domain 261)"""
+ONE251 = limbs(1 << 251)
+
+
+def eval9(prim, ld, g, lds=None):
+    """lean_gamma_eval9: ld(q) = input q (domain 256, normalised, S <= 10); lds(q) = the same input from shifted loads (domain 261,
+    S <= 128); g[o] = gamma^o loaded shifted (domain 261)"""
+    if prim == "ADD_INVERSES":
+        v0 = ld(0)
+        t = mul(mul(g[1], v0), lds(1))
+        return add(add(v0, ld(1)), t)
+    if prim == "AFF_L2":
+        v0 = ld(0)
+        A = mul(mul(g[2], v0), lds(1))
+        A = add(A, mul(g[1], ld(2)))
+        return add(add(A, v0), ld(1))
+    if prim == "PT_BIT_CHOICE":
+        b = ld(0)
+        by = add(mul(b, norm(sub_bias(ld(2), [ONE256], BIAS8))), ONE251)
+        return add(mul(b, ld(1)), mul(g[1], by))
+    if prim == "LOGUP_LAYER":
+        v1, v3 = ld(1), ld(3)
+        A = mul(ld(0), v3)
+        A = add(A, mul(v1, ld(2)))
+        return add(A, mul(g[1], mul(v1, v3)))
     if prim in ("AFF_L1", "AFF_L1_BC"):
         v3, v2, v0 = ld(3), ld(2), ld(0)
         A = mul(v0, v3)
@@ -266,6 +289,14 @@ def eval9(prim, ld, g):
 
 
 def ref_eval(prim, v, g):
+    if prim == "ADD_INVERSES":
+        return (v[0] + v[1] + g[1] * v[0] * v[1]) % P
+    if prim == "AFF_L2":
+        return (v[0] + v[1] + g[1] * v[2] + g[2] * v[0] * v[1]) % P
+    if prim == "PT_BIT_CHOICE":
+        return (v[0] * v[1] + g[1] * (v[0] * (v[2] - 1) + 1)) % P
+    if prim == "LOGUP_LAYER":
+        return (v[0] * v[3] + v[1] * v[2] + g[1] * v[1] * v[3]) % P
     if prim in ("AFF_L1", "AFF_L1_BC"):
         A = v[0] * v[3] + g[1] * v[2] * v[1] + g[2] * (v[1] * v[3] + 5 * v[0] * v[2])
         if prim == "AFF_L1_BC":
@@ -281,7 +312,9 @@ def ref_eval(prim, v, g):
     return ((v[0] + v[1]) * v[3] + g[1] * v[2] * v[3] + g[2] * v[3] * v[3] + g[3] * v[0] * v[1]) % P
 
 
-N_IN = {"AFF_L1": 4, "AFF_L1_BC": 6, "AFF_L3": 3, "PROJ_L1": 6, "PROJ_L2": 4, "PROJ_L3": 4}
+N_IN = {"AFF_L1": 4, "AFF_L1_BC": 6, "AFF_L3": 3, "PROJ_L1": 6, "PROJ_L2": 4, "PROJ_L3": 4, "AFF_L2": 3, "PT_BIT_CHOICE": 3, "ADD_INVERSES": 2,
+        "LOGUP_LAYER": 4}
+TERMS_256 = ("AFF_L2", "ADD_INVERSES")   # their terms stay in domain 256: the accumulators sit five places higher
 
 
 def test_large_round_kernels_in_the_raw_form():
@@ -312,13 +345,18 @@ def test_large_round_kernels_in_the_raw_form():
                         if not h:
                             return x1
                         return norm(sub_bias(add(x1, x1), [load_raw(p0[q])], BIAS8))
-                    t = mul(eval9(prim, ld, g9), w)
+                    def lds(q, h=h):
+                        x1 = load_shifted(p1[q])
+                        if not h:
+                            return x1
+                        return norm(sub_bias(add(x1, x1), [load_shifted(p0[q])], BIAS64))
+                    t = mul(eval9(prim, ld, g9, lds), w)
                     a[h] = norm(add(a[h], t))
                     v = [unmont(p1[q]) if not h else (2 * unmont(p1[q]) - unmont(p0[q])) % P for q in range(ni)]
                     exp[h] = (exp[h] + ref_eval(prim, v, [unmont(x) for x in gam]) * w_ref) % P
                 if it & 15 == 15:
                     a = [mul(x, ONE261) for x in a]
-            K = limbs(pow(2, 276 if vecvec else 271, P))
+            K = limbs(pow(2, (271 if vecvec else 266) if prim in TERMS_256 else (276 if vecvec else 271), P))
             got = [store_raw(mul(x, K)) for x in a]
             assert got == [mont(e) for e in exp], (prim, vecvec)
 
