@@ -249,18 +249,35 @@ def main():
         streams = [torch.cuda.Stream() for _ in range(depth)]
         recv = [torch.empty(world * ncols * wpr * 4, dtype=torch.int64, device="cuda") for _ in range(depth)] if rcomm is not None else None
 
+        # RCCL sees ONE stream: every all-gather is enqueued on comm_stream, ordered after its step's kernels and before that plan's
+        # next run by events (collectives of one communicator issued from several streams are legal but serialised inside RCCL in
+        # ways this box cannot rehearse with more than one rank)
+        comm_stream = torch.cuda.Stream() if rcomm is not None else None
+        gathered = [None] * depth
+
         def launch(j):
-            with torch.cuda.stream(streams[j % depth]):
-                plans[j % depth].run(d_pts, d_sc)
+            k = j % depth
+            with torch.cuda.stream(streams[k]):
+                if gathered[k] is not None:
+                    streams[k].wait_event(gathered[k])      # the previous gather of this plan's window points has read them
+                plans[k].run(d_pts, d_sc)
                 if rcomm is not None:
                     p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
-                    ffi.check(L.gm_msm_window_points(plans[j % depth].h, C.byref(p), C.byref(nc), C.byref(cl)))
-                    rcomm.all_gather_dev(p, recv[j % depth], ncols * wpr * 32)      # ncclAllGather, asynchronous on this stream
+                    ffi.check(L.gm_msm_window_points(plans[k].h, C.byref(p), C.byref(nc), C.byref(cl)))
+                    ran = torch.cuda.Event()
+                    ran.record(streams[k])
+            if rcomm is not None:
+                comm_stream.wait_event(ran)
+                with torch.cuda.stream(comm_stream):
+                    rcomm.all_gather_dev(p, recv[k], ncols * wpr * 32)      # ncclAllGather, asynchronous
+                    gathered[k] = torch.cuda.Event()
+                    gathered[k].record(comm_stream)
 
         def finish(j):
             with torch.cuda.stream(streams[j % depth]):
                 if rcomm is not None:
-                    g = recv[j % depth].cpu().numpy().view(np.uint64).reshape(world, ncols, wpr, 4)   # waits for step j's stream only
+                    gathered[j % depth].synchronize()                                                  # step j's kernels and its gather
+                    g = recv[j % depth].cpu().numpy().view(np.uint64).reshape(world, ncols, wpr, 4)
                     raw_ = np.ascontiguousarray(np.transpose(g, (1, 0, 2, 3)).reshape(ncols, world * wpr, 4))
                 elif world > 1:
                     p, nc, cl = C.c_void_p(), C.c_uint64(), C.c_uint64()
