@@ -370,7 +370,7 @@ def main():
         "metric": "msm_points_per_sec", "value": main_res["value"], "unit": "points/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
-        "dtype": "u32 limbs (256-bit Montgomery, BLS12-381 Fr)", "data": "synthetic",
+        "dtype": "u32 limbs, u64 column accumulators (BLS12-381 Fr in Montgomery form: 9 x 29-bit limbs in registers, 8 x 32 in memory)", "data": "synthetic",
         "config": {"workload": "pippenger_msm x_logsize=%d d_logsize=%d nbits=%d (bandersnatch, %d windows)" % (
             x_log, d_log, nbits, y_size), "x_logsize": x_log, "d_logsize": d_log, "nbits": nbits,
             "windows_per_gpu": wpr, "sharding": "windows" if world > 1 else "none", "transport": transport},
