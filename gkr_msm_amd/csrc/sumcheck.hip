@@ -1483,7 +1483,12 @@ static int32_t tail_stage(TailStage** out) {
 }
 
 static bool stage_enabled() {
-    static const bool v = [] { const char* e = getenv("GM_SC_NO_TAIL"); return !(e && e[0] == '1'); }();
+    // the stage kernel is itself a pre-enqueued mechanism: GM_SC_NO_PIPELINE=1 (plain rounds: kernel, sync, fold) switches it off too
+    static const bool v = [] {
+        const char* e = getenv("GM_SC_NO_TAIL");
+        const char* p = getenv("GM_SC_NO_PIPELINE");
+        return !(e && e[0] == '1') && !(p && p[0] == '1');
+    }();
     return v;
 }
 static bool spin_for(volatile uint32_t* slot, uint32_t want) {
