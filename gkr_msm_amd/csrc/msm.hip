@@ -921,9 +921,11 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
             cur_lvl ^= 1;
             cells_cur = cells_next;
         }
-        hipLaunchKernelGGL(k_add_tail, dim3(nrows), dim3(64), 0, s, p->lvl[cur_lvl][0], p->lvl[cur_lvl][1], p->lvl[cur_lvl][2],
-                           p->lvl[cur_lvl ^ 1][0], p->lvl[cur_lvl ^ 1][1], p->lvl[cur_lvl ^ 1][2], p->off[0], nrows,
-                           tail_level, p->x_log, p->bsum[0], p->bsum[1], p->bsum[2]);
+        // the last level: every row is down to 0 or 2 cells (x_logsize halvings of at most 2^x_logsize cells): one thread per row
+        // (the row-owned multi-level kernel k_add_tail spent 86 us here with one busy lane per 64-lane workgroup)
+        hipLaunchKernelGGL((k_add_last<false>), dim3(ceil_div(nrows, 128)), dim3(128), 0, s, (const Fr*)nullptr, (const uint32_t*)nullptr,
+                           p->lvl[cur_lvl][0], p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[0] + (uint64_t)tail_level * stride, nrows,
+                           p->bsum[0], p->bsum[1], p->bsum[2]);
         GM_LAUNCH_CHECK();
     }
     STAGE_MARK(6);
