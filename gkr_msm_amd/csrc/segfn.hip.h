@@ -100,6 +100,8 @@ enum {
     FN_P_AFF_L3_A = 74,   // G0 m v0                         in: v0, v2          (m = 1 - d v2, q = 1 + d v2)
     FN_P_AFF_L3_B = 75,   // G1 q v1                         in: v1, v2
     FN_P_AFF_L3_C = 76,   // G2 m q                          in: v2
+    FN_P_LOGUP_A = 77,    // v3 (G0 v0 + G1 v1)              in: v0, v1, v3      (a d + b c, b d)
+    FN_P_LOGUP_B = 78,    // G0 v1 v2                        in: v1, v2
 };
 GM_HD bool prim_is_part(int prim) { return prim >= 64; }
 
@@ -111,6 +113,7 @@ inline bool seg_plan_split_terms(const SegPlan& sp, SegPlan* out) {
     static const PartDef P_L3[3] = {{FN_P_PROJ_L3_A, 3, {0, 2, 3}}, {FN_P_PROJ_L3_B, 3, {1, 2, 3}}, {FN_P_PROJ_L3_C, 2, {2, 3, 0}}};
     static const PartDef A_L1[2] = {{FN_P_AFF_L1_A, 3, {0, 2, 3}}, {FN_P_AFF_L1_B, 3, {1, 2, 3}}};
     static const PartDef A_L3[3] = {{FN_P_AFF_L3_A, 2, {0, 2, 0}}, {FN_P_AFF_L3_B, 2, {1, 2, 0}}, {FN_P_AFF_L3_C, 1, {2, 0, 0}}};
+    static const PartDef LGU[2] = {{FN_P_LOGUP_A, 3, {0, 1, 3}}, {FN_P_LOGUP_B, 2, {1, 2, 0}}};
     SegPlan r = sp;
     r.nseg = 0;
     bool any = false;
@@ -124,6 +127,7 @@ inline bool seg_plan_split_terms(const SegPlan& sp, SegPlan* out) {
             case FN_PROJ_L3: pd = P_L3; np = 3; break;
             case FN_AFF_L1: pd = A_L1; np = 2; break;
             case FN_AFF_L3: pd = A_L3; np = 3; break;
+            case FN_LOGUP_LAYER: pd = LGU; np = 2; break;
             default: break;
         }
         if (!pd) {

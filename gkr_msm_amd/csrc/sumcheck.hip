@@ -510,6 +510,8 @@ __device__ __forceinline__ Fr stage_part_eval(int prim, int out0, const Fr* v, c
         }
         case FN_P_AFF_L1_A: return fr_mul(v[0], fr_add(G(0, v[2]), x5(G(2, v[1]))));           // v0, v2, v3
         case FN_P_AFF_L1_B: return fr_mul(v[0], fr_add(G(1, v[1]), G(2, v[2])));               // v1, v2, v3
+        case FN_P_LOGUP_A: return fr_mul(v[2], fr_add(G(0, v[0]), G(1, v[1])));                // v0, v1, v3
+        case FN_P_LOGUP_B: return G(0, fr_mul(v[0], v[1]));                                    // v1, v2
         case FN_P_AFF_L3_A: return G(0, fr_mul(fr_sub(fr_one(), fr_mul_by_d(v[1])), v[0]));    // v0, v2
         case FN_P_AFF_L3_B: return G(1, fr_mul(fr_add(fr_one(), fr_mul_by_d(v[1])), v[0]));    // v1, v2
         default: {                                                                             // FN_P_AFF_L3_C: v2
