@@ -571,53 +571,6 @@ __global__ void __launch_bounds__(1024) k_offsets_levels_par(const uint32_t* __r
     if (tid == 1023) off[nrows] = tot;
 }
 
-// Tail of the bucket-sum tree: once rows are short, one 64-lane workgroup owns one row and runs ALL remaining levels
-// for it, ping-ponging between the two level buffers (rows are independent, so no cross-workgroup dependency).
-// Levels first_level .. x_log - 1; the last one writes the dense bucket sum (same semantics as k_add_last).
-__global__ void __launch_bounds__(64) k_add_tail(Fr* __restrict__ ax, Fr* __restrict__ ay, Fr* __restrict__ az,
-                                                  Fr* __restrict__ bx_, Fr* __restrict__ by_, Fr* __restrict__ bz_,
-                                                  const uint32_t* __restrict__ off_all, uint32_t nrows, uint32_t first_level,
-                                                  uint32_t x_log, Fr* __restrict__ sx, Fr* __restrict__ sy, Fr* __restrict__ sz) {
-    const uint32_t r = blockIdx.x, lane = threadIdx.x;
-    Fr *ix = ax, *iy = ay, *iz = az, *ox = bx_, *oy = by_, *oz = bz_;
-    for (uint32_t lvl = first_level; lvl < x_log; lvl++) {
-        const uint32_t* offi = off_all + (uint64_t)lvl * (nrows + 1);
-        const uint32_t in0 = offi[r], len = offi[r + 1] - in0, half = len >> 1;
-        if (lvl + 1 == x_log) {
-            if (lane == 0) {
-                Point3 P = pt_identity(), Q = pt_identity();
-                if (len) {
-                    P.x = fr_load(ix + in0); P.y = fr_load(iy + in0); P.z = fr_load(iz + in0);
-                    Q.x = fr_load(ix + in0 + 1); Q.y = fr_load(iy + in0 + 1); Q.z = fr_load(iz + in0 + 1);
-                }
-                const Point3 res = proj_add(P, Q);
-                fr_store(sx + r, res.x); fr_store(sy + r, res.y); fr_store(sz + r, res.z);
-            }
-        } else {
-            const uint32_t* offo = off_all + (uint64_t)(lvl + 1) * (nrows + 1);
-            const uint32_t out0 = offo[r], olen = offo[r + 1] - out0;
-            for (uint32_t p = lane; p < olen; p += 64) {
-                Point3 res;
-                if (p < half) {
-                    const uint64_t a = (uint64_t)in0 + 2 * p;
-                    Point3 P, Q;
-                    P.x = fr_load(ix + a); P.y = fr_load(iy + a); P.z = fr_load(iz + a);
-                    Q.x = fr_load(ix + a + 1); Q.y = fr_load(iy + a + 1); Q.z = fr_load(iz + a + 1);
-                    res = proj_add(P, Q);
-                } else {
-                    res = pt_identity();
-                }
-                fr_store(ox + out0 + p, res.x); fr_store(oy + out0 + p, res.y); fr_store(oz + out0 + p, res.z);
-            }
-            __syncthreads();  // single-wave workgroup: orders this level's stores before the next level's loads
-            Fr* t;
-            t = ix; ix = ox; ox = t;
-            t = iy; iy = oy; oy = t;
-            t = iz; iz = oz; oz = t;
-        }
-    }
-}
-
 // last bintree level: every row has 0 or 2 cells; output is dense over rows
 // (vecvec_map_split_to_dense, vecvec.rs:608-654: an empty row contributes the row pad)
 template <bool LEVEL0>
@@ -891,7 +844,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
                        nrows);
     GM_LAUNCH_CHECK();
     // 4. bucket sums: x_log levels of pairwise adds.  Level l reads the layout off_all[l] and writes off_all[l + 1];
-    //    the first levels are flat launches over all cells, the short-row tail is one launch (k_add_tail).
+    //    flat launches over all cells; the last level (every row 0 or 2 cells) by one thread per row (k_add_last).
     uint64_t cap_out = p->cap0;
     const uint32_t stride = nrows + 1;
     if (p->x_log == 1) {
@@ -905,9 +858,8 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
                            p->off[0] + stride, nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2], p->blk_row + p->blk_first[0]);
         GM_LAUNCH_CHECK();
         STAGE_MARK(5);
-        // The row-owned tail kernel can take over any number of trailing levels in one launch.  Measured on MI355X
-        // (config B) it does not pay before the last level: a lone wave needs ~1 us per field multiplication, so 14
-        // fused levels cost as much as 14 small launches; it is used for the last level only.
+        // (A row-owned kernel that ran several trailing levels in one launch was measured and dropped: a lone wave needs ~0.6 us
+        // per field multiplication, so fused small levels cost what the small launches cost.)
         const uint32_t tail_level = p->x_log - 1;
         int cur_lvl = 0;
         uint64_t cells_cur = cap_out;
@@ -922,7 +874,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
             cells_cur = cells_next;
         }
         // the last level: every row is down to 0 or 2 cells (x_logsize halvings of at most 2^x_logsize cells): one thread per row
-        // (the row-owned multi-level kernel k_add_tail spent 86 us here with one busy lane per 64-lane workgroup)
+        // (a row-owned workgroup per row spent 86 us here with one busy lane in 64)
         hipLaunchKernelGGL((k_add_last<false>), dim3(ceil_div(nrows, 128)), dim3(128), 0, s, (const Fr*)nullptr, (const uint32_t*)nullptr,
                            p->lvl[cur_lvl][0], p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[0] + (uint64_t)tail_level * stride, nrows,
                            p->bsum[0], p->bsum[1], p->bsum[2]);
