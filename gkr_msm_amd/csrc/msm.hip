@@ -467,73 +467,10 @@ __global__ void __launch_bounds__(128) k_add_level(const Fr* __restrict__ ix, co
     }
 }
 
-// Offsets of every level in one launch: level 0 from the bucket populations, level l+1 from level l.
-// off_all[l * (nrows + 1) + r]; single 1024-thread block, same scan as k_offsets_scan.
-// FROM_OFF: `row_len` is an offsets table (nrows + 1 entries, even row lengths) and level 0 reproduces it -- the
-// VecVec sumcheck precomputes the row layouts of all its sparse rounds this way (bind_21, vecvec.rs:420-441).
-template <bool FROM_OFF>
-__global__ void __launch_bounds__(1024) k_offsets_all_levels(const uint32_t* __restrict__ row_len, uint32_t* __restrict__ off_all,
-                                                              uint32_t nrows, uint32_t nlevels) {
-    __shared__ uint32_t wave_tot[2][16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t per = (nrows + 1023) / 1024;
-    const uint32_t r0 = tid * per;
-    const uint32_t r1 = (r0 + per < nrows) ? r0 + per : nrows;
-    constexpr uint32_t PER_MAX = 16;  // row lengths of this thread's chunk stay in registers across levels
-    uint32_t cur[PER_MAX];
-    const bool in_regs = per <= PER_MAX;
-    if (in_regs) {
-#pragma unroll
-        for (uint32_t k = 0; k < PER_MAX; k++) {
-            const uint32_t r = r0 + k;
-            uint32_t l = (k < per && r < r1) ? (FROM_OFF ? row_len[r + 1] - row_len[r] : row_len[r]) : 0u;
-            cur[k] = l + (l & 1u);
-        }
-    }
-    for (uint32_t lvl = 0; lvl < nlevels; lvl++) {
-        const uint32_t* src = lvl ? off_all + (uint64_t)(lvl - 1) * (nrows + 1) : row_len;
-        uint32_t* off = off_all + (uint64_t)lvl * (nrows + 1);
-        uint32_t sum = 0;
-        if (in_regs) {
-            if (lvl) {
-#pragma unroll
-                for (uint32_t k = 0; k < PER_MAX; k++) { const uint32_t h = cur[k] >> 1; cur[k] = h + (h & 1u); }
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < PER_MAX; k++) sum += cur[k];
-        } else {
-            for (uint32_t r = r0; r < r1; r++) sum += lvl ? row_value<1>(src, r) : (FROM_OFF ? src[r + 1] - src[r] : row_value<0>(src, r));
-        }
-        uint32_t inc = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(inc, d, 64);
-            if ((int)lane >= d) inc += t;
-        }
-        if (lane == 63) wave_tot[lvl & 1][wave] = inc;
-        __syncthreads();  // double-buffered totals: one barrier per level is enough when lengths live in registers
-        uint32_t base = 0, tot = 0;
-        for (uint32_t w = 0; w < 16; w++) { const uint32_t v = wave_tot[lvl & 1][w]; tot += v; if (w < wave) base += v; }
-        uint32_t run = base + inc - sum;
-        if (in_regs) {
-#pragma unroll
-            for (uint32_t k = 0; k < PER_MAX; k++) {
-                if (k < per && r0 + k < r1) off[r0 + k] = run;
-                run += cur[k];
-            }
-        } else {
-            for (uint32_t r = r0; r < r1; r++) {
-                off[r] = run;
-                run += lvl ? row_value<1>(src, r) : (FROM_OFF ? src[r + 1] - src[r] : row_value<0>(src, r));
-            }
-        }
-        if (tid == 1023) off[nrows] = tot;
-        if (!in_regs) __syncthreads();  // the next level re-reads this level's offsets from memory
-    }
-}
-
-// The same table with one workgroup per level: the length of a row at level l follows from its level-0 length alone (halve and
-// re-pad l times), so the levels do not depend on each other -- 20 scans side by side instead of 20 in a row (80 us -> ~10 us at
+// Offsets of every level, one workgroup per level: off_all[l * (nrows + 1) + r]; level 0 from the bucket populations (or, FROM_OFF,
+// from an offsets table whose even row lengths it reproduces -- the VecVec sumcheck precomputes the row layouts of all its sparse
+// rounds this way: bind_21, vecvec.rs:420-441).  The length of a row at level l follows from its level-0 length alone (halve and
+// re-pad l times), so the levels do not depend on each other: 20 scans side by side instead of 20 in a row (80 us -> ~14 us at
 // config B, on a stretch of the step where nothing else runs).
 template <bool FROM_OFF>
 __global__ void __launch_bounds__(1024) k_offsets_levels_par(const uint32_t* __restrict__ row_len, uint32_t* __restrict__ off_all,

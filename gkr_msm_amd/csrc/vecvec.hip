@@ -407,7 +407,7 @@ int32_t gm::vv_from_msm(const gm_msm_plan* p, const uint64_t* d_points_xy, uint3
     v->nrows = p->nrows; v->row_logsize = p->x_log; v->col_logsize = y_logsize + p->d_log;
     v->row_base = p->y0 << p->d_log;
     v->sharded = partial;
-    // the plan holds the row layouts of all x_logsize levels (k_offsets_all_levels): keep a copy with the image, so that the
+    // the plan holds the row layouts of all x_logsize levels (k_offsets_levels_par): keep a copy with the image, so that the
     // witness builder's splits and every layer's sumcheck object take their layouts from it
     const size_t lvl_words = (size_t)p->nrows + 1, tab_bytes = (size_t)p->x_log * lvl_words * 4;
     v->off_levels.reset(new DevBuf());
