@@ -2262,7 +2262,8 @@ struct ScDenseDeg2 : gm_sc {
         const VVArgs none{nullptr, 0, nullptr, nullptr, nullptr};
         const int lean = (!split && cols.k <= 6) ? lean_prim_of(sp) : 0;
         // results of pre-enqueued kernels land in the pinned staging: it must be this object's alone for the duration
-        if (split && !sh.comm && pipeline_enabled() && (rs.own_pinned || pinned_exclusive() || k_enq > round_idx))
+        static const bool pipe_large = [] { const char* e = getenv("GM_SC_PIPE_LARGE_DENSE"); return !(e && e[0] == '0'); }();   // A/B switch
+        if ((split || pipe_large) && !sh.comm && pipeline_enabled() && (rs.own_pinned || pinned_exclusive() || k_enq > round_idx))
             return unipoly_pipelined(coeffs, npairs, eq_cur, cp);
         if (lean) {
             LeanCols lc;
@@ -2306,14 +2307,30 @@ struct ScDenseDeg2 : gm_sc {
         static const bool v = [] { const char* e = getenv("GM_SC_NO_PIPELINE"); return !(e && e[0] == '1'); }();
         return v;
     }
+    // the round kernel of a pre-enqueued round, by size: split mode for small rounds, the lean kernel of a single-primitive layer or
+    // the generic kernel for large ones (large rounds are pre-enqueued too: the fold and the next round kernel are then already
+    // in the stream when the challenge arrives, ~10 us of launch latency per round)
     int32_t launch_small_round(const ColPtrs& cp, const Fr* eq, uint64_t npairs, uint32_t round) {
-        const dim3 grid = round_grid(npairs, 2 * sp.nseg);
+        const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
+        const dim3 grid = round_grid(npairs, split ? 2 * sp.nseg : 1);
         const VVArgs none{nullptr, 0, nullptr, nullptr, nullptr};
+        const int lean = (!split && cols.k <= 6) ? lean_prim_of(sp) : 0;
         const FinishCtx fc = rs.ctx();
-        hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq, d_gamma.fr(), npairs, none, fc);
+        if (lean) {
+            LeanCols lc;
+            for (int i = 0; i < cols.k; i++) lc.p[i] = cp.p[i];
+            const int pi = prof_begin(stream, lean * 4 + 0, cols.k, npairs, nullptr, 2 * lean_eval_muls(lean) + 2);
+            int32_t rc = launch_deg2_lean<false>(lean, grid, stream, lc, eq, d_gamma.fr(), npairs, none, fc);
+            prof_end(stream, pi);
+            if (rc) return rc;
+        } else if (split) {
+            hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq, d_gamma.fr(), npairs, none, fc);
+        } else {
+            hipLaunchKernelGGL((k_round_deg2<false, false>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq, d_gamma.fr(), npairs, none, fc);
+        }
         GM_LAUNCH_CHECK();
         k_seq[round & 63] = fc.seq;
-        prof_small_round(64.0 * cols.k * (double)npairs);
+        if (!lean) prof_small_round(64.0 * cols.k * (double)npairs);
         return GM_OK;
     }
     // ---- persistent stage (see k_stage): rounds [tail_r0, num_vars) run inside one launch
