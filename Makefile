@@ -7,7 +7,7 @@ OBJ := $(patsubst gkr_msm_amd/csrc/%.hip,build/%.o,$(SRC))
 HDR := $(wildcard gkr_msm_amd/csrc/*.inc) $(wildcard gkr_msm_amd/csrc/*.hip.h) $(wildcard gkr_msm_amd/csrc/*.hpp) include/gkrmsm.h
 LIB := gkr_msm_amd/libgkrmsm_hip.so
 
-all: $(LIB) oracle examples
+all: $(LIB) oracle examples ubench
 
 $(LIB): $(OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ) -ldl
@@ -25,8 +25,14 @@ build/examples/%: examples/%.c include/gkrmsm.h $(LIB)
 	@mkdir -p build/examples
 	gcc -std=c11 -O2 -Wall -Wextra -D_POSIX_C_SOURCE=199309L -Iinclude $< -o $@ -Lgkr_msm_amd -lgkrmsm_hip -Wl,-rpath,'$$ORIGIN/../../gkr_msm_amd'
 
+# device-side self-checks that tests/ run on the GPU box (prebuilt here: the 14 x 28 one takes hipcc three minutes)
+ubench: build/ubench/fq14_test
+build/ubench/%: scripts/ubench/%.hip $(HDR)
+	@mkdir -p build/ubench
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -w -mllvm -enable-misched=0 -o $@ $<
+
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle examples clean
+.PHONY: all oracle examples ubench clean
