@@ -186,16 +186,52 @@ __device__ __forceinline__ G1Jac g1_pair(const G1SrcJac& s, uint32_t c0, bool tw
 }
 
 // one tree level: out cell j of row r = in cell 2p (+ in cell 2p+1 when the row has it), p = j - off_out[r]
+static constexpr uint32_t G1_ROWS_LDS = 512;
 template <class Src>
 __global__ void __launch_bounds__(128) k_g1_level(Src src, const uint32_t* __restrict__ off_in,
                                                    const uint32_t* __restrict__ off_out, uint32_t nrows,
                                                    G1Jac* __restrict__ out, const uint32_t* __restrict__ br) {
+    // the 128 results of a workgroup are 18 KB of contiguous output: staged in LDS and written as whole lines (a lane storing
+    // its own 144 bytes leaves every 128-byte line half written per store instruction: 248 bytes of HBM writes per result measured)
+    __shared__ uint4 stage[128 * 9];
+    // the rows this workgroup's cells lie in (k_g1_block_rows) are few: their offsets go to LDS in one round trip and the row search
+    // runs there instead of as a chain of up to seven dependent global loads per lane
+    __shared__ uint32_t s_off[G1_ROWS_LDS];
+    const uint32_t total = off_out[nrows];
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= off_out[nrows]) return;
-    const uint32_t r = g1_find_row_tab(off_out, nrows, br, j);
-    const uint32_t p = j - off_out[r];
-    const uint32_t in0 = off_in[r], len = off_in[r + 1] - in0;
-    g1_store(out + j, g1_pair(src, in0 + 2 * p, 2 * p + 1 < len));
+    uint32_t rlo = br[blockIdx.x], rhi = br[blockIdx.x + 1] + 1;   // off_out[rlo] <= j < off_out[rhi]
+    if (rhi > nrows) rhi = nrows;
+    const bool in_lds = rhi - rlo <= G1_ROWS_LDS;
+    if (in_lds)
+        for (uint32_t k = threadIdx.x; k < rhi - rlo; k += 128) s_off[k] = off_out[rlo + k];
+    __syncthreads();
+    if (j < total) {
+        uint32_t r, o_r;
+        if (in_lds) {
+            uint32_t lo = 0, hi = rhi - rlo;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_off[mid] <= j) lo = mid; else hi = mid;
+            }
+            r = rlo + lo;
+            o_r = s_off[lo];
+        } else {
+            r = g1_find_row_tab(off_out, nrows, br, j);
+            o_r = off_out[r];
+        }
+        const uint32_t p = j - o_r;
+        const uint32_t in0 = off_in[r], len = off_in[r + 1] - in0;
+        const G1Jac v = g1_pair(src, in0 + 2 * p, 2 * p + 1 < len);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 9; k++) stage[threadIdx.x * 9 + k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    }
+    __syncthreads();
+    const uint32_t b0 = blockIdx.x * blockDim.x;
+    if (b0 >= total) return;
+    const uint32_t nv = (total - b0 < 128u ? total - b0 : 128u) * 9;
+    uint4* o4 = reinterpret_cast<uint4*>(out + b0);
+    for (uint32_t k = threadIdx.x; k < nv; k += 128) o4[k] = stage[k];
 }
 
 // rows of at most one cell -> dense output (empty rows = infinity)
