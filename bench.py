@@ -244,7 +244,7 @@ def main():
         # Depth: 2 steps in flight when a step is milliseconds of large kernels; 4 when a rank's share is small (x_logsize 20 over
         # 8 ranks: ~25 launches of 10-200 us, a 0.93 ms dependency chain for 0.5 ms of work -- measured on one GPU with
         # scripts/quick_rank_share_time.py: 0.97 ms unpipelined, 0.66 ms at depth 2, 0.55 ms at depth 4).
-        depth = 4 if (world > 1 and wpr * n <= (1 << 24)) else 2
+        depth = int(os.environ.get("GM_BENCH_DEPTH", "0")) or (4 if (world > 1 and wpr * n <= (1 << 24)) else 2)
         plans = [plan] + [harness.MsmPlan(x_log, d_log, y_size, y0, y1) for _ in range(depth - 1)]
         streams = [torch.cuda.Stream() for _ in range(depth)]
         recv = [torch.empty(world * ncols * wpr * 4, dtype=torch.int64, device="cuda") for _ in range(depth)] if rcomm is not None else None
