@@ -124,6 +124,37 @@ __device__ __forceinline__ Point9 pt9_load(const Fr* x, const Fr* y, const Fr* z
 __device__ __forceinline__ void pt9_store(Fr* x, Fr* y, Fr* z, uint64_t i, const Point9& p) {
     fr9_store(x + i, p.x); fr9_store(y + i, p.y); fr9_store(z + i, p.z);
 }
+// Cells that one level kernel writes and the next one reads stay in the 9 x 29 form, exactly as the products leave them (limbs
+// < 2^29, value below 13 p: inside what the formulas assume of a loaded value, L 2^29 and S 32): no division by 32, no
+// conditional subtraction and no repacking on the way out (~100 VALU instructions per coordinate), no shifting on the way in (17).
+// 9 words = 36 bytes per cell, moved as 16 + 16 + 4 bytes (4-byte aligned: global memory takes unaligned wide accesses).
+// Only the last level canonicalises (its output is the bucket sums).
+struct __attribute__((packed, aligned(4))) Raw9Quad {
+    uint32_t a, b, c, d;
+};
+__device__ __forceinline__ Fr9 fr9_load_raw9(const uint32_t* __restrict__ col, uint64_t i) {
+    const uint32_t* p = col + 9 * i;
+    const Raw9Quad q0 = *reinterpret_cast<const Raw9Quad*>(p), q1 = *reinterpret_cast<const Raw9Quad*>(p + 4);
+    Fr9 r;
+    r.l[0] = q0.a; r.l[1] = q0.b; r.l[2] = q0.c; r.l[3] = q0.d; r.l[4] = q1.a; r.l[5] = q1.b; r.l[6] = q1.c; r.l[7] = q1.d; r.l[8] = p[8];
+    return r;
+}
+__device__ __forceinline__ void fr9_store_raw9(uint32_t* __restrict__ col, uint64_t i, const Fr9& v) {
+    uint32_t* p = col + 9 * i;
+    Raw9Quad q0, q1;
+    q0.a = v.l[0]; q0.b = v.l[1]; q0.c = v.l[2]; q0.d = v.l[3]; q1.a = v.l[4]; q1.b = v.l[5]; q1.c = v.l[6]; q1.d = v.l[7];
+    *reinterpret_cast<Raw9Quad*>(p) = q0;
+    *reinterpret_cast<Raw9Quad*>(p + 4) = q1;
+    p[8] = v.l[8];
+}
+__device__ __forceinline__ Point9 pt9_load_raw9(const uint32_t* x, const uint32_t* y, const uint32_t* z, uint64_t i) {
+    Point9 p;
+    p.x = fr9_load_raw9(x, i); p.y = fr9_load_raw9(y, i); p.z = fr9_load_raw9(z, i);
+    return p;
+}
+__device__ __forceinline__ void pt9_store_raw9(uint32_t* x, uint32_t* y, uint32_t* z, uint64_t i, const Point9& p) {
+    fr9_store_raw9(x, i, p.x); fr9_store_raw9(y, i, p.y); fr9_store_raw9(z, i, p.z);
+}
 __device__ __forceinline__ Point9 pt9_identity() {
     Point9 p;
     p.x = fr9_zero(); p.y = fr9_one(); p.z = fr9_one();
@@ -423,7 +454,7 @@ __device__ __forceinline__ uint32_t find_row_tab(const uint32_t* __restrict__ of
 // bintree level 0: gather affine points by index, add pairs (2p, 2p+1) of every row
 __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* __restrict__ cells,
                              const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
-                             uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz,
+                             uint32_t nrows, uint32_t* __restrict__ ox, uint32_t* __restrict__ oy, uint32_t* __restrict__ oz,
                              const uint32_t* __restrict__ br) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = off_out[nrows];
@@ -442,16 +473,16 @@ __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* _
             x2 = fr9_zero();
             y2 = fr9_one();
         }
-        pt9_store(ox, oy, oz, j, aff_add9(x1, y1, x2, y2));
+        pt9_store_raw9(ox, oy, oz, j, aff_add9(x1, y1, x2, y2));
     } else {
-        pt_store(ox, oy, oz, j, pt_identity());  // f(row_pad): l3(l2(l1(0,1,0,1))) = (0,1,1)
+        pt9_store_raw9(ox, oy, oz, j, pt9_identity());  // f(row_pad): l3(l2(l1(0,1,0,1))) = (0,1,1)
     }
 }
 
 // bintree level >= 1
-__global__ void __launch_bounds__(128) k_add_level(const Fr* __restrict__ ix, const Fr* __restrict__ iy, const Fr* __restrict__ iz,
+__global__ void __launch_bounds__(128) k_add_level(const uint32_t* __restrict__ ix, const uint32_t* __restrict__ iy, const uint32_t* __restrict__ iz,
                             const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
-                            uint32_t nrows, Fr* __restrict__ ox, Fr* __restrict__ oy, Fr* __restrict__ oz,
+                            uint32_t nrows, uint32_t* __restrict__ ox, uint32_t* __restrict__ oy, uint32_t* __restrict__ oz,
                             const uint32_t* __restrict__ br) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = off_out[nrows];
@@ -461,9 +492,9 @@ __global__ void __launch_bounds__(128) k_add_level(const Fr* __restrict__ ix, co
     const uint32_t in0 = off_in[r], half = (off_in[r + 1] - in0) >> 1;
     if (p < half) {
         const uint64_t a = (uint64_t)in0 + 2 * p;
-        pt9_store(ox, oy, oz, j, proj_add9(pt9_load(ix, iy, iz, a), pt9_load(ix, iy, iz, a + 1)));
+        pt9_store_raw9(ox, oy, oz, j, proj_add9(pt9_load_raw9(ix, iy, iz, a), pt9_load_raw9(ix, iy, iz, a + 1)));
     } else {
-        pt_store(ox, oy, oz, j, pt_identity());
+        pt9_store_raw9(ox, oy, oz, j, pt9_identity());
     }
 }
 
@@ -512,7 +543,7 @@ __global__ void __launch_bounds__(1024) k_offsets_levels_par(const uint32_t* __r
 // (vecvec_map_split_to_dense, vecvec.rs:608-654: an empty row contributes the row pad)
 template <bool LEVEL0>
 __global__ void k_add_last(const Fr* __restrict__ points_xy, const uint32_t* __restrict__ cells,
-                           const Fr* __restrict__ ix, const Fr* __restrict__ iy, const Fr* __restrict__ iz,
+                           const uint32_t* __restrict__ ix, const uint32_t* __restrict__ iy, const uint32_t* __restrict__ iz,
                            const uint32_t* __restrict__ off_in, uint32_t nrows, Fr* __restrict__ ox,
                            Fr* __restrict__ oy, Fr* __restrict__ oz) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,12 +559,13 @@ __global__ void k_add_last(const Fr* __restrict__ points_xy, const uint32_t* __r
         }
         res = aff_add(x1, y1, x2, y2);
     } else {
-        Point3 P = pt_identity(), Q = pt_identity();
+        Point9 P = pt9_identity(), Q = pt9_identity();   // the level buffers hold the 9 x 29 form
         if (len) {
-            P.x = fr_load(ix + in0); P.y = fr_load(iy + in0); P.z = fr_load(iz + in0);
-            Q.x = fr_load(ix + in0 + 1); Q.y = fr_load(iy + in0 + 1); Q.z = fr_load(iz + in0 + 1);
+            P = pt9_load_raw9(ix, iy, iz, in0);
+            Q = pt9_load_raw9(ix, iy, iz, (uint64_t)in0 + 1);
         }
-        res = proj_add(P, Q);
+        const Point9 R = proj_add9(P, Q);
+        res.x = fr9_to(R.x); res.y = fr9_to(R.y); res.z = fr9_to(R.z);
     }
     fr_store(ox + r, res.x);
     fr_store(oy + r, res.y);
@@ -678,8 +710,8 @@ extern "C" int32_t gm_msm_plan_create(uint32_t x_logsize, uint32_t d_logsize, ui
     ALLOC(p->blk_row, (uint64_t)p->blk_first[p->blk_nlev] + 1);
     ALLOC(p->cells, cells_in + 2);
     for (int c = 0; c < 3; c++) {
-        ALLOC(p->lvl[0][c], p->cap0);
-        ALLOC(p->lvl[1][c], p->cap1);
+        ALLOC(p->lvl[0][c], 9 * p->cap0 + 4);
+        ALLOC(p->lvl[1][c], 9 * p->cap1 + 4);
         ALLOC(p->bsum[c], p->nrows);
     }
     ALLOC(p->win_pts, (uint64_t)3 * (d_logsize + 1) * p->nwin);
@@ -786,7 +818,7 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
     const uint32_t stride = nrows + 1;
     if (p->x_log == 1) {
         hipLaunchKernelGGL((k_add_last<true>), dim3(ceil_div(nrows, 128)), dim3(128), 0, s, pts, p->cells,
-                           (const Fr*)nullptr, (const Fr*)nullptr, (const Fr*)nullptr, p->off[0], nrows, p->bsum[0],
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, p->off[0], nrows, p->bsum[0],
                            p->bsum[1], p->bsum[2]);
         GM_LAUNCH_CHECK();
     } else {

@@ -18,7 +18,8 @@ struct gm_msm_plan {
     uint32_t* blk_row = nullptr;   // first row of every 128-cell block of every level's output layout (k_block_rows)
     uint32_t blk_first[33] = {};  // level l's entries start at blk_first[l]; blk_nlev levels
     uint32_t blk_nlev = 0;
-    Fr* lvl[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    // level buffers: cells in the 9 x 29 form as the products leave it (msm.hip), 9 words = 36 bytes per cell and column
+    uint32_t* lvl[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     Fr* bsum[3] = {nullptr, nullptr, nullptr};
     Fr* win_pts = nullptr;
     Fr* tri_scratch = nullptr;
