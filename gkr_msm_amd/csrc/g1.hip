@@ -176,6 +176,43 @@ struct G1SrcJac {
     }
 };
 
+// intermediate cells of the tree: the 14 x 28 form as an addition leaves it (g1.hip.h, G1P14), 42 words = 168 bytes per cell --
+// neither the conversion to the wire form on the way out (3 x ~140 instructions) nor the one back on the way in (6 x ~100)
+static constexpr uint32_t G1_CELL_WORDS = 42;
+struct __attribute__((packed, aligned(8))) G1Quad {
+    uint32_t a, b, c, d;
+};
+struct G1SrcCells {
+    const uint32_t* cells;
+    __device__ __forceinline__ G1P14 get(uint32_t cell) const {
+        const uint32_t* p = cells + (size_t)cell * G1_CELL_WORDS;
+        uint32_t w[G1_CELL_WORDS];
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const G1Quad q = *reinterpret_cast<const G1Quad*>(p + 4 * k);
+            w[4 * k] = q.a; w[4 * k + 1] = q.b; w[4 * k + 2] = q.c; w[4 * k + 3] = q.d;
+        }
+        w[40] = p[40]; w[41] = p[41];
+        G1P14 r;
+#pragma unroll
+        for (int i = 0; i < 14; i++) { r.x.l[i] = w[i]; r.y.l[i] = w[14 + i]; r.z.l[i] = w[28 + i]; }
+        return r;
+    }
+};
+// one output cell of a level, in the cell form
+__device__ __forceinline__ G1P14 g1_pair14(const G1SrcAff& s, uint32_t c0, bool two) {
+    const G1Aff a = s.get(c0);
+    return two ? g1_add_aff14p(a, s.get(c0 + 1)) : g1p14_from(g1_from_aff(a));
+}
+__device__ __forceinline__ G1P14 g1_pair14(const G1SrcJac& s, uint32_t c0, bool two) {
+    const G1P14 a = g1p14_from(s.get(c0));
+    return two ? g1_add14p(a, g1p14_from(s.get(c0 + 1))) : a;
+}
+__device__ __forceinline__ G1P14 g1_pair14(const G1SrcCells& s, uint32_t c0, bool two) {
+    const G1P14 a = s.get(c0);
+    return two ? g1_add14p(a, s.get(c0 + 1)) : a;
+}
+__device__ __forceinline__ G1Jac g1_pair(const G1SrcCells& s, uint32_t c0, bool) { return g1p14_to(s.get(c0)); }
 __device__ __forceinline__ G1Jac g1_pair(const G1SrcAff& s, uint32_t c0, bool two) {
     const G1Aff a = s.get(c0);
     return two ? g1_add_aff(a, s.get(c0 + 1)) : g1_from_aff(a);
@@ -190,10 +227,10 @@ static constexpr uint32_t G1_ROWS_LDS = 512;
 template <class Src>
 __global__ void __launch_bounds__(128) k_g1_level(Src src, const uint32_t* __restrict__ off_in,
                                                    const uint32_t* __restrict__ off_out, uint32_t nrows,
-                                                   G1Jac* __restrict__ out, const uint32_t* __restrict__ br) {
-    // the 128 results of a workgroup are 18 KB of contiguous output: staged in LDS and written as whole lines (a lane storing
-    // its own 144 bytes leaves every 128-byte line half written per store instruction: 248 bytes of HBM writes per result measured)
-    __shared__ uint4 stage[128 * 9];
+                                                   uint32_t* __restrict__ out, const uint32_t* __restrict__ br) {
+    // the 128 results of a workgroup are 21 KB of contiguous output: staged in LDS and written as whole lines (a lane storing
+    // its own cell leaves every 128-byte line partly written per store instruction: 1.7x the bytes in HBM writes measured)
+    __shared__ uint2 stage[128 * (G1_CELL_WORDS / 2)];
     // the rows this workgroup's cells lie in (k_g1_block_rows) are few: their offsets go to LDS in one round trip and the row search
     // runs there instead of as a chain of up to seven dependent global loads per lane
     __shared__ uint32_t s_off[G1_ROWS_LDS];
@@ -221,17 +258,21 @@ __global__ void __launch_bounds__(128) k_g1_level(Src src, const uint32_t* __res
         }
         const uint32_t p = j - o_r;
         const uint32_t in0 = off_in[r], len = off_in[r + 1] - in0;
-        const G1Jac v = g1_pair(src, in0 + 2 * p, 2 * p + 1 < len);
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+        const G1P14 v = g1_pair14(src, in0 + 2 * p, 2 * p + 1 < len);
+        uint2* st = stage + threadIdx.x * (G1_CELL_WORDS / 2);
 #pragma unroll
-        for (int k = 0; k < 9; k++) stage[threadIdx.x * 9 + k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        for (int k = 0; k < 7; k++) {
+            st[k] = make_uint2(v.x.l[2 * k], v.x.l[2 * k + 1]);
+            st[7 + k] = make_uint2(v.y.l[2 * k], v.y.l[2 * k + 1]);
+            st[14 + k] = make_uint2(v.z.l[2 * k], v.z.l[2 * k + 1]);
+        }
     }
     __syncthreads();
     const uint32_t b0 = blockIdx.x * blockDim.x;
     if (b0 >= total) return;
-    const uint32_t nv = (total - b0 < 128u ? total - b0 : 128u) * 9;
-    uint4* o4 = reinterpret_cast<uint4*>(out + b0);
-    for (uint32_t k = threadIdx.x; k < nv; k += 128) o4[k] = stage[k];
+    const uint32_t nv = (total - b0 < 128u ? total - b0 : 128u) * (G1_CELL_WORDS / 2);
+    uint2* o2 = reinterpret_cast<uint2*>(out + (size_t)b0 * G1_CELL_WORDS);
+    for (uint32_t k = threadIdx.x; k < nv; k += 128) o2[k] = stage[k];
 }
 
 // rows of at most one cell -> dense output (empty rows = infinity)
@@ -513,7 +554,7 @@ static int32_t g1_engine_layout(uint64_t ntasks, uint32_t nkeys, G1Layout* L) {
     L->sort_tmp = st;
     L->scan_tmp = sc;
     L->total = al(st) + al(sc) + 2 * al(ntasks * 4) + 35 * al(((size_t)nkeys + 1) * 4) + al(64) + al((ntasks / 64 + (size_t)34 * (nkeys / 32 + 3) + 64) * 4) +
-               al((ntasks / 2 + nkeys + 1) * sizeof(G1Jac)) + al((ntasks / 4 + nkeys + 1) * sizeof(G1Jac)) + 4096;
+               al((ntasks / 2 + nkeys + 1) * (size_t)G1_CELL_WORDS * 4) + al((ntasks / 4 + nkeys + 1) * (size_t)G1_CELL_WORDS * 4) + 4096;
     return GM_OK;
 }
 
@@ -535,8 +576,8 @@ static int32_t g1_sum_by_key(G1Scratch& ws, const G1Aff* src_aff, const G1Jac* s
     const size_t ostride = al(orow * 4) / 4;
     (void)ws.carve(orow * 4);   // (reserved)
     uint32_t* d_max = (uint32_t*)ws.carve(64);
-    G1Jac* bufA = (G1Jac*)ws.carve((ntasks / 2 + nkeys + 1) * sizeof(G1Jac));
-    G1Jac* bufB = (G1Jac*)ws.carve((ntasks / 4 + nkeys + 1) * sizeof(G1Jac));
+    uint32_t* bufA = (uint32_t*)ws.carve((ntasks / 2 + nkeys + 1) * (size_t)G1_CELL_WORDS * 4);
+    uint32_t* bufB = (uint32_t*)ws.carve((ntasks / 4 + nkeys + 1) * (size_t)G1_CELL_WORDS * 4);
     uint32_t* blk_row = (uint32_t*)ws.carve((ntasks / 64 + (size_t)34 * (nkeys / 32 + 3) + 64) * 4);
     if (ws.used > ws.cap) return set_err(GM_ERR_STATE, "G1 scratch under-reserved (%zu > %zu)", ws.used, ws.cap);
 
@@ -587,17 +628,17 @@ static int32_t g1_sum_by_key(G1Scratch& ws, const G1Aff* src_aff, const G1Jac* s
     if (src_aff) hipLaunchKernelGGL((k_g1_level<G1SrcAff>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sa, off_all, off_all + ostride, nkeys, bufA, blk_row + ba.first[0]);
     else hipLaunchKernelGGL((k_g1_level<G1SrcJac>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sj, off_all, off_all + ostride, nkeys, bufA, blk_row + ba.first[0]);
     GM_LAUNCH_CHECK();
-    G1Jac *cur = bufA, *nxt = bufB;
+    uint32_t *cur = bufA, *nxt = bufB;
     for (uint32_t l = 2; l <= nlev; l++) {
         bound = bound / 2 + nkeys;
-        const G1SrcJac sl{cur, nullptr};
-        hipLaunchKernelGGL((k_g1_level<G1SrcJac>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sl, off_all + (l - 1) * ostride,
+        const G1SrcCells sl{cur};
+        hipLaunchKernelGGL((k_g1_level<G1SrcCells>), dim3(ceil_div(bound, 128)), dim3(128), 0, s, sl, off_all + (l - 1) * ostride,
                            off_all + l * ostride, nkeys, nxt, blk_row + ba.first[l - 1]);
         GM_LAUNCH_CHECK();
-        G1Jac* t = cur; cur = nxt; nxt = t;
+        uint32_t* t = cur; cur = nxt; nxt = t;
     }
-    const G1SrcJac sl{cur, nullptr};
-    hipLaunchKernelGGL((k_g1_rows_out<G1SrcJac>), dim3(ceil_div(nkeys, 128)), dim3(128), 0, s, sl, off_all + nlev * ostride, nkeys, out);
+    const G1SrcCells sl{cur};
+    hipLaunchKernelGGL((k_g1_rows_out<G1SrcCells>), dim3(ceil_div(nkeys, 128)), dim3(128), 0, s, sl, off_all + nlev * ostride, nkeys, out);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -117,18 +117,43 @@ GM_HD G1Jac g1_add_aff_c(const G1Aff& p, const G1Aff& q) {
 // S = value / q, L = limb bound below the top limb; loads and products come out with L < 2^28, S <= 1.1.
 // The P = +-Q cases are detected on H = U2 - U1 (fq14_maybe_zero: exact for "no", rare false "maybe") and handed, with the
 // original operands, to the 12 x 32 formulas above.
+// A point in this form: limbs normalised (< 2^28), S <= 10.2 (what an addition leaves) or 1.1 (a load); infinity is z = 0 exactly
+// (a point at infinity only ever enters as a converted input or through the exact path, both of which give all-zero limbs; the Z3
+// of an addition with H != 0 is a product of non-zero residues).  The sum-by-key tree keeps its intermediate cells like this
+// (g1.hip: 42 words per cell) and converts to the canonical wire form once, at the end.
+struct G1P14 {
+    Fq14 x, y, z;
+};
+__device__ __forceinline__ bool fq14_limbs_zero(const Fq14& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) o |= a.l[i];
+    return o == 0;
+}
+__device__ __forceinline__ G1P14 g1p14_from(const G1Jac& p) {
+    G1P14 r;
+    r.x = fq14_from(p.x); r.y = fq14_from(p.y); r.z = fq14_from(p.z);
+    return r;
+}
+__device__ __forceinline__ G1Jac g1p14_to(const G1P14& p) {
+    G1Jac r;
+    r.x = fq14_to(p.x); r.y = fq14_to(p.y); r.z = fq14_to(p.z);
+    return r;
+}
 // shared tail; independent products go two at a time (fq14_mul2 / fq14_sqr2).
 // ZKIND 0: Z3 = 2 H (affine + affine);  1: Z3 = 2 za H (mixed, za = Z1);  2: Z3 = 2 za zb H (general, za zb = Z1 Z2)
+// U1, S1, za, zb: limbs < 2^28, S <= 10.2.
 template <int ZKIND>
-__device__ __forceinline__ G1Jac g1_tail14(const Fq14& U1, const Fq14& S1, const Fq14& H, const Fq14& d, const Fq14& za, const Fq14& zb) {
+__device__ __forceinline__ G1P14 g1_tail14(const Fq14& U1, const Fq14& S1, const Fq14& H, const Fq14& d, const Fq14& za, const Fq14& zb) {
     // H, d: a - b + 4 q, L < 2^29.6, S < 5.2
     Fq14 HH, dd, J, V, dW, YJ, ZZ, ZH;
     fq14_sqr2(H, d, HH, dd);                                          // S 1.02; rr^2 = 4 dd
     const Fq14 I = fq14_shl<2>(HH);                                   // (2H)^2: L < 2^30, S 4.1
-    fq14_mul2(H, I, U1, I, J, V);                                     // 2^59.6: S 1.01
+    fq14_mul2(H, I, U1, I, J, V);                                     // 2^59.6: S 1.02
     const Fq14 T = fq14_norm(fq14_add(J, fq14_shl<1>(V)));            // J + 2V: S 3.1
-    const Fq14 X3 = fq14_norm(fq14_sub4(fq14_shl<2>(dd), T));         // S 8.2
-    const Fq14 W = fq14_sub16(V, X3);                                 // L < 2^29.6, S 17.1
+    G1P14 r;
+    r.x = fq14_norm(fq14_sub4(fq14_shl<2>(dd), T));                   // S 8.2
+    const Fq14 W = fq14_sub16(V, r.x);                                // L < 2^29.6, S 17.1
     if (ZKIND == 2) {
         fq14_mul2(S1, J, za, zb, YJ, ZZ);
         fq14_mul2(d, W, ZZ, H, dW, ZH);                               // 2^59.2: S 1.04
@@ -138,24 +163,36 @@ __device__ __forceinline__ G1Jac g1_tail14(const Fq14& U1, const Fq14& S1, const
     } else {
         fq14_mul2(d, W, S1, J, dW, YJ);
     }
-    const Fq14 Y3 = fq14_shl<1>(fq14_sub4(dW, YJ));                   // rr (V - X3) - 2 S1 J: L < 2^30.6, S 10.1
-    const Fq14 Z3 = fq14_shl<1>(ZKIND == 0 ? H : ZH);
-    G1Jac r;
-    r.x = fq14_to(X3); r.y = fq14_to(Y3); r.z = fq14_to(Z3);
+    r.y = fq14_norm(fq14_shl<1>(fq14_sub4(dW, YJ)));                  // rr (V - X3) - 2 S1 J: S 10.1
+    r.z = fq14_norm(fq14_shl<1>(ZKIND == 0 ? H : ZH));                // S 10.2
     return r;
 }
+// general addition on this form (inputs: limbs < 2^28, S <= 10.2)
+__device__ __forceinline__ G1P14 g1_add14p(const G1P14& p, const G1P14& q) {
+    if (fq14_limbs_zero(p.z)) return q;
+    if (fq14_limbs_zero(q.z)) return p;
+    Fq14 Z1Z1, Z2Z2, U1, U2, A, B, S1, S2;
+    fq14_sqr2(p.z, q.z, Z1Z1, Z2Z2);
+    fq14_mul2(p.x, Z2Z2, q.x, Z1Z1, U1, U2);
+    const Fq14 H = fq14_sub4(U2, U1);
+    if (fq14_maybe_zero(H)) return g1p14_from(g1_add_c(g1p14_to(p), g1p14_to(q)));
+    fq14_mul2(p.y, q.z, q.y, p.z, A, B);
+    fq14_mul2(A, Z2Z2, B, Z1Z1, S1, S2);
+    return g1_tail14<2>(U1, S1, H, fq14_sub4(S2, S1), p.z, q.z);
+}
+__device__ __forceinline__ G1P14 g1_add_aff14p(const G1Aff& p, const G1Aff& q) {
+    if (g1_aff_is_inf(p)) return g1p14_from(g1_from_aff(q));
+    if (g1_aff_is_inf(q)) return g1p14_from(g1_from_aff(p));
+    const Fq14 X1 = fq14_from(p.x), Y1 = fq14_from(p.y);
+    const Fq14 H = fq14_sub4(fq14_from(q.x), X1);
+    if (fq14_maybe_zero(H)) return g1p14_from(g1_add_aff_c(p, q));
+    return g1_tail14<0>(X1, Y1, H, fq14_sub4(fq14_from(q.y), Y1), X1, X1);
+}
+// the wire-form entry points
 __device__ __forceinline__ G1Jac g1_add14(const G1Jac& p, const G1Jac& q) {
     if (g1_is_inf(p)) return q;
     if (g1_is_inf(q)) return p;
-    const Fq14 Z1 = fq14_from(p.z), Z2 = fq14_from(q.z);
-    Fq14 Z1Z1, Z2Z2, U1, U2, A, B, S1, S2;
-    fq14_sqr2(Z1, Z2, Z1Z1, Z2Z2);
-    fq14_mul2(fq14_from(p.x), Z2Z2, fq14_from(q.x), Z1Z1, U1, U2);
-    const Fq14 H = fq14_sub4(U2, U1);
-    if (fq14_maybe_zero(H)) return g1_add_c(p, q);
-    fq14_mul2(fq14_from(p.y), Z2, fq14_from(q.y), Z1, A, B);
-    fq14_mul2(A, Z2Z2, B, Z1Z1, S1, S2);
-    return g1_tail14<2>(U1, S1, H, fq14_sub4(S2, S1), Z1, Z2);
+    return g1p14_to(g1_add14p(g1p14_from(p), g1p14_from(q)));
 }
 __device__ __forceinline__ G1Jac g1_add_mixed14(const G1Jac& p, const G1Aff& q) {
     if (g1_aff_is_inf(q)) return p;
@@ -168,16 +205,9 @@ __device__ __forceinline__ G1Jac g1_add_mixed14(const G1Jac& p, const G1Aff& q) 
     if (fq14_maybe_zero(H)) return g1_add_mixed_c(p, q);
     const Fq14 Y1 = fq14_from(p.y);
     const Fq14 S2 = fq14_mul(t, Z1Z1);
-    return g1_tail14<1>(X1, Y1, H, fq14_sub4(S2, Y1), Z1, Z1);
+    return g1p14_to(g1_tail14<1>(X1, Y1, H, fq14_sub4(S2, Y1), Z1, Z1));
 }
-__device__ __forceinline__ G1Jac g1_add_aff14(const G1Aff& p, const G1Aff& q) {
-    if (g1_aff_is_inf(p)) return g1_from_aff(q);
-    if (g1_aff_is_inf(q)) return g1_from_aff(p);
-    const Fq14 X1 = fq14_from(p.x), Y1 = fq14_from(p.y);
-    const Fq14 H = fq14_sub4(fq14_from(q.x), X1);
-    if (fq14_maybe_zero(H)) return g1_add_aff_c(p, q);
-    return g1_tail14<0>(X1, Y1, H, fq14_sub4(fq14_from(q.y), Y1), X1, X1);
-}
+__device__ __forceinline__ G1Jac g1_add_aff14(const G1Aff& p, const G1Aff& q) { return g1p14_to(g1_add_aff14p(p, q)); }
 #define GM_G1_DEVICE_FQ14 1
 #endif
 

@@ -170,6 +170,34 @@ def tail(u1, s1, h, d, zf):
     return store(x3), store(y3), store(z3)
 
 
+def tail_cell(u1, s1, h, d, zf):
+    """g1_tail14 as the tree keeps its cells (G1P14): X3, Y3, Z3 as normalised limbs, not stored"""
+    hh = sqr(h)
+    i4 = shl(hh, 2)
+    j = mul(h, i4)
+    v = mul(u1, i4)
+    dd = sqr(d)
+    t = norm(add(j, shl(v, 1)))
+    x3 = norm(sub(shl(dd, 2), t, BIAS4, 4))
+    w = sub(v, x3, BIAS16, 16)
+    dw = mul(d, w)
+    yj = mul(s1, j)
+    y3 = norm(shl(sub(dw, yj, BIAS4, 4), 1))
+    z3 = norm(shl(h if zf is None else mul(zf, h), 1))
+    for c in (x3, y3, z3):
+        assert all(l <= M28 for l in c[:13]) and value(c) * 10 < 103 * Q   # limbs < 2^28, S <= 10.3
+    return x3, y3, z3
+
+
+def add_cells(p, q):
+    """g1_add14p on two cells (limbs < 2^28, S <= 10.3)"""
+    (a, b, z1), (c, e, z2) = p, q
+    z1z1, z2z2 = sqr(z1), sqr(z2)
+    u1, u2 = mul(a, z2z2), mul(c, z1z1)
+    s1, s2 = mul(mul(b, z2), z2z2), mul(mul(e, z1), z1z1)
+    return tail_cell(u1, s1, sub(u2, u1, BIAS4, 4), sub(s2, s1, BIAS4, 4), mul(z1, z2))
+
+
 def add_aff(x1, y1, x2, y2):
     a, b, c, e = load(x1), load(y1), load(x2), load(y2)
     return tail(a, b, sub(c, a, BIAS4, 4), sub(e, b, BIAS4, 4), None)
@@ -292,3 +320,21 @@ def test_zero_prefilter_never_misses_h_equal_zero():
         # and for a generic pair it (almost surely) does not fire
         _, h = add_mixed(x1, y1, z1, rng.randrange(Q), y2)
         assert value(h) % Q != 0
+
+
+def test_cells_stay_within_bounds_through_the_levels_of_a_tree():
+    """eight affine inputs, three levels: level 0 affine + affine into cells, the cells added pairwise twice, one store at the end"""
+    rng = random.Random(18)
+    for it in range(12):
+        pick = (lambda: rng.choice(adversarial())) if it < 4 else (lambda: rng.randrange(Q))
+        pts = [(pick(), pick()) for _ in range(8)]
+        cells, refs = [], []
+        for k in range(0, 8, 2):
+            (x1, y1), (x2, y2) = pts[k], pts[k + 1]
+            a, b, c, e = load(x1), load(y1), load(x2), load(y2)
+            cells.append(tail_cell(a, b, sub(c, a, BIAS4, 4), sub(e, b, BIAS4, 4), None))
+            refs.append(ref_add_aff(x1, y1, x2, y2))
+        while len(cells) > 1:
+            cells = [add_cells(cells[k], cells[k + 1]) for k in range(0, len(cells), 2)]
+            refs = [ref_add_jac(*refs[k], *refs[k + 1]) for k in range(0, len(refs), 2)]
+        assert tuple(store(c) for c in cells[0]) == refs[0]
