@@ -38,7 +38,9 @@ from gkr_msm_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FR_MUL_CEILING = 115e9     # measured: scripts/ubench/fr_mul_asm_test.hip, the 302-instruction 8 x 32-bit multiplier, all 256 CUs
-FR9_MUL_CEILING = 150e9    # measured: scripts/ubench/fr9_mul_test.hip, the 205-instruction 9 x 29-bit multiplier (MSM level kernels, large-round kernels below)
+FR9_MUL_CEILING = 175e9    # measured: scripts/ubench/fr9_rate_vs_occupancy.hip, the 205-instruction 9 x 29-bit multiplier in chains of dependent
+                           # products at <= 6 waves per SIMD or two interleaved chains (153 G at 8 waves per SIMD with one chain, the figure
+                           # quoted until the occupancy sweep); MSM level kernels, large-round kernels below
 FR9_ROUND_PRIMS = ("PROJ_L1", "PROJ_L2", "PROJ_L3", "AFF_L1", "AFF_L2", "AFF_L3", "PT_BIT_CHOICE", "ADD_INVERSES", "LOGUP_LAYER")   # large-round kernels that compute in the 9 x 29 form (sumcheck.hip: lean9_has)
 
 
