@@ -25,13 +25,14 @@ build/examples/%: examples/%.c include/gkrmsm.h $(LIB)
 	@mkdir -p build/examples
 	gcc -std=c11 -O2 -Wall -Wextra -D_POSIX_C_SOURCE=199309L -Iinclude $< -o $@ -Lgkr_msm_amd -lgkrmsm_hip -Wl,-rpath,'$$ORIGIN/../../gkr_msm_amd'
 
-# device-side self-checks that tests/ run on the GPU box (prebuilt here: the 14 x 28 one takes hipcc three minutes)
-ubench: build/ubench/fq14_test
-FQ14_TEST_SRC := scripts/ubench/fq14_test.hip gkr_msm_amd/csrc/fq14.hip.h gkr_msm_amd/csrc/g1.hip.h gkr_msm_amd/csrc/fq.hip.h gkr_msm_amd/csrc/fr9.hip.h gkr_msm_amd/csrc/fr.hip.h
+# device-side self-checks that tests/ run on the GPU box (prebuilt here: the 14 x 28 one takes hipcc three minutes); each binary
+# carries the digest of its source + the field headers, tests/ubench_util.py rebuilds only when that digest is stale
+ubench: build/ubench/fq14_test build/ubench/fr9_mul_test
+UBENCH_HDRS := gkr_msm_amd/csrc/fq14.hip.h gkr_msm_amd/csrc/g1.hip.h gkr_msm_amd/csrc/fq.hip.h gkr_msm_amd/csrc/fr9.hip.h gkr_msm_amd/csrc/fr.hip.h
 build/ubench/%: scripts/ubench/%.hip $(HDR)
 	@mkdir -p build/ubench
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -w -mllvm -enable-misched=0 -o $@ $<
-	cat $(FQ14_TEST_SRC) | sha256sum | cut -d' ' -f1 > $@.srchash
+	cat $< $(UBENCH_HDRS) | sha256sum | cut -d' ' -f1 > $@.srchash
 
 clean:
 	rm -rf build $(LIB)

@@ -30,6 +30,60 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def _spawn_ranks_if_needed():
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU) and wait for them.
+    Runs before torch / the HIP library are imported: the parent never touches a GPU and never execs; rank 0's JSON line goes to
+    the inherited stdout; a failed rank fails the run (the others are ended after a grace period so nothing keeps a GPU)."""
+    n = 1
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, GM_BENCH_SELF_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, deadline = 0, None
+    live = list(procs)
+    while live:
+        for p_ in list(live):
+            c = p_.poll()
+            if c is not None:
+                live.remove(p_)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    deadline = time.time() + 30.0      # a rank died: the others get 30 s to notice (collective time-outs), then are ended
+        if deadline is not None and time.time() > deadline:
+            for p_ in live:
+                p_.terminate()
+            for p_ in live:
+                try:
+                    p_.wait(10)
+                except subprocess.TimeoutExpired:
+                    p_.kill()
+            break
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    _spawn_ranks_if_needed()
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

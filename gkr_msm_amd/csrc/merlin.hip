@@ -313,6 +313,8 @@ extern "C" int32_t gm_merlin_reader(gm_merlin* t, gm_transcript_reader* out) {
     out->read_scalars = mt_read_scalars;
     out->challenge = mt_challenge;
     out->read_points = mt_read_points;
+    out->points_validated = 1;   // mt_read_points decompresses with the subgroup check (g1_decompress)
+    out->reserved = 0;
     return GM_OK;
 }
 // bytes of the proof not read yet (a verifier may insist on 0)

@@ -28,6 +28,7 @@ struct RcclApi {
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[256] = {0};        // what failed, captured at the failing dlopen / dlsym
 };
 
 RcclApi& rccl_api() {
@@ -39,7 +40,11 @@ RcclApi& rccl_api() {
         if (!r.lib)
             for (const char* n : names)
                 if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!r.lib) return r;
+        if (!r.lib) {
+            const char* e = dlerror();
+            snprintf(r.why, sizeof(r.why), "dlopen librccl.so.1 failed: %s", e ? e : "(no dlerror)");
+            return r;
+        }
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
@@ -47,6 +52,7 @@ RcclApi& rccl_api() {
         r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Broadcast && r.GetErrorString;
+        if (!r.ok) snprintf(r.why, sizeof(r.why), "librccl.so.1 loaded but a symbol is missing (ncclGetUniqueId/CommInitRank/CommDestroy/AllGather/Broadcast/GetErrorString)");
         return r;
     }();
     return a;
@@ -60,7 +66,7 @@ RcclApi& rccl_api() {
     } while (0)
 
 int32_t need_rccl() {
-    if (!rccl_api().ok) return set_err(GM_ERR_STATE, "RCCL is not available in this process (dlopen librccl.so.1 failed: %s)", dlerror());
+    if (!rccl_api().ok) return set_err(GM_ERR_STATE, "RCCL is not available in this process (%s)", rccl_api().why);
     return GM_OK;
 }
 
@@ -90,8 +96,13 @@ static int32_t rccl_all_gather_host(void* ctx, void* buf, uint64_t nbytes) {
     if (!r || !buf) return 1;
     if (nbytes == 0) return 0;
     const size_t total = (size_t)r->world * nbytes;
-    if (r->send.bytes < nbytes && r->send.alloc(nbytes < 4096 ? 4096 : nbytes)) return 2;
-    if (r->recv.bytes < total && r->recv.alloc(total < 65536 ? 65536 : total)) return 2;
+    {
+        // the staging outlives any prover arena: a gather issued inside a layer's ArenaScope must not carve it from there
+        // (the arena is reset after the layer and would hand the same bytes to the next layer's columns)
+        ArenaScope none(nullptr);
+        if (r->send.bytes < nbytes && r->send.alloc(nbytes < 4096 ? 4096 : nbytes)) return 2;
+        if (r->recv.bytes < total && r->recv.alloc(total < 65536 ? 65536 : total)) return 2;
+    }
     char* hb = static_cast<char*>(buf);
     const bool small = nbytes <= gm_rccl::PIN_BYTES && r->pinned;
     char* stage = small ? r->pinned : hb;   // pinned staging keeps the two copies asynchronous and short

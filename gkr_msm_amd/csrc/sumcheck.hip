@@ -489,6 +489,9 @@ struct StageArgs {
     uint32_t* d_merge;                 // device: one arrival counter per blockIdx.x (zeroed before the launch)
     uint32_t ticket0;
     uint64_t timeout_ticks;
+    uint32_t* d_arrive;                // device: residency barrier -- cumulative count of blocks that have started (bit 31: a launch gave up)
+    uint32_t arrive_target;            // ... value it has once every block of THIS launch is resident
+    uint64_t resident_ticks;           // ... how long a block waits for the others before the launch is abandoned (100 MHz ticks)
     uint64_t* d_dbg;                   // development aid: phase time stamps (nullptr normally)
 };
 
@@ -588,6 +591,36 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
     bool thin = a.n_thin > 0;   // true while the thin rounds run (reports then carry the tail weight)
     // development aid (GM_STAGE_DEBUG=1): wall-clock stamps (100 MHz) of the phases of every round, blocks 0 and 1
 #define STAGE_STAMP(k_) do { if (a.d_dbg && i == 0 && blk < 2) a.d_dbg[((size_t)blk * 32 + round) * 8 + (k_)] = wall_clock64(); } while (0)
+
+    // Residency barrier.  The blocks of a launch wait for each other every round, so all of them must be resident at once.  The
+    // host only launches what fits an EMPTY device (StageSlots), but kernels of other streams or processes may hold compute units:
+    // every block counts itself in and waits -- briefly -- until the whole grid has; the block whose patience runs out flips the
+    // abandon bit (compare-and-swap against the count it saw: "everyone is here" and "abandoned" exclude each other), reports status 2
+    // and everybody leaves, including blocks that only become resident later.  The host then runs the layer's rounds as ordinary
+    // kernels (StageRun::sums -> GM_STAGE_NOT_RESIDENT).  Nothing has been written by then: the columns are read-only here.
+    if (i == 0) {
+        int good = 0;
+        uint32_t v = __hip_atomic_fetch_add(a.d_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        const uint64_t t_begin = wall_clock64();
+        for (uint32_t it = 0;; it++) {
+            if (v & 0x80000000u) break;
+            if (v >= a.arrive_target) { good = 1; break; }
+            if ((it & 31u) == 31u && wall_clock64() - t_begin > a.resident_ticks) {
+                uint32_t seen = v;
+                if (__hip_atomic_compare_exchange_strong(a.d_arrive, &seen, v | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.h_status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                v = seen;
+                continue;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(a.d_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
 
     // Sum (s0, s1) over all reporting blocks and hand the round's sums to the host, then wait for that round's challenge;
     // false = give up.  Blocks publish their partial in device memory; the block that arrives last (agent-scope release /
@@ -1427,13 +1460,16 @@ struct RoundScratch {
     }
 };
 
-// pinned staging of k_gather_finals: one per host thread, kept for the life of the process
+// pinned staging of k_gather_finals: one per host thread and device, kept for the life of the process
 struct FinalsStage {
     Fr* h = nullptr;
     uint32_t seq = 0;
 };
 static int32_t gather_finals(const Fr* const* cur, int k, hipStream_t s, std::vector<Fr>* out) {
-    static thread_local FinalsStage st;
+    static thread_local FinalsStage per_dev[16];   // per (host thread, device), as TailStage
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    FinalsStage& st = per_dev[(dev_ >= 0 && dev_ < 16) ? dev_ : 0];
     if (!st.h) {
         GM_HIP(hipHostMalloc((void**)&st.h, (GM_MAX_COLS + 1) * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
         memset(st.h, 0, (GM_MAX_COLS + 1) * sizeof(Fr));
@@ -1459,7 +1495,7 @@ static int32_t gather_finals(const Fr* const* cur, int k, hipStream_t s, std::ve
     return GM_OK;
 }
 
-// pinned staging of k_stage: one per host thread, kept for the life of the process
+// pinned staging + device-side counters of k_stage: one per host thread and device, kept for the life of the process
 struct TailStage {
     char* base = nullptr;
     uint32_t* rep() const { return reinterpret_cast<uint32_t*>(base); }            // 2 report slots of 36 words (3 elements x 3 chunks)
@@ -1468,14 +1504,21 @@ struct TailStage {
     Fr* finals() const { return reinterpret_cast<Fr*>(base + 1024); }              // 32 slots per column: what the launch leaves of it
     uint32_t* fin_seq() const { return reinterpret_cast<uint32_t*>(finals() + 32 * GM_MAX_COLS); }   // [segment][slice]
     uint32_t counter = 0;
-    // device state of the launches of this host thread (never memset: the kernel leaves its counters at zero, tags are unique)
+    // device state of the launches of this host thread on this device (never memset: the kernel leaves its counters at zero, tags
+    // are unique)
     uint32_t* d_state = nullptr;
     bool d_state_dirty = true;
+    uint32_t arrive_total = 0;   // blocks counted in by the residency barrier since the state was last zeroed
     static constexpr size_t BYTES = 1024 + 32 * GM_MAX_COLS * sizeof(Fr) + (size_t)GM_MAX_SEGS * STAGE_MAX_SLICES * 4;
-    static constexpr size_t STATE_BYTES = 256 + 2 * GM_MAX_SEGS * 4;
+    static constexpr size_t STATE_BYTES = 256 + 2 * GM_MAX_SEGS * 4 + 64;   // relay | round counters | merge counters | residency word
+    static constexpr size_t ARRIVE_WORD = (256 + 2 * GM_MAX_SEGS * 4) / 4;
 };
+static inline int cur_device_slot() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < 16) ? d : 0; }
+// one per (host thread, device): a thread that drives several GPUs (gm_set_device between calls) gets device-side counters and
+// pinned staging of its own on each of them
 static int32_t tail_stage(TailStage** out) {
-    static thread_local TailStage st;
+    static thread_local TailStage per_dev[16];
+    TailStage& st = per_dev[cur_device_slot()];
     if (!st.base) {
         GM_HIP(hipHostMalloc((void**)&st.base, TailStage::BYTES, hipHostMallocCoherent | hipHostMallocMapped));
         memset(st.base, 0, TailStage::BYTES);
@@ -1575,6 +1618,8 @@ static bool stage_plan_is_narrow(const SegPlan& sp) {
 }
 // StageRun::launch could not get its share of the device without waiting (internal; never leaves the library)
 #define GM_STAGE_BUSY 1000
+// StageRun::sums, first round of a launch: the grid did not become resident as a whole, the launch has left without touching anything
+#define GM_STAGE_NOT_RESIDENT 1001
 
 // One launch of k_stage seen from the host.  A VecVec object that enters its thin rounds creates it; the dense object it hands
 // over to (bind_into_dense) keeps using the same launch.
@@ -1655,9 +1700,11 @@ struct StageRun {
             GM_HIP(hipMalloc((void**)&st->d_state, TailStage::STATE_BYTES));
             st->d_state_dirty = true;
         }
+        if (st->arrive_total > 0x40000000u) st->d_state_dirty = true;   // the cumulative arrival count stays far below bit 31
         if (st->d_state_dirty) {
             GM_HIP(hipMemsetAsync(st->d_state, 0, TailStage::STATE_BYTES, s));
             st->d_state_dirty = false;
+            st->arrive_total = 0;
         }
         void* state_p = st->d_state;
         a.h_rep = st->rep(); a.h_finals = st->finals(); a.h_fin_seq = st->fin_seq();
@@ -1665,6 +1712,7 @@ struct StageRun {
         a.d_relay = reinterpret_cast<uint32_t*>(state_p);
         a.d_round_cnt = reinterpret_cast<uint32_t*>(state_p) + 32;
         a.d_merge = reinterpret_cast<uint32_t*>(state_p) + 64;
+        a.d_arrive = reinterpret_cast<uint32_t*>(state_p) + TailStage::ARRIVE_WORD;
         a.d_part = dpart.fr();
         a.d_xbuf = xbuf.fr();
         if (debug()) {
@@ -1688,6 +1736,14 @@ struct StageRun {
             return set_err(GM_ERR_STATE, "stage launch: the device stayed full of other threads' stage kernels (%u units wanted, %u in flight, "
                            "capacity %u; gm_set_wait_timeout_ms)", want, StageSlots::get().in_flight[slot_dev], StageSlots::get().cap(slot_dev));
         slots_held = want;
+        {
+            // GM_STAGE_FORCE_NONRESIDENT=1 (tests): the barrier waits for one block more than the grid has and gives up at once
+            static const bool force_nr = [] { const char* e = getenv("GM_STAGE_FORCE_NONRESIDENT"); return e && e[0] == '1'; }();
+            static const uint64_t res_ticks = [] { const char* e = getenv("GM_STAGE_RESIDENT_MS"); return (uint64_t)(e && atoi(e) > 0 ? atoi(e) : 10) * 100000ull; }();
+            st->arrive_total += gx * nsl;
+            a.arrive_target = st->arrive_total + (force_nr ? 1u : 0u);
+            a.resident_ticks = force_nr ? 2000ull : res_ticks;
+        }
         if (narrow) hipLaunchKernelGGL(k_stage<3>, dim3(gx, nsl), dim3(256), 0, s, sp, cp, d_gamma, a);
         else hipLaunchKernelGGL(k_stage<6>, dim3(gx, nsl), dim3(256), 0, s, sp, cp, d_gamma, a);
         GM_LAUNCH_CHECK();
@@ -1711,17 +1767,27 @@ struct StageRun {
         Fr v[3];
         auto all = [&] { return read_chunks(rep, want, &v[0]) && read_chunks(rep + 12, want, &v[1]) && read_chunks(rep + 24, want, &v[2]); };
         bool seen = false;
+        volatile uint32_t* stat = reinterpret_cast<volatile uint32_t*>(st->status());
         for (int spin = 0; spin < 400000 && !seen; spin++) {
-            seen = all();
+            seen = all() || *stat != 0;
             if (!seen) __builtin_ia32_pause();
         }
         if (!seen) {
             const auto t0 = std::chrono::steady_clock::now();
             while (!seen && std::chrono::steady_clock::now() - t0 < wait_timeout_host() + std::chrono::milliseconds(200))
-                for (int spin = 0; spin < 10000 && !seen; spin++) seen = all();
+                for (int spin = 0; spin < 10000 && !seen; spin++) seen = all() || *stat != 0;
         }
-        if (*reinterpret_cast<volatile uint32_t*>(st->status())) {
-            *reinterpret_cast<volatile uint32_t*>(st->status()) = 0;
+        if (*stat == 2u && r == 0) {
+            // the grid never became resident as a whole (other work on the device): the launch has left, nothing was written
+            *stat = 0;
+            st->d_state_dirty = true;
+            published = total();   // no waiting block is left behind
+            (void)hipStreamSynchronize(stream);
+            if (slots_held) { StageSlots::get().release(slot_dev, slots_held); slots_held = 0; }
+            return GM_STAGE_NOT_RESIDENT;
+        }
+        if (*stat) {
+            *stat = 0;
             st->d_state_dirty = true;
             return set_err(GM_ERR_STATE, "the stage kernel timed out waiting for a challenge (gm_set_wait_timeout_ms)");
         }
@@ -2334,7 +2400,7 @@ struct ScDenseDeg2 : gm_sc {
         return GM_OK;
     }
     // ---- persistent stage (see k_stage): rounds [tail_r0, num_vars) run inside one launch
-    bool tail_active = false;
+    bool tail_active = false, tail_denied = false;   // denied: a launch was abandoned at its residency barrier, do not try again
     uint32_t tail_r0 = 0;
     std::shared_ptr<StageRun> stage;
     int stage_round() const { return stage->n_thin + (int)(round_idx - tail_r0); }
@@ -2434,7 +2500,7 @@ struct ScDenseDeg2 : gm_sc {
 
     int32_t unipoly_pipelined(std::vector<Fr>* coeffs, uint64_t npairs, const Fr* eq_cur, const ColPtrs& cp) {
         const uint32_t r = round_idx;
-        const bool tail_ok = stage_enabled() && sp.nseg <= 32 && (rs.own_pinned || pinned_exclusive());
+        const bool tail_ok = !tail_denied && stage_enabled() && sp.nseg <= 32 && (rs.own_pinned || pinned_exclusive());
         if (!tail_active && tail_ok && stage_fits(r, npairs) && k_enq <= r) {
             int32_t rc = launch_tail(cp, r, npairs);   // the object starts small: everything runs in the tail
             if (rc) return rc;
@@ -2443,6 +2509,15 @@ struct ScDenseDeg2 : gm_sc {
         if (tail_active && r >= tail_r0) {
             Fr a1, a2;
             int32_t rc = tail_round_sums(&a1, &a2);
+            if (rc == GM_STAGE_NOT_RESIDENT && r == tail_r0) {
+                // the launch left before its first round (residency barrier): this and the following rounds as ordinary kernels
+                stage.reset();
+                tail_active = false;
+                tail_denied = true;
+                host_r0 = 0xffffffffu;
+                k_enq = r;
+                return unipoly_pipelined(coeffs, npairs, eq_cur, cp);
+            }
             if (rc) return rc;
             const Fr total1 = fr_mul(a1, multiplier), total2 = fr_mul(a2, multiplier);
             if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);
@@ -2624,8 +2699,15 @@ struct ScVecVecDeg2 : gm_sc {
         }
         if (stage_active) {
             int32_t rc = stage->sums((int)(already_bound - stage_r0), &acc[0], &acc[1], &acc[2]);
-            if (rc) return rc;
-        } else {
+            if (rc == GM_STAGE_NOT_RESIDENT && already_bound == stage_r0) {
+                // the launch left before its first round (residency barrier): this and the following rounds as ordinary kernels
+                stage.reset();
+                stage_active = false;
+                stage_denied = true;
+                k_enq = already_bound;
+            } else if (rc) return rc;
+        }
+        if (!stage_active) {
         // every sparse round (large ones too: the fold and the next round kernel are then already in the stream when the
         // challenge arrives, ~8 us of launch latency per round) enqueues its fold behind a gate and the next round's kernel
         const bool piped = !sh.comm && ScDenseDeg2::pipeline_enabled() &&
@@ -2718,10 +2800,10 @@ struct ScVecVecDeg2 : gm_sc {
 
     // ---- persistent stage (k_stage): the thin sparse rounds + bind_into_dense + the whole dense stage in one launch
     std::shared_ptr<StageRun> stage;
-    bool stage_active = false, stage_armed = false;
+    bool stage_active = false, stage_armed = false, stage_denied = false;
     uint32_t stage_r0 = 0;     // already_bound of the launch's first round
     bool stage_ok() const {
-        if (!stage_enabled() || sh.comm || !pinned_exclusive() || k > 16 || col_logsize < 1 || nrows > (1u << col_logsize)) return false;
+        if (stage_denied || !stage_enabled() || sh.comm || !pinned_exclusive() || k > 16 || col_logsize < 1 || nrows > (1u << col_logsize)) return false;
         for (uint32_t i = 0; i < col_logsize; i++)
             if (fr_eq(point[i], fr_one())) return false;   // the dense stage would need the generic object (from12 divides by 1 - q)
         return true;

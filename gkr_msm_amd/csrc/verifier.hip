@@ -56,9 +56,9 @@ struct Reader {
         }
         for (uint64_t i = 0; i < n; i++) {
             VERIFY(g1_aff_on_curve(out[i]), "a proof point is not on the curve (deserialize_compressed)");
-            // recorded mode holds raw affine points; a reader callback delivers points its deserializer has validated (the
-            // built-in one does: g1_decompress), so the ~70 us membership test is not repeated behind it
-            if (!cb) VERIFY(g1_aff_in_subgroup_host(out[i]), "a proof point is outside the prime-order subgroup (deserialize_compressed, Validate::Yes)");
+            // recorded mode holds raw affine points; a reader callback skips the ~70 us membership test only when it says its
+            // deserializer has done it (gm_transcript_reader::points_validated; the built-in merlin reader does: g1_decompress)
+            if (!cb || !cb->points_validated) VERIFY(g1_aff_in_subgroup_host(out[i]), "a proof point is outside the prime-order subgroup (deserialize_compressed, Validate::Yes)");
         }
         pi += n;
         return GM_OK;

@@ -54,7 +54,8 @@ READ_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
 
 class GmTranscriptReader(C.Structure):
     """gm_transcript_reader: the caller's transcript in verifier mode"""
-    _fields_ = [("ctx", C.c_void_p), ("read_scalars", READ_CB), ("challenge", CHALLENGE_CB), ("read_points", READ_CB)]
+    _fields_ = [("ctx", C.c_void_p), ("read_scalars", READ_CB), ("challenge", CHALLENGE_CB), ("read_points", READ_CB),
+                ("points_validated", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 ALL_GATHER_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)

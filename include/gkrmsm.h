@@ -323,6 +323,11 @@ typedef struct gm_transcript_reader {
     int32_t (*read_scalars)(void* ctx, uint64_t n, uint64_t* out);
     int32_t (*challenge)(void* ctx, uint32_t n, uint32_t bitsize, uint64_t* out);
     int32_t (*read_points)(void* ctx, uint64_t n, uint64_t* out_aff);
+    /* non-zero: read_points has already checked prime-order subgroup membership (ark's deserialize_compressed with Validate::Yes,
+     * proof_transcript.rs read_points; gm_merlin_reader sets it).  Zero -- the default of a zero-initialised struct -- makes the
+     * verifier run the check itself on every point read (~70 us each). */
+    uint32_t points_validated;
+    uint32_t reserved;
 } gm_transcript_reader;
 int32_t gm_pippenger_verify_tr(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_size, uint32_t y_logsize,
                                uint32_t commitment_log_multiplicity, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,

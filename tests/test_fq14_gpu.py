@@ -4,34 +4,20 @@ g1_add14 / g1_add_mixed14 / g1_add_aff14) against the 12 x 32 path, on the devic
 and a chain of 101 dependent additions must end in the same point -- scripts/ubench/fq14_test.hip (prebuilt by `make`, built here
 when missing).  tests/test_fq14_model_cpu.py is the integer model with the bound assertions; the G1 kernels that use the form are
 pinned by the oracle tests (test_g1_gpu.py, test_pushforward_gpu.py, test_pippenger_full_gpu.py)."""
-import hashlib
 import os
-import shutil
 import subprocess
+import sys
 
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ubench_util import ubench_exe  # noqa: E402
+
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_fq14_field_and_g1_additions_match_the_12x32_path(tmp_path):
-    exe = os.path.join(ROOT, "build", "ubench", "fq14_test")
-    src = os.path.join(ROOT, "scripts", "ubench", "fq14_test.hip")
-    hdrs = [os.path.join(ROOT, "gkr_msm_amd", "csrc", h) for h in ("fq14.hip.h", "g1.hip.h", "fq.hip.h", "fr9.hip.h", "fr.hip.h")]
-    h = hashlib.sha256()
-    for f in [src] + hdrs:   # the Makefile records the same digest next to the binary it builds (file times do not survive a copy)
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-    stamp = exe + ".srchash"
-    fresh = os.path.exists(exe) and os.path.exists(stamp) and open(stamp).read().strip() == h.hexdigest()
-    if not fresh:
-        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        if not os.path.exists(hipcc):
-            pytest.skip("no prebuilt build/ubench/fq14_test and no hipcc on this box")
-        exe = str(tmp_path / "fq14_test")
-        subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-w", "-mllvm", "-enable-misched=0", "-o", exe, src],
-                              timeout=1200)
+    exe = ubench_exe("fq14_test", tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr

@@ -255,3 +255,17 @@ def test_stage_launch_denied_falls_back_to_ordinary_rounds():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_prover_gpu.py"), "-x", "-q", "-k",
                           "matches_oracle and (9-8-64 or 7-6-128 or 5-3-16)"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "3 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_stage_launch_not_resident_falls_back_to_ordinary_rounds():
+    """a k_stage launch whose grid does not become resident as a whole (kernels of other streams / processes hold compute units)
+    is abandoned at its residency barrier and the layer's rounds run as ordinary kernels: GM_STAGE_FORCE_NONRESIDENT=1 makes every
+    launch's barrier wait for one block more than the grid has (child process: read once); the proofs must still equal the oracle's"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GM_STAGE_FORCE_NONRESIDENT="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_prover_gpu.py"), "-x", "-q", "-k",
+                          "matches_oracle and (9-8-64 or 7-6-128 or 5-3-16)"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "3 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -220,3 +220,61 @@ def test_committed_proof_fixture_verifies():
     h0, h1 = VF.kzg_mock_vk(p["tau"])
     assert VF.kzg_verify_pair(p["pair"], h0, h1)
     assert p["pair"][0] == G.mul(p["pair"][1], p["tau"])
+
+
+def test_a_third_party_reader_gets_the_subgroup_check_unless_it_opts_out(proof):
+    """gm_transcript_reader::points_validated: a reader that delivers raw affine points (flag 0, the zero-initialised default)
+    keeps the reference's Validate::Yes guarantee -- the verifier runs the membership test itself; only a reader that says it has
+    validated (the built-in merlin reader does) skips it"""
+    import ctypes as C
+    import numpy as np
+    from gkr_msm_amd import codec, ffi
+    p = proof
+    L = ffi.lib()
+    h = C.c_void_p()
+    ffi.check(L.gm_merlin_create_verifier(b"x", 1, b"\0", 1, C.byref(h)))
+    rd0 = ffi.GmTranscriptReader()
+    ffi.check(L.gm_merlin_reader(h, C.byref(rd0)))
+    assert rd0.points_validated == 1
+    L.gm_merlin_destroy(h)
+    bad_pt = G.add(p["points"][0], _cofactor_torsion_point())
+
+    def run(points, validated):
+        sc = codec.to_mont_limbs(list(p["scalars"])).reshape(-1)
+        pt = codec.g1_aff_to_limbs(points).reshape(-1)
+        tp = codec.ints_to_limbs(p["tape"]).reshape(-1)
+        pos = {"s": 0, "p": 0, "t": 0}
+
+        def serve(arr, key, width):
+            def cb(ctx, n, out):
+                a, b = pos[key] * width, (pos[key] + n) * width
+                if b > len(arr):
+                    return 1
+                for i in range(a, b):
+                    out[i - a] = int(arr[i])
+                pos[key] += n
+                return 0
+            return cb
+
+        def chal(ctx, n, bits, out):
+            a, b = pos["t"] * 4, (pos["t"] + n) * 4
+            if b > len(tp):
+                return 1
+            for i in range(a, b):
+                out[i - a] = int(tp[i])
+            pos["t"] += n
+            return 0
+        rd = ffi.GmTranscriptReader(None, ffi.READ_CB(serve(sc, "s", 4)), ffi.CHALLENGE_CB(chal), ffi.READ_CB(serve(pt, "p", 12)),
+                                    1 if validated else 0, 0)
+        cp, ce = codec.to_mont_limbs(list(p["claims"][0])), codec.to_mont_limbs(list(p["claims"][1]))
+        g0l, kk = codec.g1_aff_to_limbs([p["g0"]]), codec.to_mont_limbs([p["k"]])
+        pair = np.zeros(24, dtype=np.uint64)
+        rc = L.gm_pippenger_verify_tr(*p["shape"], cp.ctypes.data, ce.ctypes.data, g0l.ctypes.data, kk.ctypes.data, C.byref(rd),
+                                      pair.ctypes.data)
+        return rc, (L.gm_last_error() or b"").decode()
+    rc, _ = run(p["points"], False)
+    assert rc == 0
+    rc, msg = run([bad_pt] + p["points"][1:], False)
+    assert rc != 0 and "subgroup" in msg
+    rc, msg = run([bad_pt] + p["points"][1:], True)      # the reader vouched for its points: no membership test behind it
+    assert rc == 0 or "subgroup" not in msg             # (gm_last_error keeps the previous call's text after a success)
