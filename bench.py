@@ -83,6 +83,14 @@ def _spawn_ranks_if_needed():
 
 if __name__ == "__main__":
     _spawn_ranks_if_needed()
+    if os.environ.get("GM_BENCH_SPAWN_CHECK"):
+        # test hook of the launcher (tests/test_bench_spawn_cpu.py): a rank reports how it was started and leaves before anything
+        # touches a GPU; "fail:<r>" makes rank r exit non-zero
+        chk = os.environ["GM_BENCH_SPAWN_CHECK"]
+        print("spawn-check rank %s of %s local %s port %s self_spawned %s" % (
+            os.environ.get("RANK"), os.environ.get("WORLD_SIZE"), os.environ.get("LOCAL_RANK"), os.environ.get("MASTER_PORT"),
+            os.environ.get("GM_BENCH_SELF_SPAWNED", "0")), flush=True)
+        sys.exit(3 if chk == "fail:%s" % os.environ.get("RANK") else 0)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -134,7 +142,20 @@ def host_info():
                     break
     except Exception:
         pass
-    return {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cpu_model": model}
+    return {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "usable_cpus": usable_cpus(), "cpu_model": model}
+
+
+def usable_cpus():
+    """hardware threads this process may actually use: the affinity mask, cut by a cgroup CPU quota when there is one"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(math.ceil(int(q) / int(per)))))
+    except Exception:
+        pass
+    return n
 
 
 def make_scalars(n, nbits, seed=0x474B524D):
@@ -174,7 +195,8 @@ def main():
     ap.add_argument("--d-logsize", type=int, default=8)
     ap.add_argument("--nbits", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU port (0 = every usable hardware thread; the MSM leg "
+                    "cannot use more than its windows, as the reference's rayon loop over windows)")
     ap.add_argument("--no-sumcheck", action="store_true")
     ap.add_argument("--cpu-sumcheck-xlog", type=int, default=20, help="CPU prover sample (config B itself by default: ~25 s)")
     ap.add_argument("--cpu-faithful-xlog", type=int, default=17, help="sample of the 'reference-faithful' CPU variant (serial round loops)")
@@ -190,7 +212,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (bench.py starts its own ranks when no launcher did)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     # GM_BENCH_BACKEND=gloo rehearses the N > 1 flow on a box with fewer GPUs than ranks (ranks then share devices and the
     # small exchanges go over gloo on host tensors); the real runs use RCCL over xGMI, one GPU per rank.
@@ -231,6 +253,32 @@ def main():
     y0, y1 = gdist.window_range(rank, world, y_size)
     wpr = y1 - y0
     ncols = 3 * (d_log + 1)
+    world_, rcomm_, y0_, y1_ = world, rcomm, y0, y1     # msm_leg(solo=True) shadows them with the one-GPU values
+
+    def gather_floats(v):
+        """one float per rank, in rank order, on every rank"""
+        if dist is None:
+            return [float(v)]
+        t = torch.tensor([v], dtype=torch.float64, device=xdev)
+        o = torch.empty(world_, dtype=torch.float64, device=xdev)
+        dist.all_gather_into_tensor(o, t)
+        return [float(x) for x in o.cpu()]
+
+    # which GPUs the native communicator really spans: every rank contributes (rank, a digest of its device's UUID / PCI address)
+    # through ncclAllGather itself
+    rccl_seen = None
+    if rcomm is not None and world > 1:
+        import hashlib
+        pr_ = torch.cuda.get_device_properties(local_rank)
+        ident = "%s|%s|%s|%s" % (getattr(pr_, "uuid", ""), getattr(pr_, "pci_domain_id", ""), getattr(pr_, "pci_bus_id", ""),
+                                 getattr(pr_, "pci_device_id", ""))
+        dig = int.from_bytes(hashlib.sha256(ident.encode()).digest()[:7], "little")
+        mine_ = torch.tensor([rank, dig], dtype=torch.int64, device="cuda")
+        all_ = torch.empty(2 * world, dtype=torch.int64, device="cuda")
+        rcomm.all_gather_dev(C.c_void_p(mine_.data_ptr()), all_, 16)
+        torch.cuda.synchronize()
+        got_ = all_.cpu().numpy().reshape(world, 2)
+        rccl_seen = {"ranks": int(len(set(int(v) for v in got_[:, 0]))), "distinct_devices": int(len(set(int(v) for v in got_[:, 1])))}
 
     def sync_all():
         if dist is not None:
@@ -268,10 +316,13 @@ def main():
             d_sc = harness.to_dev(sc)
         return d_pts, d_sc, sc, bcast_ms
 
-    def msm_leg(x_log, steps, warmup, keep=False):
-        """the timed MSM loop at one shape; returns the result dict (+ plan / operands when keep)"""
+    def msm_leg(x_log, steps, warmup, keep=False, solo=False):
+        """the timed MSM loop at one shape; returns the result dict (+ plan / operands when keep).  solo: every rank runs the WHOLE
+        unsharded MSM on its own GPU, no exchange -- the N = 1 figure measured in the same run, on the same boxes"""
         n = 1 << x_log
         d_pts, d_sc, sc, bcast_ms = make_inputs(x_log)
+        world, rcomm, y0, y1 = (1, None, 0, y_size) if solo else (world_, rcomm_, y0_, y1_)
+        wpr = y1 - y0
         plan = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
 
         def step():
@@ -360,7 +411,9 @@ def main():
         for j in range(max(steps - depth + 1, 0), steps):
             result, raw = finish(j)
         sync_all()
-        dt = max_over_ranks(time.perf_counter() - t0)
+        dt_local = time.perf_counter() - t0
+        dt = max_over_ranks(dt_local)
+        per_rank_ms = [round(v / steps * 1e3, 4) for v in gather_floats(dt_local)]
         for pl in plans[1:]:
             pl.close()
         del plans, recv
@@ -398,7 +451,8 @@ def main():
                                             "frac": round(alg_bytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                             "fr_mul_per_s": round(fr_mul0 / (alone * 1e-3), 1),
                                             "valu_frac_of_measured_ceiling": round(fr_mul0 / (alone * 1e-3) / FR9_MUL_CEILING, 3)}
-        res = {"x_logsize": x_log, "value": round(n * steps / dt, 1), "ms_per_step": round(ms_per_step, 4), "roofline": roofline,
+        res = {"x_logsize": x_log, "value": round(n * steps / dt, 1), "ms_per_step": round(ms_per_step, 4),
+               "per_rank_ms_per_step": per_rank_ms, "pipeline_depth": depth, "roofline": roofline,
                "stage_ms": stages, "result_x": hex(result[0]),
                # SURVEY 8(d)'s whole-MSM unit: 96 B of compulsory HBM traffic per point (64 B point + 32 B scalar)
                "whole_msm": {"algorithmic_bytes_per_point": 96, "achieved_GBps": round(96 * n / (ms_per_step * 1e-3) / 1e9, 2),
@@ -433,9 +487,20 @@ def main():
         "roofline": main_res["roofline"], "stage_ms": main_res["stage_ms"], "result_x": main_res["result_x"],
         "whole_msm": main_res["whole_msm"],
     }
-    for k in ("operand_broadcast_ms", "operand_bytes"):
+    for k in ("operand_broadcast_ms", "operand_bytes", "per_rank_ms_per_step", "pipeline_depth"):
         if k in main_res:
             out[k] = main_res[k]
+    if world > 1:
+        out["rccl_ranks_seen"] = rccl_seen["ranks"] if rccl_seen else 0
+        out["rccl_distinct_devices"] = rccl_seen["distinct_devices"] if rccl_seen else 0
+        # the N = 1 figure of the SAME run: every rank runs the whole unsharded MSM on its own GPU (replicas, no exchange)
+        try:
+            solo = msm_leg(x_main, args.steps, args.warmup, solo=True)
+            out["n1_same_run"] = {"value": solo["value"], "ms_per_step": solo["ms_per_step"], "per_rank_ms_per_step": solo["per_rank_ms_per_step"],
+                                  "note": "x_logsize=%d unsharded on every GPU at once; value = one GPU's points/s (slowest rank)" % x_main}
+            out["per_gpu_efficiency"] = {"value_strong": round(out["value"] / (world * solo["value"]), 4)}
+        except Exception as e:
+            out["n1_same_run"] = {"error": repr(e)[:300]}
 
     # ---- second headline: sumcheck rounds/sec of the image-part prover (triangle + bintree GKR) at the same config
     if world == 1 and not args.no_sumcheck:
@@ -612,8 +677,24 @@ def main():
                                    x_log, d_log, nbits)}
             w.close()
             del w
+            # the unsharded prover on every GPU at once, same run: what one GPU does alone
+            plan_u = harness.MsmPlan(x_log, d_log, y_size)
+            plan_u.run(d_pts, d_sc)
+            wu = harness.PipWitness(plan_u, d_pts, y_log)
+            wu.prove_image_part(r_pt, r_evs, tape)
+            sync_all()
+            ru = wu.prove_image_part(r_pt, r_evs, tape)
+            u_dt = max_over_ranks(ru["call_s"])
+            same = ru["msgs"] == res["msgs"] and ru["evs"] == res["evs"]
+            out["sumcheck"]["unsharded_same_run"] = {"prove_ms": round(u_dt * 1e3, 2), "rounds_per_sec": round(ru["rounds"] / u_dt, 1),
+                                                     "sharded_messages_identical": bool(same)}
+            out.setdefault("per_gpu_efficiency", {})["sharded_prover"] = round(u_dt / p_dt / world, 4)
+            wu.close()
+            plan_u.close()
+            del wu, plan_u
+            assert same, "sharded prover messages differ from the unsharded ones"
         except Exception as e:  # keep the MSM line even if the sharded prover leg fails on this node
-            out["sumcheck"] = {"error": repr(e)[:300]}
+            out.setdefault("sumcheck", {})["error"] = repr(e)[:300]
 
     # ---- N > 1: the other named shapes in the same line (weak: fixed work per GPU; config D: x_logsize = 24)
     if world > 1 and not args.no_extra_shapes:
@@ -629,6 +710,12 @@ def main():
                 r_["steps"] = steps_x
                 r_["scaling"] = "weak" if key == "weak" else "BASELINE.json configs[3]"
                 r_["windows_per_gpu"] = wpr
+                if key == "weak" and "n1_same_run" in out and "value" in out["n1_same_run"]:
+                    out.setdefault("per_gpu_efficiency", {})["weak"] = round(r_["value"] / (world * out["n1_same_run"]["value"]), 4)
+                if key == "config_d":
+                    solo_d = msm_leg(xl, 3, 1, solo=True)
+                    r_["n1_same_run"] = {"value": solo_d["value"], "ms_per_step": solo_d["ms_per_step"]}
+                    out.setdefault("per_gpu_efficiency", {})["config_d"] = round(r_["value"] / (world * solo_d["value"]), 4)
                 out[key] = r_
             except Exception as e:
                 out[key] = {"error": repr(e)[:300]}
@@ -737,7 +824,7 @@ def main():
             plan_o.close()
         if not args.no_cpu_baseline:
             import oracle_ffi as O
-            threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+            threads = args.cpu_threads or usable_cpus()
             lg2 = min(args.cpu_g1_log_points, args.g1_log_points)
             n2 = 1 << lg2
             srs_h = harness.to_host(d_srs[: 12 * n2]).reshape(n2, 12)
@@ -850,17 +937,18 @@ def main():
         import oracle_ffi as O
         L.gm_release_cached_memory()
         torch.cuda.empty_cache()
-        threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+        threads = args.cpu_threads or usable_cpus()
+        msm_threads = min(threads, y_size)      # the MSM port is parallel over windows (pushforward.rs:401), as the reference
         hinfo = host_info()
         pts_h = harness.to_host(d_pts).reshape(n, 8)
         # MSM: the whole workload on the CPU (windows in parallel = the reference's own granularity, pushforward.rs:401 /
         # msm_nonaffine.rs:123: for this leg "reference-faithful" and "fair" coincide)
         xs = min(x_log, 20)
         t1 = time.perf_counter()
-        ref = O.msm(pts_h[: 1 << xs], sc[: 1 << xs], xs, d_log, y_size, threads=threads, want_aux=False)
+        ref = O.msm(pts_h[: 1 << xs], sc[: 1 << xs], xs, d_log, y_size, threads=msm_threads, want_aux=False)
         O.msm_combine(ref["window_cols"], d_log)
         cpu_dt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round((1 << xs) / cpu_dt, 1), "unit": "points/s", "cores": threads,
+        out["cpu_baseline"] = {"value": round((1 << xs) / cpu_dt, 1), "unit": "points/s", "cores": msm_threads,
                                "kind": "port", "variant": "fair = reference-faithful (parallel over the %d windows, as the reference)" % y_size,
                                "sample": "the whole workload: same inputs, 2^%d points x %d windows, %.2f s" % (xs, y_size, cpu_dt),
                                "host": hinfo}
@@ -918,7 +1006,9 @@ def main():
                 out["pippenger_plus_sumcheck_wall"] = {"cpu_s": round(cpu_wall, 2), "gpu_s": round(gpu_wall, 4),
                                                        "speedup": round(cpu_wall / gpu_wall, 1),
                                                        "what": "MSM + witness build + image-part prover at x_logsize=%d d_logsize=%d nbits=%d, "
-                                                               "C port with %d threads vs 1 MI355X" % (x_log, d_log, nbits, threads)}
+                                                               "C port with %d threads (MSM: %d, one per window) of %d usable vs 1 MI355X" % (
+                                                                   x_log, d_log, nbits, threads, msm_threads, hinfo["usable_cpus"]),
+                                                       "target_10x_met": bool(cpu_wall / gpu_wall >= 10.0)}
             if "gen1" in out and "error" not in out["gen1"]:
                 lp2, lb2 = min(args.cpu_gen1_log_points, args.gen1_log_points), 8
                 b8 = np.random.default_rng(12).integers(0, 2, size=(1 << (lp2 + lb2)), dtype=np.uint8)

@@ -17,8 +17,11 @@ OpenMP on the host cores):
   configs[1] sharded: the image-part prover of config B with its bucket rows split over 4 ranks (4 processes sharing the one GPU,
               gloo): every message equal to the unsharded proof, which the first test pins to the oracle
 
-The x = 20 prover check needs ~30 s of CPU and ~20 GiB of host memory for the oracle's witness trace; when the host has less
-than 40 GiB available the prover leg (only) drops to x_logsize = 18 and says so."""
+  configs[2]  gen-1 gkr_msm_prove at 2^20 points x 2^8 bits and the WHOLE gen-2 proof at x_logsize=20 (the oracle stops at 2^16:
+              checked through the library verifier, the final claims against the committed columns, the pairing, tampering)
+
+Nothing here shrinks silently: a host without the memory the oracle leg needs FAILS the test (the GPU boxes have terabytes), and
+every test records the size it ran (conftest.record_at_size -> the session summary and gpurun_out/at_size_runs.json)."""
 import ctypes as C
 import os
 import sys
@@ -39,12 +42,18 @@ def host_threads():
     return max(1, min(os.cpu_count() or 1, 32))
 
 
-def avail_gib():
-    try:
-        import psutil
-        return psutil.virtual_memory().available / 2 ** 30
-    except Exception:
-        return 0.0
+def require_host_gib(need, what):
+    """the named size or a failure -- never a smaller size"""
+    import psutil   # a missing psutil is a failure too (it used to read as 0 GiB and shrink every test)
+    have = psutil.virtual_memory().available / 2 ** 30
+    if have < need:
+        pytest.fail("%s needs %d GiB of host memory for the oracle leg, %.0f GiB available: not run at a smaller size" % (what, need, have))
+    return have
+
+
+def record(test, **fields):
+    from conftest import record_at_size
+    return record_at_size(test, **fields)
 
 
 def device_inputs(x_log, nbits, seed):
@@ -125,15 +134,13 @@ def check_image_part(plan, d_pts, pts_host, sc, x_log, d_log, nbits, seed):
 def test_config_b_msm_and_image_part_at_full_size():
     """BASELINE.json configs[1] (pippenger.rs:462-559 at x_logsize=20, d_logsize=8, nbits=256)"""
     x_log, d_log, nbits = 20, 8, 256
+    require_host_gib(40, "config B's prover leg (x_logsize 20)")
+    t0 = time.perf_counter()
     plan, d_pts, d_sc, pts_host, sc = check_msm(x_log, d_log, nbits, 0x474B524D534D)
-    if avail_gib() >= 40:
-        g = check_image_part(plan, d_pts, pts_host, sc, x_log, d_log, nbits, 7)
-        assert g["rounds"] == 1518
-    else:
-        print("[at-size] host has %.0f GiB available: the prover leg runs at x_logsize=18 instead of 20" % avail_gib())
-        plan.close()
-        plan, d_pts, d_sc, pts_host, sc = check_msm(18, d_log, nbits, 0x474B524D534D)
-        check_image_part(plan, d_pts, pts_host, sc, 18, d_log, nbits, 7)
+    g = check_image_part(plan, d_pts, pts_host, sc, x_log, d_log, nbits, 7)
+    assert g["rounds"] == 1518
+    record("config_b_msm_and_image_part", x_logsize=x_log, d_logsize=d_log, nbits=nbits, rounds=g["rounds"], messages=len(g["msgs"]),
+           seconds=round(time.perf_counter() - t0, 1), checked="every MSM stage + every prover message vs the C oracle")
     plan.close()
     ffi.lib().gm_release_cached_memory()
     torch.cuda.empty_cache()
@@ -148,6 +155,7 @@ def test_config_a_msm_image_part_and_whole_proof():
     from pyref import g1 as G
     from pyref import pairing as PR
     x_log, d_log, nbits = 16, 8, 128
+    t0 = time.perf_counter()
     plan, d_pts, d_sc, pts_host, sc = check_msm(x_log, d_log, nbits, 0xA11CE)
     g = check_image_part(plan, d_pts, pts_host, sc, x_log, d_log, nbits, 8)
     y_size = nbits // d_log
@@ -166,6 +174,9 @@ def test_config_a_msm_image_part_and_whole_proof():
     except VF.Rejected:
         pass
     print("[at-size] config A whole proof: %d bytes, verified (y_size %d)" % (len(proof), y_size))
+    record("config_a_msm_image_part_and_whole_proof", x_logsize=x_log, d_logsize=d_log, nbits=nbits, rounds=g["rounds"],
+           proof_bytes=len(proof), seconds=round(time.perf_counter() - t0, 1),
+           checked="MSM + image-part prover vs the C oracle; whole gen-2 proof through verifier + pairing")
     del s
     ffi.lib().gm_release_cached_memory()
     torch.cuda.empty_cache()
@@ -175,9 +186,8 @@ def test_gen1_at_the_reference_bench_size():
     """gkr_msm_prove at log_num_points = 16, 2^8 scalar bits: the top of the reference's bench grid
     (benches/gkr_msm_simple.rs:97-107), every transcript message vs the C oracle"""
     lp, lb = 16, 8
-    if avail_gib() < 24:
-        lp = 14
-        print("[at-size] host has %.0f GiB available: gen-1 runs at log_num_points=14" % avail_gib())
+    require_host_gib(24, "gen-1 at log_num_points 16")
+    t_begin = time.perf_counter()
     n = 1 << lp
     d_pts = H.dev_empty(n * 8)
     ffi.check(ffi.lib().gm_gen_points(C.c_void_p(d_pts.data_ptr()), n, 0x6E31, H.cur_stream()))
@@ -197,6 +207,8 @@ def test_gen1_at_the_reference_bench_size():
     assert codec.from_mont_limbs(c["point"]) == g["point"] and codec.from_mont_limbs(c["evs"]) == g["evs"]
     print("[at-size] gen-1 gkr_msm_prove 2^%d points x 2^%d bits: %d rounds, %d messages bit-exact vs the C oracle (%.1f s on the CPU)" % (
         lp, lb, g["rounds"], len(g["msgs"]), cpu_s))
+    record("gen1_at_the_reference_bench_size", log_num_points=lp, log_num_scalar_bits=lb, rounds=g["rounds"], messages=len(g["msgs"]),
+           seconds=round(time.perf_counter() - t_begin, 1), checked="every transcript message vs the C oracle")
     torch.cuda.empty_cache()
 
 
@@ -206,9 +218,8 @@ def test_config_d_one_ranks_share_of_the_window_sharded_msm():
     oracle computes the same four windows from the scalars shifted down to them (digit k of `s >> 8 y0` is digit y0 + k of s)."""
     from gkr_msm_amd import dist as gdist
     x_log, d_log, nbits, world = 24, 8, 256, 8
-    if avail_gib() < 24:
-        x_log = 22
-        print("[at-size] host has %.0f GiB available: config D share runs at x_logsize=22" % avail_gib())
+    require_host_gib(24, "config D's share (x_logsize 24)")
+    t_begin = time.perf_counter()
     y_size = nbits // d_log
     d_pts, d_sc, sc = device_inputs(x_log, nbits, 0xD0D0)
     pts_host = H.to_host(d_pts).reshape(-1, 8)
@@ -236,6 +247,8 @@ def test_config_d_one_ranks_share_of_the_window_sharded_msm():
         print("[at-size] config D share of rank %d (windows %d..%d, x_logsize %d): bucket sums + window points bit-exact (%.1f s on the CPU)" % (
             rank, y0, y1 - 1, x_log, cpu_s))
         plan.close()
+    record("config_d_one_ranks_share", x_logsize=x_log, d_logsize=d_log, nbits=nbits, ranks_checked=[0, 5], world=world,
+           seconds=round(time.perf_counter() - t_begin, 1), checked="bucket sums + window points of 4 windows vs the C oracle")
     del d_pts, d_sc
     ffi.lib().gm_release_cached_memory()
     torch.cuda.empty_cache()
@@ -299,8 +312,8 @@ def test_config_b_image_part_sharded_over_four_ranks():
     round) at config B's full size, world 4 on the one GPU"""
     import torch.multiprocessing as mp
     world, x_log, d_log, nbits = 4, 20, 8, 256
-    if avail_gib() < 64:
-        x_log = 17
+    require_host_gib(64, "config B sharded over 4 processes")
+    t_begin = time.perf_counter()
     ffi.lib().gm_release_cached_memory()
     torch.cuda.empty_cache()
     ctx = mp.get_context("spawn")
@@ -323,6 +336,8 @@ def test_config_b_image_part_sharded_over_four_ranks():
         assert ok, "rank %d: %s" % (rank, info)
     print("[at-size] config B image-part prover sharded over %d ranks (x_logsize %d): %d rounds, %s per rank, equal to the unsharded proof" % (
         world, x_log, res[0][3], res[0][2]))
+    record("config_b_image_part_sharded_over_four_ranks", x_logsize=x_log, world=world, rounds=res[0][3],
+           seconds=round(time.perf_counter() - t_begin, 1), checked="every message equal to the unsharded proof on every rank")
 
 
 def test_config_e_dry_run_of_one_ranks_share_of_the_sharded_prover():
@@ -333,8 +348,7 @@ def test_config_e_dry_run_of_one_ranks_share_of_the_sharded_prover():
     that its bucket sums are the window-sharded MSM's (pinned by the config D test above), and how long it takes."""
     from gkr_msm_amd import dist as gdist
     x_log, d_log, nbits, world, rank = 24, 8, 256, 8, 3
-    if avail_gib() < 24:
-        x_log = 20
+    require_host_gib(24, "config E's dry run (x_logsize 24)")
     y_size = nbits // d_log
     y_log = (y_size - 1).bit_length()
     d_pts, d_sc, sc = device_inputs(x_log, nbits, 0xE0E0)
@@ -379,10 +393,104 @@ def test_config_e_dry_run_of_one_ranks_share_of_the_sharded_prover():
     print("[at-size] config E dry run, rank %d of %d at x_logsize %d: witness %.0f ms, %d rounds in %.0f ms (%.0f rounds/s), %d exchanges, "
           "%.1f GiB of HBM in use" % (rank, world, x_log, t_wit * 1e3, g["rounds"], g["call_s"] * 1e3, g["rounds"] / g["call_s"],
                                       comm.calls, (total - free) / 2 ** 30))
+    record("config_e_dry_run_of_one_ranks_share", x_logsize=x_log, world=world, rank=rank, rounds=g["rounds"],
+           seconds=round(g["call_s"] + t_wit, 2), hbm_GiB=round((total - free) / 2 ** 30, 1), checked="fits and runs; bucket-sum rows = the MSM's")
     w.close()
     plan.close()
     del d_pts, d_sc
     ffi.lib().gm_release_cached_memory()
+    torch.cuda.empty_cache()
+
+
+def test_config_c_gen1_at_two_to_the_twenty_points():
+    """BASELINE.json configs[2], gen-1 (gkr_msm_simple.rs:86-338) at 2^20 points x 2^8 scalar bits -- 16 times past what the CPU
+    oracle finishes in a test.  Checked through size-independent properties: the library's verifier (BintreeVerifier /
+    SumcheckPolyMapVerifier / SplitVerifier, protocol/bintree.rs:313-395) accepts the prover's stream and ends on the prover's
+    claim; that claim is TRUE -- the three final evaluations equal the multilinear extensions of the base columns (bit, px, py;
+    gkr_msm_simple.rs:120,161-165) at the final point, computed here from the inputs (px / py with Python integers on the host, the
+    2^28-entry bit column by 28 folds of gm_dense_bind); the claimed output (256 x 3) is what the verifier started from; an altered
+    stream is rejected."""
+    from gkr_msm_amd import verifier as VF
+    lp, lb = 20, 8
+    t_begin = time.perf_counter()
+    n = 1 << lp
+    d_pts = H.dev_empty(n * 8)
+    ffi.check(ffi.lib().gm_gen_points(C.c_void_p(d_pts.data_ptr()), n, 0x6E32, H.cur_stream()))
+    rng = np.random.default_rng(31)
+    bits = torch.from_numpy(rng.integers(0, 2, size=(n << lb), dtype=np.uint8)).cuda()
+    tape = [int.from_bytes(rng.bytes(64), "little") % P for _ in range(6000)]
+    g = H.gkr_msm_prove(d_pts, bits, lp, lb, tape, msgs_cap=1 << 16)
+    ffi.lib().gm_release_cached_memory()
+    torch.cuda.empty_cache()
+    assert g["rounds"] > 1000 and len(g["point"]) == lp + lb
+    got = VF.gkr_msm_verify(lp, lb, g["msgs"], tape[: g["tape_used"]])
+    assert got["point"] == g["point"] and got["evs"] == g["evs"] and got["tape_used"] == g["tape_used"]
+    # the final claim against the inputs: index = point * 2^lb + bit, point[0] <-> the most significant index bit
+    r_pt, r_bit = g["point"][:lp], g["point"][lp:]
+    pts_host = codec.from_mont_limbs(H.to_host(d_pts).reshape(-1, 4))     # x0, y0, x1, y1, ...
+
+    def mle(vals, pt):
+        cur = list(vals)
+        for f in reversed(pt):
+            cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
+        return cur[0]
+    assert mle(pts_host[0::2], r_pt) == g["evs"][1], "px claim"
+    assert mle(pts_host[1::2], r_pt) == g["evs"][2], "py claim"
+    one = torch.from_numpy(codec.to_mont_limbs([1]).view(np.int64).reshape(1, 4)).cuda()
+    col = bits.to(torch.int64).reshape(-1, 1) * one                        # (2^28, 4): 0 or the Montgomery form of 1
+    cols = [col.reshape(-1)]
+    del col
+    for f in reversed(g["point"]):
+        cols = H.dense_bind(cols, f)
+    assert codec.from_mont_limbs(H.to_host(cols[0]).reshape(1, 4))[0] == g["evs"][0], "bit claim"
+    bad = list(g["msgs"])
+    bad[len(bad) // 2] = (bad[len(bad) // 2] + 1) % P
+    with pytest.raises(VF.Rejected):
+        VF.gkr_msm_verify(lp, lb, bad, tape[: g["tape_used"]])
+    record("config_c_gen1_2^20", log_num_points=lp, log_num_scalar_bits=lb, rounds=g["rounds"], messages=len(g["msgs"]),
+           prove_ms=round(g["call_s"] * 1e3, 1), seconds=round(time.perf_counter() - t_begin, 1),
+           checked="verifier accepts + final claims equal the MLEs of the inputs + tampered stream rejected")
+    del cols, bits, d_pts
+    ffi.lib().gm_release_cached_memory()
+    torch.cuda.empty_cache()
+
+
+def test_config_c_whole_gen2_proof_at_x_logsize_20():
+    """BASELINE.json configs[2], gen-2: PippengerWG::new + Pippenger::prove (pippenger.rs:37-70, 122-294) at x_logsize=20,
+    d_logsize=8, nbits=256 under the built-in merlin transcript (real Fiat-Shamir), then verify_pippenger (pippenger.rs:562-606):
+    the library verifier reads the proof bytes back, returns the prover's pairing pair, the pairing equation holds against the
+    SRS's tau and fails against another; altered proofs are refused by the verifier or by the pairing."""
+    from test_verifier_gpu import _prove_merlin, _setup
+    from gkr_msm_amd import verifier as VF
+    from pyref import g1 as G
+    from pyref import pairing as PR
+    x_log, d_log, nbits = 20, 8, 256
+    t_begin = time.perf_counter()
+    s = _setup(x_log, d_log, nbits, 0, 20, device_srs=True)
+    t0 = time.perf_counter()
+    proof, pair = _prove_merlin(s, b"config-c")
+    prove_s = time.perf_counter() - t0
+    got = VF.pippenger_verify_merlin(*s["shape"], s["claims"][0], s["claims"][1], G.GEN, 2, b"config-c", proof)
+    assert got == pair
+    h1 = PR.g2_mul(PR.G2_GEN, s["tau"])
+    assert VF.kzg_verify_pair(got, PR.G2_GEN, h1)
+    assert not VF.kzg_verify_pair(got, PR.G2_GEN, PR.g2_mul(PR.G2_GEN, s["tau"] + 1))
+    refused = 0
+    for pos in (7, len(proof) // 3, len(proof) // 2, len(proof) - 9):
+        bad = bytearray(proof)
+        bad[pos] ^= 4
+        try:
+            alt = VF.pippenger_verify_merlin(*s["shape"], s["claims"][0], s["claims"][1], G.GEN, 2, b"config-c", bytes(bad))
+            assert not VF.kzg_verify_pair(alt, PR.G2_GEN, h1)
+        except VF.Rejected:
+            refused += 1
+    assert refused >= 2
+    record("config_c_whole_gen2_proof", x_logsize=x_log, d_logsize=d_log, nbits=nbits, clm=0, proof_bytes=len(proof),
+           prove_ms=round(prove_s * 1e3, 1), seconds=round(time.perf_counter() - t_begin, 1),
+           checked="merlin proof bytes -> library verifier -> pairing accepts; wrong tau and altered bytes refused")
+    del s
+    ffi.lib().gm_release_cached_memory()
+    ffi.check(ffi.lib().gm_g1_release_scratch())
     torch.cuda.empty_cache()
 
 

@@ -14,7 +14,8 @@ from pyref import pippenger as PP
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("x_log,d_log,nbits,clm", [(3, 2, 8, 0), (3, 2, 8, 1), (4, 2, 6, 0), (4, 3, 12, 2)])
+@pytest.mark.parametrize("x_log,d_log,nbits,clm", [(3, 2, 8, 0), (3, 2, 8, 1), (4, 2, 6, 0), (4, 3, 12, 2),
+                                                  (3, 2, 40, 4)])   # clm = 4 (BASELINE.json configs[4]): 16 windows per commitment matrix, the last matrix partial
 def test_full_prover_matches_oracle_and_verifies(x_log, d_log, nbits, clm):
     y_size = (nbits + d_log - 1) // d_log
     y_log = (y_size - 1).bit_length()
@@ -34,7 +35,7 @@ def test_full_prover_matches_oracle_and_verifies(x_log, d_log, nbits, clm):
     out = GK.pippenger_dense_output(st["wg"], y_log, d_log)
     r = [rng.next_fr() for _ in range(y_log)]
     claims = GK.pippenger_claims(out, r)
-    tape = [rng.next_bits(512) for _ in range(4000)]
+    tape = [rng.next_bits(512) for _ in range(8000)]
     tr = PP.Transcript(tape)
     inv = KN.setup_inverses(k, nv)
     want_pair = PP.pippenger_prove(tr, st, claims, y_size, y_log, d_log, x_log, clm, basis, inv, k)

@@ -52,7 +52,7 @@ def _oracle_proof(x_log, d_log, nbits, clm, seed):
     out = GK.pippenger_dense_output(st["wg"], y_log, d_log)
     r = [rng.next_fr() for _ in range(y_log)]
     claims = GK.pippenger_claims(out, r)
-    tape = [rng.next_bits(512) for _ in range(4000)]
+    tape = [rng.next_bits(512) for _ in range(8000)]
     tr = PP.Transcript(tape)
     pair = PP.pippenger_prove(tr, st, claims, y_size, y_log, d_log, x_log, clm, basis, KN.setup_inverses(k, nv), k)
     dev_tape = [t % F.P if i in tr.wide else t & ((1 << 128) - 1) for i, t in enumerate(tape[: tr.pos])]
@@ -60,7 +60,7 @@ def _oracle_proof(x_log, d_log, nbits, clm, seed):
                 tape=dev_tape, raw_tape=tape, pair=pair, g0=basis[0], k=k, tau=tau)
 
 
-@pytest.fixture(scope="module", params=[(3, 2, 8, 0), (3, 2, 8, 1), (4, 3, 12, 2)])
+@pytest.fixture(scope="module", params=[(3, 2, 8, 0), (3, 2, 8, 1), (4, 3, 12, 2), (3, 2, 40, 4)])
 def proof(request):
     return _oracle_proof(*request.param, seed=123 + sum(request.param))
 
