@@ -971,41 +971,66 @@ __host__ __device__ constexpr bool lean9_terms_256(int prim) { return prim == FN
 // when the formula first needs it, in an order that keeps at most three inputs live: nine registers per value is what pushed the
 // six-input primitives to 256 VGPRs when all inputs were loaded up front.  Result: domain 251, L <= 5 2^29, S <= 30.
 // lds(q): the same input from shifted loads (domain 261, L 2^29 with a top limb below 2^29.9, S <= 128)
+// Both evaluation points of a pair side by side (a: the point "1" = p1, b: the point "2" = 2 p1 - p0): every operation of the layer
+// function is applied to both, the two products of a step as ONE interleaved instruction stream (fr9_mul2: the multiply-add that
+// consumes its predecessor's result costs a wait state, alternating two independent chains hides every one of them).  A pair is
+// then loaded ONCE per round kernel instead of once per evaluation point (profiles/r02: 317 MB of HBM traffic per launch for 155 MB
+// of pairs).  Limb / value bounds per operation are those of the scalar helpers, component-wise.
+struct Fr9x2 {
+    Fr9 a, b;
+    __device__ __forceinline__ Fr9x2() {}
+    __device__ __forceinline__ Fr9x2(const Fr9& x, const Fr9& y) : a(x), b(y) {}
+    __device__ __forceinline__ explicit Fr9x2(const Fr9& c) : a(c), b(c) {}
+};
+__device__ __forceinline__ Fr9x2 fr9_mul(const Fr9x2& x, const Fr9x2& y) { Fr9x2 r; fr9_mul2(x.a, y.a, x.b, y.b, r.a, r.b); return r; }
+__device__ __forceinline__ Fr9x2 fr9_mul(const Fr9& c, const Fr9x2& y) { Fr9x2 r; fr9_mul2(c, y.a, c, y.b, r.a, r.b); return r; }
+__device__ __forceinline__ Fr9x2 fr9_mul(const Fr9x2& x, const Fr9& c) { Fr9x2 r; fr9_mul2(x.a, c, x.b, c, r.a, r.b); return r; }
+__device__ __forceinline__ Fr9x2 fr9_sqr(const Fr9x2& x) { return Fr9x2(fr9_sqr(x.a), fr9_sqr(x.b)); }
+__device__ __forceinline__ Fr9x2 fr9_add(const Fr9x2& x, const Fr9x2& y) { return Fr9x2(fr9_add(x.a, y.a), fr9_add(x.b, y.b)); }
+__device__ __forceinline__ Fr9x2 fr9_add(const Fr9x2& x, const Fr9& c) { return Fr9x2(fr9_add(x.a, c), fr9_add(x.b, c)); }
+__device__ __forceinline__ Fr9x2 fr9_add(const Fr9& c, const Fr9x2& x) { return Fr9x2(fr9_add(c, x.a), fr9_add(c, x.b)); }
+__device__ __forceinline__ Fr9x2 fr9_mul5(const Fr9x2& x) { return Fr9x2(fr9_mul5(x.a), fr9_mul5(x.b)); }
+__device__ __forceinline__ Fr9x2 fr9_norm(const Fr9x2& x) { return Fr9x2(fr9_norm(x.a), fr9_norm(x.b)); }
+__device__ __forceinline__ Fr9x2 fr9_sub8(const Fr9x2& x, const Fr9x2& y) { return Fr9x2(fr9_sub8(x.a, y.a), fr9_sub8(x.b, y.b)); }
+__device__ __forceinline__ Fr9x2 fr9_sub8(const Fr9x2& x, const Fr9& c) { return Fr9x2(fr9_sub8(x.a, c), fr9_sub8(x.b, c)); }
+__device__ __forceinline__ Fr9x2 fr9_sub8(const Fr9& c, const Fr9x2& x) { return Fr9x2(fr9_sub8(c, x.a), fr9_sub8(c, x.b)); }
+
 template <int PRIM, typename LD, typename LDS>
-__device__ __forceinline__ Fr9 lean_gamma_eval9(const LD& ld, const LDS& lds, const Fr* __restrict__ g) {
+__device__ __forceinline__ auto lean_gamma_eval9(const LD& ld, const LDS& lds, const Fr* __restrict__ g) -> decltype(ld(0)) {
+    typedef decltype(ld(0)) V;   // Fr9: one evaluation point; Fr9x2: both points of the pair side by side (k_round_deg2_lean9x2)
     if (PRIM == FN_ADD_INVERSES) {
         // v0 + v1 + g1 v0 v1, every term in domain 256
-        const Fr9 v0 = ld(0);
-        const Fr9 t = fr9_mul(fr9_mul(fr9_load(g + 1), v0), lds(1));                     // S 5.5, then 5.5 x 128 / 70.66 + 1 = 11
+        const V v0 = ld(0);
+        const V t = fr9_mul(fr9_mul(fr9_load(g + 1), v0), lds(1));                     // S 5.5, then 5.5 x 128 / 70.66 + 1 = 11
         return fr9_add(fr9_add(v0, ld(1)), t);                                           // L 3 2^29, S 31
     } else if (PRIM == FN_AFF_L2) {
         // v0 + v1 + g1 v2 + g2 v0 v1, every term in domain 256
-        const Fr9 v0 = ld(0);
-        Fr9 A = fr9_mul(fr9_mul(fr9_load(g + 2), v0), lds(1));                           // S 11
+        const V v0 = ld(0);
+        V A = fr9_mul(fr9_mul(fr9_load(g + 2), v0), lds(1));                           // S 11
         A = fr9_add(A, fr9_mul(fr9_load(g + 1), ld(2)));                                 // S 5.5
         return fr9_add(fr9_add(A, v0), ld(1));                                           // L 4 2^29, S 36.5
     } else if (PRIM == FN_PT_BIT_CHOICE) {
         // b x + g1 (b (y - 1) + 1): the constant one joins in domain 251
-        const Fr9 b = ld(0);
-        const Fr9 by = fr9_add(fr9_mul(b, fr9_norm(fr9_sub8(ld(2), fr9_one256()))), fr9_one251());   // S 3.5 + 0.06, L 2^30
+        const V b = ld(0);
+        const V by = fr9_add(fr9_mul(b, fr9_norm(fr9_sub8(ld(2), fr9_one256()))), fr9_one251());   // S 3.5 + 0.06, L 2^30
         return fr9_add(fr9_mul(b, ld(1)), fr9_mul(fr9_load(g + 1), by));                 // L 2 2^29, S 5.5
     } else if (PRIM == FN_LOGUP_LAYER) {
         // a d + b c + g1 b d
-        const Fr9 v1 = ld(1), v3 = ld(3);
-        Fr9 A = fr9_mul(ld(0), v3);
+        const V v1 = ld(1), v3 = ld(3);
+        V A = fr9_mul(ld(0), v3);
         A = fr9_add(A, fr9_mul(v1, ld(2)));
         return fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v1, v3)));                    // L 3 2^29, S 7
     } else if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
         // v0 v3 + g1 v2 v1 + g2 (v1 v3 + 5 v0 v2) [+ g3 (v4^2 - v4) + g4 (v5^2 - v5)]
-        Fr9 A, t;
+        V A, t;
         {
-            const Fr9 v3 = ld(3), v2 = ld(2);
+            const V v3 = ld(3), v2 = ld(2);
             {
-                const Fr9 v0 = ld(0);
+                const V v0 = ld(0);
                 A = fr9_mul(v0, v3);                                                      // S 2.42
                 t = fr9_mul5(fr9_mul(v0, v2));                                            // - a = 5: L 5 2^29, S 12.1
             }
-            const Fr9 v1 = ld(1);
+            const V v1 = ld(1);
             t = fr9_add(t, fr9_mul(v1, v3));                                              // L 6 2^29, S 14.5
             A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v2, v1)));                    // g: S 32; product S 2.1
         }
@@ -1014,40 +1039,40 @@ __device__ __forceinline__ Fr9 lean_gamma_eval9(const LD& ld, const LDS& lds, co
             // b^2 - b = b (b - 1): (b - 1 + 8 p) normalised has S 18, the product S 3.5, times gamma S 2.6
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const Fr9 b = ld(4 + k);
+                const V b = ld(4 + k);
                 A = fr9_add(A, fr9_mul(fr9_load(g + 3 + k), fr9_mul(b, fr9_norm(fr9_sub8(b, fr9_one256())))));
             }
         }
         return A;
     } else if (PRIM == FN_AFF_L3 || PRIM == FN_PROJ_L3) {
-        const Fr9 dxy = fr9_mul(ld(PRIM == FN_AFF_L3 ? 2 : 3), fr9_coeff_d());           // d in domain 261: dxy in 256, S 1.14
-        const Fr9 base = PRIM == FN_AFF_L3 ? fr9_one256() : ld(2);
-        const Fr9 m = fr9_norm(fr9_sub8(base, dxy));                                      // S 18
-        const Fr9 q = fr9_add(base, dxy);                                                 // L 2^30, S 11.2
-        Fr9 A = fr9_mul(m, ld(0));                                                        // S 3.5
+        const V dxy = fr9_mul(ld(PRIM == FN_AFF_L3 ? 2 : 3), fr9_coeff_d());           // d in domain 261: dxy in 256, S 1.14
+        const V base = PRIM == FN_AFF_L3 ? V(fr9_one256()) : ld(2);
+        const V m = fr9_norm(fr9_sub8(base, dxy));                                      // S 18
+        const V q = fr9_add(base, dxy);                                                 // L 2^30, S 11.2
+        V A = fr9_mul(m, ld(0));                                                        // S 3.5
         A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(q, ld(1))));                      // 2^30 x 2^29; S 2.6 -> 2.2
         return fr9_add(A, fr9_mul(fr9_load(g + 2), fr9_mul(m, q)));                       // S 3.9 -> 2.8
     } else if (PRIM == FN_PROJ_L1) {
         // v0 v4 + g1 v3 v1 + g2 (v1 v4 + 5 v0 v3) + g3 v2 v5
-        Fr9 A, t;
+        V A, t;
         {
-            const Fr9 v3 = ld(3), v4 = ld(4);
+            const V v3 = ld(3), v4 = ld(4);
             {
-                const Fr9 v0 = ld(0);
+                const V v0 = ld(0);
                 A = fr9_mul(v0, v4);
                 t = fr9_mul5(fr9_mul(v0, v3));
             }
-            const Fr9 v1 = ld(1);
+            const V v1 = ld(1);
             t = fr9_add(t, fr9_mul(v1, v4));                                              // L 6 2^29, S 14.5
             A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v3, v1)));
         }
         A = fr9_add(A, fr9_mul(fr9_load(g + 2), t));
         return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(ld(2), ld(5))));               // L 4 2^29, S 14.2
     } else {  // FN_PROJ_L2: (v0 + v1) v3 + g1 v2 v3 + g2 v3^2 + g3 v0 v1
-        Fr9 A;
-        const Fr9 v0 = ld(0), v1 = ld(1);
+        V A;
+        const V v0 = ld(0), v1 = ld(1);
         {
-            const Fr9 v3 = ld(3);
+            const V v3 = ld(3);
             A = fr9_mul(fr9_add(v0, v1), v3);                                             // 2^30 x 2^29; S 3.8
             A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(ld(2), v3)));
             A = fr9_add(A, fr9_mul(fr9_load(g + 2), fr9_sqr(v3)));
@@ -1106,6 +1131,51 @@ __global__ void __launch_bounds__(SC_THREADS, 3) k_round_deg2_lean9(LeanCols col
     const Fr9 K = lean9_terms_256(PRIM) ? (VECVEC ? fr9_two271() : fr9_two266()) : (VECVEC ? fr9_two276() : fr9_two271());
     acc[0] = fr9_to_raw(fr9_mul(a0, K));
     acc[1] = fr9_to_raw(fr9_mul(a1, K));
+    block_reduce_finish<NACC>(acc, fc);
+}
+
+// The same round sums with every pair loaded ONCE: both evaluation points go through the layer function side by side (Fr9x2).
+// Twice the live values of k_round_deg2_lean9 (two waves per SIMD instead of three), in exchange for half the loads and two
+// interleaved multiplier chains.  Same field values, bit for bit.  GM_LEAN_X2=0 goes back to the one-point-at-a-time kernel.
+template <int PRIM, bool VECVEC>
+__global__ void __launch_bounds__(SC_THREADS, 2) k_round_deg2_lean9x2(LeanCols cols, const Fr* __restrict__ eq, const Fr* __restrict__ gp,
+                                                                    uint64_t npairs_dense, VVArgs vv, FinishCtx fc) {
+    constexpr int NACC = VECVEC ? 3 : 2;
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    if (VECVEC) {
+        for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
+            const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+        }
+    }
+    Fr9x2 a = Fr9x2(fr9_zero());   // domain 241 (VecVec) / 246 (dense); normalised, S grows by <= 1.5 per pair
+    uint32_t it = 0;
+    const uint64_t npairs = VECVEC ? (uint64_t)(vv.off[vv.nrows] >> 1) : npairs_dense;
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS, it++) {
+        Fr9 w;
+        if (VECVEC) {
+            const uint32_t cell0 = (uint32_t)(2 * i);
+            const uint32_t r = vv.coarse ? find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0) : find_row(vv.off, vv.nrows, cell0);
+            w = fr9_mul(fr9_load_raw(eq + ((cell0 - vv.off[r]) >> 1)), fr9_load_raw(vv.row_coef + r));   // domain 251, S 1.02
+        } else {
+            w = fr9_load_raw(eq + i);                                                                      // domain 256, S 1
+        }
+        auto ld = [&](int q) -> Fr9x2 {
+            const Fr9 p0 = fr9_load_raw(cols.p[q] + 2 * i), p1 = fr9_load_raw(cols.p[q] + 2 * i + 1);
+            return Fr9x2(p1, fr9_norm(fr9_sub8(fr9_add(p1, p1), p0)));      // p1 | 2 p1 - p0 + 8 p: S 10
+        };
+        auto lds = [&](int q) -> Fr9x2 {
+            const Fr9 p0 = fr9_load(cols.p[q] + 2 * i), p1 = fr9_load(cols.p[q] + 2 * i + 1);   // the limbs of 32 X: domain 261, S 32
+            return Fr9x2(p1, fr9_norm(fr9_sub64(fr9_add(p1, p1), p0)));    // 2 p1 - p0 + 64 p: S 128, top limb < 2^29.9
+        };
+        const Fr9x2 t = fr9_mul(lean_gamma_eval9<PRIM>(ld, lds, gp), w);   // L <= 5 2^29 x 2^29; S <= 37 x 1.02 / 70.66 + 1 = 1.6
+        a = fr9_norm(fr9_add(a, t));
+        if ((it & 15u) == 15u) a = fr9_mul(a, fr9_one());   // S <= 16 x 3 + 2: back below 2 (times one in domain 261 keeps the domain)
+    }
+    const Fr9 K = lean9_terms_256(PRIM) ? (VECVEC ? fr9_two271() : fr9_two266()) : (VECVEC ? fr9_two276() : fr9_two271());
+    a = fr9_mul(a, K);
+    acc[0] = fr9_to_raw(a.a);
+    acc[1] = fr9_to_raw(a.b);
     block_reduce_finish<NACC>(acc, fc);
 }
 
@@ -1887,6 +1957,19 @@ static int32_t launch_deg2_lean(int prim, dim3 grid, hipStream_t s, const LeanCo
 #define GM_LEAN_CASE(P)                                                                                                  \
     case P: hipLaunchKernelGGL((k_round_deg2_lean<P, VECVEC>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, npairs, va, fc); break;
     static const bool use9 = [] { const char* e = getenv("GM_LEAN_FR9"); return !(e && e[0] == '0'); }();
+    static const bool usex2 = [] { const char* e = getenv("GM_LEAN_X2"); return !(e && e[0] == '0'); }();
+    if (use9 && usex2 && lean9_has(prim)) {
+#define GM_LEAN9X2_CASE(P)                                                                                               \
+    case P: hipLaunchKernelGGL((k_round_deg2_lean9x2<P, VECVEC>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, npairs, va, fc); break;
+        switch (prim) {
+            GM_LEAN9X2_CASE(FN_AFF_L1) GM_LEAN9X2_CASE(FN_AFF_L3) GM_LEAN9X2_CASE(FN_PROJ_L1) GM_LEAN9X2_CASE(FN_PROJ_L2)
+            GM_LEAN9X2_CASE(FN_PROJ_L3) GM_LEAN9X2_CASE(LEAN_AFF_L1_BC) GM_LEAN9X2_CASE(FN_AFF_L2) GM_LEAN9X2_CASE(FN_PT_BIT_CHOICE)
+            GM_LEAN9X2_CASE(FN_ADD_INVERSES) GM_LEAN9X2_CASE(FN_LOGUP_LAYER)
+        }
+#undef GM_LEAN9X2_CASE
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
     if (use9 && lean9_has(prim)) {
 #define GM_LEAN9_CASE(P)                                                                                                 \
     case P: hipLaunchKernelGGL((k_round_deg2_lean9<P, VECVEC>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, npairs, va, fc); break;

@@ -13,7 +13,8 @@ from pyref.sumcheck import TapeTranscript
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("x_log,d_log,nbits", [(3, 2, 8), (4, 2, 6), (3, 3, 15), (5, 2, 4), (6, 3, 24), (5, 4, 16)])
+@pytest.mark.parametrize("x_log,d_log,nbits", [(3, 2, 8), (4, 2, 6), (3, 3, 15), (5, 2, 4), (6, 3, 24), (5, 4, 16),
+                                              (10, 8, 40)])   # pushforward_works (pushforward.rs:1050-1189): x_logsize 10, y_size 5, d_logsize 8
 def test_pushforward_matches_oracle(x_log, d_log, nbits):
     y_size = (nbits + d_log - 1) // d_log
     y_log = (y_size - 1).bit_length()
