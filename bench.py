@@ -119,11 +119,13 @@ SEED = 0x474B524D534D      # "GKRMSM"
 # HBM traffic per launch of the dominant kernels at config B from the committed PMC passes (profiles/r02/*_pmc_hbm.csv:
 # (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction); None for any other shape
 PMC_TRAFFIC_MSM_B = None
+PMC_TRAFFIC_GE1_B = None   # bytes per step of all k_add_level + k_add_tail launches together
 PMC_TRAFFIC_SC_B = {}      # kernel name -> bytes per launch (profiles/r02/prover_pmc_per_launch.json, written by scripts/summarise_profiles.py)
 try:
     with open(os.path.join(ROOT, "profiles", "r02", "prover_pmc_per_launch.json")) as _f:
         PMC_TRAFFIC_SC_B = json.load(_f)
     PMC_TRAFFIC_MSM_B = PMC_TRAFFIC_SC_B.get("k_add_level0")
+    PMC_TRAFFIC_GE1_B = PMC_TRAFFIC_SC_B.get("k_add_levels_ge1_per_step")
 except Exception:
     pass
 
@@ -451,7 +453,31 @@ def main():
                                             "frac": round(alg_bytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                             "fr_mul_per_s": round(fr_mul0 / (alone * 1e-3), 1),
                                             "valu_frac_of_measured_ceiling": round(fr_mul0 / (alone * 1e-3) / FR9_MUL_CEILING, 3)}
-        res = {"x_logsize": x_log, "value": round(n * steps / dt, 1), "ms_per_step": round(ms_per_step, 4),
+        # the level kernels above level 0 (k_add_level on the flat levels, k_add_tail on the late ones), summed over their launches of
+        # one step: by time they are the largest stage.  Algorithmic bytes per addition as SURVEY 8(d): two projective points read
+        # (2 x 96 B), one written (96 B); 12 field multiplications.  Exact pair counts from the row layouts of the run.
+        roofline_ge1 = None
+        try:
+            cells = (C.c_uint64 * (x_log + 1))()
+            ffi.check(L.gm_msm_level_cells(plan.h, cells, x_log + 1, harness.cur_stream()))
+            adds = [int(cells[l]) // 2 for l in range(1, x_log)]
+            t_ge1 = stages["add_levels_ge1"]
+            if t_ge1 > 0 and adds:
+                tot_adds = sum(adds)
+                b_ge1 = tot_adds * 288
+                m_ge1 = tot_adds * 12
+                ach1 = b_ge1 / (t_ge1 * 1e-3) / 1e9
+                roofline_ge1 = {"bound": "hbm", "kernel": "k_add_level (levels 1..%d) + k_add_tail (the late levels)" % (x_log - 1),
+                                "achieved": round(ach1, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach1 / HBM_PEAK_GBS, 4),
+                                "traffic": PMC_TRAFFIC_GE1_B if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None,
+                                "ms_per_step": round(t_ge1, 4), "additions_per_step": tot_adds, "algorithmic_bytes_per_step": b_ge1,
+                                "fr_mul_per_step": m_ge1, "fr_mul_per_s": round(m_ge1 / (t_ge1 * 1e-3), 1),
+                                "valu_frac_of_measured_ceiling": round(m_ge1 / (t_ge1 * 1e-3) / FR9_MUL_CEILING, 3),
+                                "largest_levels_additions": adds[:4],
+                                "note": "unoverlapped (the untimed stage-breakdown pass); launches: levels 1..L0-1 flat, one k_add_tail for the rest"}
+        except Exception as e:
+            roofline_ge1 = {"error": repr(e)[:200]}
+        res = {"x_logsize": x_log, "value": round(n * steps / dt, 1), "ms_per_step": round(ms_per_step, 4), "roofline_levels_ge1": roofline_ge1,
                "per_rank_ms_per_step": per_rank_ms, "pipeline_depth": depth, "roofline": roofline,
                "stage_ms": stages, "result_x": hex(result[0]),
                # SURVEY 8(d)'s whole-MSM unit: 96 B of compulsory HBM traffic per point (64 B point + 32 B scalar)
@@ -484,7 +510,8 @@ def main():
         "config": {"workload": "pippenger_msm x_logsize=%d d_logsize=%d nbits=%d (bandersnatch, %d windows)" % (
             x_log, d_log, nbits, y_size), "x_logsize": x_log, "d_logsize": d_log, "nbits": nbits,
             "windows_per_gpu": wpr, "sharding": "windows" if world > 1 else "none", "transport": transport},
-        "roofline": main_res["roofline"], "stage_ms": main_res["stage_ms"], "result_x": main_res["result_x"],
+        "roofline": main_res["roofline"], "roofline_levels_ge1": main_res["roofline_levels_ge1"], "stage_ms": main_res["stage_ms"],
+        "result_x": main_res["result_x"],
         "whole_msm": main_res["whole_msm"],
     }
     for k in ("operand_broadcast_ms", "operand_bytes", "per_rank_ms_per_step", "pipeline_depth"):

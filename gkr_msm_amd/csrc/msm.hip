@@ -33,6 +33,7 @@ static constexpr int CHUNK = 1024;  // x-range handled by one wave in the scatte
 struct Point3 {
     Fr x, y, z;
 };
+typedef uint32_t gm_u4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ Point3 pt_identity() {
     Point3 p;
@@ -573,6 +574,229 @@ __global__ void k_add_last(const Fr* __restrict__ points_xy, const uint32_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// The late levels in ONE launch (levels L0 .. x_logsize - 1), thread = bucket row.
+//
+// With uniformly distributed digits a row holds ~2^(x - d) points, so at level L0 = x - d - 2 it is down to ~4 cells; the flat
+// kernels then run 10+ more launches of a few thousand additions each, 12-14 us per launch of pure latency.  Here a thread takes
+// its whole row through the remaining levels in registers:
+//   * the pairwise tree over its (at most 16) cells, exactly the association of the flat levels (cells 2i, 2i + 1 of every level;
+//     a missing right operand is the level's pad cell = the identity (0, 1, 1), pushforward.rs:380-381 / vecvec.rs:579-594);
+//   * then one "add the identity" per remaining level.  The projective formulas with (0, 1, 1) as the second operand collapse to
+//         (x, y, z) + (0, 1, 1) = (x z^3, y z^3, z^4)
+//     (A = 0, B = y, zz = z, s = x, t = y, X = x z, Y = y z, dxy = 0, m = q = z^2 in twisted_edwards_ops.rs:36-65): the SAME field
+//     elements as the 12-multiplication evaluation, with 2 squarings and 3 products.
+// Rows longer than 16 cells at L0 (skewed digits: e.g. the top window of 252-bit scalars has 16 buckets for all 2^20 points) go to
+// dedicated waves of the same launch: 64 lanes on one row, the tree in registers with the sums moving through the cross-lane
+// network (rows of more than 128 cells first run whole levels through the level buffers, like the flat kernels).
+// Measured at config B: 96 us for what took the flat launches ~130 us (a lone wave needs ~0.8 us per dependent multiplication
+// here); on one rank's share of an 8-way sharded run, whose step is a chain of small launches, 0.716 -> 0.671 ms per step.
+__device__ __forceinline__ Point9 add_identity9(const Point9& p) {
+    // inputs: an addition's outputs or loaded cells (L 2^29, S <= 32)
+    const Fr9 z2 = fr9_sqr(p.z);                       // S 15.5
+    const Fr9 z3 = fr9_mul(z2, p.z);                   // S 8
+    Point9 r;
+    r.x = fr9_mul(p.x, z3);                            // S 4.7
+    r.y = fr9_mul(p.y, z3);
+    r.z = fr9_sqr(z2);                                 // S 4.4
+    return r;
+}
+// 16 + 16 + 4 bytes with the device-coherent bit (another lane of this wave wrote / will read them through memory)
+__device__ __forceinline__ Fr9 fr9_load_raw9_coh(const uint32_t* __restrict__ col, uint64_t i) {
+    const uint32_t* p = col + 9 * i;
+    gm_u4_t q0, q1;
+    uint32_t w;
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\tglobal_load_dword %2, %3, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(w) : "v"(p) : "memory");
+    Fr9 r;
+    r.l[0] = q0.x; r.l[1] = q0.y; r.l[2] = q0.z; r.l[3] = q0.w; r.l[4] = q1.x; r.l[5] = q1.y; r.l[6] = q1.z; r.l[7] = q1.w; r.l[8] = w;
+    return r;
+}
+__device__ __forceinline__ void fr9_store_raw9_coh(uint32_t* __restrict__ col, uint64_t i, const Fr9& v) {
+    uint32_t* p = col + 9 * i;
+    const gm_u4_t q0 = {v.l[0], v.l[1], v.l[2], v.l[3]}, q1 = {v.l[4], v.l[5], v.l[6], v.l[7]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\tglobal_store_dword %0, %3, off offset:32 sc1"
+                 :: "v"(p), "v"(q0), "v"(q1), "v"(v.l[8]) : "memory");
+}
+__device__ __forceinline__ Point9 pt9_load_raw9_coh(const uint32_t* x, const uint32_t* y, const uint32_t* z, uint64_t i) {
+    Point9 p;
+    p.x = fr9_load_raw9_coh(x, i); p.y = fr9_load_raw9_coh(y, i); p.z = fr9_load_raw9_coh(z, i);   // rare path (rows > 128 cells): kept simple
+    return p;
+}
+struct LvlBufs {
+    uint32_t* c[2][3];   // the two level buffers (x, y, z columns of 9-word cells)
+};
+
+// lane q of the wave takes the Point9 of lane `from` (27 dwords through the cross-lane network)
+__device__ __forceinline__ Point9 pt9_shfl(const Point9& v, int from) {
+    Point9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.x.l[i] = __shfl(v.x.l[i], from, 64);
+        r.y.l[i] = __shfl(v.y.l[i], from, 64);
+        r.z.l[i] = __shfl(v.z.l[i], from, 64);
+    }
+    return r;
+}
+
+#define GM_TAIL_FAT_WAVES 64
+// grid: ceil(nrows / 64) "thin" blocks (thread = row; rows of at most 16 cells), then GM_TAIL_FAT_WAVES blocks that look for the
+// longer rows (row % GM_TAIL_FAT_WAVES == its index) and take each of them with all 64 lanes.
+// Code size matters here: an addition is ~2 700 instructions (22 KB) and a lone wave that runs straight-line code fetches every
+// line of it from L2 (the first version, 13 inlined additions, took 620 us for 50 us of arithmetic).  Both paths are therefore
+// LOOPS around ONE proj_add9 and ONE add_identity9 site; which operands a step takes is decided by moves around them.
+__global__ void __launch_bounds__(64) k_add_tail(LvlBufs lb, const uint32_t* __restrict__ off_all, uint32_t nrows, uint32_t L0,
+                                                 uint32_t x_log, uint32_t n_thin_blocks, Fr* __restrict__ ox, Fr* __restrict__ oy,
+                                                 Fr* __restrict__ oz) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t stride = nrows + 1;
+    const uint32_t* off0 = off_all + (uint64_t)L0 * stride;
+    const int src = (int)((L0 - 1) & 1u);                           // level l reads buffer (l - 1) & 1 and writes l & 1
+    const uint32_t nlev = x_log - L0;                               // >= 4 (host)
+    if (blockIdx.x < n_thin_blocks) {
+        const uint32_t r = lane * n_thin_blocks + blockIdx.x;
+        if (r >= nrows) return;
+        const uint32_t in0 = off0[r];
+        const uint32_t c = off0[r + 1] - in0;                       // even: the rows are padded (k_add_level writes the pad cells)
+        if (c > 16) return;                                         // a long row: one of the fat waves has it
+        const uint32_t* ix = lb.c[src][0];
+        const uint32_t* iy = lb.c[src][1];
+        const uint32_t* iz = lb.c[src][2];
+        // The 16-leaf tree over the row's cells as 15 steps through one addition site (a missing operand = the level's pad cell, the
+        // identity; steps without a left operand cost nothing), then one add-the-identity step per remaining level.  A binary
+        // counter with one pending sum per tree level (U, V, W):
+        //   step   0      1      2        3      4      5      6         7      8      9        10     11     12     13     14
+        //   T =   c0+c1  c2+c3  U+T      c4+c5  c6+c7  U+T    V+T       c8+c9  c10+11 U+T      c12+13 c14+15 U+T    V+T    W+T
+        //   keep  U             V        U                    W         U             V        U
+        Point9 T = pt9_identity(), U = T, V = T, W = T;
+        bool hasT = false, hasU = false, hasV = false, hasW = false;
+#pragma unroll 1
+        for (uint32_t st = 0; st < nlev + 11; st++) {
+            Point9 A = T, B = T;
+            bool pa = hasT, pb = false;
+            const bool leaf_step = st == 0 || st == 1 || st == 3 || st == 4 || st == 7 || st == 8 || st == 10 || st == 11;
+            if (leaf_step) {
+                const uint32_t leaf = st == 0 ? 0u : st == 1 ? 2u : st == 3 ? 4u : st == 4 ? 6u : st == 7 ? 8u : st == 8 ? 10u : st == 10 ? 12u : 14u;
+                pa = pb = leaf < c;
+                if (pa) {
+                    A = pt9_load_raw9(ix, iy, iz, (uint64_t)in0 + leaf);
+                    B = pt9_load_raw9(ix, iy, iz, (uint64_t)in0 + leaf + 1);
+                }
+            } else if (st == 2 || st == 5 || st == 9 || st == 12) {
+                A = U; pa = hasU; pb = hasT;
+            } else if (st == 6 || st == 13) {
+                A = V; pa = hasV; pb = hasT;
+            } else if (st == 14) {
+                A = W; pa = hasW; pb = hasT;
+            }
+            Point9 S = pt9_identity();
+            if (__any(pa && pb)) {
+                const Point9 F = proj_add9(A, B);
+                if (pa && pb) S = F;
+            }
+            if (__any(pa && !pb)) {
+                const Point9 I = add_identity9(A);
+                if (pa && !pb) S = I;
+            }
+            T = S;
+            hasT = pa;
+            if (st == 0 || st == 3 || st == 7 || st == 10) { U = T; hasU = hasT; }
+            if (st == 2 || st == 9) { V = T; hasV = hasT; }
+            if (st == 6) { W = T; hasW = hasT; }
+        }
+        // c == 0: an empty row stays the pad, (0, 1, 1) at every level
+        fr_store(ox + r, fr9_to(T.x));
+        fr_store(oy + r, fr9_to(T.y));
+        fr_store(oz + r, fr9_to(T.z));
+        return;
+    }
+    // ---- a fat wave: rows w, w + F, w + 2 F, ... ; every long one among them with all 64 lanes
+    const uint32_t w = blockIdx.x - n_thin_blocks;
+    for (uint32_t base = w; base < nrows; base += 64u * GM_TAIL_FAT_WAVES) {
+        const uint32_t rr = base + lane * GM_TAIL_FAT_WAVES;
+        const uint32_t cc = rr < nrows ? off0[rr + 1] - off0[rr] : 0u;
+        uint64_t fat = __ballot(cc > 16);
+        while (fat) {
+            const int fl = __ffsll((unsigned long long)fat) - 1;
+            fat &= fat - 1;
+            const uint32_t rf = __shfl(rr, fl, 64);
+            int cur = src;
+            uint32_t lvl = L0;
+            uint32_t n_in = __shfl(cc, fl, 64);
+            // (i) rows of more than 128 cells: whole levels through the level buffers, like the flat kernels
+            for (; n_in > 128; lvl++) {
+                const uint32_t* offi = off_all + (uint64_t)lvl * stride;
+                const uint32_t* offo = offi + stride;
+                const uint32_t i0 = offi[rf], o0 = offo[rf], n_out = offo[rf + 1] - o0;
+                const bool first = lvl == L0;
+                for (uint32_t p = lane; p < n_out; p += 64) {
+                    Point9 v;
+                    if (p < (n_in >> 1)) {
+                        const uint64_t a = (uint64_t)i0 + 2 * p;
+                        const Point9 A = first ? pt9_load_raw9(lb.c[cur][0], lb.c[cur][1], lb.c[cur][2], a)
+                                               : pt9_load_raw9_coh(lb.c[cur][0], lb.c[cur][1], lb.c[cur][2], a);
+                        const Point9 B = first ? pt9_load_raw9(lb.c[cur][0], lb.c[cur][1], lb.c[cur][2], a + 1)
+                                               : pt9_load_raw9_coh(lb.c[cur][0], lb.c[cur][1], lb.c[cur][2], a + 1);
+                        v = proj_add9(A, B);
+                    } else {
+                        v = pt9_identity();
+                    }
+                    fr9_store_raw9_coh(lb.c[cur ^ 1][0], (uint64_t)o0 + p, v.x);
+                    fr9_store_raw9_coh(lb.c[cur ^ 1][1], (uint64_t)o0 + p, v.y);
+                    fr9_store_raw9_coh(lb.c[cur ^ 1][2], (uint64_t)o0 + p, v.z);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left before its lanes read them back
+                __builtin_amdgcn_wave_barrier();
+                n_in = n_out;
+                cur ^= 1;
+            }
+            // (ii) at most 64 pairs: one per lane from memory, then the tree above them in registers (lane q takes the sums of lanes
+            // 2 q and 2 q + 1 through the cross-lane network; a missing right neighbour is the level's pad cell, the identity), then
+            // the identity once per remaining level -- all through one addition site
+            uint32_t n = n_in;                      // operands of the coming step: cells in memory (first step), sums in lanes after
+            Point9 v = pt9_identity();
+            bool from_mem = true;
+            const uint32_t i0 = off_all[(uint64_t)lvl * stride + rf];
+            const bool first = lvl == L0;
+#pragma unroll 1
+            for (; lvl < x_log; lvl++) {
+                Point9 A, B;
+                if (from_mem) {
+                    A = B = pt9_identity();
+                    if (2 * lane + 1 < n) {
+                        const uint64_t a = (uint64_t)i0 + 2 * lane;
+                        A = first ? pt9_load_raw9(lb.c[cur][0], lb.c[cur][1], lb.c[cur][2], a) : pt9_load_raw9_coh(lb.c[cur][0], lb.c[cur][1], lb.c[cur][2], a);
+                        B = first ? pt9_load_raw9(lb.c[cur][0], lb.c[cur][1], lb.c[cur][2], a + 1)
+                                  : pt9_load_raw9_coh(lb.c[cur][0], lb.c[cur][1], lb.c[cur][2], a + 1);
+                    }
+                } else {
+                    A = pt9_shfl(v, (int)((2 * lane) & 63));
+                    B = pt9_shfl(v, (int)((2 * lane + 1) & 63));
+                }
+                const uint32_t m = (n + 1) >> 1;                     // sums after this step
+                const bool pa = lane < m, pb = 2 * lane + 1 < n;
+                Point9 S = pt9_identity();
+                if (__any(pa && pb)) {
+                    const Point9 F = proj_add9(A, B);
+                    if (pa && pb) S = F;
+                }
+                if (__any(pa && !pb)) {
+                    const Point9 I = add_identity9(A);
+                    if (pa && !pb) S = I;
+                }
+                v = S;
+                n = m;
+                from_mem = false;
+            }
+            if (lane == 0) {
+                fr_store(ox + rf, fr9_to(v.x));
+                fr_store(oy + rf, fr9_to(v.y));
+                fr_store(oz + rf, fr9_to(v.z));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Bucket reduction, one workgroup per window.  Restates pippenger_ending.rs:46-58 (two splits at the
 // top two digit bits) + triangle_add.rs:101-158 (layers 0..d-2) + `last_step` (triangle_add.rs:88-99).
 // Window w owns nd = 2^d bucket sums; all intermediate points live in LDS.
@@ -757,6 +981,17 @@ extern "C" int32_t gm_msm_profile_read(gm_msm_plan* p, float* h_ms, int32_t n) {
 
 extern "C" size_t gm_msm_plan_workspace_bytes(const gm_msm_plan* p) { return p ? p->bytes : 0; }
 
+extern "C" int32_t gm_msm_level_cells(const gm_msm_plan* p, uint64_t* h_cells, uint32_t n, void* stream) {
+    GM_REQUIRE(p && h_cells && n >= p->x_log + 1, "need x_logsize + 1 counts");
+    std::vector<uint32_t> v(p->x_log + 1, 0u);
+    // table l of off[0] is the layout level l reads; its last entry is the layout's cell count (levels 0 .. x_log - 1 exist)
+    for (uint32_t l = 0; l < p->x_log; l++)
+        GM_HIP(hipMemcpyAsync(&v[l], p->off[0] + (uint64_t)l * (p->nrows + 1) + p->nrows, 4, hipMemcpyDeviceToHost, as_stream(stream)));
+    GM_HIP(hipStreamSynchronize(as_stream(stream)));
+    for (uint32_t l = 0; l <= p->x_log; l++) h_cells[l] = v[l];
+    return GM_OK;
+}
+
 extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const uint64_t* d_scalars, void* stream) {
     GM_REQUIRE(p && d_points_xy && d_scalars, "null argument");
     hipStream_t s = as_stream(stream);
@@ -827,9 +1062,17 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
                            p->off[0] + stride, nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2], p->blk_row + p->blk_first[0]);
         GM_LAUNCH_CHECK();
         STAGE_MARK(5);
-        // (A row-owned kernel that ran several trailing levels in one launch was measured and dropped: a lone wave needs ~0.6 us
-        // per field multiplication, so fused small levels cost what the small launches cost.)
-        const uint32_t tail_level = p->x_log - 1;
+        // (A first row-owned kernel for the trailing levels, one workgroup per row, was measured and dropped in round 1: its lanes
+        // idled.  k_add_tail gives every LANE a row and adds the identity with 5 multiplications instead of 12.)
+        // levels tail_L0 .. x_log - 1 by the row-owned tail kernel (k_add_tail) when at least three levels are left for it
+        static const bool no_tail = [] { const char* e = getenv("GM_MSM_NO_TAIL"); return e && e[0] == '1'; }();
+        uint32_t tail_L0 = 0;
+        if (!no_tail && p->x_log >= 5) {   // the 16-leaf tree of the tail kernel spans four levels
+            const int want = (int)p->x_log - (int)p->d_log - 2;
+            tail_L0 = (uint32_t)(want < 1 ? 1 : want);
+            if (tail_L0 > p->x_log - 4) tail_L0 = p->x_log - 4;
+        }
+        const uint32_t tail_level = tail_L0 ? tail_L0 : p->x_log - 1;
         int cur_lvl = 0;
         uint64_t cells_cur = cap_out;
         for (uint32_t level = 1; level < tail_level; level++) {
@@ -844,9 +1087,19 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
         }
         // the last level: every row is down to 0 or 2 cells (x_logsize halvings of at most 2^x_logsize cells): one thread per row
         // (a row-owned workgroup per row spent 86 us here with one busy lane in 64)
+        if (tail_L0) {
+            LvlBufs lb;
+            for (int b = 0; b < 2; b++)
+                for (int c = 0; c < 3; c++) lb.c[b][c] = p->lvl[b][c];
+            // level l reads buffer (l - 1) & 1: that is cur_lvl here (level 0 wrote buffer 0)
+            const uint32_t n_thin = ceil_div(nrows, 64);
+            hipLaunchKernelGGL(k_add_tail, dim3(n_thin + GM_TAIL_FAT_WAVES), dim3(64), 0, s, lb, p->off[0], nrows, tail_L0, p->x_log, n_thin,
+                               p->bsum[0], p->bsum[1], p->bsum[2]);
+        } else {
         hipLaunchKernelGGL((k_add_last<false>), dim3(ceil_div(nrows, 128)), dim3(128), 0, s, (const Fr*)nullptr, (const uint32_t*)nullptr,
                            p->lvl[cur_lvl][0], p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[0] + (uint64_t)tail_level * stride, nrows,
                            p->bsum[0], p->bsum[1], p->bsum[2]);
+        }
         GM_LAUNCH_CHECK();
     }
     STAGE_MARK(6);

@@ -83,7 +83,7 @@ struct gm_rccl {
     DevBuf send, recv;          // device staging of the host-buffer all-gather (grown on demand)
     char* pinned = nullptr;     // pinned host staging for small payloads (world * PIN_BYTES)
     static constexpr size_t PIN_BYTES = 64 << 10;
-    uint64_t calls = 0, bytes = 0;
+    uint64_t calls = 0, bytes = 0, dev_calls = 0;
     ~gm_rccl() {
         if (pinned) (void)hipHostFree(pinned);
         if (comm && rccl_api().ok) (void)rccl_api().CommDestroy(comm);
@@ -114,6 +114,16 @@ static int32_t rccl_all_gather_host(void* ctx, void* buf, uint64_t nbytes) {
     if (small) memcpy(hb, stage, total);
     r->calls++;
     r->bytes += nbytes;
+    return 0;
+}
+
+// gm_comm::all_gather_dev over RCCL: asynchronous on the caller's stream
+static int32_t rccl_all_gather_dev_cb(void* ctx, const void* d_send, void* d_recv, uint64_t nbytes, void* stream) {
+    gm_rccl* r = static_cast<gm_rccl*>(ctx);
+    if (!r || !d_send || !d_recv) return 1;
+    if (nbytes == 0) return 0;
+    if (rccl_api().AllGather(d_send, d_recv, nbytes, ncclUint8, r->comm, as_stream(stream)) != ncclSuccess) return 4;
+    r->dev_calls++;
     return 0;
 }
 
@@ -161,6 +171,7 @@ int32_t gm_comm_rccl_as_comm(gm_rccl* r, gm_comm* out) {
     out->rank = r->rank;
     out->world = r->world;
     out->all_gather = rccl_all_gather_host;
+    out->all_gather_dev = rccl_all_gather_dev_cb;
     return GM_OK;
 }
 
@@ -182,7 +193,7 @@ int32_t gm_comm_rccl_broadcast_dev(gm_rccl* r, void* d_buf, uint64_t bytes, uint
 
 int32_t gm_comm_rccl_stats(const gm_rccl* r, uint64_t* host_all_gathers, uint64_t* bytes_per_rank_total) {
     GM_REQUIRE(r, "null argument");
-    if (host_all_gathers) *host_all_gathers = r->calls;
+    if (host_all_gathers) *host_all_gathers = r->calls + r->dev_calls;   // exchanges of either form
     if (bytes_per_rank_total) *bytes_per_rank_total = r->bytes;
     return GM_OK;
 }

@@ -264,6 +264,20 @@ __global__ void k_upload_small(SmallVals sv, int n, Fr* __restrict__ dst) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) fr_store(dst + i, sv.v[i]);
 }
 
+// Sharded rounds with a device-side collective (gm_comm::all_gather_dev): every rank's round kernel leaves its partial sums in a
+// device slot (4 field elements), the slots are all-gathered on the prover's stream, and this one wave adds the `world` parts mod p
+// and reports ONCE to pinned host memory -- one host hop per round instead of D2H + host gather + H2D + D2H + a stream sync.
+__global__ void __launch_bounds__(64) k_sum_ranks(const Fr* __restrict__ all, uint32_t world, int nacc, Fr* __restrict__ h_out, uint32_t seq) {
+    if ((int)threadIdx.x < nacc) {
+        Fr s = fr_zero();
+        for (uint32_t r = 0; r < world; r++) s = fr_add(s, fr_load(all + (size_t)r * 4 + threadIdx.x));
+        coh_store_sys(h_out + threadIdx.x, s);
+        coh_drain();
+    }
+    __syncthreads();   // the sums have reached host memory before the sequence word is written
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(h_out + 7), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One segment of the gamma-combined layer function at the "1" point (h = 0: p1) or the "2" point (h = 1: 2 p1 - p0)
 // of the pair starting at cell0:  sum_{o in segment} gamma^o f_o(.)
 __device__ __forceinline__ Fr eval_seg(const Seg& g, const ColPtrs& cols, const Fr* __restrict__ gp, uint64_t cell0, int h) {
@@ -1487,6 +1501,32 @@ struct RoundScratch {
         if (expect == 0) expect = ++seq_counter();
         return FinishCtx{partial.fr(), reinterpret_cast<uint32_t*>(counter.p), h_result, expect};
     }
+    // ---- sharded rounds over a device-side collective (see k_sum_ranks)
+    DevBuf xslot, xall;
+    static bool dev_exchange(const Shard& sh) {
+        static const bool off = [] { const char* e = getenv("GM_SHARD_HOST_EXCHANGE"); return e && e[0] == '1'; }();   // A/B switch
+        return sh.comm && sh.comm->all_gather_dev && !off;
+    }
+    // the round kernel reports into this rank's device slot instead of pinned memory
+    int32_t ctx_dev(const Shard& sh, FinishCtx* fc) {
+        if (!xslot.p) {
+            int32_t rc = xslot.alloc(8 * sizeof(Fr));
+            if (rc) return rc;
+            rc = xall.alloc((size_t)sh.world * 4 * sizeof(Fr));
+            if (rc) return rc;
+        }
+        *fc = ctx();
+        fc->out = xslot.fr();
+        return GM_OK;
+    }
+    // all-gather of the slots + the one-wave sum, both on the prover's stream; finish() then sees the SUMS in pinned memory
+    int32_t exchange(const Shard& sh, int nacc, hipStream_t s) {
+        const int32_t rc = sh.comm->all_gather_dev(sh.comm->ctx, xslot.p, xall.p, 4 * sizeof(Fr), s);
+        if (rc) return set_err(GM_ERR_STATE, "gm_comm all_gather_dev failed with %d", rc);
+        hipLaunchKernelGGL(k_sum_ranks, dim3(1), dim3(64), 0, s, xall.fr(), sh.world, nacc, h_result, expect);
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
     // The launch writes `nacc` results and then the sequence number into the pinned buffer.  Poll the sequence
     // slot (a PCIe write lands in ~2 us; hipStreamSynchronize costs 10-20 us per round); fall back to the stream
     // synchronisation if it has not shown up after a bounded spin.
@@ -2214,7 +2254,13 @@ struct ScDense : gm_sc {
         const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
         const int ny = split ? D * (kind == 1 ? 1 : sp.nseg) : 1;
         const dim3 grid = round_grid(npairs, ny);
-        const FinishCtx fc = rs.ctx();
+        FinishCtx fc;
+        if (RoundScratch::dev_exchange(sh)) {
+            int32_t rc = rs.ctx_dev(sh, &fc);
+            if (rc) return rc;
+        } else {
+            fc = rs.ctx();
+        }
         const int lean = (kind == 0 && D == 3 && !split && cols.k <= 7) ? lean_prim_of(sp) : 0;
         if (kind == 2) {
             FoldedCols fcols;
@@ -2296,13 +2342,18 @@ struct ScDense : gm_sc {
                 k_enq = round_idx + 2;
             }
             Fr acc[4];
+            const bool devx = RoundScratch::dev_exchange(sh);
+            if (devx) {
+                int32_t rc = rs.exchange(sh, D, stream);
+                if (rc) return rc;
+            }
             int32_t rc = rs.finish_seq(k_seq[round_idx & 63], D, stream, acc, !fold_pending);
             if (rc) return rc;
             if (rs.ticket_word()[1]) {
                 rs.ticket_word()[1] = 0;   // the staging may be shared with later objects: report once
                 return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge (gm_set_wait_timeout_ms)");
             }
-            if (sh.comm) {
+            if (sh.comm && !devx) {
                 rc = shard_sum_fr(sh, acc, D);
                 if (rc) return rc;
             }
@@ -2414,26 +2465,37 @@ struct ScDenseDeg2 : gm_sc {
         static const bool pipe_large = [] { const char* e = getenv("GM_SC_PIPE_LARGE_DENSE"); return !(e && e[0] == '0'); }();   // A/B switch
         if ((split || pipe_large) && !sh.comm && pipeline_enabled() && (rs.own_pinned || pinned_exclusive() || k_enq > round_idx))
             return unipoly_pipelined(coeffs, npairs, eq_cur, cp);
+        const bool devx = RoundScratch::dev_exchange(sh);
+        FinishCtx fc0;
+        if (devx) {
+            int32_t rc = rs.ctx_dev(sh, &fc0);
+            if (rc) return rc;
+        } else {
+            fc0 = rs.ctx();
+        }
         if (lean) {
             LeanCols lc;
             for (int i = 0; i < cols.k; i++) lc.p[i] = cols.cur[i];
             const int pi = prof_begin(stream, lean * 4 + 0, cols.k, npairs, nullptr, 2 * lean_eval_muls(lean) + 2);
-            int32_t rc = launch_deg2_lean<false>(lean, grid, stream, lc, eq_cur, d_gamma.fr(), npairs, none,
-                                                 rs.ctx());
+            int32_t rc = launch_deg2_lean<false>(lean, grid, stream, lc, eq_cur, d_gamma.fr(), npairs, none, fc0);
             prof_end(stream, pi);
             if (rc) return rc;
         } else if (split)
             hipLaunchKernelGGL((k_round_deg2<false, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp,
-                               eq_cur, d_gamma.fr(), npairs, none, rs.ctx());
+                               eq_cur, d_gamma.fr(), npairs, none, fc0);
         else
             hipLaunchKernelGGL((k_round_deg2<false, false>), grid, dim3(SC_THREADS), 0, stream, sp, cp,
-                               eq_cur, d_gamma.fr(), npairs, none, rs.ctx());
+                               eq_cur, d_gamma.fr(), npairs, none, fc0);
         GM_LAUNCH_CHECK();
         if (!lean) prof_small_round(64.0 * cols.k * (double)npairs);
+        if (devx) {
+            int32_t rc = rs.exchange(sh, 2, stream);
+            if (rc) return rc;
+        }
         Fr acc[4];
         int32_t rc = rs.finish(2, stream, acc);
         if (rc) return rc;
-        if (sh.comm) {
+        if (sh.comm && !devx) {
             rc = shard_sum_fr(sh, acc, 2);
             if (rc) return rc;
         }
@@ -2844,13 +2906,18 @@ struct ScVecVecDeg2 : gm_sc {
                 k_enq = already_bound + 2;
             }
         }
+        const bool devx = RoundScratch::dev_exchange(sh);
+        if (devx) {
+            int32_t rc = rs.exchange(sh, 3, stream);
+            if (rc) return rc;
+        }
         int32_t rc = rs.finish_seq(k_seq[already_bound & 63], 3, stream, acc, !fold_pending);
         if (rc) return rc;
         if (rs.ticket_word()[1]) {
                 rs.ticket_word()[1] = 0;   // the staging may be shared with later objects: report once
                 return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge (gm_set_wait_timeout_ms)");
             }
-        if (sh.comm) {
+        if (sh.comm && !devx) {
             rc = shard_sum_fr(sh, acc, 3);
             if (rc) return rc;
         }
@@ -2946,7 +3013,13 @@ struct ScVecVecDeg2 : gm_sc {
         const dim3 grid = round_grid(gx, split ? 2 * sp.nseg : 1);
         const VVArgs va{off, nrows, d_row_coef.fr() + row_base, eq_pre, coarse_for(off)};
         const int lean = (!split && k <= 6) ? lean_prim_of(sp) : 0;
-        const FinishCtx fc = rs.ctx();
+        FinishCtx fc;
+        if (RoundScratch::dev_exchange(sh)) {
+            int32_t rc = rs.ctx_dev(sh, &fc);
+            if (rc) return rc;
+        } else {
+            fc = rs.ctx();
+        }
         if (lean) {
             LeanCols lc;
             for (int i = 0; i < k; i++) lc.p[i] = cols_now[i];

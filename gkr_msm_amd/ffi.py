@@ -73,9 +73,13 @@ class GmScProfileRow(C.Structure):
                 ("max_ms_pairs", C.c_double)]
 
 
+ALL_GATHER_DEV_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
 class GmComm(C.Structure):
-    """gm_comm: rank / world and one host-buffer all-gather"""
-    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", ALL_GATHER_CB)]
+    """gm_comm: rank / world, one host-buffer all-gather and, optionally (NULL by default), the same collective on device buffers"""
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", ALL_GATHER_CB),
+                ("all_gather_dev", ALL_GATHER_DEV_CB)]
 
 
 _SIGS = {
@@ -184,6 +188,7 @@ _SIGS = {
     "gm_msm_second_phase": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, vp]),
     "gm_msm_profile": (C.c_int32, [vp, C.c_int32]),
     "gm_msm_profile_read": (C.c_int32, [vp, C.POINTER(C.c_float), C.c_int32]),
+    "gm_msm_level_cells": (C.c_int32, [vp, u64p, C.c_uint32, vp]),
     "gm_msm_combine_host": (C.c_int32, [vp, C.c_uint32, C.c_uint32, vp]),
     "gm_msm_te": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "gm_g1_msm": (C.c_int32, [vp, vp, C.c_uint64, C.c_int32, C.c_uint32, vp, vp]),

@@ -250,6 +250,9 @@ int32_t gm_msm_second_phase(const gm_msm_plan* plan, const uint64_t* h_r, uint32
  * offsets, scatter, level-0 add, levels >= 1, bucket reduction; -1 where not recorded). */
 int32_t gm_msm_profile(gm_msm_plan* plan, int32_t mode);
 int32_t gm_msm_profile_read(gm_msm_plan* plan, float* h_ms, int32_t n);
+/* cells of the row layout of every level of the LAST run (x_logsize + 1 counts: level l's input layout, pad cells included;
+ * level l >= 1 adds h_cells[l] / 2 pairs); synchronises the stream.  Bench accounting of the level kernels' bytes and products. */
+int32_t gm_msm_level_cells(const gm_msm_plan* plan, uint64_t* h_cells, uint32_t n, void* stream);
 
 /* Final recombination acc = sum_w 2^(d*w) sum_{i>=1} 2^(i-1) P[i][w] on the host from the window points
  * of ALL windows (h_cols: 3*(d+1) columns x n_windows, Montgomery); writes affine (x,y), 8 x u64. */
@@ -369,6 +372,11 @@ typedef struct gm_comm {
     void* ctx;
     uint32_t rank, world;   /* world: a power of two dividing y_size */
     int32_t (*all_gather)(void* ctx, void* h_buf, uint64_t bytes_per_rank);
+    /* optional (NULL: the host form above serves every exchange): the same collective on DEVICE buffers, asynchronous on `stream`
+     * -- d_recv receives world * bytes_per_rank bytes, rank-major.  When present the per-round sums of the sharded provers never
+     * leave the device before they are added up: round kernel -> device slot -> this all-gather -> a one-wave sum -> ONE report
+     * to the host (gm_comm_rccl_as_comm sets it: ncclAllGather). */
+    int32_t (*all_gather_dev)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream);
 } gm_comm;
 /* host-only self-test of a gm_comm (no GPU): sums the field elements h_vals[0..n) of all ranks in place (Montgomery) */
 int32_t gm_comm_sum_fr(const gm_comm* comm, uint64_t* h_vals, uint32_t n);
