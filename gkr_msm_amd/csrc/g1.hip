@@ -421,26 +421,23 @@ __global__ void __launch_bounds__(128) k_g1_prepare_tables(const G1Aff* __restri
     g1_aff_store(tables + t, g1_to_aff(acc));  // G::normalize_batch (binary_msm.rs:41)
 }
 
-// pushforward outer buckets: task (y, x) adds basis[x + N * (y mod comm_mul)] to row (y / comm_mul) * stride + v[y][x]
-__global__ void __launch_bounds__(256) k_g1_outer_tasks_u16(const uint16_t* __restrict__ v, uint64_t N, uint32_t y0, uint32_t ny,
-                                                             uint32_t clm, uint32_t stride, uint32_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ idx) {
+// pushforward outer buckets: task (y, x) adds basis[x + N * slot(y mod comm_mul)] to row (y / comm_mul - m0) * stride + v[y][x].
+// slot: where slice s = y mod comm_mul of the KZG basis sits in the basis array the caller handed over -- the identity for a
+// process that holds the whole key, a compact index for a rank of a window-sharded run that holds only the slices of its windows
+// (gm_msm_g1_outer_part); m0 = the first commitment matrix the plan's windows touch.
+struct G1Slots {
+    uint16_t slot[256];   // clm <= 8
+};
+template <typename V>
+__global__ void __launch_bounds__(256) k_g1_outer_tasks(const V* __restrict__ v, uint64_t N, uint32_t y0, uint32_t ny, uint32_t clm,
+                                                         uint32_t m0, G1Slots sl, uint32_t stride, uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ idx) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N * ny) return;
     const uint32_t yl = (uint32_t)(t / N), y = y0 + yl;
     const uint64_t x = t % N;
-    keys[t] = (y >> clm) * stride + v[t];
-    idx[t] = (uint32_t)(x + N * (y & ((1u << clm) - 1)));
-}
-__global__ void __launch_bounds__(256) k_g1_outer_tasks_u32(const uint32_t* __restrict__ v, uint64_t N, uint32_t y0, uint32_t ny,
-                                                             uint32_t clm, uint32_t stride, uint32_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ idx) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= N * ny) return;
-    const uint32_t yl = (uint32_t)(t / N), y = y0 + yl;
-    const uint64_t x = t % N;
-    keys[t] = (y >> clm) * stride + v[t];
-    idx[t] = (uint32_t)(x + N * (y & ((1u << clm) - 1)));
+    keys[t] = ((y >> clm) - m0) * stride + (uint32_t)v[t];
+    idx[t] = (uint32_t)(x + N * sl.slot[y & ((1u << clm) - 1)]);
 }
 
 // plain keyed tasks: key = mapping[i] (Pullback::bucketed_msm, pullback.rs:44-46), point i
@@ -1180,16 +1177,12 @@ extern "C" int32_t gm_g1_binary_msm(const uint8_t* d_coefs, const uint64_t* d_ta
 //   d_d_outer:  n_mat * 2^d_logsize Jacobian points, d_c_outer: n_mat * c_stride (c_stride = longest bucket row of the run,
 //               returned in *c_stride; the reference's c_outer_buckets[m] is the prefix of length c_upper_bound[m] <= c_stride,
 //               the remaining entries are the point at infinity); h_d_comm / h_c_comm: n_mat affine points.
-extern "C" int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_basis_aff, uint32_t clm, uint64_t* d_d_outer,
-                                   uint64_t* d_c_outer, uint64_t c_outer_cap, uint32_t* c_stride, uint64_t* h_d_comm,
-                                   uint64_t* h_c_comm, void* stream) {
-    GM_REQUIRE(plan && d_basis_aff && d_d_outer && d_c_outer && c_stride, "null argument");
-    GM_REQUIRE(plan->y0 == 0 && plan->nwin == plan->y_size, "the outer buckets need a plan over all windows");
-    GM_REQUIRE(clm <= 8 && plan->x_log + clm < 31, "bad commitment_log_multiplicity");
-    hipStream_t s = as_stream(stream);
+// shared by gm_msm_g1_outer (whole key, all windows) and gm_msm_g1_outer_part (one rank's windows and key slices)
+static int32_t g1_outer_core(const gm_msm_plan* plan, const G1Aff* basis, const G1Slots& sl, uint32_t clm, G1Jac* d_d_outer, G1Jac* d_c_outer,
+                             uint64_t c_outer_cap, uint32_t* c_stride, std::vector<G1Jac>* d_sums, std::vector<G1Jac>* c_sums, hipStream_t s) {
     const uint64_t N = plan->N;
     const uint32_t ny = plan->nwin, nd = 1u << plan->d_log;
-    const uint32_t n_mat = (ny + (1u << clm) - 1) >> clm;
+    const uint32_t m0 = plan->y0 >> clm, n_mat = ((plan->y1 - 1) >> clm) - m0 + 1;   // the matrices this plan's windows touch
     const uint64_t ntasks = N * ny;
     // longest bucket row = max counter + 1
     std::vector<uint32_t> rl(plan->nrows);
@@ -1207,30 +1200,100 @@ extern "C" int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_ba
     if (wneed > need) need = wneed;
     int32_t rc = ws.reserve(need);
     if (rc) return rc;
-    const G1Aff* basis = reinterpret_cast<const G1Aff*>(d_basis_aff);
     for (int which = 0; which < 2; which++) {
         ws.used = 0;
         uint32_t* keys = (uint32_t*)ws.carve(ntasks * 4);
         uint32_t* idx = (uint32_t*)ws.carve(ntasks * 4);
         const uint32_t stride = which ? cmax : nd;
         if (which == 0)
-            hipLaunchKernelGGL(k_g1_outer_tasks_u16, dim3(ceil_div(ntasks, 256)), dim3(256), 0, s, plan->digits, N, 0u, ny, clm, stride,
-                               keys, idx);
+            hipLaunchKernelGGL((k_g1_outer_tasks<uint16_t>), dim3(ceil_div(ntasks, 256)), dim3(256), 0, s, plan->digits, N, plan->y0, ny, clm, m0, sl,
+                               stride, keys, idx);
         else
-            hipLaunchKernelGGL(k_g1_outer_tasks_u32, dim3(ceil_div(ntasks, 256)), dim3(256), 0, s, plan->counter, N, 0u, ny, clm, stride,
-                               keys, idx);
+            hipLaunchKernelGGL((k_g1_outer_tasks<uint32_t>), dim3(ceil_div(ntasks, 256)), dim3(256), 0, s, plan->counter, N, plan->y0, ny, clm, m0, sl,
+                               stride, keys, idx);
         GM_LAUNCH_CHECK();
-        G1Jac* outp = reinterpret_cast<G1Jac*>(which ? d_c_outer : d_d_outer);
+        G1Jac* outp = which ? d_c_outer : d_d_outer;
         rc = g1_sum_by_key(ws, basis, nullptr, keys, idx, ntasks, n_mat * stride, outp, s);
         if (rc) return rc;
-        uint64_t* h_comm = which ? h_c_comm : h_d_comm;
-        if (h_comm) {
+        std::vector<G1Jac>* sums = which ? c_sums : d_sums;
+        if (sums) {
             ws.used = 0;
-            std::vector<G1Jac> r;
-            rc = g1_weighted_sums(ws, outp, n_mat, stride, &r, s);
+            rc = g1_weighted_sums(ws, outp, n_mat, stride, sums, s);
             if (rc) return rc;
-            for (uint32_t m = 0; m < n_mat; m++) put_aff(h_comm + 12 * (size_t)m, r[m]);
         }
+    }
+    return GM_OK;
+}
+
+extern "C" int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_basis_aff, uint32_t clm, uint64_t* d_d_outer,
+                                   uint64_t* d_c_outer, uint64_t c_outer_cap, uint32_t* c_stride, uint64_t* h_d_comm,
+                                   uint64_t* h_c_comm, void* stream) {
+    GM_REQUIRE(plan && d_basis_aff && d_d_outer && d_c_outer && c_stride, "null argument");
+    GM_REQUIRE(plan->y0 == 0 && plan->nwin == plan->y_size, "the outer buckets need a plan over all windows (sharded: gm_msm_g1_outer_part)");
+    GM_REQUIRE(clm <= 8 && plan->x_log + clm < 31, "bad commitment_log_multiplicity");
+    G1Slots sl;
+    for (uint32_t i = 0; i < 256; i++) sl.slot[i] = (uint16_t)i;   // the whole key: slice s at s
+    std::vector<G1Jac> ds, cs;
+    const int32_t rc = g1_outer_core(plan, reinterpret_cast<const G1Aff*>(d_basis_aff), sl, clm, reinterpret_cast<G1Jac*>(d_d_outer),
+                                     reinterpret_cast<G1Jac*>(d_c_outer), c_outer_cap, c_stride, h_d_comm ? &ds : nullptr,
+                                     h_c_comm ? &cs : nullptr, as_stream(stream));
+    if (rc) return rc;
+    for (size_t m = 0; m < ds.size(); m++) put_aff(h_d_comm + 12 * m, ds[m]);
+    for (size_t m = 0; m < cs.size(); m++) put_aff(h_c_comm + 12 * m, cs[m]);
+    return GM_OK;
+}
+
+// One rank's part of the same, for a window-sharded plan (commitment_log_multiplicity > 0 makes one commitment matrix
+// span 2^clm windows, i.e. several ranks: pushforward.rs:395-396, 431-456).  The rank holds only the key slices its windows use:
+//   d_basis_local   n_slots * 2^x_logsize affine points; h_slot[s] (s < 2^clm) = where slice s (kzg_basis[s * 2^x .. (s + 1) * 2^x))
+//                   sits in it, or -1 when the rank does not hold it (using such a slice is an error)
+//   d_d_outer / d_c_outer   this rank's PARTIAL outer buckets of the matrices m0 .. m0 + n_mat_local - 1 its windows touch
+//                   (m0 = y_begin >> clm), n_mat_local * 2^d_logsize and n_mat_local * c_stride Jacobian points
+//   h_d_part / h_c_part     n_mat_local Jacobian points each: the rank's share of d_comm[m], c_comm[m] = sum_i i * bucket_i
+// Everything the protocol does with the outer buckets is LINEAR in them (the weighted sums here, the eq-weighted MSMs of the second
+// phase, pushforward.rs:599-604), so what crosses GPUs is one group element per matrix and commitment: gm_g1_combine_parts.
+extern "C" int32_t gm_msm_g1_outer_part(const gm_msm_plan* plan, const uint64_t* d_basis_local, const int32_t* h_slot, uint32_t clm,
+                                        uint64_t* d_d_outer, uint64_t* d_c_outer, uint64_t c_outer_cap, uint32_t* c_stride,
+                                        uint32_t* first_matrix, uint32_t* n_matrices, uint64_t* h_d_part_jac, uint64_t* h_c_part_jac,
+                                        void* stream) {
+    GM_REQUIRE(plan && d_basis_local && h_slot && d_d_outer && d_c_outer && c_stride && h_d_part_jac && h_c_part_jac, "null argument");
+    GM_REQUIRE(clm <= 8, "bad commitment_log_multiplicity");
+    G1Slots sl;
+    uint32_t n_slots = 0;
+    for (uint32_t i = 0; i < 256; i++) sl.slot[i] = 0;
+    for (uint32_t y = plan->y0; y < plan->y1; y++) {
+        const int32_t v = h_slot[y & ((1u << clm) - 1)];
+        GM_REQUIRE(v >= 0 && v < 256, "window %u needs key slice %u, which this rank does not hold", y, y & ((1u << clm) - 1));
+        sl.slot[y & ((1u << clm) - 1)] = (uint16_t)v;
+        if ((uint32_t)v + 1 > n_slots) n_slots = (uint32_t)v + 1;
+    }
+    GM_REQUIRE(((uint64_t)n_slots << plan->x_log) < (1ull << 32), "local key too large for 32-bit point indices");
+    std::vector<G1Jac> ds, cs;
+    const int32_t rc = g1_outer_core(plan, reinterpret_cast<const G1Aff*>(d_basis_local), sl, clm, reinterpret_cast<G1Jac*>(d_d_outer),
+                                     reinterpret_cast<G1Jac*>(d_c_outer), c_outer_cap, c_stride, &ds, &cs, as_stream(stream));
+    if (rc) return rc;
+    if (first_matrix) *first_matrix = plan->y0 >> clm;
+    if (n_matrices) *n_matrices = (uint32_t)ds.size();
+    memcpy(h_d_part_jac, ds.data(), ds.size() * sizeof(G1Jac));
+    memcpy(h_c_part_jac, cs.data(), cs.size() * sizeof(G1Jac));
+    return GM_OK;
+}
+
+// The cross-GPU EC combine: every rank contributes n Jacobian points (the point at infinity where it has nothing), the ranks'
+// contributions are all-gathered (n * 144 bytes per rank) and added per slot on the host; h_out_aff: n affine points, the same on
+// every rank.  Group addition is exact and commutative: the result does not depend on the order of the ranks.
+extern "C" int32_t gm_g1_combine_parts(const gm_comm* comm, const uint64_t* h_parts_jac, uint32_t n, uint64_t* h_out_aff) {
+    GM_REQUIRE(comm && comm->all_gather && h_parts_jac && h_out_aff && n >= 1, "bad argument");
+    const size_t bytes = (size_t)n * sizeof(G1Jac);
+    std::vector<char> all((size_t)comm->world * bytes, 0);
+    memcpy(all.data() + (size_t)comm->rank * bytes, h_parts_jac, bytes);
+    const int32_t rc = comm->all_gather(comm->ctx, all.data(), bytes);
+    if (rc) return set_err(GM_ERR_STATE, "gm_comm all_gather failed with %d", rc);
+    const G1Jac* a = reinterpret_cast<const G1Jac*>(all.data());
+    for (uint32_t i = 0; i < n; i++) {
+        G1Jac acc = g1_inf();
+        for (uint32_t r = 0; r < comm->world; r++) acc = g1_add(acc, a[(size_t)r * n + i]);
+        put_aff(h_out_aff + 12 * (size_t)i, acc);
     }
     return GM_OK;
 }

@@ -687,6 +687,36 @@ def msm_g1_outer(plan, d_basis_aff, clm, c_cap_per_mat):
     return d_d, d_c, stride.value, codec.g1_aff_from_limbs(hd), codec.g1_aff_from_limbs(hc)
 
 
+def msm_g1_outer_part(plan, d_basis_local, slot_of_slice, clm, c_cap_per_mat):
+    """one rank's part of the outer buckets (gm_msm_g1_outer_part): returns dict(first_matrix, n_matrices, c_stride, d_part, c_part)
+    with d_part / c_part = numpy (n_matrices, 18) uint64 Jacobian points, the rank's share of d_comm / c_comm"""
+    cm = 1 << clm
+    m0, m1 = plan.y_begin >> clm, (plan.y_end - 1) >> clm
+    n_loc = m1 - m0 + 1
+    nd = 1 << plan.d_logsize
+    d_d = dev_empty(18 * n_loc * nd)
+    d_c = dev_empty(18 * n_loc * c_cap_per_mat)
+    slots = np.full(cm, -1, dtype=np.int32)
+    for s_, v in slot_of_slice.items():
+        slots[s_] = v
+    stride, fm, nm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    hd = np.zeros((n_loc, 18), dtype=np.uint64)
+    hc = np.zeros((n_loc, 18), dtype=np.uint64)
+    ffi.check(ffi.lib().gm_msm_g1_outer_part(plan.h, _p(d_basis_local), slots.ctypes.data, clm, _p(d_d), _p(d_c), n_loc * c_cap_per_mat,
+                                             C.byref(stride), C.byref(fm), C.byref(nm), hd.ctypes.data, hc.ctypes.data, cur_stream()))
+    return dict(first_matrix=fm.value, n_matrices=nm.value, c_stride=stride.value, d_part=hd, c_part=hc, d_outer=d_d, c_outer=d_c)
+
+
+def g1_combine_parts(comm, parts_jac, n_total, first):
+    """cross-rank EC combine (gm_g1_combine_parts): parts_jac (k, 18) placed at slots first .. first + k - 1 of n_total, the other slots
+    the point at infinity; returns the n_total affine sums (the same on every rank)"""
+    buf = np.zeros((n_total, 18), dtype=np.uint64)
+    buf[first:first + len(parts_jac)] = parts_jac
+    out = np.zeros((n_total, 12), dtype=np.uint64)
+    ffi.check(ffi.lib().gm_g1_combine_parts(C.byref(comm.c), buf.ctypes.data, n_total, out.ctypes.data))
+    return codec.g1_aff_from_limbs(out)
+
+
 def g1_fixed_base_register(d_bases_aff, n):
     """precompute the window multiples of a base array (a proving key); later g1_msm calls on the same tensor take the fixed-base path"""
     ffi.check(ffi.lib().gm_g1_fixed_base_register(_p(d_bases_aff), n, cur_stream()))

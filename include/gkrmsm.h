@@ -640,6 +640,17 @@ int32_t gm_g1_binary_msm(const uint8_t* d_coefs, const uint64_t* d_tables_aff, u
 int32_t gm_msm_g1_outer(const gm_msm_plan* plan, const uint64_t* d_basis_aff, uint32_t commitment_log_multiplicity,
                         uint64_t* d_d_outer_jac, uint64_t* d_c_outer_jac, uint64_t c_outer_cap, uint32_t* c_stride,
                         uint64_t* h_d_comm_aff, uint64_t* h_c_comm_aff, void* stream);
+/* One rank's part of gm_msm_g1_outer for a window-sharded plan, and the cross-GPU combine (pushforward.rs:395-396,
+ * 431-456: with commitment_log_multiplicity > 0 a commitment matrix spans 2^clm windows, i.e. several ranks).  The rank holds only
+ * the KZG key slices of its windows: d_basis_local = n_slots * 2^x_logsize affine points, h_slot[s] = index of slice s
+ * (kzg_basis[s * 2^x_logsize ..]) in it or -1.  Outputs: the rank's PARTIAL outer buckets of matrices first_matrix ..
+ * first_matrix + n_matrices - 1 and its share of d_comm / c_comm (n_matrices Jacobian points each).  The protocol only ever takes
+ * linear images of the outer buckets, so gm_g1_combine_parts -- all-gather of n points per rank, added on the host -- is the whole
+ * exchange: one group element per matrix and commitment. */
+int32_t gm_msm_g1_outer_part(const gm_msm_plan* plan, const uint64_t* d_basis_local, const int32_t* h_slot, uint32_t clm,
+                             uint64_t* d_d_outer, uint64_t* d_c_outer, uint64_t c_outer_cap, uint32_t* c_stride,
+                             uint32_t* first_matrix, uint32_t* n_matrices, uint64_t* h_d_part_jac, uint64_t* h_c_part_jac, void* stream);
+int32_t gm_g1_combine_parts(const struct gm_comm* comm, const uint64_t* h_parts_jac, uint32_t n, uint64_t* h_out_aff);
 int32_t gm_g1_generator(uint64_t* h_out_aff);   /* the standard generator, affine wire form (mock_setup's g0) */
 int32_t gm_g1_to_affine(const uint64_t* d_in_jac, uint64_t n, uint64_t* d_out_aff, void* stream);
 int32_t gm_g1_from_affine(const uint64_t* d_in_aff, uint64_t n, uint64_t* d_out_jac, void* stream);

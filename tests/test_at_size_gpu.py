@@ -402,6 +402,51 @@ def test_config_e_dry_run_of_one_ranks_share_of_the_sharded_prover():
     torch.cuda.empty_cache()
 
 
+def test_config_e_one_ranks_share_of_the_commitments_at_clm_4():
+    """BASELINE.json configs[4]'s commitments: x_logsize=24, commitment_log_multiplicity=4, windows sharded 8 ways.  The KZG key has
+    2 * 2^28 - 1 points (pippenger.rs:475-480; 51 GB affine): no rank holds it whole and nobody builds fixed-base tables for it
+    (1.5 KB per base).  Rank 3 owns windows 12..15, which use key slices 12..15 of matrix 0 (kzg_basis[x + 2^24 * (y mod 16)],
+    pushforward.rs:417): 4 x 2^24 affine points = 6.4 GB on the device.  Its PART of the outer buckets (2 x 2^26 G1 additions) and of
+    d_comm / c_comm runs at full size here; the exchange with the other seven ranks is one group element per matrix and commitment
+    (gm_g1_combine_parts; exercised with real ranks at small sizes in tests/test_sharded_g1_gpu.py).  Checked: it fits and runs, and
+    the part is LINEAR -- the same windows accumulated against the key slices in another slot order give the same share."""
+    from gkr_msm_amd import dist as gdist
+    x_log, d_log, nbits, world, rank, clm = 24, 8, 256, 8, 3, 4
+    require_host_gib(8, "config E's commitment share")
+    y_size = nbits // d_log
+    n = 1 << x_log
+    d_pts, d_sc, sc = device_inputs(x_log, nbits, 0xE1E1)
+    y0, y1 = gdist.window_range(rank, world, y_size)
+    plan = H.MsmPlan(x_log, d_log, y_size, y0, y1)
+    plan.run(d_pts, d_sc)
+    need = sorted({y % (1 << clm) for y in range(y0, y1)})
+    assert need == [12, 13, 14, 15]
+    d_local = H.g1_gen_points(len(need) * n, 0x4B5A47)          # the rank's four key slices (synthetic points: any key works here)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    part = H.msm_g1_outer_part(plan, d_local, {s_: i for i, s_ in enumerate(need)}, clm, n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    free, total = torch.cuda.mem_get_info()
+    assert part["first_matrix"] == 0 and part["n_matrices"] == 1
+    # the same share with the slices stored in reverse order: same group elements
+    loc_h = H.to_host(d_local).reshape(len(need), -1)
+    d_rev = H.to_dev(loc_h[::-1].copy().reshape(-1))
+    del loc_h
+    part2 = H.msm_g1_outer_part(plan, d_rev, {s_: len(need) - 1 - i for i, s_ in enumerate(need)}, clm, n)
+    assert codec.g1_jac_from_limbs(part["d_part"]) == codec.g1_jac_from_limbs(part2["d_part"])
+    assert codec.g1_jac_from_limbs(part["c_part"]) == codec.g1_jac_from_limbs(part2["c_part"])
+    print("[at-size] config E commitment share, rank %d of %d: 2 x 2^26 G1 additions + 2 weighted sums in %.0f ms, %.1f GiB of HBM in use" % (
+        rank, world, dt * 1e3, (total - free) / 2 ** 30))
+    record("config_e_commitment_share_clm4", x_logsize=x_log, clm=clm, world=world, rank=rank, key_slices=need, local_key_GB=round(len(need) * n * 96 / 1e9, 1),
+           ms=round(dt * 1e3, 1), hbm_GiB=round((total - free) / 2 ** 30, 1), checked="fits and runs; share independent of the slice slot order")
+    del d_local, d_rev, part, part2, d_pts, d_sc
+    plan.close()
+    ffi.lib().gm_release_cached_memory()
+    ffi.check(ffi.lib().gm_g1_release_scratch())
+    torch.cuda.empty_cache()
+
+
 def test_config_c_gen1_at_two_to_the_twenty_points():
     """BASELINE.json configs[2], gen-1 (gkr_msm_simple.rs:86-338) at 2^20 points x 2^8 scalar bits -- 16 times past what the CPU
     oracle finishes in a test.  Checked through size-independent properties: the library's verifier (BintreeVerifier /
