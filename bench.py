@@ -116,13 +116,14 @@ def round_kernel_ceiling(name):
 P = codec.P
 SEED = 0x474B524D534D      # "GKRMSM"
 
-# HBM traffic per launch of the dominant kernels at config B from the committed PMC passes (profiles/r02/*_pmc_hbm.csv:
+# HBM traffic per launch of the dominant kernels at config B from the committed PMC passes (profiles/r03/*_pmc_hbm.csv:
 # (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction); None for any other shape
 PMC_TRAFFIC_MSM_B = None
 PMC_TRAFFIC_GE1_B = None   # bytes per step of all k_add_level + k_add_tail launches together
-PMC_TRAFFIC_SC_B = {}      # kernel name -> bytes per launch (profiles/r02/prover_pmc_per_launch.json, written by scripts/summarise_profiles.py)
+PMC_TRAFFIC_SC_B = {}      # kernel name -> bytes per launch (profiles/r03/prover_pmc_per_launch.json, written by scripts/summarise_profiles.py)
 try:
-    with open(os.path.join(ROOT, "profiles", "r02", "prover_pmc_per_launch.json")) as _f:
+    _pj = [os.path.join(ROOT, "profiles", r_, "prover_pmc_per_launch.json") for r_ in ("r03", "r02")]
+    with open([p_ for p_ in _pj if os.path.exists(p_)][0]) as _f:
         PMC_TRAFFIC_SC_B = json.load(_f)
     PMC_TRAFFIC_MSM_B = PMC_TRAFFIC_SC_B.get("k_add_level0")
     PMC_TRAFFIC_GE1_B = PMC_TRAFFIC_SC_B.get("k_add_levels_ge1_per_step")
@@ -269,7 +270,7 @@ def main():
     # which GPUs the native communicator really spans: every rank contributes (rank, a digest of its device's UUID / PCI address)
     # through ncclAllGather itself
     rccl_seen = None
-    if rcomm is not None and world > 1:
+    if rcomm is not None:
         import hashlib
         pr_ = torch.cuda.get_device_properties(local_rank)
         ident = "%s|%s|%s|%s" % (getattr(pr_, "uuid", ""), getattr(pr_, "pci_domain_id", ""), getattr(pr_, "pci_bus_id", ""),
@@ -517,6 +518,8 @@ def main():
     for k in ("operand_broadcast_ms", "operand_bytes", "per_rank_ms_per_step", "pipeline_depth"):
         if k in main_res:
             out[k] = main_res[k]
+    if world == 1 and rccl_seen:
+        out["rccl_ranks_seen"], out["rccl_distinct_devices"] = rccl_seen["ranks"], rccl_seen["distinct_devices"]   # world-1 rehearsal
     if world > 1:
         out["rccl_ranks_seen"] = rccl_seen["ranks"] if rccl_seen else 0
         out["rccl_distinct_devices"] = rccl_seen["distinct_devices"] if rccl_seen else 0

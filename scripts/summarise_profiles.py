@@ -3,7 +3,7 @@
 profiles/<round>/: kernel statistics, HBM traffic per launch (two PMC passes; FETCH_SIZE doubled per the gfx950 note in
 MI355X_MICROARCH.md) and the per-launch traffic table bench.py reads for `sumcheck.roofline.traffic`.
 
-usage: summarise_profiles.py gpurun_out/r02_prof profiles/r02"""
+usage: summarise_profiles.py gpurun_out/r03_prof profiles/r03"""
 import collections
 import csv
 import glob
@@ -42,7 +42,7 @@ def durations(path):
     return acc
 
 
-for tag in ("bench", "msm", "prover"):
+for tag in ("bench", "msm", "prover", "g1"):
     ks = one("%s_kt/*/*kernel_stats.csv" % tag)
     if ks:
         shutil.copy(ks, os.path.join(dst, "%s_kernel_stats.csv" % ("msm_only" if tag == "msm" else tag)))
@@ -51,7 +51,8 @@ for f in ("bench_profiled_run.json", "msm_only_profiled_run.json"):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 
 per_launch = {}
-for tag in ("msm", "prover"):
+launches_of = {}
+for tag in ("msm", "prover", "g1"):
     ff, wf, kt = one("%s_FETCH_SIZE/*/*counter_collection.csv" % tag), one("%s_WRITE_SIZE/*/*counter_collection.csv" % tag), one("%s_kt/*/*kernel_trace.csv" % tag)
     if not (ff and wf):
         continue
@@ -63,7 +64,7 @@ for tag in ("msm", "prover"):
         n = len(fetch[k])
         secs = sum(dur.get(k, [])) * (n / max(len(dur.get(k, [])), 1)) if dur.get(k) else 0.0
         rows.append((2 * fb + wb, k, n, fb / n, wb / n, (fb + wb) / n, (2 * fb + wb) / n, secs))
-    with open(os.path.join(dst, "%s_pmc_hbm.csv" % ("msm_bench" if tag == "msm" else "prover")), "w") as out:
+    with open(os.path.join(dst, "%s_pmc_hbm.csv" % ("msm_bench" if tag == "msm" else tag)), "w") as out:
         out.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes per launch = counter (KB) * 1024, mean over the launches\n")
         out.write("# of that kernel; hbm_bytes_fetch_x2 applies the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads; gathers are\n")
         out.write("# uncalibrated, so the raw sum is listed too).  avg_GB_per_s = corrected bytes / kernel time of a --kernel-trace run of the same command.\n")
@@ -72,19 +73,38 @@ for tag in ("msm", "prover"):
             if tot < 1e7:
                 continue
             out.write("%s,%d,%d,%d,%d,%d,%s\n" % (k, n, f1, w1, raw, cor, ("%.0f" % (tot / secs / 1e9)) if secs > 0 else ""))
-            per_launch[k] = int(cor)
+            if tag != "g1":
+                per_launch[k] = int(cor)
+                launches_of[k] = n
 
 # kernel names as bench.py prints them (k_round_deg2_lean<PROJ_L1,vecvec> ...) from the template arguments rocprof shows
 PRIM = {1: "AFF_L1", 2: "AFF_L2", 3: "AFF_L3", 4: "PROJ_L1", 5: "PROJ_L2", 6: "PROJ_L3", 10: "PT_BIT_CHOICE", 100: "AFF_L1+BITCHECK",
         11: "ADD_INVERSES", 12: "LOGUP_LAYER"}
 table = {}
 for k, v in per_launch.items():
-    if k.startswith("k_round_deg2_lean<") or k.startswith("k_round_deg2_lean9<"):   # the 9 x 29-bit instances print under the same name
+    if k.startswith("k_round_deg2_lean<") or k.startswith("k_round_deg2_lean9<") or k.startswith("k_round_deg2_lean9x2<"):   # all forms print under the bench's one name
         a, b = k[k.index("<") + 1:-1].split(",")
         # only the LARGE launches are what bench.py times; the PMC mean is over all launches of the kernel, which are the same set
         table["k_round_deg2_lean<%s,%s>" % (PRIM.get(int(a), a), "vecvec" if b.strip() == "true" else "dense")] = v
     elif k == "k_add_level0":
         table["k_add_level0"] = v
+# all launches of the level kernels above level 0 of ONE step: the MSM PMC run is `bench.py --steps 3 --warmup 1` = 3 timed + 1 warm-up
+# + 2 pipeline-priming + 1 stage-breakdown step = 7 steps (bench.py msm_leg)
+ge1 = 0.0
+for k in ("k_add_level", "k_add_tail"):
+    if k in per_launch:
+        ge1 += per_launch[k] * launches_of[k]
+steps_in_pmc_run = launches_of.get("k_add_level0", 0)
+if ge1 and steps_in_pmc_run:
+    table["k_add_levels_ge1_per_step"] = int(ge1 / steps_in_pmc_run)
 with open(os.path.join(dst, "prover_pmc_per_launch.json"), "w") as f:
     json.dump(table, f, indent=1, sort_keys=True)
+# SQ-counter passes: per kernel, the largest launch (scripts/pmc_sq_summary.py)
+import subprocess
+for w in ("prover", "msm", "g1"):
+    for n_ in (1, 2):
+        cc = one("%s_sq%d/*/*counter_collection.csv" % (w, n_))
+        if cc:
+            with open(os.path.join(dst, "%s_pmc_sq%d.csv" % (w, n_)), "w") as out:
+                subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_sq_summary.py"), cc], stdout=out, check=False)
 print("wrote", sorted(os.listdir(dst)))
