@@ -876,11 +876,13 @@ __device__ __forceinline__ constexpr int lean_n_in(int prim) {
 // sum_o gamma^o f_o(v) for the whole (single-primitive) layer function; g[o] = gamma^o on the device
 template <int PRIM>
 __device__ __forceinline__ Fr lean_gamma_eval(const Fr* v, const Fr* __restrict__ g) {
+    // the same re-association as lean_gamma_eval9 (every gamma power multiplies an input once): exact identities
     if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
-        Fr A = fr_mul(v[0], v[3]);
-        A = fr_add(A, fr_mul(fr_load(g + 1), fr_mul(v[2], v[1])));
-        const Fr t = fr_sub(fr_mul(v[1], v[3]), fr_mul_by_a(fr_mul(v[0], v[2])));
-        A = fr_add(A, fr_mul(fr_load(g + 2), t));
+        const Fr g2 = fr_load(g + 2);
+        const Fr g2v2 = fr_mul(g2, v[2]);
+        const Fr t1 = fr_add(v[3], fr_add(fr_dbl(fr_dbl(g2v2)), g2v2));                   // v3 + 5 g2 v2   (-a = 5)
+        const Fr t2 = fr_add(fr_mul(fr_load(g + 1), v[2]), fr_mul(g2, v[3]));
+        Fr A = fr_add(fr_mul(v[0], t1), fr_mul(v[1], t2));
         if (PRIM == LEAN_AFF_L1_BC) {
             A = fr_add(A, fr_mul(fr_load(g + 3), fr_sub(fr_sqr(v[4]), v[4])));
             A = fr_add(A, fr_mul(fr_load(g + 4), fr_sub(fr_sqr(v[5]), v[5])));
@@ -889,34 +891,30 @@ __device__ __forceinline__ Fr lean_gamma_eval(const Fr* v, const Fr* __restrict_
     } else if (PRIM == FN_AFF_L2) {
         Fr A = fr_add(v[0], v[1]);
         A = fr_add(A, fr_mul(fr_load(g + 1), v[2]));
-        return fr_add(A, fr_mul(fr_load(g + 2), fr_mul(v[0], v[1])));
+        return fr_add(A, fr_mul(fr_mul(fr_load(g + 2), v[0]), v[1]));
     } else if (PRIM == FN_AFF_L3 || PRIM == FN_PROJ_L3) {
         const Fr dxy = fr_mul_by_d(v[PRIM == FN_AFF_L3 ? 2 : 3]);
         const Fr base = PRIM == FN_AFF_L3 ? fr_one() : v[2];
         const Fr m = fr_sub(base, dxy), q = fr_add(base, dxy);
-        Fr A = fr_mul(m, v[0]);
-        A = fr_add(A, fr_mul(fr_load(g + 1), fr_mul(q, v[1])));
-        return fr_add(A, fr_mul(fr_load(g + 2), fr_mul(m, q)));
+        const Fr A = fr_mul(m, fr_add(v[0], fr_mul(fr_load(g + 2), q)));
+        return fr_add(A, fr_mul(fr_load(g + 1), fr_mul(q, v[1])));
     } else if (PRIM == FN_PROJ_L1) {
-        Fr A = fr_mul(v[0], v[4]);
-        A = fr_add(A, fr_mul(fr_load(g + 1), fr_mul(v[3], v[1])));
-        const Fr t = fr_sub(fr_mul(v[1], v[4]), fr_mul_by_a(fr_mul(v[0], v[3])));
-        A = fr_add(A, fr_mul(fr_load(g + 2), t));
+        const Fr g2 = fr_load(g + 2);
+        const Fr g2v3 = fr_mul(g2, v[3]);
+        const Fr t1 = fr_add(v[4], fr_add(fr_dbl(fr_dbl(g2v3)), g2v3));                   // v4 + 5 g2 v3
+        const Fr t2 = fr_add(fr_mul(fr_load(g + 1), v[3]), fr_mul(g2, v[4]));
+        const Fr A = fr_add(fr_mul(v[0], t1), fr_mul(v[1], t2));
         return fr_add(A, fr_mul(fr_load(g + 3), fr_mul(v[2], v[5])));
     } else if (PRIM == FN_PROJ_L2) {
-        Fr A = fr_mul(fr_add(v[0], v[1]), v[3]);
-        A = fr_add(A, fr_mul(fr_load(g + 1), fr_mul(v[2], v[3])));
-        A = fr_add(A, fr_mul(fr_load(g + 2), fr_sqr(v[3])));
-        return fr_add(A, fr_mul(fr_load(g + 3), fr_mul(v[0], v[1])));
+        const Fr u = fr_add(fr_add(v[0], v[1]), fr_add(fr_mul(fr_load(g + 1), v[2]), fr_mul(fr_load(g + 2), v[3])));
+        return fr_add(fr_mul(v[3], u), fr_mul(fr_load(g + 3), fr_mul(v[0], v[1])));
     } else if (PRIM == FN_ADD_INVERSES) {
-        return fr_add(fr_add(v[0], v[1]), fr_mul(fr_load(g + 1), fr_mul(v[0], v[1])));
+        return fr_add(fr_add(v[0], v[1]), fr_mul(fr_mul(fr_load(g + 1), v[0]), v[1]));
     } else if (PRIM == FN_LOGUP_LAYER) {
-        const Fr n = fr_add(fr_mul(v[0], v[3]), fr_mul(v[1], v[2]));
-        return fr_add(n, fr_mul(fr_load(g + 1), fr_mul(v[1], v[3])));
-    } else {  // FN_PT_BIT_CHOICE: (b, x, y) -> (b x, b (y - 1) + 1)
-        Fr A = fr_mul(v[0], v[1]);
-        const Fr by = fr_add(fr_mul(v[0], fr_sub(v[2], fr_one())), fr_one());
-        return fr_add(A, fr_mul(fr_load(g + 1), by));
+        return fr_add(fr_mul(v[3], fr_add(v[0], fr_mul(fr_load(g + 1), v[1]))), fr_mul(v[1], v[2]));
+    } else {  // FN_PT_BIT_CHOICE: (b, x, y) -> (b x, b (y - 1) + 1): b (x + g1 (y - 1)) + g1
+        const Fr g1 = fr_load(g + 1);
+        return fr_add(fr_mul(v[0], fr_add(v[1], fr_mul(g1, fr_sub(v[2], fr_one())))), g1);
     }
 }
 
@@ -1009,9 +1007,14 @@ __device__ __forceinline__ Fr9x2 fr9_sub8(const Fr9x2& x, const Fr9x2& y) { retu
 __device__ __forceinline__ Fr9x2 fr9_sub8(const Fr9x2& x, const Fr9& c) { return Fr9x2(fr9_sub8(x.a, c), fr9_sub8(x.b, c)); }
 __device__ __forceinline__ Fr9x2 fr9_sub8(const Fr9& c, const Fr9x2& x) { return Fr9x2(fr9_sub8(c, x.a), fr9_sub8(c, x.b)); }
 
+// Round 3: the gamma combination is re-associated so that every gamma power multiplies an INPUT once and the products of two inputs
+// are shared -- e.g. PROJ_L1 = v0 (v4 + 5 g2 v3) + v1 (g1 v3 + g2 v4) + g3 v2 v5: 7 multiplications instead of 8, PROJ_L2 =
+// v3 (v0 + v1 + g1 v2 + g2 v3) + g3 v0 v1: 5 instead of 7.  Exact field identities: the same round sums, bit for bit.
 template <int PRIM, typename LD, typename LDS>
 __device__ __forceinline__ auto lean_gamma_eval9(const LD& ld, const LDS& lds, const Fr* __restrict__ g) -> decltype(ld(0)) {
     typedef decltype(ld(0)) V;   // Fr9: one evaluation point; Fr9x2: both points of the pair side by side (k_round_deg2_lean9x2)
+    // bounds: ld(q) L 2^29, S <= 10, domain 256; a gamma power g_k = fr9_load(g + k) L 2^29, S 32, domain 261; g_k x input: domain 256,
+    // S 32 x 10 / 70.66 + 1 = 5.53; a product needs 9 L_a L_b + 2^62 < 2^64, i.e. L_a L_b <= 2^60.4
     if (PRIM == FN_ADD_INVERSES) {
         // v0 + v1 + g1 v0 v1, every term in domain 256
         const V v0 = ld(0);
@@ -1024,31 +1027,27 @@ __device__ __forceinline__ auto lean_gamma_eval9(const LD& ld, const LDS& lds, c
         A = fr9_add(A, fr9_mul(fr9_load(g + 1), ld(2)));                                 // S 5.5
         return fr9_add(fr9_add(A, v0), ld(1));                                           // L 4 2^29, S 36.5
     } else if (PRIM == FN_PT_BIT_CHOICE) {
-        // b x + g1 (b (y - 1) + 1): the constant one joins in domain 251
-        const V b = ld(0);
-        const V by = fr9_add(fr9_mul(b, fr9_norm(fr9_sub8(ld(2), fr9_one256()))), fr9_one251());   // S 3.5 + 0.06, L 2^30
-        return fr9_add(fr9_mul(b, ld(1)), fr9_mul(fr9_load(g + 1), by));                 // L 2 2^29, S 5.5
+        // b x + g1 (b (y - 1) + 1) = b (x + g1 (y - 1)) + g1: two products per point; g1 in domain 251 is loop-invariant
+        const Fr9 g1 = fr9_load(g + 1);
+        const V ym1 = fr9_norm(fr9_sub8(ld(2), fr9_one256()));                            // S 18, domain 256
+        const V u = fr9_add(ld(1), fr9_mul(g1, ym1));                                    // g1 (y - 1): S 9.2; sum L 2^30, S 19.2
+        return fr9_add(fr9_mul(ld(0), u), fr9_mul(g1, fr9_one251()));                    // S 3.7 + 1.0: L 2 2^29, domain 251
     } else if (PRIM == FN_LOGUP_LAYER) {
-        // a d + b c + g1 b d
-        const V v1 = ld(1), v3 = ld(3);
-        V A = fr9_mul(ld(0), v3);
-        A = fr9_add(A, fr9_mul(v1, ld(2)));
-        return fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v1, v3)));                    // L 3 2^29, S 7
+        // a d + b c + g1 b d = d (a + g1 b) + b c: three products
+        const V v1 = ld(1);
+        const V u = fr9_add(ld(0), fr9_mul(fr9_load(g + 1), v1));                        // L 2^30, S 15.5, domain 256
+        return fr9_add(fr9_mul(ld(3), u), fr9_mul(v1, ld(2)));                           // S 3.2 + 2.4: L 2 2^29, domain 251
     } else if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
-        // v0 v3 + g1 v2 v1 + g2 (v1 v3 + 5 v0 v2) [+ g3 (v4^2 - v4) + g4 (v5^2 - v5)]
-        V A, t;
+        // v0 v3 + g1 v2 v1 + g2 (v1 v3 + 5 v0 v2) = v0 (v3 + 5 g2 v2) + v1 (g1 v2 + g2 v3) [+ g3 (v4^2 - v4) + g4 (v5^2 - v5)]
+        V A;
         {
-            const V v3 = ld(3), v2 = ld(2);
-            {
-                const V v0 = ld(0);
-                A = fr9_mul(v0, v3);                                                      // S 2.42
-                t = fr9_mul5(fr9_mul(v0, v2));                                            // - a = 5: L 5 2^29, S 12.1
-            }
-            const V v1 = ld(1);
-            t = fr9_add(t, fr9_mul(v1, v3));                                              // L 6 2^29, S 14.5
-            A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v2, v1)));                    // g: S 32; product S 2.1
+            const V v2 = ld(2), v3 = ld(3);
+            const Fr9 g2 = fr9_load(g + 2);
+            const V t1 = fr9_norm(fr9_add(v3, fr9_mul5(fr9_mul(g2, v2))));               // 5 x 5.53 + 10: S 37.7, normalised: L 2^29
+            const V t2 = fr9_add(fr9_mul(fr9_load(g + 1), v2), fr9_mul(g2, v3));         // L 2^30, S 11.1
+            A = fr9_mul(ld(0), t1);                                                       // S 6.3, domain 251
+            A = fr9_add(A, fr9_mul(ld(1), t2));                                           // S 2.6: L 2 2^29, S 8.9
         }
-        A = fr9_add(A, fr9_mul(fr9_load(g + 2), t));                                      // 2^29 x 6 2^29; S 7.6
         if (PRIM == LEAN_AFF_L1_BC) {
             // b^2 - b = b (b - 1): (b - 1 + 8 p) normalised has S 18, the product S 3.5, times gamma S 2.6
 #pragma unroll
@@ -1057,41 +1056,37 @@ __device__ __forceinline__ auto lean_gamma_eval9(const LD& ld, const LDS& lds, c
                 A = fr9_add(A, fr9_mul(fr9_load(g + 3 + k), fr9_mul(b, fr9_norm(fr9_sub8(b, fr9_one256())))));
             }
         }
-        return A;
+        return A;                                                                         // L <= 4 2^29, S <= 14.1
     } else if (PRIM == FN_AFF_L3 || PRIM == FN_PROJ_L3) {
-        const V dxy = fr9_mul(ld(PRIM == FN_AFF_L3 ? 2 : 3), fr9_coeff_d());           // d in domain 261: dxy in 256, S 1.14
+        // m v0 + g1 q v1 + g2 m q = m (v0 + g2 q) + g1 (q v1),  m = base - d xy, q = base + d xy
+        const V dxy = fr9_mul(ld(PRIM == FN_AFF_L3 ? 2 : 3), fr9_coeff_d());             // d in domain 261: dxy in 256, S 1.14
         const V base = PRIM == FN_AFF_L3 ? V(fr9_one256()) : ld(2);
-        const V m = fr9_norm(fr9_sub8(base, dxy));                                      // S 18
-        const V q = fr9_add(base, dxy);                                                 // L 2^30, S 11.2
-        V A = fr9_mul(m, ld(0));                                                        // S 3.5
-        A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(q, ld(1))));                      // 2^30 x 2^29; S 2.6 -> 2.2
-        return fr9_add(A, fr9_mul(fr9_load(g + 2), fr9_mul(m, q)));                       // S 3.9 -> 2.8
+        const V m = fr9_norm(fr9_sub8(base, dxy));                                        // S 18
+        const V q = fr9_add(base, dxy);                                                   // L 2^30, S 11.2
+        const V u = fr9_add(ld(0), fr9_mul(fr9_load(g + 2), q));                          // g2 q: 2^29 x 2^30, S 6.1, domain 256; sum L 2^30, S 16.1
+        V A = fr9_mul(m, u);                                                              // S 5.1, domain 251
+        return fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(q, ld(1))));                   // q v1: S 2.6 -> 2.2; L 2 2^29, S 7.3
     } else if (PRIM == FN_PROJ_L1) {
-        // v0 v4 + g1 v3 v1 + g2 (v1 v4 + 5 v0 v3) + g3 v2 v5
-        V A, t;
+        // v0 v4 + g1 v3 v1 + g2 (v1 v4 + 5 v0 v3) + g3 v2 v5 = v0 (v4 + 5 g2 v3) + v1 (g1 v3 + g2 v4) + g3 v2 v5
+        V A;
         {
             const V v3 = ld(3), v4 = ld(4);
-            {
-                const V v0 = ld(0);
-                A = fr9_mul(v0, v4);
-                t = fr9_mul5(fr9_mul(v0, v3));
-            }
-            const V v1 = ld(1);
-            t = fr9_add(t, fr9_mul(v1, v4));                                              // L 6 2^29, S 14.5
-            A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(v3, v1)));
+            const Fr9 g2 = fr9_load(g + 2);
+            const V t1 = fr9_norm(fr9_add(v4, fr9_mul5(fr9_mul(g2, v3))));               // S 37.7, normalised: L 2^29
+            const V t2 = fr9_add(fr9_mul(fr9_load(g + 1), v3), fr9_mul(g2, v4));         // L 2^30, S 11.1
+            A = fr9_mul(ld(0), t1);                                                       // S 6.3, domain 251
+            A = fr9_add(A, fr9_mul(ld(1), t2));                                           // S 2.6
         }
-        A = fr9_add(A, fr9_mul(fr9_load(g + 2), t));
-        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(ld(2), ld(5))));               // L 4 2^29, S 14.2
-    } else {  // FN_PROJ_L2: (v0 + v1) v3 + g1 v2 v3 + g2 v3^2 + g3 v0 v1
-        V A;
+        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(ld(2), ld(5))));               // S 2.1: L 3 2^29, S 11
+    } else {  // FN_PROJ_L2: (v0 + v1) v3 + g1 v2 v3 + g2 v3^2 + g3 v0 v1 = v3 (v0 + v1 + g1 v2 + g2 v3) + g3 v0 v1
         const V v0 = ld(0), v1 = ld(1);
+        V A;
         {
             const V v3 = ld(3);
-            A = fr9_mul(fr9_add(v0, v1), v3);                                             // 2^30 x 2^29; S 3.8
-            A = fr9_add(A, fr9_mul(fr9_load(g + 1), fr9_mul(ld(2), v3)));
-            A = fr9_add(A, fr9_mul(fr9_load(g + 2), fr9_sqr(v3)));
+            const V u = fr9_add(fr9_add(v0, v1), fr9_add(fr9_mul(fr9_load(g + 1), ld(2)), fr9_mul(fr9_load(g + 2), v3)));   // L 4 2^29 = 2^31, S 31.1
+            A = fr9_mul(v3, u);                                                           // 9 x 2^29 x 2^31 + 2^62 = 2^63.7; S 5.4, domain 251
         }
-        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(v0, v1)));                     // L 4 2^29, S 10.1
+        return fr9_add(A, fr9_mul(fr9_load(g + 3), fr9_mul(v0, v1)));                     // S 2.1: L 2 2^29, S 7.5
     }
 }
 
@@ -2095,10 +2090,10 @@ static const char* sc_class_name(int cls) {
 }
 // Fr multiplications of lean_gamma_eval<PRIM> (one evaluation of the gamma-combined layer function)
 static int lean_eval_muls(int prim) {
-    switch (prim) {
-        case FN_AFF_L1: return 6; case LEAN_AFF_L1_BC: return 10; case FN_AFF_L2: return 3; case FN_AFF_L3: return 6;
-        case FN_PROJ_L1: return 8; case FN_PROJ_L2: return 7; case FN_PROJ_L3: return 6; case FN_ADD_INVERSES: return 2;
-        case FN_LOGUP_LAYER: return 4; case FN_PT_BIT_CHOICE: return 3; default: return 0;
+    switch (prim) {   // after the round-3 re-association (lean_gamma_eval9)
+        case FN_AFF_L1: return 5; case LEAN_AFF_L1_BC: return 9; case FN_AFF_L2: return 3; case FN_AFF_L3: return 5;
+        case FN_PROJ_L1: return 7; case FN_PROJ_L2: return 5; case FN_PROJ_L3: return 5; case FN_ADD_INVERSES: return 2;
+        case FN_LOGUP_LAYER: return 3; case FN_PT_BIT_CHOICE: return 2; default: return 0;
     }
 }
 // returns the record index to close with prof_end, or -1
