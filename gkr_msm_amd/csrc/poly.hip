@@ -194,6 +194,59 @@ __global__ void __launch_bounds__(1024) k_eq_small_pair(EqPairArgs q) {
         __syncthreads();
     }
 }
+// The same sequences with the big levels spread over the chip (round 3).  The doubling structure is a tree: the entries of level i
+// below node b of level T are a function of that node alone, so 2^T workgroups each walk the T multiplications from the root to
+// their node (one lane) and then expand ONLY their subtree through LDS: the last level of a 2^13-entry table is 512 entries per
+// workgroup instead of 8192 in one (38 us -> ~13 us per VecVec layer at config B, 54 layers per proof).  Every entry is computed by
+// the same operations in the same order as in k_eq_small (m = r w, lo = w - m): identical field elements.
+// grid (2^EQ_TOP, number of sequences); workgroup (0, s) also stores the levels 0 .. T of sequence s (<= 2^T entries each) and, for
+// the pair form, workgroup (1, 1) the scalars.
+#define EQ_TOP 4
+__device__ __forceinline__ Fr eq_path_value(const EqSmallArgs& a, uint32_t level, uint32_t node) {
+    Fr w = a.mult;
+    for (uint32_t i = 1; i <= level; i++) {
+        const Fr m = fr_mul(a.pt[i - 1], w);
+        w = ((node >> (level - i)) & 1u) ? m : fr_sub(w, m);
+    }
+    return w;
+}
+__global__ void __launch_bounds__(256) k_eq_small_tree(EqPairArgs q) {
+    __shared__ Fr buf[2][1024];
+    const EqSmallArgs& a = q.a[blockIdx.y];
+    const uint32_t b = blockIdx.x, i0 = threadIdx.x;
+    if (blockIdx.y == 1 && b == 1 && i0 < q.n_scal) fr_store(q.scal_dst + i0, q.scal[i0]);
+    const uint32_t T = a.nlev < EQ_TOP ? a.nlev : EQ_TOP;
+    if (b == 0) {   // the top of the tree: levels 0 .. T, every node from its own path
+        for (uint32_t e = i0; e < (2u << T) - 1u; e += blockDim.x) {
+            uint32_t lv = 0;
+            while ((2u << lv) - 1u <= e) lv++;
+            const uint32_t node = e - ((1u << lv) - 1u);
+            fr_store(a.level[lv] + node, eq_path_value(a, lv, node));
+        }
+    }
+    if (b >= (1u << T) || a.nlev <= T) return;
+    if (i0 == 0) buf[T & 1][0] = eq_path_value(a, T, b);
+    __syncthreads();
+    for (uint32_t i = T + 1; i <= a.nlev; i++) {
+        const uint32_t np = 1u << (i - 1 - T);          // parents of this workgroup at level i - 1
+        const Fr r = a.pt[i - 1];
+        Fr* dst = a.level[i] + ((uint64_t)b << (i - T));
+        for (uint32_t j = i0; j < np; j += blockDim.x) {
+            const Fr w = buf[(i - 1) & 1][j];
+            const Fr m = fr_mul(r, w);
+            const Fr lo = fr_sub(w, m);
+            fr_store(dst + 2 * j, lo);
+            fr_store(dst + 2 * j + 1, m);
+            if (2 * np <= 1024) { buf[i & 1][2 * j] = lo; buf[i & 1][2 * j + 1] = m; }
+        }
+        __syncthreads();
+    }
+}
+static bool eq_tree_enabled() {
+    static const bool v = [] { const char* e = getenv("GM_EQ_TREE"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 // false: does not fit one launch (a sequence longer than EQ_SMALL_LEVELS or too many scalars): use launch_eq_sequence
 bool launch_eq_pair(const Fr& mult0, const Fr* pt0, uint32_t nvars0, Fr* const* levels0, const Fr& mult1, const Fr* pt1, uint32_t nvars1,
                     Fr* const* levels1, const Fr* scal, uint32_t n_scal, Fr* scal_dst, hipStream_t s) {
@@ -208,7 +261,11 @@ bool launch_eq_pair(const Fr& mult0, const Fr* pt0, uint32_t nvars0, Fr* const* 
     for (uint32_t i = 0; i < n_scal; i++) q.scal[i] = scal[i];
     q.scal_dst = scal_dst;
     q.n_scal = n_scal;
-    hipLaunchKernelGGL(k_eq_small_pair, dim3(2), dim3(1024), 0, s, q);
+    // the tree form needs every level's local share to fit its LDS line: nlev - EQ_TOP <= 10
+    if (eq_tree_enabled() && nvars0 <= EQ_TOP + 10 && nvars1 <= EQ_TOP + 10)
+        hipLaunchKernelGGL(k_eq_small_tree, dim3(1u << EQ_TOP, 2), dim3(256), 0, s, q);
+    else
+        hipLaunchKernelGGL(k_eq_small_pair, dim3(2), dim3(1024), 0, s, q);
     return hipGetLastError() == hipSuccess;
 }
 
@@ -220,7 +277,16 @@ int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* con
         a.nlev = small;
         for (uint32_t i = 0; i <= small; i++) a.level[i] = levels[i];
         for (uint32_t i = 0; i < small; i++) a.pt[i] = pt[i];
-        hipLaunchKernelGGL(k_eq_small, dim3(1), dim3(small >= 10 ? 1024 : 256), 0, s, a);
+        if (eq_tree_enabled() && small > EQ_TOP + 2) {
+            EqPairArgs q;
+            q.a[0] = a;
+            q.a[1] = a;
+            q.n_scal = 0;
+            q.scal_dst = nullptr;
+            hipLaunchKernelGGL(k_eq_small_tree, dim3(1u << EQ_TOP, 1), dim3(256), 0, s, q);
+        } else {
+            hipLaunchKernelGGL(k_eq_small, dim3(1), dim3(small >= 10 ? 1024 : 256), 0, s, a);
+        }
         GM_LAUNCH_CHECK();
     }
     for (uint32_t i = small + 1; i <= nvars; i++) {
