@@ -188,7 +188,20 @@ struct FinishCtx {
     uint32_t* counter;   // zero between launches (the last block resets it)
     Fr* out;             // pinned host memory (device-visible); element 7 doubles as the sequence slot
     uint32_t seq;        // written (system scope) after the results: the host polls it instead of a stream sync
+    unsigned long long* acc;   // 3 x 8 limb accumulators (64-bit, one 128-byte line each), zero between launches; grids of <= 512 blocks
+                               // add their block sums into them with atomics instead of storing partials (see k_stage's exchange)
 };
+#define FINISH_ATOMIC_MAX_BLOCKS 512u
+// V = sum of <= 512 canonical field elements given as eight 64-bit limb sums (low words lo, bits 32.. hi): V mod p
+__device__ __forceinline__ Fr limb_sums_mod_p(const uint32_t* lo8, const uint32_t* hi8) {
+    Fr lo, hi, c32;
+#pragma unroll
+    for (int l = 0; l < 8; l++) { lo.l[l] = lo8[l]; hi.l[l] = hi8[l]; }
+    // 2^32 in Montgomery form (2^32 R mod p): hi < 2^233 < p is a canonical operand, lo < 2^256 < 2.21 p needs two conditional subtractions
+    c32.l[0] = 0xcaaf6b13u; c32.l[1] = 0x355094eau; c32.l[2] = 0x69a568efu; c32.l[3] = 0xf6b10cb3u;
+    c32.l[4] = 0x40cc3869u; c32.l[5] = 0xe2c926a6u; c32.l[6] = 0xed269aadu; c32.l[7] = 0x736a6d3bu;
+    return fr_add(fr_reduce_once(fr_reduce_once(lo)), fr_mul(hi, c32));
+}
 
 // sum of `v` over the 64 lanes of the wave; the result is valid in lane 0
 __device__ __forceinline__ Fr wave_sum(Fr v) {
@@ -227,6 +240,40 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
     __shared__ uint32_t is_last;
     const uint32_t nblk = gridDim.x * gridDim.y;
     const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (fc.acc && nblk <= FINISH_ATOMIC_MAX_BLOCKS) {
+        // small and medium grids: no second pass over stored partials (they are what a latency-bound round waits for)
+        __shared__ uint32_t s_lo[8 * NACC], s_hi[8 * NACC];
+        const Fr tot = block_sum<NACC>(acc, red);
+        if (threadIdx.x < NACC) {
+#pragma unroll
+            for (int l = 0; l < 8; l++)
+                (void)__hip_atomic_fetch_add(fc.acc + (threadIdx.x * 8 + l) * 16, (unsigned long long)tot.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            coh_drain();
+        }
+        __syncthreads();   // this block's additions have been performed before the counter moves
+        if (threadIdx.x == 0) {
+            const uint32_t prev = __hip_atomic_fetch_add(fc.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = (prev == nblk - 1) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!is_last) return;
+        if (threadIdx.x < 8 * NACC) {
+            const unsigned long long v = __hip_atomic_exchange(fc.acc + threadIdx.x * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_lo[threadIdx.x] = (uint32_t)v;
+            s_hi[threadIdx.x] = (uint32_t)(v >> 32);
+        }
+        __syncthreads();
+        if (threadIdx.x < NACC) {
+            coh_store_sys(fc.out + threadIdx.x, limb_sums_mod_p(s_lo + 8 * threadIdx.x, s_hi + 8 * threadIdx.x));
+            coh_drain();
+        }
+        __syncthreads();  // the results have reached host memory before the sequence word is written
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(fc.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(fc.out + 7), fc.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     {
         const Fr tot = block_sum<NACC>(acc, red);
         // hand-off without cache-wide fences (see the coherent helpers above): write-through stores, drained, then the counter
@@ -503,6 +550,7 @@ struct StageArgs {
     uint32_t* d_merge;                 // device: one arrival counter per blockIdx.x (zeroed before the launch)
     uint32_t ticket0;
     uint64_t timeout_ticks;
+    unsigned long long* d_acc;         // device: per round 3 sums x 8 limb accumulators (64-bit, one 128-byte line each), zero between launches
     uint32_t* d_arrive;                // device: residency barrier -- cumulative count of blocks that have started (bit 31: a launch gave up)
     uint32_t arrive_target;            // ... value it has once every block of THIS launch is resident
     uint64_t resident_ticks;           // ... how long a block waits for the others before the launch is abandoned (100 MHz ticks)
@@ -589,7 +637,7 @@ template <int MAXIN>
 __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const Fr* __restrict__ gp, StageArgs a) {
     __shared__ Fr xch[MAXIN][256];
     __shared__ Fr red[4][2];
-    __shared__ Fr red3[4][3];
+    __shared__ uint32_t acc_lo[24], acc_hi[24];
     __shared__ Fr ts;
     __shared__ int ok;
     __shared__ uint32_t is_last;
@@ -649,44 +697,49 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
         __syncthreads();
         const uint32_t want = a.ticket0 + round;
         STAGE_STAMP(2);
+        // Cross-block sum without a second pass over the partials: every block adds the eight 32-bit limbs of its (canonical) sum to
+        // eight 64-bit accumulators of the round (no-return atomics: < 2^40 after 256 blocks), each in a 128-byte line of its own so
+        // that the atomics of one value spread over L2 channels; the block that arrives last swaps the accumulators out (leaving
+        // zeros for the next launch) and reduces V = L + 2^32 H mod p -- L the low words (< 2.21 p: two conditional subtractions), H the
+        // high bytes (< 2^232: one Montgomery product with 2^32) -- three lanes, one per sum, in parallel.  Sums of integers: the same
+        // field elements as a chain of fr_add.  (Before: every block stored its partial, the last block loaded all of them and ran
+        // three wave reductions: ~4.5 us per round against ~2.)
+        unsigned long long* accb = a.d_acc + (size_t)round * (3 * 8 * 16);
         if (i == 0) {
             const Fr t0 = fr_add(fr_add(red[0][0], red[1][0]), fr_add(red[2][0], red[3][0]));
-            const Fr t1 = fr_add(fr_add(red[0][1], red[1][1]), fr_add(red[2][1], red[3][1]));
-            // hand-off without cache-wide fences: device-coherent (sc1) stores, drained, then the counter; the reader uses
-            // device-coherent loads (a release / acquire pair would write back and invalidate the whole L2 every round)
-            coh_store_dev(a.d_part + 2 * blk, t0);
-            if (thin) coh_store_dev(a.d_part + 2 * blk + 1, t1);
-            coh_drain();
+            const uint32_t which = blockIdx.x & 1u;
+#pragma unroll
+            for (int l = 0; l < 8; l++)
+                (void)__hip_atomic_fetch_add(accb + (which * 8 + l) * 16, (unsigned long long)t0.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (with_w) {
+                const Fr t1 = fr_add(fr_add(red[0][1], red[1][1]), fr_add(red[2][1], red[3][1]));
+#pragma unroll
+                for (int l = 0; l < 8; l++)
+                    (void)__hip_atomic_fetch_add(accb + (16 + l) * 16, (unsigned long long)t1.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            coh_drain();   // the additions have been performed before the counter moves
             const uint32_t prev = __hip_atomic_fetch_add(a.d_round_cnt + round, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             is_last = (prev == nrep - 1) ? 1u : 0u;
         }
         __syncthreads();
         STAGE_STAMP(3);
         if (is_last) {
-            // the block that arrived last adds the partials up per evaluation point and reports; all four waves load (one or two
-            // partials per thread: the loads of a lane are dependent round trips), then wave sums and one pass over the wave totals.
-            // It also leaves the round's counter at zero for the next launch (the state buffer is never memset).
+            // It also leaves the round's counter and accumulators at zero for the next launch (the state buffer is never memset).
             if (i == 0) __hip_atomic_store(a.d_round_cnt + round, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            Fr r0 = fr_zero(), r1 = fr_zero(), rw = fr_zero();   // sums at point 1, at point 2, tail weight
-            for (uint32_t b2 = i; b2 < nrep; b2 += 256) {
-                const Fr v = coh_load_dev(a.d_part + 2 * b2);
-                if ((b2 % gridDim.x) & 1) r1 = fr_add(r1, v); else r0 = fr_add(r0, v);
-                if (thin && (b2 % gridDim.x) == 0) rw = fr_add(rw, coh_load_dev(a.d_part + 2 * b2 + 1));
+            const uint32_t nacc = thin ? 24u : 16u;
+            if (i < nacc) {
+                const unsigned long long v = __hip_atomic_exchange(accb + i * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc_lo[i] = (uint32_t)v;
+                acc_hi[i] = (uint32_t)(v >> 32);
             }
-            r0 = wave_sum(r0);
-            r1 = wave_sum(r1);
-            if (thin) rw = wave_sum(rw);
-            if (lane == 0) { red3[wave][0] = r0; red3[wave][1] = r1; red3[wave][2] = rw; }
             __syncthreads();   // is_last is uniform over the block
-            if (i == 0) {
-                r0 = fr_add(fr_add(red3[0][0], red3[1][0]), fr_add(red3[2][0], red3[3][0]));
-                r1 = fr_add(fr_add(red3[0][1], red3[1][1]), fr_add(red3[2][1], red3[3][1]));
-                if (thin) rw = fr_add(fr_add(red3[0][2], red3[1][2]), fr_add(red3[2][2], red3[3][2]));
+            if (i < 3) {
+                Fr out = fr_zero();
+                if (i < 2 || thin) {
+                    out = limb_sums_mod_p(acc_lo + 8 * i, acc_hi + 8 * i);
+                }
                 // report slot of this round: a slot is rewritten two rounds later, after the host has read it
-                uint32_t* dst = a.h_rep + 36 * (round & 1);
-                fr_chunks_store_sys(dst, r0, want);
-                fr_chunks_store_sys(dst + 12, r1, want);
-                fr_chunks_store_sys(dst + 24, rw, want);
+                fr_chunks_store_sys(a.h_rep + 36 * (round & 1) + 12 * i, out, want);
             }
         }
         STAGE_STAMP(4);
@@ -1464,7 +1517,7 @@ struct gm_sc {
 namespace {
 
 struct RoundScratch {
-    DevBuf partial, counter;
+    DevBuf partial, counter, accbuf;
     Fr* h_result = nullptr;  // pinned, device-visible
     bool own_pinned = false;
     int32_t init(hipStream_t s) {
@@ -1473,6 +1526,9 @@ struct RoundScratch {
         rc = counter.alloc(256);  // [0] last-block counter, [64..96) the device copy of a pre-enqueued fold's challenge,
         if (rc) return rc;        // [128..224) the relay of k_tail_rounds
         GM_HIP(hipMemsetAsync(counter.p, 0, 256, s));
+        rc = accbuf.alloc(24 * 128);   // the limb accumulators of block_reduce_finish (3 sums x 8 limbs, one line each)
+        if (rc) return rc;
+        GM_HIP(hipMemsetAsync(accbuf.p, 0, 24 * 128, s));
         if (shared_pinned()) {
             h_result = shared_pinned();
             own_pinned = false;
@@ -1494,7 +1550,8 @@ struct RoundScratch {
     FinishCtx ctx() {
         expect = ++seq_counter();
         if (expect == 0) expect = ++seq_counter();
-        return FinishCtx{partial.fr(), reinterpret_cast<uint32_t*>(counter.p), h_result, expect};
+        return FinishCtx{partial.fr(), reinterpret_cast<uint32_t*>(counter.p), h_result, expect,
+                         reinterpret_cast<unsigned long long*>(accbuf.p)};
     }
     // ---- sharded rounds over a device-side collective (see k_sum_ranks)
     DevBuf xslot, xall;
@@ -1612,6 +1669,8 @@ struct TailStage {
     // device state of the launches of this host thread on this device (never memset: the kernel leaves its counters at zero, tags
     // are unique)
     uint32_t* d_state = nullptr;
+    unsigned long long* d_acc = nullptr;   // the rounds' limb accumulators (k_stage's exchange): 32 rounds x 24 lines of 128 bytes
+    static constexpr size_t ACC_BYTES = (size_t)32 * 24 * 128;
     bool d_state_dirty = true;
     uint32_t arrive_total = 0;   // blocks counted in by the residency barrier since the state was last zeroed
     static constexpr size_t BYTES = 1024 + 32 * GM_MAX_COLS * sizeof(Fr) + (size_t)GM_MAX_SEGS * STAGE_MAX_SLICES * 4;
@@ -1803,11 +1862,13 @@ struct StageRun {
         // A launch that was aborted (time-out, failing transcript) may leave counters behind: the next launch zeroes again.
         if (!st->d_state) {
             GM_HIP(hipMalloc((void**)&st->d_state, TailStage::STATE_BYTES));
+            GM_HIP(hipMalloc((void**)&st->d_acc, TailStage::ACC_BYTES));
             st->d_state_dirty = true;
         }
         if (st->arrive_total > 0x40000000u) st->d_state_dirty = true;   // the cumulative arrival count stays far below bit 31
         if (st->d_state_dirty) {
             GM_HIP(hipMemsetAsync(st->d_state, 0, TailStage::STATE_BYTES, s));
+            GM_HIP(hipMemsetAsync(st->d_acc, 0, TailStage::ACC_BYTES, s));
             st->d_state_dirty = false;
             st->arrive_total = 0;
         }
@@ -1818,6 +1879,7 @@ struct StageRun {
         a.d_round_cnt = reinterpret_cast<uint32_t*>(state_p) + 32;
         a.d_merge = reinterpret_cast<uint32_t*>(state_p) + 64;
         a.d_arrive = reinterpret_cast<uint32_t*>(state_p) + TailStage::ARRIVE_WORD;
+        a.d_acc = st->d_acc;
         a.d_part = dpart.fr();
         a.d_xbuf = xbuf.fr();
         if (debug()) {
