@@ -546,6 +546,8 @@ struct StageArgs {
     const uint32_t* h_tkt;             // pinned: the host publishes t_r as three chunks tagged ticket0 + r at 12 (r & 1) words
     uint32_t* h_status;
     uint32_t* d_relay;                 // device: the relayed challenge of round r as three chunks at 12 (r & 1) words
+    const uint32_t* d_tkt_bar;         // fine-grained DEVICE memory the host writes t_r into directly (large BAR), same layout as h_tkt; nullptr:
+                                       // block 0 polls h_tkt over PCIe and relays through d_relay
     Fr* d_xbuf;                        // device: hand-over of the slices' last elements, [gridDim.x][6][STAGE_MAX_SLICES]
     uint32_t* d_merge;                 // device: one arrival counter per blockIdx.x (zeroed before the launch)
     uint32_t ticket0;
@@ -747,7 +749,16 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
             int good = 0;
             Fr t = fr_zero();
             const uint64_t t_begin = wall_clock64();
-            if (blk == 0) {
+            if (a.d_tkt_bar) {
+                // the host stores the challenge straight into device memory: every block polls it there -- no PCIe read, no relay hop
+                const uint32_t* src = a.d_tkt_bar + 12 * (round & 1);
+                for (uint32_t it = 0;; it++) {
+                    if ((it & 255u) == 255u && wall_clock64() - t_begin > a.timeout_ticks) break;
+                    if (fr_chunks_load<true>(src, &t, want, a.ticket0 + 0x4000u)) { good = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!good && blk == 0) __hip_atomic_store(a.h_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else if (blk == 0) {
                 const uint32_t* src = a.h_tkt + 12 * (round & 1);
                 for (uint32_t it = 0;; it++) {   // polling over PCIe until the bound: a slow (interpreted, traced) transcript is fine
                     if ((it & 255u) == 255u && wall_clock64() - t_begin > a.timeout_ticks) break;
@@ -1669,6 +1680,8 @@ struct TailStage {
     // device state of the launches of this host thread on this device (never memset: the kernel leaves its counters at zero, tags
     // are unique)
     uint32_t* d_state = nullptr;
+    uint32_t* tkt_bar = nullptr;            // 256 bytes of fine-grained device memory the host writes challenges into (large BAR), or nullptr
+    bool tkt_bar_tried = false;
     unsigned long long* d_acc = nullptr;   // the rounds' limb accumulators (k_stage's exchange): 32 rounds x 24 lines of 128 bytes
     static constexpr size_t ACC_BYTES = (size_t)32 * 24 * 128;
     bool d_state_dirty = true;
@@ -1865,6 +1878,30 @@ struct StageRun {
             GM_HIP(hipMalloc((void**)&st->d_acc, TailStage::ACC_BYTES));
             st->d_state_dirty = true;
         }
+        if (!st->tkt_bar_tried) {
+            // Challenges straight into device memory when the device exposes it to the host (large BAR) and a probe write arrives;
+            // GM_STAGE_BAR=0 keeps the PCIe-poll + relay scheme (A/B, and the fall-back wherever the probe fails)
+            st->tkt_bar_tried = true;
+            static const bool off = [] { const char* e = getenv("GM_STAGE_BAR"); return e && e[0] == '0'; }();
+            int large_bar = 0, dev_ = 0;
+            (void)hipGetDevice(&dev_);
+            if (!off && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_) == hipSuccess && large_bar) {
+                uint32_t* p = nullptr;
+                if (hipExtMallocWithFlags((void**)&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && p) {
+                    bool good = hipMemset(p, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                    if (good) {
+                        reinterpret_cast<volatile uint32_t*>(p)[40] = 0x5eed1234u;   // probe: a host store the device must see
+                        _mm_sfence();
+                        uint32_t back = 0;
+                        good = hipMemcpy(&back, p + 40, 4, hipMemcpyDeviceToHost) == hipSuccess && back == 0x5eed1234u;
+                        reinterpret_cast<volatile uint32_t*>(p)[40] = 0;
+                        _mm_sfence();
+                    }
+                    if (good) st->tkt_bar = p; else (void)hipFree(p);
+                }
+                (void)hipGetLastError();
+            }
+        }
         if (st->arrive_total > 0x40000000u) st->d_state_dirty = true;   // the cumulative arrival count stays far below bit 31
         if (st->d_state_dirty) {
             GM_HIP(hipMemsetAsync(st->d_state, 0, TailStage::STATE_BYTES, s));
@@ -1875,6 +1912,7 @@ struct StageRun {
         void* state_p = st->d_state;
         a.h_rep = st->rep(); a.h_finals = st->finals(); a.h_fin_seq = st->fin_seq();
         a.h_tkt = st->tkt(); a.h_status = st->status();
+        a.d_tkt_bar = st->tkt_bar;
         a.d_relay = reinterpret_cast<uint32_t*>(state_p);
         a.d_round_cnt = reinterpret_cast<uint32_t*>(state_p) + 32;
         a.d_merge = reinterpret_cast<uint32_t*>(state_p) + 64;
@@ -1976,7 +2014,12 @@ struct StageRun {
         }
     }
     void publish(int r, const Fr& t) {
-        write_chunks(st->tkt() + 12 * (r & 1), t, ticket0 + (uint32_t)r);
+        if (st->tkt_bar) {
+            write_chunks(st->tkt_bar + 12 * (r & 1), t, ticket0 + (uint32_t)r);
+            _mm_sfence();   // device memory is mapped write-combining on the host: push the three stores out now
+        } else {
+            write_chunks(st->tkt() + 12 * (r & 1), t, ticket0 + (uint32_t)r);
+        }
         published = r + 1;
     }
     // elements per column the launch leaves behind (1 = the final evaluations) and the slices that hold them
@@ -2004,8 +2047,10 @@ struct StageRun {
     ~StageRun() {
         if (launched && st && published < total()) {   // never leave waiting blocks behind: the release tag lets every wait of this launch through
             st->d_state_dirty = true;
-            write_chunks(st->tkt(), fr_zero(), ticket0 + 0x4000u);
-            write_chunks(st->tkt() + 12, fr_zero(), ticket0 + 0x4000u);
+            uint32_t* tk = st->tkt_bar ? st->tkt_bar : st->tkt();
+            write_chunks(tk, fr_zero(), ticket0 + 0x4000u);
+            write_chunks(tk + 12, fr_zero(), ticket0 + 0x4000u);
+            _mm_sfence();
             (void)hipStreamSynchronize(stream);
         }
         // every block is past its last wait (the finals were collected, or the release tag let them through)
