@@ -3177,6 +3177,9 @@ struct ScVecVecDeg2 : gm_sc {
             d->claim_ = claim_next;
             d->cols.k = k;
             d->cols.cur.assign(k, nullptr);
+            // 1 / (1 - point_j) of the vertical coordinates: already inverted with the row coordinates (a field inversion costs the
+            // host ~15 us, and this is the moment every block of the launch is waiting for the next challenge)
+            if (inv_eq0.size() >= col_logsize) d->inv_eq0.assign(inv_eq0.begin(), inv_eq0.begin() + col_logsize);
             d->adopt_stage(stage);
             dense2 = std::move(d);
             return GM_OK;
@@ -3325,6 +3328,7 @@ int32_t ScVecVecDeg2::bind_into_dense_deg2(const Fr& t) {
     d->point.assign(point.begin(), point.begin() + col_logsize);
     d->multiplier = fr_mul(multiplier, eq_bind_factor(point[binding_var_idx], t));  // vecvec_eq.rs:177-180
     d->claim_ = evaluate_univar(cached, t);
+    if (inv_eq0.size() >= col_logsize) d->inv_eq0.assign(inv_eq0.begin(), inv_eq0.begin() + col_logsize);
     const uint32_t nd = sh.comm ? nrows : (1u << col_logsize);  // sharded: this rank's slice of the rows
     std::vector<const Fr*> cptr;
     ColPtrs ci;
@@ -3414,6 +3418,7 @@ extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, co
     if (rc) return rc;
     rc = so->rs.init(so->stream);
     if (rc) return rc;
+    so->inv_eq0 = batch_inv_one_minus(so->point);   // now, while the device builds the eq tables: not when the first round's sums are in
     *out = so.release();
     return GM_OK;
 }
@@ -3557,6 +3562,7 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
     }
     rc = so->rs.init(so->stream);
     if (rc) return rc;
+    so->inv_eq0 = batch_inv_one_minus(so->point);   // see gm_sc_dense_deg2_create
     *out = so.release();
     return GM_OK;
 }
