@@ -61,8 +61,34 @@ static const std::vector<std::vector<Fr>>& lagrange_matrix(int n) {
     return M;
 }
 
+// inverses of 2 and 6 (Montgomery), once per thread
+static const Fr& inv_small(int which) {
+    static thread_local Fr v[2];
+    static thread_local bool have = false;
+    if (!have) { v[0] = fr_inv(fr_from_u64(2)); v[1] = fr_inv(fr_from_u64(6)); have = true; }
+    return v[which];
+}
+
 std::vector<Fr> unipoly_from_evals(const std::vector<Fr>& evals) {
     const int n = (int)evals.size();
+    if (n == 4) {
+        // the degree-3 case of every eq-factored round (from12): Newton / finite differences instead of the 4 x 4 matrix --
+        // 3 products by constants where the matrix spends 16; the same coefficients (unique interpolation, exact arithmetic):
+        //   c3 = (e3 - 3 e2 + 3 e1 - e0) / 6,  c2 = (-e3 + 4 e2 - 5 e1 + 2 e0) / 2,  c1 = (2 e3 - 9 e2 + 18 e1 - 11 e0) / 6,  c0 = e0
+        const Fr &e0 = evals[0], &e1 = evals[1], &e2 = evals[2], &e3 = evals[3];
+        auto x2 = [](const Fr& a) { return fr_dbl(a); };
+        auto x3 = [](const Fr& a) { return fr_add(fr_dbl(a), a); };
+        const Fr d1 = fr_sub(e1, e0), d2 = fr_sub(e2, e1), d3 = fr_sub(e3, e2);          // first differences
+        const Fr s1 = fr_sub(d2, d1), s2 = fr_sub(d3, d2);                                // second differences
+        const Fr t3 = fr_sub(s2, s1);                                                     // third difference = 6 c3
+        const Fr c3 = fr_mul(t3, inv_small(1));
+        // p(x) = e0 + d1 x + s1 x (x - 1) / 2 + t3 x (x - 1) (x - 2) / 6
+        //      = e0 + (d1 - s1 / 2 + t3 / 3) x + (s1 / 2 - t3 / 2) x^2 + (t3 / 6) x^3
+        const Fr c2 = fr_mul(fr_sub(s1, t3), inv_small(0));
+        const Fr c1 = fr_add(fr_sub(d1, fr_mul(s1, inv_small(0))), x2(c3));              // t3 / 3 = 2 c3
+        (void)x3;
+        return std::vector<Fr>{e0, c1, c2, c3};
+    }
     const std::vector<std::vector<Fr>>& M = lagrange_matrix(n);
     std::vector<Fr> coeffs(n, fr_zero());
     for (int i = 0; i < n; i++)
@@ -2921,7 +2947,7 @@ struct ScVecVecDeg2 : gm_sc {
     DevBuf d_gamma, d_row_coef, d_eq_seq, d_prefix;
     std::vector<uint64_t> eq_level_off;  // offset of level i of the padded eq sequence inside d_eq_seq
     std::vector<uint32_t> eq_level_len;
-    std::vector<Fr> row_coef_tail;       // row_eq_coefs_tail_sums (host)
+    Fr row_coef_tail_nrows = fr_zero();  // row_eq_coefs_tail_sums[nrows] (host): the only entry the rounds read
     RoundScratch rs;
     Fr claim_, multiplier;
     std::vector<Fr> cached, inv_eq0;
@@ -3037,7 +3063,7 @@ struct ScVecVecDeg2 : gm_sc {
             colsum = fr_add(colsum, o == 0 ? pc[o] : fr_mul(pc[o], gamma_pows[o]));
         }
         Fr extra = fr_mul(padsum, w[0]);
-        if (!sh.comm && nrows < (1u << col_logsize)) extra = fr_add(extra, fr_mul(colsum, row_coef_tail[nrows]));
+        if (!sh.comm && nrows < (1u << col_logsize)) extra = fr_add(extra, fr_mul(colsum, row_coef_tail_nrows));
         const Fr total1 = fr_mul(fr_add(acc[0], extra), multiplier);
         const Fr total2 = fr_mul(fr_add(acc[1], extra), multiplier);
         if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);
@@ -3515,8 +3541,7 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         lv[polys->col_logsize] = so->d_row_coef.fr();
         row_lv = lv;   // launched below, together with the padded row sequence
         // row_eq_coefs_tail_sums[nrows] = sum_{j >= nrows} eq(point[0..col], j) = 1 - eq_sum(point[0..col], nrows)
-        so->row_coef_tail.assign(((size_t)1 << polys->col_logsize) + 1, fr_zero());
-        so->row_coef_tail[so->nrows] = fr_sub(fr_one(), eq_sum_host(so->point.data(), polys->col_logsize, so->nrows));
+        so->row_coef_tail_nrows = fr_sub(fr_one(), eq_sum_host(so->point.data(), polys->col_logsize, so->nrows));   // (a 2^col-entry host vector was zero-filled here for this one entry: 262 KB per layer at config B)
     }
     // padded_eq_poly_sequence(padded, point[row vars])  (utils.rs:189-220): levels 0..n_seq_vars
     {
