@@ -13,10 +13,13 @@ int32_t launch_dense_map(const SegPlan& sp, const Fr* const* in, Fr* const* out,
 int32_t launch_dense_map_split(const SegPlan& sp, const Fr* const* in, Fr* const* out, uint64_t n, uint32_t lo_bit,
                                uint32_t bundle, hipStream_t s);
 int32_t launch_dense_fold(const Fr* const* in, Fr* const* out, int k, uint64_t n_out, const Fr& t, hipStream_t s);
-int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s);
+// extra: up to 16 field elements the same launch stores at extra_dst (a layer's gamma powers: one launch less)
+int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s, const Fr* extra = nullptr,
+                           uint32_t n_extra = 0, Fr* extra_dst = nullptr);
 // two small sequences + a few scalars in one launch (poly.hip); false = does not fit, use launch_eq_sequence
 bool launch_eq_pair(const Fr& mult0, const Fr* pt0, uint32_t nvars0, Fr* const* levels0, const Fr& mult1, const Fr* pt1, uint32_t nvars1,
-                    Fr* const* levels1, const Fr* scal, uint32_t n_scal, Fr* scal_dst, hipStream_t s);
+                    Fr* const* levels1, const Fr* scal, uint32_t n_scal, Fr* scal_dst, hipStream_t s, const Fr* extra = nullptr,
+                    uint32_t n_extra = 0, Fr* extra_dst = nullptr);
 
 int32_t launch_offsets_next(const uint32_t* off_in, uint32_t* off_out, uint32_t nrows, hipStream_t s);
 int32_t launch_offsets_all_from_off(const uint32_t* off0, uint32_t* off_all, uint32_t nrows, uint32_t nlevels, hipStream_t s);

@@ -1195,7 +1195,8 @@ __global__ void __launch_bounds__(256) k_pull(const uint16_t* __restrict__ dg, c
     fr_store(c_pull + i, fr_load(eq_c + ct[i]));
 }
 
-int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s);
+int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s, const Fr* extra = nullptr,
+                           uint32_t n_extra = 0, Fr* extra_dst = nullptr);
 
 }  // namespace gm
 

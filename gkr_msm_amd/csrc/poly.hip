@@ -172,11 +172,15 @@ struct EqPairArgs {
     Fr scal[16];
     Fr* scal_dst;
     uint32_t n_scal;
+    Fr extra[16];     // e.g. the layer's gamma powers: stored by workgroup (2, 0) of the tree form / workgroup 0 of the pair form
+    Fr* extra_dst;
+    uint32_t n_extra;
 };
 __global__ void __launch_bounds__(1024) k_eq_small_pair(EqPairArgs q) {
     __shared__ Fr buf[2][1024];
     const EqSmallArgs& a = q.a[blockIdx.x];
     if (blockIdx.x == 1 && threadIdx.x < q.n_scal) fr_store(q.scal_dst + threadIdx.x, q.scal[threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x < q.n_extra) fr_store(q.extra_dst + threadIdx.x, q.extra[threadIdx.x]);
     if (threadIdx.x == 0) { fr_store(a.level[0], a.mult); buf[0][0] = a.mult; }
     __syncthreads();
     for (uint32_t i = 1; i <= a.nlev; i++) {
@@ -215,6 +219,7 @@ __global__ void __launch_bounds__(256) k_eq_small_tree(EqPairArgs q) {
     const EqSmallArgs& a = q.a[blockIdx.y];
     const uint32_t b = blockIdx.x, i0 = threadIdx.x;
     if (blockIdx.y == 1 && b == 1 && i0 < q.n_scal) fr_store(q.scal_dst + i0, q.scal[i0]);
+    if (blockIdx.y == 0 && b == 2 && i0 < q.n_extra) fr_store(q.extra_dst + i0, q.extra[i0]);
     const uint32_t T = a.nlev < EQ_TOP ? a.nlev : EQ_TOP;
     if (b == 0) {   // the top of the tree: levels 0 .. T, every node from its own path
         for (uint32_t e = i0; e < (2u << T) - 1u; e += blockDim.x) {
@@ -242,6 +247,9 @@ __global__ void __launch_bounds__(256) k_eq_small_tree(EqPairArgs q) {
         __syncthreads();
     }
 }
+__global__ void __launch_bounds__(64) k_store_extra(EqPairArgs q) {
+    if (threadIdx.x < q.n_extra) fr_store(q.extra_dst + threadIdx.x, q.extra[threadIdx.x]);
+}
 static bool eq_tree_enabled() {
     static const bool v = [] { const char* e = getenv("GM_EQ_TREE"); return !(e && e[0] == '0'); }();
     return v;
@@ -249,8 +257,9 @@ static bool eq_tree_enabled() {
 
 // false: does not fit one launch (a sequence longer than EQ_SMALL_LEVELS or too many scalars): use launch_eq_sequence
 bool launch_eq_pair(const Fr& mult0, const Fr* pt0, uint32_t nvars0, Fr* const* levels0, const Fr& mult1, const Fr* pt1, uint32_t nvars1,
-                    Fr* const* levels1, const Fr* scal, uint32_t n_scal, Fr* scal_dst, hipStream_t s) {
-    if (nvars0 > EQ_SMALL_LEVELS || nvars1 > EQ_SMALL_LEVELS || n_scal > 16) return false;
+                    Fr* const* levels1, const Fr* scal, uint32_t n_scal, Fr* scal_dst, hipStream_t s, const Fr* extra, uint32_t n_extra,
+                    Fr* extra_dst) {
+    if (nvars0 > EQ_SMALL_LEVELS || nvars1 > EQ_SMALL_LEVELS || n_scal > 16 || n_extra > 16) return false;
     EqPairArgs q;
     q.a[0].mult = mult0; q.a[0].nlev = nvars0;
     for (uint32_t i = 0; i <= nvars0; i++) q.a[0].level[i] = levels0[i];
@@ -261,6 +270,9 @@ bool launch_eq_pair(const Fr& mult0, const Fr* pt0, uint32_t nvars0, Fr* const* 
     for (uint32_t i = 0; i < n_scal; i++) q.scal[i] = scal[i];
     q.scal_dst = scal_dst;
     q.n_scal = n_scal;
+    for (uint32_t i = 0; i < n_extra; i++) q.extra[i] = extra[i];
+    q.extra_dst = extra_dst;
+    q.n_extra = n_extra;
     // the tree form needs every level's local share to fit its LDS line: nlev - EQ_TOP <= 10
     if (eq_tree_enabled() && nvars0 <= EQ_TOP + 10 && nvars1 <= EQ_TOP + 10)
         hipLaunchKernelGGL(k_eq_small_tree, dim3(1u << EQ_TOP, 2), dim3(256), 0, s, q);
@@ -269,8 +281,10 @@ bool launch_eq_pair(const Fr& mult0, const Fr* pt0, uint32_t nvars0, Fr* const* 
     return hipGetLastError() == hipSuccess;
 }
 
-int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s) {
+int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* const* levels, hipStream_t s, const Fr* extra, uint32_t n_extra,
+                           Fr* extra_dst) {
     const uint32_t small = nvars < EQ_SMALL_LEVELS ? nvars : EQ_SMALL_LEVELS;
+    bool extra_done = n_extra == 0;
     {
         EqSmallArgs a;
         a.mult = mult;
@@ -283,11 +297,31 @@ int32_t launch_eq_sequence(const Fr& mult, const Fr* pt, uint32_t nvars, Fr* con
             q.a[1] = a;
             q.n_scal = 0;
             q.scal_dst = nullptr;
+            q.n_extra = 0;
+            q.extra_dst = nullptr;
+            if (!extra_done && n_extra <= 16) {
+                for (uint32_t i = 0; i < n_extra; i++) q.extra[i] = extra[i];
+                q.extra_dst = extra_dst;
+                q.n_extra = n_extra;
+                extra_done = true;
+            }
             hipLaunchKernelGGL(k_eq_small_tree, dim3(1u << EQ_TOP, 1), dim3(256), 0, s, q);
         } else {
             hipLaunchKernelGGL(k_eq_small, dim3(1), dim3(small >= 10 ? 1024 : 256), 0, s, a);
         }
         GM_LAUNCH_CHECK();
+    }
+    if (!extra_done) {   // no tree launch to ride on: a launch of its own
+        for (uint32_t base = 0; base < n_extra; base += 16) {
+            EqPairArgs q;
+            q.a[0].nlev = 0; q.a[1].nlev = 0;
+            q.n_scal = 0; q.scal_dst = nullptr;
+            q.n_extra = n_extra - base < 16 ? n_extra - base : 16;
+            for (uint32_t i = 0; i < q.n_extra; i++) q.extra[i] = extra[base + i];
+            q.extra_dst = extra_dst + base;
+            hipLaunchKernelGGL(k_store_extra, dim3(1), dim3(64), 0, s, q);
+            GM_LAUNCH_CHECK();
+        }
     }
     for (uint32_t i = small + 1; i <= nvars; i++) {
         const uint64_t np = 1ull << (i - 1);
@@ -348,5 +382,5 @@ extern "C" int32_t gm_eq_table(const uint64_t* h_multiplier, const uint64_t* h_p
     Fr* sc = reinterpret_cast<Fr*>(d_scratch);
     for (uint32_t i = 0; i < nvars; i++) lv[i] = sc + ((1ull << i) - 1);
     lv[nvars] = reinterpret_cast<Fr*>(d_out);
-    return launch_eq_sequence(mult, pt, nvars, lv, as_stream(stream));
+    return launch_eq_sequence(mult, pt, nvars, lv, as_stream(stream), nullptr, 0, nullptr);
 }

@@ -1554,18 +1554,38 @@ struct gm_sc {
 namespace {
 
 struct RoundScratch {
-    DevBuf partial, counter, accbuf;
+    DevBuf partial;
+    // the arrival counter (+ the device copy of a pre-enqueued fold's challenge) and the limb accumulators: a few hundred bytes that
+    // every kernel leaves at zero -- kept per (host thread, device) for the life of the process instead of allocated and memset per
+    // object (two fill launches per layer, ~9 us of a late layer's ~45 us of set-up).  One thread = one stream: the objects of a
+    // thread that are alive together (a VecVec object and its dense stage, the two lock-step objects of the pushforward argument)
+    // run their kernels one after the other.
+    struct Persistent { void* p = nullptr; };
+    struct CounterView { void* p = nullptr; } counter, accbuf;
+    static int32_t persistent(void** counter_p, void** acc_p) {
+        static thread_local Persistent per_dev[16];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        Persistent& e = per_dev[(dev >= 0 && dev < 16) ? dev : 0];
+        if (!e.p) {
+            GM_HIP(hipMalloc(&e.p, 256 + 24 * 128));
+            GM_HIP(hipMemset(e.p, 0, 256 + 24 * 128));
+            GM_HIP(hipDeviceSynchronize());   // once per thread and device: the zeros are in place before any stream uses them
+        }
+        *counter_p = e.p;
+        *acc_p = static_cast<char*>(e.p) + 256;
+        return GM_OK;
+    }
     Fr* h_result = nullptr;  // pinned, device-visible
     bool own_pinned = false;
     int32_t init(hipStream_t s) {
         int32_t rc = partial.alloc((size_t)SC_MAX_BLOCKS * 3 * sizeof(Fr));
         if (rc) return rc;
-        rc = counter.alloc(256);  // [0] last-block counter, [64..96) the device copy of a pre-enqueued fold's challenge,
-        if (rc) return rc;        // [128..224) the relay of k_tail_rounds
-        GM_HIP(hipMemsetAsync(counter.p, 0, 256, s));
-        rc = accbuf.alloc(24 * 128);   // the limb accumulators of block_reduce_finish (3 sums x 8 limbs, one line each)
+        // counter: [0] last-block counter, [64..96) the device copy of a pre-enqueued fold's challenge; accbuf: the limb accumulators
+        // of block_reduce_finish (3 sums x 8 limbs, one 128-byte line each)
+        rc = persistent(&counter.p, &accbuf.p);
         if (rc) return rc;
-        GM_HIP(hipMemsetAsync(accbuf.p, 0, 24 * 128, s));
+        (void)s;
         if (shared_pinned()) {
             h_result = shared_pinned();
             own_pinned = false;
@@ -2308,6 +2328,9 @@ static int32_t upload_gamma(const std::vector<Fr>& gp, DevBuf* d, hipStream_t s)
     if (rc) return rc;
     return upload_small(gp.data(), gp.size(), d->fr(), s);
 }
+// the same without a launch of its own: the eq-table launch that follows stores the powers (launch_eq_pair / launch_eq_sequence
+// take them as `extra`); one launch less at the head of every layer, where the host's launch rate is what the device waits for
+static int32_t alloc_gamma(const std::vector<Fr>& gp, DevBuf* d) { return d->alloc(gp.size() * sizeof(Fr) + 32); }
 
 static std::vector<Fr> make_gamma_pows(const Fr& gamma, int count) {
     std::vector<Fr> g = {fr_one(), gamma};
@@ -3433,14 +3456,15 @@ extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, co
     so->multiplier = fr_one();
     rc = so->cols.init(so->sp.n_ins, reinterpret_cast<const Fr* const*>(d_cols), 1ull << so->loc_vars);
     if (rc) return rc;
-    rc = upload_gamma(so->gamma_pows, &so->d_gamma, so->stream);
+    rc = alloc_gamma(so->gamma_pows, &so->d_gamma);
     if (rc) return rc;
     // eq_poly_sequence(point[0 .. n-1])  (dense_eq.rs:85): levels 0..n-1, level i has 2^i entries
     rc = so->d_eq.alloc(((size_t)1 << num_vars) * sizeof(Fr));
     if (rc) return rc;
     std::vector<Fr*> lv(num_vars);
     for (uint32_t i = 0; i < num_vars; i++) lv[i] = so->d_eq.fr() + ((1ull << i) - 1);
-    rc = launch_eq_sequence(fr_one(), so->point.data(), num_vars - 1, lv.data(), so->stream);
+    rc = launch_eq_sequence(fr_one(), so->point.data(), num_vars - 1, lv.data(), so->stream, so->gamma_pows.data(),
+                            (uint32_t)so->gamma_pows.size(), so->d_gamma.fr());
     if (rc) return rc;
     rc = so->rs.init(so->stream);
     if (rc) return rc;
@@ -3516,7 +3540,7 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         rc = so->bufB.back()->alloc((size_t)(polys->total / 4 + 2 * so->nrows + 2) * sizeof(Fr));
         if (rc) return rc;
     }
-    rc = upload_gamma(so->gamma_pows, &so->d_gamma, s);
+    rc = alloc_gamma(so->gamma_pows, &so->d_gamma);   // stored by the eq-table launch below
     if (rc) return rc;
     // EQPolyData::new (vecvec.rs:85-119)
     uint32_t max_seg_log = 0;
@@ -3569,7 +3593,10 @@ extern "C" int32_t gm_sc_vecvec_deg2_create(const gm_fn* f, const gm_vv* polys, 
         // levels padded..n_seq_vars are the ordinary doubling levels started from the scalar m; both sequences and the scalar levels
         // in one launch when they fit (they do for every shape with col_logsize, row variables <= 14)
         if (!launch_eq_pair(fr_one(), so->point.data(), polys->col_logsize, row_lv.data(), m, pt + padded, n_seq_vars - padded, lv.data(),
-                            scal.data(), (uint32_t)scal.size(), so->d_eq_seq.fr(), s)) {
+                            scal.data(), (uint32_t)scal.size(), so->d_eq_seq.fr(), s, so->gamma_pows.data(), (uint32_t)so->gamma_pows.size(),
+                            so->d_gamma.fr())) {
+            rc = upload_small(so->gamma_pows.data(), so->gamma_pows.size(), so->d_gamma.fr(), s);
+            if (rc) return rc;
             rc = launch_eq_sequence(fr_one(), so->point.data(), polys->col_logsize, row_lv.data(), s);
             if (rc) return rc;
             rc = upload_small(scal.data(), scal.size(), so->d_eq_seq.fr(), s);
