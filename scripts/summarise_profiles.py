@@ -17,8 +17,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)   # the newest run when a directory was collected twice
+    return f[-1] if f else None
 
 
 def key(n):
