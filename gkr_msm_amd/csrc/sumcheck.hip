@@ -548,6 +548,35 @@ __device__ __forceinline__ int fr_chunks_load(const uint32_t* p, Fr* out, uint32
     return 0;
 }
 
+// The gate of a pre-enqueued fold inside the fold itself (small folds, when the host can write challenges into device memory -- the
+// large BAR, see TailStage / RoundScratch::bar): lane 0 of every workgroup polls the challenge's self-validating chunks in DEVICE
+// memory (no PCIe read per poll, so hundreds of pollers are fine), the workgroup takes it from LDS.  Saves the gate launch and the
+// kernel boundary between gate and fold (~3-5 us per pre-enqueued round).  Timeout: status word, stale challenge, host reports.
+struct GateArgs {
+    const uint32_t* bar_slot;   // nullptr: the challenge comes through d_t (k_fold_gate ran in front of this kernel)
+    uint32_t ticket;
+    uint32_t* status;
+    uint64_t timeout_ticks;
+};
+__device__ __forceinline__ Fr gated_challenge(const GateArgs& g, const Fr* __restrict__ d_t) {
+    if (!g.bar_slot) return fr_load(d_t);
+    __shared__ Fr t_sh;
+    if (threadIdx.x == 0) {
+        Fr t = fr_zero();
+        const uint64_t t_begin = wall_clock64();
+        bool good = false;
+        for (uint32_t it = 0;; it++) {
+            if ((it & 255u) == 255u && wall_clock64() - t_begin > g.timeout_ticks) break;
+            if (fr_chunks_load<true>(g.bar_slot, &t, g.ticket, g.ticket) == 1) { good = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!good && blockIdx.x == 0 && blockIdx.y == 0) __hip_atomic_store(g.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        t_sh = t;
+    }
+    __syncthreads();
+    return t_sh;
+}
+
 #define STAGE_MAX_BLOCKS 512
 #define STAGE_MAX_SLICES 64
 #define STAGE_MAX_ROUNDS 16
@@ -949,6 +978,15 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
     }
 }
 
+__global__ void __launch_bounds__(256) k_dense_fold_gated(ColPtrs in, ColPtrsMut out, uint64_t n_out, GateArgs g) {
+    const Fr t = gated_challenge(g, nullptr);
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const Fr* src = in.p[blockIdx.y];
+    const Fr p0 = fr_load(src + 2 * i), p1 = fr_load(src + 2 * i + 1);
+    fr_store(out.p[blockIdx.y] + i, fr_add(p0, fr_mul(t, fr_sub(p1, p0))));
+}
+
 // ------------------------------------------------------------------------------------------ lean large-round kernels
 // The generic kernels above keep every segment's inputs, outputs and both evaluation points live at once (256 VGPRs plus
 // AGPR spills: one wave per SIMD, ~45 G mul/s).  Large rounds of single-primitive layers -- every bintree layer and every
@@ -1050,6 +1088,37 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
         }
     }
     block_reduce_finish<NACC>(acc, fc);
+}
+
+// The medium sparse rounds of a single-primitive layer (<= 2^14 pairs: latency-bound, one (pair, evaluation point) per thread as
+// k_round_deg2<true, true>, blockIdx.y = the point) with the re-associated gamma combination instead of prim_exec + one product per
+// output: PROJ_L1 7 + 2 multiplications on a thread's critical path instead of 9 + 3 + 2.
+template <int PRIM>
+__global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean_split(LeanCols cols, const Fr* __restrict__ eq, const Fr* __restrict__ gp, VVArgs vv,
+                                                                       FinishCtx fc) {
+    constexpr int NI = lean_n_in(PRIM);
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    if (blockIdx.y == 0) {
+        for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
+            const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+        }
+    }
+    const uint64_t npairs = (uint64_t)(vv.off[vv.nrows] >> 1);
+    const int h = blockIdx.y & 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
+        const uint32_t cell0 = (uint32_t)(2 * i);
+        const uint32_t r = vv.coarse ? find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0) : find_row(vv.off, vv.nrows, cell0);
+        const Fr w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
+        Fr v[NI];
+#pragma unroll
+        for (int q = 0; q < NI; q++) {
+            const Fr p1 = fr_load(cols.p[q] + 2 * i + 1);
+            v[q] = h ? fr_sub(fr_dbl(p1), fr_load(cols.p[q] + 2 * i)) : p1;
+        }
+        acc[h] = fr_add(acc[h], fr_mul(lean_gamma_eval<PRIM>(v, gp), w));
+    }
+    block_reduce_finish<3>(acc, fc);
 }
 
 // ---- the same large rounds in the 9 x 29-bit form (fr9.hip.h).  Inputs are loaded raw (the limbs of the stored value: domain
@@ -1416,8 +1485,9 @@ __global__ void __launch_bounds__(SC_THREADS) k_prefix_sums_levels(const Fr* __r
 __global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut out, const uint32_t* __restrict__ off_in,
                                                          const uint32_t* __restrict__ off_out, uint32_t nrows, Fr t,
                                                          PadCols pad, const Fr* __restrict__ d_t, int ncols,
-                                                         const uint32_t* __restrict__ coarse_out) {
-    if (d_t) t = fr_load(d_t);  // pre-enqueued fold: the challenge arrives through the gate kernel (k_fold_gate)
+                                                         const uint32_t* __restrict__ coarse_out, GateArgs g) {
+    if (g.bar_slot) t = gated_challenge(g, nullptr);   // pre-enqueued small fold: the gate is in here
+    else if (d_t) t = fr_load(d_t);  // pre-enqueued fold: the challenge arrives through the gate kernel (k_fold_gate)
     const uint32_t j = blockIdx.x * SC_THREADS + threadIdx.x;
     const uint32_t total = off_out[nrows];
     uint32_t r;
@@ -1553,6 +1623,40 @@ struct gm_sc {
 
 namespace {
 
+// a field element as three self-validating 16-byte chunks (12 data bytes + tag), each ONE aligned store (see fr_chunks_load)
+static void write_chunks16(volatile uint32_t* p, const Fr& t, uint32_t tag) {
+    alignas(16) uint32_t c[12] = {t.l[0], t.l[1], t.l[2], tag, t.l[3], t.l[4], t.l[5], tag, t.l[6], t.l[7], 0u, tag};
+    for (int j = 0; j < 3; j++) {
+        const __m128i vv = _mm_load_si128(reinterpret_cast<const __m128i*>(c + 4 * j));
+        _mm_store_si128(reinterpret_cast<__m128i*>(const_cast<uint32_t*>(p) + 4 * j), vv);
+    }
+}
+// 4 KiB of fine-grained DEVICE memory the host can store into (large BAR), or nullptr: GM_STAGE_BAR=0, no large BAR, or the probe
+// store did not arrive.  The host writes challenges there so that waiting kernels poll device memory instead of host memory.
+static uint32_t* alloc_host_writable_device_words() {
+    static const bool off = [] { const char* e = getenv("GM_STAGE_BAR"); return e && e[0] == '0'; }();
+    int large_bar = 0, dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    uint32_t* ret = nullptr;
+    if (!off && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_) == hipSuccess && large_bar) {
+        uint32_t* p = nullptr;
+        if (hipExtMallocWithFlags((void**)&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && p) {
+            bool good = hipMemset(p, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            if (good) {
+                reinterpret_cast<volatile uint32_t*>(p)[1000] = 0x5eed1234u;   // probe: a host store the device must see
+                _mm_sfence();
+                uint32_t back = 0;
+                good = hipMemcpy(&back, p + 1000, 4, hipMemcpyDeviceToHost) == hipSuccess && back == 0x5eed1234u;
+                reinterpret_cast<volatile uint32_t*>(p)[1000] = 0;
+                _mm_sfence();
+            }
+            if (good) ret = p; else (void)hipFree(p);
+        }
+    }
+    (void)hipGetLastError();
+    return ret;
+}
+
 struct RoundScratch {
     DevBuf partial;
     // the arrival counter (+ the device copy of a pre-enqueued fold's challenge) and the limb accumulators: a few hundred bytes that
@@ -1560,9 +1664,11 @@ struct RoundScratch {
     // object (two fill launches per layer, ~9 us of a late layer's ~45 us of set-up).  One thread = one stream: the objects of a
     // thread that are alive together (a VecVec object and its dense stage, the two lock-step objects of the pushforward argument)
     // run their kernels one after the other.
-    struct Persistent { void* p = nullptr; };
+    struct Persistent { void* p = nullptr; uint32_t* bar = nullptr; };
     struct CounterView { void* p = nullptr; } counter, accbuf;
-    static int32_t persistent(void** counter_p, void** acc_p) {
+    uint32_t* bar = nullptr;   // host-writable device words (4 challenge slots of 12 words) of this thread and device, or nullptr
+    const uint32_t* bar_slot(uint32_t round) const { return bar ? bar + 12 * (round & 3) : nullptr; }
+    static int32_t persistent(void** counter_p, void** acc_p, uint32_t** bar_p) {
         static thread_local Persistent per_dev[16];
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1571,7 +1677,9 @@ struct RoundScratch {
             GM_HIP(hipMalloc(&e.p, 256 + 24 * 128));
             GM_HIP(hipMemset(e.p, 0, 256 + 24 * 128));
             GM_HIP(hipDeviceSynchronize());   // once per thread and device: the zeros are in place before any stream uses them
+            e.bar = alloc_host_writable_device_words();
         }
+        *bar_p = e.bar;
         *counter_p = e.p;
         *acc_p = static_cast<char*>(e.p) + 256;
         return GM_OK;
@@ -1583,7 +1691,7 @@ struct RoundScratch {
         if (rc) return rc;
         // counter: [0] last-block counter, [64..96) the device copy of a pre-enqueued fold's challenge; accbuf: the limb accumulators
         // of block_reduce_finish (3 sums x 8 limbs, one 128-byte line each)
-        rc = persistent(&counter.p, &accbuf.p);
+        rc = persistent(&counter.p, &accbuf.p, &bar);
         if (rc) return rc;
         (void)s;
         if (shared_pinned()) {
@@ -1649,9 +1757,23 @@ struct RoundScratch {
         return c;
     }
     void publish(uint32_t round, const Fr& t, uint32_t ticket) {
+        if (bar) {   // a fold with its gate inside may be polling device memory (gated_challenge)
+            write_chunks16(bar + 12 * (round & 3), t, ticket);
+            _mm_sfence();
+        }
         *t_slot(round) = t;
         std::atomic_thread_fence(std::memory_order_release);
         *reinterpret_cast<volatile uint32_t*>(ticket_word()) = ticket;
+    }
+    // small pre-enqueued folds carry their gate inside (no k_fold_gate launch) when the host can write into device memory
+    GateArgs gate_in_fold(uint32_t round, uint32_t ticket, uint64_t fold_blocks) const {
+        static const bool off = [] { const char* e = getenv("GM_FOLD_GATE_INSIDE"); return e && e[0] == '0'; }();
+        GateArgs g;
+        g.bar_slot = (!off && bar && fold_blocks <= 512) ? bar + 12 * (round & 3) : nullptr;
+        g.ticket = ticket;
+        g.status = const_cast<uint32_t*>(reinterpret_cast<volatile uint32_t*>(ticket_word())) + 1;
+        g.timeout_ticks = wait_timeout_ticks();
+        return g;
     }
     // can_sync = false: a pre-enqueued fold is waiting in the stream for a challenge the host has not published yet, so a
     // stream synchronisation would wait for it; keep polling (bounded by wall time) instead
@@ -1928,25 +2050,7 @@ struct StageRun {
             // Challenges straight into device memory when the device exposes it to the host (large BAR) and a probe write arrives;
             // GM_STAGE_BAR=0 keeps the PCIe-poll + relay scheme (A/B, and the fall-back wherever the probe fails)
             st->tkt_bar_tried = true;
-            static const bool off = [] { const char* e = getenv("GM_STAGE_BAR"); return e && e[0] == '0'; }();
-            int large_bar = 0, dev_ = 0;
-            (void)hipGetDevice(&dev_);
-            if (!off && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_) == hipSuccess && large_bar) {
-                uint32_t* p = nullptr;
-                if (hipExtMallocWithFlags((void**)&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && p) {
-                    bool good = hipMemset(p, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-                    if (good) {
-                        reinterpret_cast<volatile uint32_t*>(p)[40] = 0x5eed1234u;   // probe: a host store the device must see
-                        _mm_sfence();
-                        uint32_t back = 0;
-                        good = hipMemcpy(&back, p + 40, 4, hipMemcpyDeviceToHost) == hipSuccess && back == 0x5eed1234u;
-                        reinterpret_cast<volatile uint32_t*>(p)[40] = 0;
-                        _mm_sfence();
-                    }
-                    if (good) st->tkt_bar = p; else (void)hipFree(p);
-                }
-                (void)hipGetLastError();
-            }
+            st->tkt_bar = alloc_host_writable_device_words();
         }
         if (st->arrive_total > 0x40000000u) st->d_state_dirty = true;   // the cumulative arrival count stays far below bit 31
         if (st->d_state_dirty) {
@@ -2051,14 +2155,7 @@ struct StageRun {
         if (w) *w = v[2];
         return GM_OK;
     }
-    static void write_chunks(volatile uint32_t* p, const Fr& t, uint32_t tag) {
-        // each chunk is one aligned 16-byte store (the device validates every chunk on its own)
-        alignas(16) uint32_t c[12] = {t.l[0], t.l[1], t.l[2], tag, t.l[3], t.l[4], t.l[5], tag, t.l[6], t.l[7], 0u, tag};
-        for (int j = 0; j < 3; j++) {
-            const __m128i vv = _mm_load_si128(reinterpret_cast<const __m128i*>(c + 4 * j));
-            _mm_store_si128(reinterpret_cast<__m128i*>(const_cast<uint32_t*>(p) + 4 * j), vv);
-        }
-    }
+    static void write_chunks(volatile uint32_t* p, const Fr& t, uint32_t tag) { write_chunks16(p, t, tag); }
     void publish(int r, const Fr& t) {
         if (st->tkt_bar) {
             write_chunks(st->tkt_bar + 12 * (r & 1), t, ticket0 + (uint32_t)r);
@@ -2179,6 +2276,20 @@ static int32_t launch_deg2_lean(int prim, dim3 grid, hipStream_t s, const LeanCo
 #undef GM_LEAN_CASE
     GM_LAUNCH_CHECK();
     return GM_OK;
+}
+
+static bool launch_deg2_lean_split(int prim, dim3 grid, hipStream_t s, const LeanCols& lc, const Fr* eq, const Fr* gp, const VVArgs& va,
+                                   const FinishCtx& fc) {
+    static const bool off = [] { const char* e = getenv("GM_LEAN_SPLIT"); return e && e[0] == '0'; }();
+    if (off) return false;
+#define GM_LS_CASE(P) \
+    case P: hipLaunchKernelGGL((k_round_deg2_lean_split<P>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, va, fc); return true;
+    switch (prim) {
+        GM_LS_CASE(FN_AFF_L1) GM_LS_CASE(FN_AFF_L2) GM_LS_CASE(FN_AFF_L3) GM_LS_CASE(FN_PROJ_L1) GM_LS_CASE(FN_PROJ_L2) GM_LS_CASE(FN_PROJ_L3)
+        GM_LS_CASE(LEAN_AFF_L1_BC)
+        default: return false;
+    }
+#undef GM_LS_CASE
 }
 
 static int32_t launch_generic3_lean(int prim, dim3 grid, hipStream_t s, const LeanCols& lc, const Fr* gp, uint64_t npairs,
@@ -2482,9 +2593,14 @@ struct ScDense : gm_sc {
                 fold_ticket = ++RoundScratch::ticket_counter();
                 if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
                 Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
-                hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(round_idx), rs.ticket_word(), fold_ticket,
-                                   rs.ticket_word() + 1, d_t, wait_timeout_ticks());
-                hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(npairs, 256), cols.k), dim3(256), 0, stream, ci, co, npairs, d_t);
+                const GateArgs ga = rs.gate_in_fold(round_idx, fold_ticket, (uint64_t)ceil_div(npairs, 256) * cols.k);
+                if (ga.bar_slot) {
+                    hipLaunchKernelGGL(k_dense_fold_gated, dim3(ceil_div(npairs, 256), cols.k), dim3(256), 0, stream, ci, co, npairs, ga);
+                } else {
+                    hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(round_idx), rs.ticket_word(), fold_ticket,
+                                       rs.ticket_word() + 1, d_t, wait_timeout_ticks());
+                    hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(npairs, 256), cols.k), dim3(256), 0, stream, ci, co, npairs, d_t);
+                }
                 prof_fold(96.0 * cols.k * (double)npairs);
                 GM_LAUNCH_CHECK();
                 fold_pending = true;
@@ -2838,9 +2954,14 @@ struct ScDenseDeg2 : gm_sc {
             if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
             const uint64_t n_out = npairs;
             Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
-            hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(r), rs.ticket_word(), fold_ticket, rs.ticket_word() + 1, d_t,
-                               wait_timeout_ticks());
-            hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(n_out, 256), cols.k), dim3(256), 0, stream, ci, co, n_out, d_t);
+            const GateArgs ga = rs.gate_in_fold(r, fold_ticket, (uint64_t)ceil_div(n_out, 256) * cols.k);
+            if (ga.bar_slot) {
+                hipLaunchKernelGGL(k_dense_fold_gated, dim3(ceil_div(n_out, 256), cols.k), dim3(256), 0, stream, ci, co, n_out, ga);
+            } else {
+                hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(r), rs.ticket_word(), fold_ticket, rs.ticket_word() + 1, d_t,
+                                   wait_timeout_ticks());
+                hipLaunchKernelGGL(k_dense_fold_dev, dim3(ceil_div(n_out, 256), cols.k), dim3(256), 0, stream, ci, co, n_out, d_t);
+            }
             prof_fold(96.0 * cols.k * (double)n_out);
             GM_LAUNCH_CHECK();
             fold_pending = true;
@@ -3032,10 +3153,12 @@ struct ScVecVecDeg2 : gm_sc {
             fold_ticket = ++RoundScratch::ticket_counter();
             if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
             Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
-            hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(already_bound), rs.ticket_word(), fold_ticket,
-                               rs.ticket_word() + 1, d_t, wait_timeout_ticks());
+            const GateArgs ga = rs.gate_in_fold(already_bound, fold_ticket, (uint64_t)ceil_div(nx_bound, SC_THREADS) * ((k + 1) / 2));
+            if (!ga.bar_slot)
+                hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(already_bound), rs.ticket_word(), fold_ticket,
+                                   rs.ticket_word() + 1, d_t, wait_timeout_ticks());
             hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(nx_bound, SC_THREADS), (k + 1) / 2), dim3(SC_THREADS), 0, stream, ci, co, off_cur,
-                               nx_off, nrows, fr_zero(), pd, (const Fr*)d_t, k, coarse_for(nx_off));
+                               nx_off, nrows, fr_zero(), pd, (const Fr*)d_t, k, coarse_for(nx_off), ga);
             GM_LAUNCH_CHECK();
             prof_fold(96.0 * k * (double)(cells_bound / 2));
             fold_pending = true;
@@ -3178,9 +3301,15 @@ struct ScVecVecDeg2 : gm_sc {
             int32_t rc = launch_deg2_lean<true>(lean, grid, stream, lc, eq_row, d_gamma.fr(), (uint64_t)0, va, fc);
             prof_end(stream, pi);
             if (rc) return rc;
-        } else if (split)
-            hipLaunchKernelGGL((k_round_deg2<true, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
-                               (uint64_t)0, va, fc);
+        } else if (split) {
+            // single-primitive layers: the lean split kernel (two workgroup rows, one per evaluation point)
+            const int lean_s = k <= 6 ? lean_prim_of(sp) : 0;
+            LeanCols lc;
+            for (int i = 0; i < k && i < 7; i++) lc.p[i] = cols_now[i];
+            if (!(lean_s && launch_deg2_lean_split(lean_s, dim3(grid.x, 2), stream, lc, eq_row, d_gamma.fr(), va, fc)))
+                hipLaunchKernelGGL((k_round_deg2<true, true>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
+                                   (uint64_t)0, va, fc);
+        }
         else
             hipLaunchKernelGGL((k_round_deg2<true, false>), grid, dim3(SC_THREADS), 0, stream, sp, cp, eq_row, d_gamma.fr(),
                                (uint64_t)0, va, fc);
@@ -3267,7 +3396,7 @@ struct ScVecVecDeg2 : gm_sc {
                 pd.v[i] = row_pad[i];
             }
             hipLaunchKernelGGL(k_vv_fold, dim3(ceil_div(new_bound, SC_THREADS), (k + 1) / 2), dim3(SC_THREADS), 0, stream, ci, co,
-                               off_cur, off_next, nrows, t, pd, (const Fr*)nullptr, k, coarse_for(off_next));
+                               off_cur, off_next, nrows, t, pd, (const Fr*)nullptr, k, coarse_for(off_next), GateArgs{nullptr, 0u, nullptr, 0ull});
             GM_LAUNCH_CHECK();
             prof_fold(96.0 * k * (double)(cells_bound / 2));
             for (int i = 0; i < k; i++) cur[i] = co.p[i];
