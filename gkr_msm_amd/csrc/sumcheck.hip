@@ -1661,18 +1661,18 @@ struct RoundScratch {
     DevBuf partial;
     // the arrival counter (+ the device copy of a pre-enqueued fold's challenge) and the limb accumulators: a few hundred bytes that
     // every kernel leaves at zero -- kept per (host thread, device) for the life of the process instead of allocated and memset per
-    // object (two fill launches per layer, ~9 us of a late layer's ~45 us of set-up).  One thread = one stream: the objects of a
-    // thread that are alive together (a VecVec object and its dense stage, the two lock-step objects of the pushforward argument)
-    // run their kernels one after the other.
+    // object (two fill launches per layer, ~9 us of a late layer's ~45 us of set-up).  Keyed by the STREAM as well: objects that share
+    // a stream (a VecVec object and its dense stage, the two lock-step objects of the pushforward argument) run their kernels one
+    // after the other; a thread that drives two streams gets two sets.
     struct Persistent { void* p = nullptr; uint32_t* bar = nullptr; };
     struct CounterView { void* p = nullptr; } counter, accbuf;
     uint32_t* bar = nullptr;   // host-writable device words (4 challenge slots of 12 words) of this thread and device, or nullptr
     const uint32_t* bar_slot(uint32_t round) const { return bar ? bar + 12 * (round & 3) : nullptr; }
-    static int32_t persistent(void** counter_p, void** acc_p, uint32_t** bar_p) {
-        static thread_local Persistent per_dev[16];
+    static int32_t persistent(hipStream_t stream, void** counter_p, void** acc_p, uint32_t** bar_p) {
+        static thread_local std::map<std::pair<int, hipStream_t>, Persistent> sets;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        Persistent& e = per_dev[(dev >= 0 && dev < 16) ? dev : 0];
+        Persistent& e = sets[std::make_pair(dev, stream)];
         if (!e.p) {
             GM_HIP(hipMalloc(&e.p, 256 + 24 * 128));
             GM_HIP(hipMemset(e.p, 0, 256 + 24 * 128));
@@ -1691,9 +1691,8 @@ struct RoundScratch {
         if (rc) return rc;
         // counter: [0] last-block counter, [64..96) the device copy of a pre-enqueued fold's challenge; accbuf: the limb accumulators
         // of block_reduce_finish (3 sums x 8 limbs, one 128-byte line each)
-        rc = persistent(&counter.p, &accbuf.p, &bar);
+        rc = persistent(s, &counter.p, &accbuf.p, &bar);
         if (rc) return rc;
-        (void)s;
         if (shared_pinned()) {
             h_result = shared_pinned();
             own_pinned = false;
