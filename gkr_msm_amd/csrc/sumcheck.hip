@@ -205,10 +205,11 @@ __device__ __forceinline__ Fr coh_load_sys(const Fr* p) {
     return r;
 }
 
-// Block-wide sum of NACC field elements per thread, then the cross-block sum inside the same launch:
-// every block publishes its partial, the block that arrives last (agent-scope release / acquire around one
-// device counter) adds the partials up and writes the NACC results straight into pinned host memory, so a round is
-// ONE kernel + ONE stream synchronisation.  Field addition is exact, the order of the blocks does not matter.
+// Block-wide sum of NACC field elements per thread, then the cross-block sum inside the same launch: a round is ONE kernel + ONE
+// host poll.  Grids of <= 512 blocks add their block sums limb by limb into 64-bit accumulators with no-return atomics and the block
+// that arrives last (a relaxed device counter behind drained write-through accesses -- no cache-wide fences) swaps the accumulators
+// out and reduces them mod p; larger grids store their partials and the last block adds them up.  Either way it writes the NACC
+// results straight into pinned host memory.  Sums of canonical values: the order of the blocks does not matter.
 struct FinishCtx {
     Fr* partial;         // gridDim.x * gridDim.y rows of NACC elements
     uint32_t* counter;   // zero between launches (the last block resets it)
@@ -497,10 +498,11 @@ __global__ void __launch_bounds__(64) k_gather_finals(ColPtrs cols, int k, Fr* _
 //   * bind_into_dense (vecvec_eq.rs:157-175): row -> one dense element, regrouped into pairs through LDS;
 //   * the whole dense stage (13 rounds at config B) -- or all rounds of a dense object that starts small (triangle layers).
 // Grid: x = 2 * segment + evaluation point, y = slice of 256 rows / dense elements.  Per round a block (i) evaluates its
-// segment of the layer function on its pairs, reduces over the block and writes its partial sum + a sequence word straight
-// into pinned host memory (the host adds the partials and does the O(1) scalar tail: from12, transcript, challenge),
-// (ii) waits for the challenge -- block (0, 0) polls the host's ticket and relays it through device memory, so one wave
-// crosses PCIe -- (iii) folds its own inputs and regroups the pairs through LDS.  Slices never exchange data until each is
+// segment of the layer function on its pairs, reduces over the block and adds its sum into the round's limb accumulators; the
+// block that arrives last reduces them mod p and writes ONE report (three self-validating values) into pinned host memory (the host
+// does the O(1) scalar tail: from12, transcript, challenge), (ii) waits for the challenge -- in device memory the host writes
+// directly over the large BAR, or, without one, block (0, 0) polls the host's ticket over PCIe and relays it through device
+// memory -- (iii) folds its own inputs and regroups the pairs through LDS.  Slices never exchange data until each is
 // down to one element; then every slice hands its element to slice 0 through device memory (release / acquire around a
 // counter) and slice 0 finishes alone.  All blocks are co-resident (<= 512 blocks of 256 threads), so waiting is safe; every
 // wait is bounded (gm_set_wait_timeout_ms): on timeout a block flags `status` and leaves.
@@ -594,7 +596,6 @@ struct StageArgs {
     PadCols row_pad, col_pad;          // thin only
     uint32_t* h_rep;                   // pinned: the round's report at 36 (round & 1) words: sum at point 1, at point 2, tail weight,
                                        // each as three self-validating chunks (see fr_chunks_store_sys)
-    Fr* d_part;                        // device: 2 partial sums per block (2b: the round sum, 2b+1: the tail weight)
     uint32_t* d_round_cnt;             // device: one arrival counter per round (zeroed before the launch)
     Fr* h_finals;                      // pinned: what is left of column c after the last round, 32 slots per column
     uint32_t* h_fin_seq;               // pinned: word [segment][slice] = ticket0 + rounds once that block's part is written
@@ -1979,7 +1980,7 @@ struct StageRun {
     int published = 0;                    // rounds whose challenge the host has published
     uint32_t gx = 0, nsl = 1;
     int merge_after = 0;                  // dense rounds 0..merge_after report from every slice, later ones from slice 0 only
-    DevBuf xbuf, dpart, dbg;
+    DevBuf xbuf, dbg;
     static bool debug() {
         static const bool v = [] { const char* e = getenv("GM_STAGE_DEBUG"); return e && e[0] == '1'; }();
         return v;
@@ -2035,8 +2036,6 @@ struct StageRun {
             rc = xbuf.alloc((size_t)gx * 6 * STAGE_MAX_SLICES * sizeof(Fr));
             if (rc) return rc;
         }
-        rc = dpart.alloc((size_t)2 * gx * nsl * sizeof(Fr));
-        if (rc) return rc;
         // small device state: [0, 128) relay, [128, 256) one arrival counter per round, [256, ..) one merge counter per
         // blockIdx.x.  It belongs to the host thread and is zeroed once: a launch leaves its counters at zero, relay tags are unique.
         // A launch that was aborted (time-out, failing transcript) may leave counters behind: the next launch zeroes again.
@@ -2067,7 +2066,6 @@ struct StageRun {
         a.d_merge = reinterpret_cast<uint32_t*>(state_p) + 64;
         a.d_arrive = reinterpret_cast<uint32_t*>(state_p) + TailStage::ARRIVE_WORD;
         a.d_acc = st->d_acc;
-        a.d_part = dpart.fr();
         a.d_xbuf = xbuf.fr();
         if (debug()) {
             rc = dbg.alloc(2 * 32 * 8 * 8);
