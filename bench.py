@@ -707,9 +707,8 @@ def main():
                 out[key] = {"error": repr(e)[:300]}
 
     # ---- N > 1: the same prover sharded by windows / bucket rows: per-round all-gather of the partial sums
-    # It runs LAST and under a watchdog: it is the one leg whose collective pattern (a device-side all-gather per round, ~1 300 per
-    # proof) has only been rehearsed with a world-1 communicator on the builder's one-GPU box; if it stalls on a real node the
-    # MSM line -- the metric -- must still come out.
+    # It runs LAST and under a watchdog: it has only been rehearsed with ranks sharing the builder's one-GPU box; if it stalls on a
+    # real node the MSM line -- the metric -- must still come out.
     if world > 1 and not args.no_sumcheck:
         import threading
 
@@ -728,7 +727,23 @@ def main():
                 plan.run(d_pts, d_sc)
                 torch.cuda.synchronize()
             y_log = (y_size - 1).bit_length()
-            comm = rcomm if rcomm is not None else gdist.Comm(dist, rank, world, device=xdev if backend == "nccl" else None)
+            # The per-round sums (<= 96 B per rank) are wanted on the HOST -- they go into the transcript -- so the ranks of the node
+            # exchange them between their host threads through shared memory (gm_comm_shm_*, the default): the device side of a
+            # sharded round is then the unsharded one, pre-enqueued folds and the persistent stage kernel included.
+            # GM_BENCH_PROVER_COMM=rccl: the device-side exchange (ncclAllGather + a one-wave sum per round); =torch: torch.distributed.
+            which = os.environ.get("GM_BENCH_PROVER_COMM", "shm")
+            if which == "shm":
+                tok = torch.tensor([int.from_bytes(os.urandom(6), "little")], dtype=torch.int64, device=xdev if backend == "nccl" else "cpu")
+                dist.broadcast(tok, src=0)
+                comm = gdist.ShmComm("/gm-bench-%x" % int(tok.item()), rank, world)
+                prover_transport = "host shared memory between the ranks' host threads (gm_comm_shm); RCCL carries operands and window points"
+            elif which == "rccl" and rcomm is not None:
+                comm, prover_transport = rcomm, transport + ", device-side exchange of the round sums"
+            else:
+                comm = gdist.Comm(dist, rank, world, device=xdev if backend == "nccl" else None)
+                prover_transport = "torch.distributed (%s)" % backend
+            stage0 = (C.c_uint64(), C.c_uint64())
+            L.gm_sc_stage_counts(C.byref(stage0[0]), C.byref(stage0[1]))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             w = harness.PipWitness(plan, d_pts, y_log, comm=comm)
@@ -743,10 +758,14 @@ def main():
             sync_all()
             out["sumcheck"] = {"metric": "sumcheck_rounds_per_sec", "value": round(res["rounds"] / p_dt, 1),
                                "rounds": res["rounds"], "prove_ms": round(p_dt * 1e3, 2), "witness_build_ms": round(wit_ms, 2),
-                               "sharding": "bucket rows of %d windows per rank; %d all-gathers of <= 96 B per rank per proof" % (
-                                   wpr, comm.calls - calls0), "transport": transport,
+                               "sharding": "bucket rows of %d windows per rank; %d exchanges of <= 96 B per rank per proof" % (
+                                   wpr, comm.calls - calls0), "transport": prover_transport,
                                "workload": "prove image part (triangle + bintree GKR) x_logsize=%d d_logsize=%d nbits=%d" % (
                                    x_log, d_log, nbits)}
+            stage1 = (C.c_uint64(), C.c_uint64())
+            L.gm_sc_stage_counts(C.byref(stage1[0]), C.byref(stage1[1]))
+            out["sumcheck"]["stage_kernel_launches_per_proof"] = (stage1[0].value - stage0[0].value) // 2
+            out["sumcheck"]["stage_kernel_launches_left_early"] = stage1[1].value - stage0[1].value
             w.close()
             del w
             # the unsharded prover on every GPU at once, same run: what one GPU does alone

@@ -1,5 +1,7 @@
 // Cross-translation-unit declarations inside libgkrmsm_hip.so (not part of the ABI).
 #pragma once
+#include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -35,6 +37,15 @@ Fr eq_sum_host(const Fr* pt, uint32_t n, uint64_t k);                           
 
 // ---- sharding context: which slice of the bucket rows this process owns and how to reach the other ranks.
 // Sumcheck objects capture the current one at creation (the drivers set it around the sharded layers).
+// bound of every wait on the other side (kernels waiting for a challenge, host loops waiting for results or for another rank):
+// gm_set_wait_timeout_ms, default 20 s.  Device side: wall_clock64() ticks (100 MHz).
+inline std::atomic<uint32_t>& wait_timeout_ms() {
+    static std::atomic<uint32_t> v{20000};
+    return v;
+}
+inline uint64_t wait_timeout_ticks() { return (uint64_t)wait_timeout_ms().load() * 100000ull; }
+inline std::chrono::milliseconds wait_timeout_host() { return std::chrono::milliseconds(wait_timeout_ms().load()); }
+
 struct Shard {
     const gm_comm* comm = nullptr;  // nullptr: unsharded
     uint32_t rank = 0, world = 1, lg = 0;

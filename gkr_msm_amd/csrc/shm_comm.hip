@@ -1,0 +1,189 @@
+// One-node backing of the gm_comm seam over POSIX shared memory.
+//
+// What the sharded provers exchange every sumcheck round is 2-3 field elements per rank (<= 96 bytes), and it is the HOST that needs
+// them: the round's sums go into the Fiat-Shamir transcript, which lives on the caller's side of the ABI, and the challenge comes
+// back from there.  A device-side collective (ncclAllGather: a kernel launch + a ring over xGMI, ~20-30 us for 96 bytes) puts that
+// latency into each of the ~1500 rounds of a proof and keeps the rounds from being pre-enqueued or run inside the persistent stage
+// kernel.  All ranks of the path live on one node (one process per GPU, as the reference's rayon pool lives in one process), so the
+// small exchanges go where the data is needed anyway: every rank's host thread posts its sums in a shared-memory slot and reads
+// the others' -- a cache-line transfer between cores, well under a microsecond -- and the device side of a sharded round is exactly
+// the unsharded one (same kernels, same pre-enqueued folds, same k_stage).  The transfers that carry volume (operand replication,
+// window points) stay on RCCL (rccl_comm.hip); the once-per-proof bucket sums (0.75 MiB at config B) fit through here in chunks.
+//
+// Layout of the object: a header line, then per rank one sequence word (a cache line of its own) and two data slots of SLOT bytes.
+// all_gather number n (chunk by chunk for payloads above SLOT): write slot n & 1, store-release seq[rank] = n, then for every other
+// rank wait for seq >= n (load-acquire) and copy its slot n & 1.  A rank can be at most one call ahead of the slowest one (call n + 1
+// needs everybody's n), so slot n & 1 is rewritten only after every rank has finished reading call n.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cstring>
+#include <chrono>
+#include <memory>
+#include <string>
+#include <thread>
+
+#include "internal.hpp"
+
+using namespace gm;
+
+namespace {
+constexpr size_t SHM_SLOT = 256 << 10;       // bytes per rank and slot
+constexpr uint64_t SHM_MAGIC = 0x676d73686d303031ull;   // "gmshm001"
+struct ShmHeader {
+    std::atomic<uint64_t> magic;   // set by rank 0 once the object has its size
+    uint32_t world;
+    uint32_t pad;
+    std::atomic<uint32_t> attached;   // ranks that have mapped the object
+};
+static_assert(sizeof(ShmHeader) <= 64, "header fits its line");
+size_t shm_bytes(uint32_t world) { return 64 + (size_t)world * 64 + (size_t)world * 2 * SHM_SLOT; }
+}  // namespace
+
+struct gm_shm {
+    std::string name;
+    uint32_t rank = 0, world = 1;
+    char* base = nullptr;
+    size_t bytes = 0;
+    uint64_t seq = 0;       // all_gather chunks done by this rank
+    uint64_t calls = 0, payload = 0;
+    ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
+    std::atomic<uint64_t>* seq_of(uint32_t r) const { return reinterpret_cast<std::atomic<uint64_t>*>(base + 64 + (size_t)r * 64); }
+    char* slot(uint32_t r, uint64_t n) const { return base + 64 + (size_t)world * 64 + ((size_t)r * 2 + (n & 1)) * SHM_SLOT; }
+    ~gm_shm() {
+        if (base) munmap(base, bytes);
+    }
+};
+
+// wait until *w >= want; false on time-out (gm_set_wait_timeout_ms)
+static bool shm_wait(const std::atomic<uint64_t>* w, uint64_t want) {
+    for (int spin = 0; spin < 20000; spin++) {
+        if (w->load(std::memory_order_acquire) >= want) return true;
+        __builtin_ia32_pause();
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto limit = wait_timeout_host() + std::chrono::milliseconds(200);
+    for (uint32_t it = 0;; it++) {
+        if (w->load(std::memory_order_acquire) >= want) return true;
+        if ((it & 63u) == 63u) {
+            if (std::chrono::steady_clock::now() - t0 > limit) return false;
+            std::this_thread::yield();   // more ranks than cores (the shared-GPU rehearsals): let the others run
+        } else {
+            __builtin_ia32_pause();
+        }
+    }
+}
+
+static int32_t shm_all_gather(void* ctx, void* buf, uint64_t nbytes) {
+    gm_shm* c = static_cast<gm_shm*>(ctx);
+    if (!c || !buf) return 1;
+    char* hb = static_cast<char*>(buf);
+    for (uint64_t done = 0; done < nbytes; done += SHM_SLOT) {
+        const size_t len = (size_t)(nbytes - done < SHM_SLOT ? nbytes - done : SHM_SLOT);
+        const uint64_t n = ++c->seq;
+        memcpy(c->slot(c->rank, n), hb + (size_t)c->rank * nbytes + done, len);
+        c->seq_of(c->rank)->store(n, std::memory_order_release);
+        for (uint32_t d = 1; d < c->world; d++) {
+            const uint32_t r = (c->rank + d) % c->world;
+            if (!shm_wait(c->seq_of(r), n)) return 2;
+            memcpy(hb + (size_t)r * nbytes + done, c->slot(r, n), len);
+        }
+    }
+    c->calls++;
+    c->payload += nbytes;
+    return 0;
+}
+
+extern "C" {
+
+// Collective: every rank of the job calls it with the same name ("/gm-<job id>": unique per job, e.g. the launcher's pid and port)
+// and world.  Rank 0 creates the object (an existing one of that name is an error: a stale or duplicated job id), the others wait
+// for it to appear; all return once every rank has mapped it, and rank 0 removes the name again at that point.
+int32_t gm_comm_shm_create(const char* name, uint32_t rank, uint32_t world, gm_shm** out) {
+    GM_REQUIRE(name && name[0] == '/' && out && world >= 1 && rank < world, "bad argument (the name starts with '/')");
+    std::unique_ptr<gm_shm> c(new gm_shm());
+    c->name = name; c->rank = rank; c->world = world;
+    c->bytes = shm_bytes(world);
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto limit = wait_timeout_host() + std::chrono::milliseconds(200);
+    int fd = -1;
+    if (rank == 0) {
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return set_err(GM_ERR_STATE, "shm_open(%s, create) failed: %s (a stale or duplicated job name?)", name, strerror(errno));
+        if (ftruncate(fd, (off_t)c->bytes) != 0) {
+            const int e = errno;
+            close(fd);
+            shm_unlink(name);
+            return set_err(GM_ERR_STATE, "ftruncate(%s, %zu) failed: %s", name, c->bytes, strerror(e));
+        }
+    } else {
+        for (;;) {
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat st;
+                if (fstat(fd, &st) == 0 && (size_t)st.st_size >= c->bytes) break;   // rank 0 has sized it
+                close(fd);
+                fd = -1;
+            }
+            if (std::chrono::steady_clock::now() - t0 > limit) return set_err(GM_ERR_STATE, "shared-memory object %s did not appear (rank 0 creates it)", name);
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
+    void* p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        if (rank == 0) shm_unlink(name);
+        return set_err(GM_ERR_STATE, "mmap(%s, %zu) failed: %s", name, c->bytes, strerror(errno));
+    }
+    c->base = static_cast<char*>(p);
+    ShmHeader* h = c->hdr();
+    if (rank == 0) {
+        h->world = world;
+        h->magic.store(SHM_MAGIC, std::memory_order_release);
+    } else {
+        while (h->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+            if (std::chrono::steady_clock::now() - t0 > limit) return set_err(GM_ERR_STATE, "shared-memory object %s was never initialised", name);
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (h->world != world) return set_err(GM_ERR_STATE, "shared-memory object %s belongs to a job of %u ranks, not %u", name, h->world, world);
+    }
+    h->attached.fetch_add(1, std::memory_order_acq_rel);
+    while (h->attached.load(std::memory_order_acquire) < world) {
+        if (std::chrono::steady_clock::now() - t0 > limit)
+            return set_err(GM_ERR_STATE, "only %u of %u ranks attached to %s", h->attached.load(), world, name);
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    // everybody holds a mapping: the name is no longer needed (and a rank that dies later leaves nothing behind in /dev/shm)
+    if (rank == 0) shm_unlink(name);
+    *out = c.release();
+    return GM_OK;
+}
+
+int32_t gm_comm_shm_destroy(gm_shm* c) {
+    delete c;
+    return GM_OK;
+}
+
+// the gm_comm the sharded prover takes: host all_gather only (no all_gather_dev: the per-round sums are wanted on the host)
+int32_t gm_comm_shm_as_comm(gm_shm* c, gm_comm* out) {
+    GM_REQUIRE(c && out, "null argument");
+    out->ctx = c;
+    out->rank = c->rank;
+    out->world = c->world;
+    out->all_gather = shm_all_gather;
+    out->all_gather_dev = nullptr;
+    return GM_OK;
+}
+
+int32_t gm_comm_shm_stats(const gm_shm* c, uint64_t* all_gathers, uint64_t* bytes_per_rank_total) {
+    GM_REQUIRE(c, "null argument");
+    if (all_gathers) *all_gathers = c->calls;
+    if (bytes_per_rank_total) *bytes_per_rank_total = c->payload;
+    return GM_OK;
+}
+
+}  // extern "C"

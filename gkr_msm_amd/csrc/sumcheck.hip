@@ -164,12 +164,7 @@ Fr eq_sum_host(const Fr* pt, uint32_t n, uint64_t k) {
 // ------------------------------------------------------------------------------------------ wait bound
 // Kernels that wait on the device for the host's next challenge (k_fold_gate, k_tail_rounds) and the host loops that wait for
 // their results give up after this long (gm_set_wait_timeout_ms; default 20 s).  Device side: wall_clock64() ticks (100 MHz).
-static std::atomic<uint32_t>& wait_timeout_ms() {
-    static std::atomic<uint32_t> v{20000};
-    return v;
-}
-static inline uint64_t wait_timeout_ticks() { return (uint64_t)wait_timeout_ms().load() * 100000ull; }
-static inline std::chrono::milliseconds wait_timeout_host() { return std::chrono::milliseconds(wait_timeout_ms().load()); }
+// (wait_timeout_ms / wait_timeout_ticks / wait_timeout_host: internal.hpp -- the shared-memory communicator waits by the same bound)
 
 // ------------------------------------------------------------------------------------------ kernels
 #define SC_THREADS 256
@@ -1966,6 +1961,9 @@ static bool stage_plan_is_narrow(const SegPlan& sp) {
 // StageRun::sums, first round of a launch: the grid did not become resident as a whole, the launch has left without touching anything
 #define GM_STAGE_NOT_RESIDENT 1001
 
+// process-wide tally (gm_sc_stage_counts: tests and benches check which path a proof took)
+static std::atomic<uint64_t> g_stage_launched{0}, g_stage_left{0};
+
 // One launch of k_stage seen from the host.  A VecVec object that enters its thin rounds creates it; the dense object it hands
 // over to (bind_into_dense) keeps using the same launch.
 struct StageRun {
@@ -2101,6 +2099,7 @@ struct StageRun {
         GM_LAUNCH_CHECK();
         launched = true;
         published = 0;
+        g_stage_launched++;
         return GM_OK;
     }
     // round r of the launch: wait for the reporting blocks and add their partials up: s[h] = sum over the (segment, h) blocks,
@@ -2136,6 +2135,7 @@ struct StageRun {
             published = total();   // no waiting block is left behind
             (void)hipStreamSynchronize(stream);
             if (slots_held) { StageSlots::get().release(slot_dev, slots_held); slots_held = 0; }
+            g_stage_left++;
             return GM_STAGE_NOT_RESIDENT;
         }
         if (*stat) {
@@ -2713,6 +2713,9 @@ struct ScDenseDeg2 : gm_sc {
     int32_t unipoly(std::vector<Fr>* coeffs) override {
         if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (dense_eq.rs:109-111)");
         if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended");
+        // rounds inside a running tail launch (its first round goes through unipoly_pipelined, which handles a launch that left at the
+        // residency barrier; a launch adopted from a VecVec object has been running for rounds)
+        if (tail_active && round_idx >= tail_r0 && (round_idx > tail_r0 || stage_adopted)) return unipoly_tail(coeffs);
         if (sh.comm && loc_vars == 0) {
             int32_t rc = gather_cols();
             if (rc) return rc;
@@ -2727,9 +2730,10 @@ struct ScDenseDeg2 : gm_sc {
         const int lean = (!split && cols.k <= 6) ? lean_prim_of(sp) : 0;
         // results of pre-enqueued kernels land in the pinned staging: it must be this object's alone for the duration
         static const bool pipe_large = [] { const char* e = getenv("GM_SC_PIPE_LARGE_DENSE"); return !(e && e[0] == '0'); }();   // A/B switch
-        if ((split || pipe_large) && !sh.comm && pipeline_enabled() && (rs.own_pinned || pinned_exclusive() || k_enq > round_idx))
-            return unipoly_pipelined(coeffs, npairs, eq_cur, cp);
         const bool devx = RoundScratch::dev_exchange(sh);
+        // sharded with the round sums meeting on the host: the device side of a round is the unsharded one
+        if ((split || pipe_large) && !devx && pipeline_enabled() && (rs.own_pinned || pinned_exclusive() || k_enq > round_idx))
+            return unipoly_pipelined(coeffs, npairs, eq_cur, cp);
         FinishCtx fc0;
         if (devx) {
             int32_t rc = rs.ctx_dev(sh, &fc0);
@@ -2840,8 +2844,10 @@ struct ScDenseDeg2 : gm_sc {
         return GM_OK;
     }
     // the dense stage of a VecVec object whose k_stage launch is already running (bind_into_dense inside the kernel)
+    bool stage_adopted = false;
     void adopt_stage(const std::shared_ptr<StageRun>& run) {
         stage = run;
+        stage_adopted = true;
         tail_active = true;
         tail_r0 = 0;
         host_r0 = (uint32_t)run->n_dense;
@@ -2853,7 +2859,22 @@ struct ScDenseDeg2 : gm_sc {
     bool host_round() const { return tail_active && round_idx >= host_r0; }
     int32_t host_collect() {
         if (!hcols.empty()) return GM_OK;
-        return stage->collect(cols.k, &hcols);
+        int32_t rc = stage->collect(cols.k, &hcols);
+        if (rc || !sh.comm) return rc;
+        // sharded: the launch left this rank's slice of every column; the rounds the host finishes run on all of them, replicated
+        const size_t n = hcols[0].size(), kk = (size_t)cols.k;
+        std::vector<Fr> mine(kk * n);
+        for (size_t c = 0; c < kk; c++) memcpy(mine.data() + c * n, hcols[c].data(), n * sizeof(Fr));
+        std::vector<char> all;
+        rc = shard_all_gather(sh, mine.data(), kk * n * sizeof(Fr), &all);
+        if (rc) return rc;
+        const Fr* a = reinterpret_cast<const Fr*>(all.data());
+        for (size_t c = 0; c < kk; c++) {
+            hcols[c].resize((size_t)sh.world * n);
+            for (uint32_t r = 0; r < sh.world; r++) memcpy(hcols[c].data() + (size_t)r * n, a + ((size_t)r * kk + c) * n, n * sizeof(Fr));
+        }
+        sh = Shard();
+        return GM_OK;
     }
     int32_t host_round_sums(Fr* s1, Fr* s2) {
         int32_t rc = host_collect();
@@ -2900,16 +2921,36 @@ struct ScDenseDeg2 : gm_sc {
     }
     int32_t tail_round_sums(Fr* s1, Fr* s2) {
         if (host_round()) return host_round_sums(s1, s2);
-        return stage->sums(stage_round(), s1, s2, nullptr);
+        int32_t rc = stage->sums(stage_round(), s1, s2, nullptr);
+        if (rc || !sh.comm) return rc;
+        Fr v[2] = {*s1, *s2};   // sharded: the launch summed this rank's slice
+        rc = shard_sum_fr(sh, v, 2);
+        *s1 = v[0]; *s2 = v[1];
+        return rc;
     }
     void tail_publish(const Fr& t) {
         if (host_round()) host_fold(t);
         else stage->publish(stage_round(), t);
     }
 
+    // a round inside the tail launch (or one of the last rounds, on the host)
+    int32_t unipoly_tail(std::vector<Fr>* coeffs) {
+        Fr a1, a2;
+        int32_t rc = tail_round_sums(&a1, &a2);
+        if (rc) return rc;
+        const Fr total1 = fr_mul(a1, multiplier), total2 = fr_mul(a2, multiplier);
+        if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);
+        cached = from12_inv(total1, total2, point.back(), inv_eq0[point.size() - 1], claim_);
+        has_cached = true;
+        *coeffs = cached;
+        return GM_OK;
+    }
     int32_t unipoly_pipelined(std::vector<Fr>* coeffs, uint64_t npairs, const Fr* eq_cur, const ColPtrs& cp) {
         const uint32_t r = round_idx;
-        const bool tail_ok = !tail_denied && stage_enabled() && sp.nseg <= 32 && (rs.own_pinned || pinned_exclusive());
+        // (a sharded object keeps to pre-enqueued rounds: whether a tail launch runs would have to be agreed between the ranks, as the
+        // VecVec object does for its stage; sharded dense objects of the image part are the dense stages of VecVec layers, which
+        // are inside that launch already)
+        const bool tail_ok = !tail_denied && !sh.comm && stage_enabled() && sp.nseg <= 32 && (rs.own_pinned || pinned_exclusive());
         if (!tail_active && tail_ok && stage_fits(r, npairs) && k_enq <= r) {
             int32_t rc = launch_tail(cp, r, npairs);   // the object starts small: everything runs in the tail
             if (rc) return rc;
@@ -2940,7 +2981,7 @@ struct ScDenseDeg2 : gm_sc {
             if (rc) return rc;
             k_enq = r + 1;
         }
-        if (!fold_pending && r + 1 < num_vars && k_enq == r + 1) {
+        if (!fold_pending && loc_vars >= 2 && k_enq == r + 1) {   // (sharded: the round after this rank's last local one needs a gather first)
             // enqueue fold r (waiting for t_r) and round kernel r + 1 while round r is still running
             cols.next(&fold_dst);
             ColPtrs ci;
@@ -2985,6 +3026,10 @@ struct ScDenseDeg2 : gm_sc {
                 rs.ticket_word()[1] = 0;   // the staging may be shared with later objects: report once
                 return set_err(GM_ERR_STATE, "a pre-enqueued fold timed out waiting for its challenge (gm_set_wait_timeout_ms)");
             }
+        if (sh.comm) {
+            rc = shard_sum_fr(sh, acc, 2);
+            if (rc) return rc;
+        }
         const Fr total1 = fr_mul(acc[0], multiplier), total2 = fr_mul(acc[1], multiplier);
         if (inv_eq0.empty()) inv_eq0 = batch_inv_one_minus(point);
         cached = from12_inv(total1, total2, point.back(), inv_eq0[point.size() - 1], claim_);
@@ -3106,11 +3151,19 @@ struct ScVecVecDeg2 : gm_sc {
         if (dense) return dense->unipoly(coeffs);
         if (has_cached) return set_err(GM_ERR_STATE, "unipoly called twice without bind (vecvec_eq.rs:305-307)");
         Fr acc[4];
-        if (!stage_active && k_enq <= already_bound && cur_max_len == 2 && stage_ok()) {
+        const bool devx = RoundScratch::dev_exchange(sh);
+        const bool shard_host = sh.comm && !devx;   // sharded, the round sums meet on the host: rounds run exactly as unsharded ones
+        // Sharded: whether the stage kernel takes over must be the SAME decision on every rank (the exchanges of a staged layer and of
+        // an ordinary one differ).  It is taken once, at the first thin round -- the same round everywhere: the longest row of the WHOLE
+        // polynomial decides it -- by exchanging one word: a rank whose launch could not be made or did not become resident says so
+        // and everybody runs the layer's remaining rounds as ordinary kernels.
+        const bool deciding = shard_host && !stage_decided && cur_max_len == 2 && stage_shape_ok();
+        if (!stage_active && k_enq <= already_bound && cur_max_len == 2 && stage_ok() && (!shard_host || deciding)) {
             // every row is down to one pair: this round, the rest of the sparse stage and the whole dense stage run in one launch
             int32_t rc = launch_stage(cur.data(), off_cur, already_bound);
             if (rc) return rc;
         }
+        bool healthy = false;
         if (stage_active) {
             int32_t rc = stage->sums((int)(already_bound - stage_r0), &acc[0], &acc[1], &acc[2]);
             if (rc == GM_STAGE_NOT_RESIDENT && already_bound == stage_r0) {
@@ -3120,11 +3173,38 @@ struct ScVecVecDeg2 : gm_sc {
                 stage_denied = true;
                 k_enq = already_bound;
             } else if (rc) return rc;
+            else healthy = true;
+        }
+        if (deciding) {
+            stage_decided = true;
+            std::vector<char> all;
+            const uint32_t mine = healthy ? 1u : 0u;
+            int32_t rc = shard_all_gather(sh, &mine, sizeof(uint32_t), &all);
+            if (rc) return rc;
+            bool everybody = true;
+            for (uint32_t r = 0; r < sh.world; r++) {
+                uint32_t v;
+                memcpy(&v, all.data() + 4 * (size_t)r, 4);
+                everybody = everybody && v == 1u;
+            }
+            if (!everybody) {
+                if (stage_active) {   // another rank could not: leave the launch (its blocks are released; the columns were only read)
+                    g_stage_left++;
+                    stage.reset();
+                    stage_active = false;
+                    k_enq = already_bound;
+                }
+                stage_denied = true;
+            }
+        }
+        if (stage_active && shard_host) {
+            int32_t rc = shard_sum_fr(sh, acc, 3);
+            if (rc) return rc;
         }
         if (!stage_active) {
         // every sparse round (large ones too: the fold and the next round kernel are then already in the stream when the
         // challenge arrives, ~8 us of launch latency per round) enqueues its fold behind a gate and the next round's kernel
-        const bool piped = !sh.comm && ScDenseDeg2::pipeline_enabled() &&
+        const bool piped = !devx && ScDenseDeg2::pipeline_enabled() &&
                            (rs.own_pinned || pinned_exclusive() || k_enq > already_bound);
         if (k_enq <= already_bound) {
             int32_t rc = launch_sparse_round(cur.data(), off_cur, cells_bound, already_bound);
@@ -3177,7 +3257,6 @@ struct ScVecVecDeg2 : gm_sc {
                 k_enq = already_bound + 2;
             }
         }
-        const bool devx = RoundScratch::dev_exchange(sh);
         if (devx) {
             int32_t rc = rs.exchange(sh, 3, stream);
             if (rc) return rc;
@@ -3223,28 +3302,44 @@ struct ScVecVecDeg2 : gm_sc {
     std::shared_ptr<StageRun> stage;
     bool stage_active = false, stage_armed = false, stage_denied = false;
     uint32_t stage_r0 = 0;     // already_bound of the launch's first round
-    bool stage_ok() const {
-        if (stage_denied || !stage_enabled() || sh.comm || !pinned_exclusive() || k > 16 || col_logsize < 1 || nrows > (1u << col_logsize)) return false;
+    bool stage_decided = false;   // sharded: the ranks have agreed whether this layer's thin rounds run in the stage kernel
+    // dense rounds the launch runs on the device: all but the last few, which the host finishes (stage_host_rounds); sharded, the
+    // host takes at least the log2(world) rounds that need every rank's elements
+    int stage_dev_rounds() const {
+        int hr = stage_host_rounds(sp, (int)col_logsize);
+        if (sh.comm && hr < (int)sh.lg) hr = (int)sh.lg;
+        return (int)col_logsize - hr;
+    }
+    // what every rank sees alike: the shape fits one launch (the geometry is this rank's slice of the rows, the same on every rank)
+    bool stage_shape_ok() const {
+        if (!stage_enabled() || RoundScratch::dev_exchange(sh) || k > 16 || col_logsize < 1 || nrows > (1u << col_logsize)) return false;
+        const uint32_t nd = sh.comm ? nrows : (1u << col_logsize);
+        if (nd < 2 || (nd & (nd - 1)) != 0 || stage_dev_rounds() < 1) return false;
         for (uint32_t i = 0; i < col_logsize; i++)
             if (fr_eq(point[i], fr_one())) return false;   // the dense stage would need the generic object (from12 divides by 1 - q)
-        return true;
+        // thin rounds left once the longest row is one pair: the row variables above the first
+        const int n_thin_max = (int)n_row_vars0 - (int)already_bound - (cur_max_len > 2 ? 1 : 0);
+        return n_thin_max >= 1 && StageRun::fits(sp.nseg, nd, n_thin_max, stage_dev_rounds());
     }
+    bool stage_ok() const { return !stage_denied && pinned_exclusive() && stage_shape_ok(); }
     int32_t launch_stage(const Fr* const* cols_now, const uint32_t* off, uint32_t ab0, bool may_wait = true) {
         const int n_thin = (int)(n_row_vars0 - ab0);
-        if (n_thin < 1 || !StageRun::fits(sp.nseg, 1ull << col_logsize, n_thin, (int)col_logsize))
+        const uint32_t nd = sh.comm ? nrows : (1u << col_logsize);
+        if (n_thin < 1 || !StageRun::fits(sp.nseg, nd, n_thin, stage_dev_rounds()))
             return set_err(GM_ERR_STATE, "stage launch: shape does not fit (%d thin rounds, %u dense)", n_thin, col_logsize);
         StageArgs a;
         memset(&a, 0, sizeof(a));
         a.nrows = nrows;
-        a.n_elems = 1u << col_logsize;
+        a.n_elems = nd;
         a.n_thin = n_thin;
-        a.n_dense = (int)col_logsize - stage_host_rounds(sp, (int)col_logsize);   // the host finishes the last few rounds
+        a.n_dense = stage_dev_rounds();   // the host finishes the last few rounds
         a.off = off;
         a.row_coef = d_row_coef.fr() + row_base;
         for (int tr = 0; tr < n_thin; tr++) a.thin_eq[tr] = d_eq_seq.fr() + eq_level_off[eq_level_len.size() - 1 - (ab0 + tr)];
-        // the dense stage's eq tables are the lower levels of row_eq_coefs = eq(point[0..col_logsize]), kept in the scratch half
+        // the dense stage's eq tables are the lower levels of row_eq_coefs = eq(point[0..col_logsize]), kept in the scratch half; the
+        // kernel indexes them by the pair's index inside this rank's slice
         const Fr* levels = d_row_coef.fr() + ((size_t)1 << col_logsize);
-        for (int dr = 0; dr < a.n_dense; dr++) a.eq[dr] = levels + ((1ull << (col_logsize - 1 - dr)) - 1);
+        for (int dr = 0; dr < a.n_dense; dr++) a.eq[dr] = levels + ((1ull << (col_logsize - 1 - dr)) - 1) + (row_base >> (dr + 1));
         for (int i = 0; i < k; i++) { a.row_pad.v[i] = row_pad[i]; a.col_pad.v[i] = col_pad[i]; }
         ColPtrs cp;
         for (int i = 0; i < k; i++) cp.p[i] = cols_now[i];
@@ -3252,9 +3347,9 @@ struct ScVecVecDeg2 : gm_sc {
         int32_t rc = stage->launch(sp, cp, d_gamma.fr(), a, stream, may_wait);
         if (rc) { stage.reset(); return rc; }
         for (int tr = 0; tr < n_thin; tr++) { prof_small_round(64.0 * k * (double)nrows); prof_fold(96.0 * k * (double)nrows); }
-        for (uint32_t dr = 0; dr < col_logsize; dr++) {
-            prof_small_round(64.0 * k * (double)(1ull << (col_logsize - 1 - dr)));
-            prof_fold(96.0 * k * (double)(1ull << (col_logsize - 1 - dr)));
+        for (uint32_t dr = 0; (nd >> (dr + 1)) >= 1; dr++) {
+            prof_small_round(64.0 * k * (double)(nd >> (dr + 1)));
+            prof_fold(96.0 * k * (double)(nd >> (dr + 1)));
         }
         stage_active = true;
         stage_r0 = ab0;
@@ -3345,7 +3440,9 @@ struct ScVecVecDeg2 : gm_sc {
             d->stream = stream;
             d->sp = sp;
             d->num_vars = col_logsize;
-            d->loc_vars = col_logsize;
+            d->sh = sh;                              // sharded: the launch holds this rank's slice; host_collect gathers what it leaves
+            d->loc_vars = col_logsize - sh.lg;
+            d->glob_off = row_base;
             d->gamma_pows = gamma_pows;
             d->point.assign(point.begin(), point.begin() + col_logsize);
             d->multiplier = mult_next;
@@ -3839,6 +3936,14 @@ extern "C" int32_t gm_sc_claim(const gm_sc* so, uint64_t* h_claim) {
 }
 
 // ---- profiler ABI (see ScProf)
+// k_stage launches made by this process so far, and how many of them were left before their first round (the grid did not become
+// resident, or -- sharded -- another rank's did not)
+extern "C" int32_t gm_sc_stage_counts(uint64_t* launched, uint64_t* left_early) {
+    if (launched) *launched = g_stage_launched.load();
+    if (left_early) *left_early = g_stage_left.load();
+    return GM_OK;
+}
+
 extern "C" int32_t gm_sc_profile(int32_t mode) {
     GM_REQUIRE(mode >= 0 && mode <= 2, "mode 0 (off), 1 (time the large round kernels) or 2 (+ account every round and fold)");
     ScProf& p = sc_prof();

@@ -129,3 +129,43 @@ class RcclComm:
         self.all_gather_dev(p, recv, nbytes)
         raw = recv.cpu().numpy().view(np.uint64).reshape(self.world, ncols, wpr, 4)
         return np.ascontiguousarray(np.transpose(raw, (1, 0, 2, 3)).reshape(ncols, self.world * wpr, 4))
+
+
+class ShmComm:
+    """The library's one-node communicator over POSIX shared memory (gm_comm_shm_*, csrc/shm_comm.hip): the ranks' host threads
+    exchange the per-round sums of a sharded proof directly -- no device collective, no Python on the path.  `name` ("/gm-...")
+    must be the same on every rank and unique per job; creation is collective."""
+
+    def __init__(self, name, rank, world):
+        import ctypes as C
+        from . import ffi
+        L = ffi.lib()
+        self.L, self.rank, self.world = L, rank, world
+        self.h = C.c_void_p()
+        ffi.check(L.gm_comm_shm_create(name.encode(), rank, world, C.byref(self.h)))
+        self.c = ffi.GmComm()
+        ffi.check(L.gm_comm_shm_as_comm(self.h, C.byref(self.c)))
+
+    def close(self):
+        if self.h:
+            self.L.gm_comm_shm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def calls(self):
+        import ctypes as C
+        n, b = C.c_uint64(), C.c_uint64()
+        self.L.gm_comm_shm_stats(self.h, C.byref(n), C.byref(b))
+        return n.value
+
+    def sum_fr(self, vals):
+        """self-test of the seam: field sums over the ranks of a list of Montgomery elements (numpy uint64 (n, 4)), in place"""
+        from . import ffi
+        ffi.check(self.L.gm_comm_sum_fr(self.c, vals.ctypes.data, vals.shape[0]))
+        return vals

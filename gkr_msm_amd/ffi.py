@@ -138,6 +138,11 @@ _SIGS = {
     "gm_comm_rccl_all_gather_dev": (C.c_int32, [vp, vp, vp, C.c_uint64, vp]),
     "gm_comm_rccl_broadcast_dev": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint32, vp]),
     "gm_comm_rccl_stats": (C.c_int32, [vp, u64p, u64p]),
+    "gm_sc_stage_counts": (C.c_int32, [u64p, u64p]),
+    "gm_comm_shm_create": (C.c_int32, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "gm_comm_shm_destroy": (C.c_int32, [vp]),
+    "gm_comm_shm_as_comm": (C.c_int32, [vp, C.POINTER(GmComm)]),
+    "gm_comm_shm_stats": (C.c_int32, [vp, u64p, u64p]),
     "gm_pip_witness_destroy": (C.c_int32, [vp]),
     "gm_pip_witness_outputs": (C.c_int32, [vp, vp, u32p, u64p, vp]),
     "gm_pip_witness_bytes": (C.c_uint64, [vp]),

@@ -193,6 +193,9 @@ typedef struct gm_sc_profile_row {
     double fr_mul;       /* field multiplications over all launches */
     double max_ms_pairs; /* pairs of the launch that took max_ms (the largest one: its own roofline figure) */
 } gm_sc_profile_row;
+/* k_stage (persistent stage kernel) launches of this process so far and how many of them left before their first round (residency
+ * barrier; sharded: another rank's launch failed) -- which path a proof took, for tests and benches */
+int32_t gm_sc_stage_counts(uint64_t* launched, uint64_t* left_early);
 int32_t gm_sc_profile(int32_t mode);
 int32_t gm_sc_profile_read(gm_sc_profile_row* rows, uint32_t cap, uint32_t* n_rows, double* other_round_bytes, double* fold_bytes,
                            void* stream);
@@ -400,6 +403,22 @@ int32_t gm_comm_rccl_as_comm(gm_rccl* r, gm_comm* out);
 int32_t gm_comm_rccl_all_gather_dev(gm_rccl* r, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream);
 int32_t gm_comm_rccl_broadcast_dev(gm_rccl* r, void* d_buf, uint64_t bytes, uint32_t root, void* stream);
 int32_t gm_comm_rccl_stats(const gm_rccl* r, uint64_t* host_all_gathers, uint64_t* bytes_per_rank_total);
+
+/* One-node backing of the seam over POSIX shared memory (csrc/shm_comm.hip): the per-round sums of a sharded proof are wanted on the
+ * HOST (they go into the caller's transcript), so the ranks of one node exchange them between their host threads -- a cache-line
+ * transfer, well under a microsecond, where a device collective costs a kernel launch and a ring per round.  With this gm_comm
+ * (host all_gather, no all_gather_dev) the device side of a sharded round is the unsharded one: pre-enqueued folds and the
+ * persistent stage kernel included.  RCCL keeps the transfers that carry volume (operand replication, window points).
+ *   gm_comm_shm_create   collective: every rank calls it with the same name ("/gm-<job id>", unique per job) and world; rank 0
+ *                        creates the object (an existing name is an error), all return once every rank has mapped it, the name
+ *                        is removed again at that point (nothing is left behind in /dev/shm if a rank dies later)
+ *   gm_comm_shm_as_comm  the gm_comm for gm_pip_witness_create_sharded; payloads of any size (256 KiB chunks)
+ * Every wait is bounded by gm_set_wait_timeout_ms. */
+typedef struct gm_shm gm_shm;
+int32_t gm_comm_shm_create(const char* name, uint32_t rank, uint32_t world, gm_shm** out);
+int32_t gm_comm_shm_destroy(gm_shm* c);
+int32_t gm_comm_shm_as_comm(gm_shm* c, gm_comm* out);
+int32_t gm_comm_shm_stats(const gm_shm* c, uint64_t* all_gathers, uint64_t* bytes_per_rank_total);
 
 /* ---------------------------------------------------------------- "prove image part" (a10, a11)
  * Host-side driver over the kernels, mirroring PippengerWG::new (pippenger.rs:37-70, without the BLS12-381 G1
