@@ -111,6 +111,37 @@ __device__ __forceinline__ void fr9_mad_k(uint64_t& acc, uint32_t a, uint32_t k_
 // Montgomery product a b 2^-261 (mod p), product scanning: 153 multiply-adds, 9 quotient digits at 3 instructions each,
 // 17 shifts, 8 masks.  Limbs of a, b: 9 * max(a_i) * max(b_j) + 2^62 < 2^64 (e.g. both < 2^30, or < 2^31.5 and < 2^29).
 // Result limbs < 2^29 (top limb: what is left), value < a b / 2^261 + p.
+#ifndef GM_FR9_NO_ASM_BLOCK
+// The same product as ONE asm block (fr9_mul_asm.inc, generated by scripts/gen/gen_fr9_mul_asm.py; the C formulation below is kept
+// for reference and A/B: -DGM_FR9_NO_ASM_BLOCK).  The compiler pads every single-instruction asm statement with `s_nop 0`, and 170 of
+// those per product cost 10-16 % of the multiply-add rate at 2-8 waves per SIMD, 40 % at one (scripts/ubench/mad_nop_test.hip).
+__device__ __forceinline__ Fr9 fr9_mul(const Fr9& a, const Fr9& b) {
+    Fr9 r;
+    asm(
+#include "fr9_mul_asm.inc"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(r.l[8])
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]),
+          "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]), "v"(b.l[8])
+        : "vcc", "v2", "v3", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59");
+    return r;
+}
+__device__ __forceinline__ void fr9_mul2(const Fr9& a, const Fr9& b, const Fr9& c, const Fr9& d, Fr9& r, Fr9& q) {
+    r = fr9_mul(a, b);   // (a dependent chain of multiply-adds issues as fast as two interleaved ones once the padding is gone)
+    q = fr9_mul(c, d);
+}
+__device__ __forceinline__ Fr9 fr9_sqr(const Fr9& a) {
+    Fr9 r;
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    asm(
+#include "fr9_sqr_asm.inc"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(r.l[8]),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8])
+        : "vcc", "v2", "v3", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59");
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)t6; (void)t7;
+    return r;
+}
+#else
 __device__ __forceinline__ Fr9 fr9_mul(const Fr9& a, const Fr9& b) {
     uint32_t m[9];
     Fr9 r;
@@ -198,6 +229,8 @@ __device__ __forceinline__ Fr9 fr9_sqr(const Fr9& a) {
     r.l[8] = (uint32_t)acc;
     return r;
 }
+
+#endif  // GM_FR9_NO_ASM_BLOCK
 
 // limb-wise sum (no carry): limb bounds add, values add
 __device__ __forceinline__ Fr9 fr9_add(const Fr9& a, const Fr9& b) {

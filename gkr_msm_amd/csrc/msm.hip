@@ -100,6 +100,24 @@ __device__ __forceinline__ Point9 aff_add9(const Fr9& x1, const Fr9& y1, const F
 
 // inputs: loaded coordinates (L 2^29, S 32)
 __device__ __forceinline__ Point9 proj_add9(const Point9& p, const Point9& g) {
+#ifdef GM_ADD9_PAIRED
+    // independent products two at a time, their multiply-add chains interleaved (fr9_mul2)
+    Fr9 A, B, zz, C, X, Y, AB, dxy;
+    fr9_mul2(p.x, g.x, p.y, g.y, A, B);                                                // S 15.5
+    fr9_mul2(p.z, g.z, fr9_add(p.x, p.y), fr9_add(g.x, g.y), zz, C);                   // S 15.5, 59
+    const Fr9 s = fr9_sub2_32(C, A, B);                                                // L 2^31, S 91
+    const Fr9 t = fr9_add(B, fr9_mul5(A));                                             // L 6 2^29, S 93
+    fr9_mul2(s, zz, t, zz, X, Y);                                                      // S 21, 21.4
+    const Fr9 z2 = fr9_sqr(zz);                                                        // S 4.4
+    AB = fr9_mul(A, B);
+    dxy = fr9_mul(AB, fr9_coeff_d());                                                  // S 1.07
+    const Fr9 m = fr9_norm(fr9_sub8(z2, dxy));                                         // S 12.4
+    const Fr9 q = fr9_add(z2, dxy);                                                    // L 2^30, S 5.5
+    Point9 r;
+    fr9_mul2(m, X, q, Y, r.x, r.y);                                                    // S 4.7, 2.7
+    r.z = fr9_mul(m, q);                                                               // S 2
+    return r;
+#else
     const Fr9 A = fr9_mul(p.x, g.x), B = fr9_mul(p.y, g.y), zz = fr9_mul(p.z, g.z);   // S 15.5
     const Fr9 C = fr9_mul(fr9_add(p.x, p.y), fr9_add(g.x, g.y));                       // S 59
     const Fr9 s = fr9_sub2_32(C, A, B);                                                // L 2^31, S 91
@@ -115,6 +133,7 @@ __device__ __forceinline__ Point9 proj_add9(const Point9& p, const Point9& g) {
     r.y = fr9_mul(q, Y);                                                               // S 2.7
     r.z = fr9_mul(m, q);                                                               // S 2
     return r;
+#endif
 }
 
 __device__ __forceinline__ Point9 pt9_load(const Fr* x, const Fr* y, const Fr* z, uint64_t i) {
