@@ -119,6 +119,22 @@ __device__ __forceinline__ Fq fq14_to(const Fq14& y) {
     return fq_reduce_once(w);
 }
 
+#ifndef GM_FQ14_NO_ASM_BLOCKS
+// fq14_mul / fq14_sqr with the multiply-adds of a column in two asm blocks (generated: scripts/gen/gen_fq14_mul.py): the compiler pads
+// every asm statement with `s_nop 0`, and at the two waves per SIMD of the G1 kernels 420 of those per product cost ~15 % of the
+// multiply-add rate (scripts/ubench/mad_nop_test.hip).  The one-statement-per-instruction formulation below is the reference
+// (-DGM_FQ14_NO_ASM_BLOCKS); without the padding a dependent chain issues as fast as two interleaved ones, so the "two at a time"
+// helpers are plain pairs.
+#include "fq14_mul_gen.inc"
+__device__ __forceinline__ void fq14_mul2(const Fq14& a, const Fq14& b, const Fq14& c, const Fq14& d, Fq14& r, Fq14& q) {
+    r = fq14_mul(a, b);
+    q = fq14_mul(c, d);
+}
+__device__ __forceinline__ void fq14_sqr2(const Fq14& a, const Fq14& c, Fq14& r, Fq14& q) {
+    r = fq14_sqr(a);
+    q = fq14_sqr(c);
+}
+#else
 // Montgomery product a b 2^-392 (mod q), product scanning.  Limbs: 14 max(a_i) max(b_j) + 2^60 < 2^64.
 // Result limbs < 2^28 (top limb: what is left), value < a b / 2^392 + q.
 __device__ __forceinline__ Fq14 fq14_mul(const Fq14& a, const Fq14& b) {
@@ -239,6 +255,8 @@ __device__ __forceinline__ void fq14_sqr2(const Fq14& a, const Fq14& c, Fq14& r,
     r.l[13] = (uint32_t)acc;
     q.l[13] = (uint32_t)bcc;
 }
+
+#endif  // GM_FQ14_NO_ASM_BLOCKS
 
 __device__ __forceinline__ Fq14 fq14_add(const Fq14& a, const Fq14& b) {
     Fq14 r;
