@@ -215,7 +215,7 @@ struct FinishCtx {
 };
 #define FINISH_ATOMIC_MAX_BLOCKS 512u
 // V = sum of <= 512 canonical field elements given as eight 64-bit limb sums (low words lo, bits 32.. hi): V mod p
-__device__ __forceinline__ Fr limb_sums_mod_p(const uint32_t* lo8, const uint32_t* hi8) {
+GM_HD Fr limb_sums_mod_p(const uint32_t* lo8, const uint32_t* hi8) {
     Fr lo, hi, c32;
 #pragma unroll
     for (int l = 0; l < 8; l++) { lo.l[l] = lo8[l]; hi.l[l] = hi8[l]; }
@@ -235,6 +235,36 @@ __device__ __forceinline__ Fr wave_sum(Fr v) {
         v = fr_add(v, t);
     }
     return v;
+}
+
+// The same sum WITHOUT the modular additions: the sixteen 16-bit halves of the eight limbs summed over the wave as plain integers
+// (each below 2^22), by DPP adds -- four row shifts, two row broadcasts, no LDS traffic, no carry chains, no conditional subtractions
+// (wave_sum costs ~1 800 cycles of a lone wave, this ~400).  The cross-block accumulators take integer limb sums anyway
+// (limb_sums_mod_p reduces them once, in the block that arrives last), so a block never needs its own sum reduced.  Result: wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_acc(uint32_t x) {
+    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ void wave_half_sums(const Fr& v, uint32_t* out16) {
+    uint32_t h[16];
+#pragma unroll
+    for (int l = 0; l < 8; l++) { h[2 * l] = v.l[l] & 0xffffu; h[2 * l + 1] = v.l[l] >> 16; }
+    // row_shr:1, 2, 4, 8: lane 15 of every row of 16 holds the row's sum; row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3:
+    // lane 63 holds the wave's
+#pragma unroll
+    for (int k = 0; k < 16; k++) h[k] = dpp_acc<0x111, 0xf>(h[k]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) h[k] = dpp_acc<0x112, 0xf>(h[k]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) h[k] = dpp_acc<0x114, 0xf>(h[k]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) h[k] = dpp_acc<0x118, 0xf>(h[k]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) h[k] = dpp_acc<0x142, 0xa>(h[k]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) h[k] = dpp_acc<0x143, 0xc>(h[k]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) out16[k] = (uint32_t)__builtin_amdgcn_readlane((int)h[k], 63);
 }
 
 // block-wide sums of acc[0..NACC): wave shuffles, then one pass over the SC_THREADS / 64 wave totals.
@@ -265,11 +295,26 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
     if (fc.acc && nblk <= FINISH_ATOMIC_MAX_BLOCKS) {
         // small and medium grids: no second pass over stored partials (they are what a latency-bound round waits for)
         __shared__ uint32_t s_lo[8 * NACC], s_hi[8 * NACC];
-        const Fr tot = block_sum<NACC>(acc, red);
-        if (threadIdx.x < NACC) {
+        __shared__ uint32_t half[SC_THREADS / 64][NACC][16];
+        {
+            const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-            for (int l = 0; l < 8; l++)
-                (void)__hip_atomic_fetch_add(fc.acc + (threadIdx.x * 8 + l) * 16, (unsigned long long)tot.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int a = 0; a < NACC; a++) {
+                uint32_t hs[16];
+                wave_half_sums(acc[a], hs);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) half[wave][a][k] = hs[k];
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 * NACC) {   // one lane per (sum, limb): the block's integer limb sum (< 2^42) into the launch's accumulator
+            const uint32_t a = threadIdx.x >> 3, l = threadIdx.x & 7;
+            unsigned long long v = 0;
+#pragma unroll
+            for (int w = 0; w < SC_THREADS / 64; w++) v += (unsigned long long)half[w][a][2 * l] + ((unsigned long long)half[w][a][2 * l + 1] << 16);
+            (void)__hip_atomic_fetch_add(fc.acc + threadIdx.x * 16, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             coh_drain();
         }
         __syncthreads();   // this block's additions have been performed before the counter moves
@@ -589,8 +634,8 @@ struct StageArgs {
     const Fr* thin_eq[12];             // thin round q: entry 0 of that round's level of the row eq sequence
     const Fr* eq[STAGE_MAX_ROUNDS];    // dense round q: eq table indexed by the global pair index
     PadCols row_pad, col_pad;          // thin only
-    uint32_t* h_rep;                   // pinned: the round's report at 36 (round & 1) words: sum at point 1, at point 2, tail weight,
-                                       // each as three self-validating chunks (see fr_chunks_store_sys)
+    uint32_t* h_rep;                   // pinned: the round's report at 96 (round & 1) words: 24 self-validating chunks, one per 64-bit limb
+                                       // sum (8 limbs each of the sum at point 1, at point 2, of the tail weight): the host reduces mod p
     uint32_t* d_round_cnt;             // device: one arrival counter per round (zeroed before the launch)
     Fr* h_finals;                      // pinned: what is left of column c after the last round, 32 slots per column
     uint32_t* h_fin_seq;               // pinned: word [segment][slice] = ticket0 + rounds once that block's part is written
@@ -689,8 +734,7 @@ __device__ __forceinline__ Fr stage_eval(const Seg& g, const Fr* p0, const Fr* p
 template <int MAXIN>
 __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const Fr* __restrict__ gp, StageArgs a) {
     __shared__ Fr xch[MAXIN][256];
-    __shared__ Fr red[4][2];
-    __shared__ uint32_t acc_lo[24], acc_hi[24];
+    __shared__ uint32_t half[4][2][16];
     __shared__ Fr ts;
     __shared__ int ok;
     __shared__ uint32_t is_last;
@@ -743,10 +787,21 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
     // with up to 192 blocks, per-block reports cost ~45 us per round in PCIe write transactions alone.
     auto exchange = [&](Fr s0, Fr s1, bool with_w, uint32_t nrep) -> bool {
         STAGE_STAMP(1);
-        const Fr w0 = wave_sum(s0);
-        Fr w1 = fr_zero();
-        if (with_w) w1 = wave_sum(s1);
-        if (lane == 0) { red[wave][0] = w0; red[wave][1] = w1; }
+        {   // integer limb sums over the wave (see wave_half_sums): the block's share goes into the accumulators unreduced
+            uint32_t hs[16];
+            wave_half_sums(s0, hs);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) half[wave][0][k] = hs[k];
+            }
+            if (with_w) {
+                wave_half_sums(s1, hs);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) half[wave][1][k] = hs[k];
+                }
+            }
+        }
         __syncthreads();
         const uint32_t want = a.ticket0 + round;
         STAGE_STAMP(2);
@@ -758,41 +813,34 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
         // field elements as a chain of fr_add.  (Before: every block stored its partial, the last block loaded all of them and ran
         // three wave reductions: ~4.5 us per round against ~2.)
         unsigned long long* accb = a.d_acc + (size_t)round * (3 * 8 * 16);
-        if (i == 0) {
-            const Fr t0 = fr_add(fr_add(red[0][0], red[1][0]), fr_add(red[2][0], red[3][0]));
-            const uint32_t which = blockIdx.x & 1u;
+        if (i < 16) {   // wave 0: lanes 0-7 the limbs of the evaluation-point sum, lanes 8-15 those of the tail weight
+            const uint32_t sel = i >> 3, l = i & 7;
+            if (sel == 0 || with_w) {
+                unsigned long long v = 0;
 #pragma unroll
-            for (int l = 0; l < 8; l++)
-                (void)__hip_atomic_fetch_add(accb + (which * 8 + l) * 16, (unsigned long long)t0.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (with_w) {
-                const Fr t1 = fr_add(fr_add(red[0][1], red[1][1]), fr_add(red[2][1], red[3][1]));
-#pragma unroll
-                for (int l = 0; l < 8; l++)
-                    (void)__hip_atomic_fetch_add(accb + (16 + l) * 16, (unsigned long long)t1.l[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int w = 0; w < 4; w++) v += (unsigned long long)half[w][sel][2 * l] + ((unsigned long long)half[w][sel][2 * l + 1] << 16);
+                const uint32_t slot = sel ? 16u + l : (blockIdx.x & 1u) * 8u + l;
+                (void)__hip_atomic_fetch_add(accb + slot * 16, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            coh_drain();   // the additions have been performed before the counter moves
-            const uint32_t prev = __hip_atomic_fetch_add(a.d_round_cnt + round, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            is_last = (prev == nrep - 1) ? 1u : 0u;
+            coh_drain();   // the additions have been performed before the counter moves (one wave: the drain covers all sixteen lanes)
+            if (i == 0) {
+                const uint32_t prev = __hip_atomic_fetch_add(a.d_round_cnt + round, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                is_last = (prev == nrep - 1) ? 1u : 0u;
+            }
         }
         __syncthreads();
         STAGE_STAMP(3);
         if (is_last) {
             // It also leaves the round's counter and accumulators at zero for the next launch (the state buffer is never memset).
             if (i == 0) __hip_atomic_store(a.d_round_cnt + round, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // The 64-bit limb sums go to the host as they are, one self-validating chunk per accumulator from the lane that swapped it
+            // out: the host reduces L + 2^32 H mod p in ~0.1 us, here it cost an LDS hand-over, a barrier and a product on the path
+            // every block of the launch is waiting on.  Report slot of this round: rewritten two rounds later, after the host has read it.
             const uint32_t nacc = thin ? 24u : 16u;
-            if (i < nacc) {
-                const unsigned long long v = __hip_atomic_exchange(accb + i * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                acc_lo[i] = (uint32_t)v;
-                acc_hi[i] = (uint32_t)(v >> 32);
-            }
-            __syncthreads();   // is_last is uniform over the block
-            if (i < 3) {
-                Fr out = fr_zero();
-                if (i < 2 || thin) {
-                    out = limb_sums_mod_p(acc_lo + 8 * i, acc_hi + 8 * i);
-                }
-                // report slot of this round: a slot is rewritten two rounds later, after the host has read it
-                fr_chunks_store_sys(a.h_rep + 36 * (round & 1) + 12 * i, out, want);
+            if (i < 24) {
+                unsigned long long v = 0;
+                if (i < nacc) v = __hip_atomic_exchange(accb + i * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                chunk_store_sys(a.h_rep + 96 * (round & 1) + 4 * i, (uint32_t)v, (uint32_t)(v >> 32), 0u, want);
             }
         }
         STAGE_STAMP(4);
@@ -1834,9 +1882,9 @@ static int32_t gather_finals(const Fr* const* cur, int k, hipStream_t s, std::ve
 // pinned staging + device-side counters of k_stage: one per host thread and device, kept for the life of the process
 struct TailStage {
     char* base = nullptr;
-    uint32_t* rep() const { return reinterpret_cast<uint32_t*>(base); }            // 2 report slots of 36 words (3 elements x 3 chunks)
-    uint32_t* tkt() const { return rep() + 128; }                                  // 2 challenge slots of 12 words (3 chunks)
-    uint32_t* status() const { return rep() + 192; }
+    uint32_t* rep() const { return reinterpret_cast<uint32_t*>(base); }            // 2 report slots of 96 words (3 sums x 8 limb chunks)
+    uint32_t* tkt() const { return rep() + 192; }                                  // 2 challenge slots of 12 words (3 chunks)
+    uint32_t* status() const { return rep() + 224; }
     Fr* finals() const { return reinterpret_cast<Fr*>(base + 1024); }              // 32 slots per column: what the launch leaves of it
     uint32_t* fin_seq() const { return reinterpret_cast<uint32_t*>(finals() + 32 * GM_MAX_COLS); }   // [segment][slice]
     uint32_t counter = 0;
@@ -1987,7 +2035,8 @@ struct StageRun {
         if (!dbg.p) return;
         std::vector<uint64_t> h(2 * 32 * 8);
         if (hipMemcpy(h.data(), dbg.p, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
-        fprintf(stderr, "[k_stage %ux%u thin %d dense %d] per round, us since the round's start: block 0 | block 1\n", gx, nsl, n_thin, n_dense);
+        fprintf(stderr, "[k_stage %ux%u thin %d dense %d] host turn-around %.2f us per round (sums seen -> challenge written); per round, us since the round's start: block 0 | block 1\n",
+                gx, nsl, n_thin, n_dense, host_n ? host_us / host_n : 0.0);
         for (int r = 0; r < total(); r++) {
             fprintf(stderr, "  r%02d", r);
             for (int b = 0; b < 2; b++) {
@@ -2114,9 +2163,21 @@ struct StageRun {
     }
     int32_t sums(int r, Fr* s1, Fr* s2, Fr* w) {
         const uint32_t want = ticket0 + (uint32_t)r;
-        const volatile uint32_t* rep = st->rep() + 36 * (r & 1);
+        const volatile uint32_t* rep = st->rep() + 96 * (r & 1);
         Fr v[3];
-        auto all = [&] { return read_chunks(rep, want, &v[0]) && read_chunks(rep + 12, want, &v[1]) && read_chunks(rep + 24, want, &v[2]); };
+        // 24 chunks of {low word, high word, -, tag}: the limb sums of the three values; valid once every chunk carries the round's tag
+        auto all = [&] {
+            uint32_t lo[24], hi[24];
+            for (int c = 0; c < 24; c++)
+                if (rep[4 * c + 3] != want) return false;
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (int c = 0; c < 24; c++) { lo[c] = rep[4 * c]; hi[c] = rep[4 * c + 1]; }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (int c = 0; c < 24; c++)
+                if (rep[4 * c + 3] != want) return false;
+            for (int k = 0; k < 3; k++) v[k] = limb_sums_mod_p(lo + 8 * k, hi + 8 * k);
+            return true;
+        };
         bool seen = false;
         volatile uint32_t* stat = reinterpret_cast<volatile uint32_t*>(st->status());
         for (int spin = 0; spin < 400000 && !seen; spin++) {
@@ -2150,10 +2211,16 @@ struct StageRun {
         *s1 = v[0];
         *s2 = v[1];
         if (w) *w = v[2];
+        if (debug()) t_sums = std::chrono::steady_clock::now();
         return GM_OK;
     }
+    // development aid (GM_STAGE_DEBUG=1): the host's turn-around, from a round's sums seen to its challenge written
+    std::chrono::steady_clock::time_point t_sums;
+    double host_us = 0;
+    int host_n = 0;
     static void write_chunks(volatile uint32_t* p, const Fr& t, uint32_t tag) { write_chunks16(p, t, tag); }
     void publish(int r, const Fr& t) {
+        if (debug()) { host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_sums).count(); host_n++; }
         if (st->tkt_bar) {
             write_chunks(st->tkt_bar + 12 * (r & 1), t, ticket0 + (uint32_t)r);
             _mm_sfence();   // device memory is mapped write-combining on the host: push the three stores out now
