@@ -212,6 +212,8 @@ struct FinishCtx {
     uint32_t seq;        // written (system scope) after the results: the host polls it instead of a stream sync
     unsigned long long* acc;   // 3 x 8 limb accumulators (64-bit, one 128-byte line each), zero between launches; grids of <= 512 blocks
                                // add their block sums into them with atomics instead of storing partials (see k_stage's exchange)
+    uint32_t raw;              // 1: `out` is read by the host (RoundScratch::finish_seq), which takes the 64-bit limb sums as they are and
+                               // reduces them mod p itself (format word 1 next to the sequence number); 0: `out` receives field elements
 };
 #define FINISH_ATOMIC_MAX_BLOCKS 512u
 // V = sum of <= 512 canonical field elements given as eight 64-bit limb sums (low words lo, bits 32.. hi): V mod p
@@ -324,6 +326,22 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
         }
         __syncthreads();
         if (!is_last) return;
+        if (fc.raw && NACC <= 3) {   // (four sums would reach into the sequence slot)
+            // the last block forwards the limb sums unreduced (8 NACC <= 24 lanes of the first wave, 8 bytes each): no LDS hand-over, no
+            // barrier and no product on the path the host is waiting on
+            if (threadIdx.x < 8 * NACC) {
+                const unsigned long long v = __hip_atomic_exchange(fc.acc + threadIdx.x * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(fc.out) + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (threadIdx.x < 64) {
+                coh_drain();   // one wave: the sums have reached host memory before the sequence word is written
+                if (threadIdx.x == 0) {
+                    __hip_atomic_store(fc.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(fc.out + 7), (1ull << 32) | fc.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
         if (threadIdx.x < 8 * NACC) {
             const unsigned long long v = __hip_atomic_exchange(fc.acc + threadIdx.x * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_lo[threadIdx.x] = (uint32_t)v;
@@ -337,7 +355,7 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
         __syncthreads();  // the results have reached host memory before the sequence word is written
         if (threadIdx.x == 0) {
             __hip_atomic_store(fc.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(reinterpret_cast<uint32_t*>(fc.out + 7), fc.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(fc.out + 7), (unsigned long long)fc.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
@@ -367,7 +385,7 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
     __syncthreads();  // the results have reached host memory before the sequence word is written
     if (threadIdx.x == 0) {
         __hip_atomic_store(fc.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(fc.out + 7), fc.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(fc.out + 7), (unsigned long long)fc.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -389,7 +407,7 @@ __global__ void __launch_bounds__(64) k_sum_ranks(const Fr* __restrict__ all, ui
         coh_drain();
     }
     __syncthreads();   // the sums have reached host memory before the sequence word is written
-    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(h_out + 7), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(h_out + 7), (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One segment of the gamma-combined layer function at the "1" point (h = 0: p1) or the "2" point (h = 1: 2 p1 - p0)
@@ -1759,7 +1777,7 @@ struct RoundScratch {
         expect = ++seq_counter();
         if (expect == 0) expect = ++seq_counter();
         return FinishCtx{partial.fr(), reinterpret_cast<uint32_t*>(counter.p), h_result, expect,
-                         reinterpret_cast<unsigned long long*>(accbuf.p)};
+                         reinterpret_cast<unsigned long long*>(accbuf.p), 1u};
     }
     // ---- sharded rounds over a device-side collective (see k_sum_ranks)
     DevBuf xslot, xall;
@@ -1777,6 +1795,7 @@ struct RoundScratch {
         }
         *fc = ctx();
         fc->out = xslot.fr();
+        fc->raw = 0;   // k_sum_ranks adds field elements
         return GM_OK;
     }
     // all-gather of the slots + the one-wave sum, both on the prover's stream; finish() then sees the SUMS in pinned memory
@@ -1839,6 +1858,15 @@ struct RoundScratch {
         }
         if (!seen) GM_HIP(hipStreamSynchronize(s));
         std::atomic_thread_fence(std::memory_order_acquire);
+        if (slot[1] == 1u) {   // the launch forwarded its 64-bit limb sums (block_reduce_finish, grids of <= 512 blocks)
+            const volatile unsigned long long* raw = reinterpret_cast<const volatile unsigned long long*>(h_result);
+            for (int a = 0; a < nacc; a++) {
+                uint32_t lo[8], hi[8];
+                for (int l = 0; l < 8; l++) { const unsigned long long v = raw[8 * a + l]; lo[l] = (uint32_t)v; hi[l] = (uint32_t)(v >> 32); }
+                out[a] = limb_sums_mod_p(lo, hi);
+            }
+            return GM_OK;
+        }
         for (int a = 0; a < nacc; a++) out[a] = h_result[a];
         return GM_OK;
     }
