@@ -654,7 +654,7 @@ struct StageArgs {
     PadCols row_pad, col_pad;          // thin only
     uint32_t* h_rep;                   // pinned: the round's report at 96 (round & 1) words: 24 self-validating chunks, one per 64-bit limb
                                        // sum (8 limbs each of the sum at point 1, at point 2, of the tail weight): the host reduces mod p
-    uint32_t* d_round_cnt;             // device: one arrival counter per round (zeroed before the launch)
+    uint32_t* d_round_cnt;             // (unused since the accumulators count their own contributors)
     Fr* h_finals;                      // pinned: what is left of column c after the last round, 32 slots per column
     uint32_t* h_fin_seq;               // pinned: word [segment][slice] = ticket0 + rounds once that block's part is written
     const uint32_t* h_tkt;             // pinned: the host publishes t_r as three chunks tagged ticket0 + r at 12 (r & 1) words
@@ -755,7 +755,6 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
     __shared__ uint32_t half[4][2][16];
     __shared__ Fr ts;
     __shared__ int ok;
-    __shared__ uint32_t is_last;
     const int sgi = blockIdx.x >> 1, h = blockIdx.x & 1;
     const Seg g = sp.seg[sgi];
     const uint32_t slice = blockIdx.y, nsl = gridDim.y;
@@ -765,7 +764,6 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
 #pragma unroll
     for (int q = 0; q < MAXIN; q++) { p0[q] = fr_zero(); p1[q] = fr_zero(); }
     uint32_t round = 0;   // rounds done by this launch so far: the ticket of round r is ticket0 + r
-    bool thin = a.n_thin > 0;   // true while the thin rounds run (reports then carry the tail weight)
     // development aid (GM_STAGE_DEBUG=1): wall-clock stamps (100 MHz) of the phases of every round, blocks 0 and 1
 #define STAGE_STAMP(k_) do { if (a.d_dbg && i == 0 && blk < 2) a.d_dbg[((size_t)blk * 32 + round) * 8 + (k_)] = wall_clock64(); } while (0)
 
@@ -823,13 +821,14 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
         __syncthreads();
         const uint32_t want = a.ticket0 + round;
         STAGE_STAMP(2);
-        // Cross-block sum without a second pass over the partials: every block adds the eight 32-bit limbs of its (canonical) sum to
-        // eight 64-bit accumulators of the round (no-return atomics: < 2^40 after 256 blocks), each in a 128-byte line of its own so
-        // that the atomics of one value spread over L2 channels; the block that arrives last swaps the accumulators out (leaving
-        // zeros for the next launch) and reduces V = L + 2^32 H mod p -- L the low words (< 2.21 p: two conditional subtractions), H the
-        // high bytes (< 2^232: one Montgomery product with 2^32) -- three lanes, one per sum, in parallel.  Sums of integers: the same
-        // field elements as a chain of fr_add.  (Before: every block stored its partial, the last block loaded all of them and ran
-        // three wave reductions: ~4.5 us per round against ~2.)
+        // Cross-block sum in ONE trip to the L2: every block adds the integer limb sums of its share to the round's 64-bit accumulators
+        // (one 128-byte line each: the atomics of a value spread over L2 channels) with RETURNING adds that also count the
+        // contributors in the accumulator's top bits (limb sums stay below 2^49; the count sits from bit 52).  The block whose add
+        // arrives last at an accumulator -- the returned count says so; it may be a different block for every accumulator -- knows that
+        // accumulator's total, forwards it to the host as one self-validating chunk and leaves a zero behind for the next launch.  The
+        // host waits for all chunks of the round and reduces L + 2^32 H mod p (~0.1 us).  Sums of integers: the same field elements as
+        // a chain of fr_add.  (Before: no-return adds, a drain, an arrival counter, and the last block swapping every accumulator out:
+        // three dependent trips; before that, stored partials and a second pass: ~4.5 us per round.)
         unsigned long long* accb = a.d_acc + (size_t)round * (3 * 8 * 16);
         if (i < 16) {   // wave 0: lanes 0-7 the limbs of the evaluation-point sum, lanes 8-15 those of the tail weight
             const uint32_t sel = i >> 3, l = i & 7;
@@ -838,29 +837,18 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
 #pragma unroll
                 for (int w = 0; w < 4; w++) v += (unsigned long long)half[w][sel][2 * l] + ((unsigned long long)half[w][sel][2 * l + 1] << 16);
                 const uint32_t slot = sel ? 16u + l : (blockIdx.x & 1u) * 8u + l;
-                (void)__hip_atomic_fetch_add(accb + slot * 16, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            coh_drain();   // the additions have been performed before the counter moves (one wave: the drain covers all sixteen lanes)
-            if (i == 0) {
-                const uint32_t prev = __hip_atomic_fetch_add(a.d_round_cnt + round, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                is_last = (prev == nrep - 1) ? 1u : 0u;
+                // contributors: the blocks of this evaluation point (half of the reporting ones); the tail weight comes from segment 0's
+                const uint32_t expected = sel ? nsl : (nrep >> 1);
+                const unsigned long long prev = __hip_atomic_fetch_add(accb + slot * 16, v + (1ull << 52), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(prev >> 52) == expected - 1) {
+                    const unsigned long long tot = (prev + v) & ((1ull << 52) - 1);
+                    // report slot of this round: rewritten two rounds later, after the host has read it
+                    chunk_store_sys(a.h_rep + 96 * (round & 1) + 4 * slot, (uint32_t)tot, (uint32_t)(tot >> 32), 0u, want);
+                    __hip_atomic_store(accb + slot * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
-        __syncthreads();
         STAGE_STAMP(3);
-        if (is_last) {
-            // It also leaves the round's counter and accumulators at zero for the next launch (the state buffer is never memset).
-            if (i == 0) __hip_atomic_store(a.d_round_cnt + round, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // The 64-bit limb sums go to the host as they are, one self-validating chunk per accumulator from the lane that swapped it
-            // out: the host reduces L + 2^32 H mod p in ~0.1 us, here it cost an LDS hand-over, a barrier and a product on the path
-            // every block of the launch is waiting on.  Report slot of this round: rewritten two rounds later, after the host has read it.
-            const uint32_t nacc = thin ? 24u : 16u;
-            if (i < 24) {
-                unsigned long long v = 0;
-                if (i < nacc) v = __hip_atomic_exchange(accb + i * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                chunk_store_sys(a.h_rep + 96 * (round & 1) + 4 * i, (uint32_t)v, (uint32_t)(v >> 32), 0u, want);
-            }
-        }
         STAGE_STAMP(4);
         if (i == 0) {
             int good = 0;
@@ -938,7 +926,6 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
                     if (q < g.n_in) { p0[q] = fr_add(p0[q], fr_mul(t, fr_sub(p1[q], p0[q]))); p1[q] = a.row_pad.v[g.in[q]]; }
             }
         }
-        thin = false;
         // bind_into_dense: the last fold above left the row's value in p0; absent cells are row_pad, absent rows col_pad
 #pragma unroll
         for (int q = 0; q < MAXIN; q++)
@@ -2194,14 +2181,15 @@ struct StageRun {
         const volatile uint32_t* rep = st->rep() + 96 * (r & 1);
         Fr v[3];
         // 24 chunks of {low word, high word, -, tag}: the limb sums of the three values; valid once every chunk carries the round's tag
+        const int nchunks = r < n_thin ? 24 : 16;   // the tail weight is reported in the thin rounds only
         auto all = [&] {
-            uint32_t lo[24], hi[24];
-            for (int c = 0; c < 24; c++)
+            uint32_t lo[24] = {0}, hi[24] = {0};
+            for (int c = 0; c < nchunks; c++)
                 if (rep[4 * c + 3] != want) return false;
             std::atomic_thread_fence(std::memory_order_acquire);
-            for (int c = 0; c < 24; c++) { lo[c] = rep[4 * c]; hi[c] = rep[4 * c + 1]; }
+            for (int c = 0; c < nchunks; c++) { lo[c] = rep[4 * c]; hi[c] = rep[4 * c + 1]; }
             std::atomic_thread_fence(std::memory_order_acquire);
-            for (int c = 0; c < 24; c++)
+            for (int c = 0; c < nchunks; c++)
                 if (rep[4 * c + 3] != want) return false;
             for (int k = 0; k < 3; k++) v[k] = limb_sums_mod_p(lo + 8 * k, hi + 8 * k);
             return true;
