@@ -721,6 +721,8 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
+            L.gm_release_cached_memory()     # the extra shapes (x_logsize 24) leave tens of GiB in the library's and torch's caches
+            torch.cuda.empty_cache()
             if plan is None:     # the extra shapes released the x_logsize-20 plan and operands
                 d_pts, d_sc, sc, _ = make_inputs(x_main)
                 plan = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
