@@ -1167,6 +1167,375 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     return GM_OK;
 }
 
+}  // namespace
+
+// =================================================================================================================
+// The same argument with the matrix sharded by windows.  Every array of the argument is indexed (y, x) with the window
+// in the high bits, so a rank's windows are a contiguous slice of each of them and
+//   * c, d, c_pull, d_pull, c_adj, d_adj, p_selector_prod are built from the rank's own plan (its windows' digits and counters);
+//   * every sumcheck -- the layers of the logup main phase and the combined Prod3 + fraction sumcheck -- binds the low variables
+//     first: the sharded dense objects (round sums exchanged through gm_comm, the last log2(world) rounds replicated) serve them;
+//   * the access counts are sums over the ranks' windows (one exchange of 2^x_logsize + 2^d_logsize elements);
+//   * what does NOT stay local is the WITNESS of the logup tree: map_split_hi pairs element i with element i + len / 2, so after
+//     every level the two halves are re-spread over the ranks (new rank j: l-slice from old rank j / 2, r-slice from old rank
+//     world / 2 + j / 2).  Here that goes through the communicator's all-gather on host buffers (correct with any gm_comm and what
+//     the tests run; a node's ranks would move the slices device to device -- pairwise over xGMI -- which this box cannot rehearse);
+//     below `GM_PF_DIST_MIN` elements per rank (default 1024) a level is gathered once and the tree goes on replicated.
+// Requires y_size = 2^y_logsize (as the sharded image part) and world | y_size.  Same transcript on every rank, same messages and
+// claims as the unsharded argument.
+namespace gm {
+__global__ void __launch_bounds__(256) k_pf_psel_at(const Fr* __restrict__ points_xy, const Fr* __restrict__ eq_sel_y, Fr g1, Fr g2,
+                                                     uint32_t x_log, uint64_t base, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t gi = base + i, iy = gi >> x_log, ix = gi & ((1ull << x_log) - 1);
+    const Fr p0 = fr_load(points_xy + 2 * ix), p1 = fr_load(points_xy + 2 * ix + 1);
+    const Fr pf = fr_add(fr_add(p0, fr_mul(g1, fr_sub(p1, fr_one()))), g2);
+    fr_store(out + i, fr_mul(fr_load(eq_sel_y + iy), pf));
+}
+// out[i] = sum over the parts of parts[r * n + i]
+__global__ void __launch_bounds__(256) k_pf_sum_parts(const Fr* __restrict__ parts, uint32_t nparts, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = fr_load(parts + i);
+    for (uint32_t r = 1; r < nparts; r++) acc = fr_add(acc, fr_load(parts + (uint64_t)r * n + i));
+    fr_store(out + i, acc);
+}
+}  // namespace gm
+
+namespace {
+
+// the whole array on the host, in global order, from every rank's slice of n_loc elements (host-staged: see the header comment)
+int32_t pf_gather_slices(const Shard& sh, const Fr* d_slice, uint64_t n_loc, std::vector<Fr>* all, hipStream_t s) {
+    all->resize((size_t)sh.world * n_loc);
+    GM_HIP(hipMemcpyAsync(all->data() + (size_t)sh.rank * n_loc, d_slice, n_loc * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    const int32_t rc = sh.comm->all_gather(sh.comm->ctx, all->data(), n_loc * sizeof(Fr));
+    if (rc) return set_err(GM_ERR_STATE, "gm_comm all_gather failed with %d", rc);
+    return GM_OK;
+}
+
+struct DFrac {   // a (numerator, denominator) pair of the sharded logup tree: this rank's slice (dist) or the whole arrays
+    const Fr* num = nullptr;
+    const Fr* den = nullptr;
+    uint64_t len = 0;       // GLOBAL length
+    bool dist = false;
+    std::shared_ptr<DevBuf> keep_n, keep_d;
+};
+
+int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_log, const Shard& sh,
+                                  const uint64_t* h_claim_point, const uint64_t* h_claim_evs, Tape* tr, Fr* out_gamma,
+                                  Claims* out_matrix, Claims* out_ac_c, Claims* out_ac_d, hipStream_t s) {
+    const uint32_t x_log = plan->x_log, d_log = plan->d_log, y_size = plan->y_size, G = sh.world;
+    GM_REQUIRE(sh.comm && G >= 2 && (G & (G - 1)) == 0, "bad sharding context");
+    GM_REQUIRE(y_size == (1u << y_log), "the sharded pushforward argument needs y_size = 2^y_logsize");
+    GM_REQUIRE(y_size % G == 0 && plan->nwin == y_size / G && plan->y0 == sh.rank * plan->nwin, "rank %u of %u must own windows [%u, %u)",
+               sh.rank, G, sh.rank * (y_size / G), (sh.rank + 1) * (y_size / G));
+    const uint32_t mlog = x_log + y_log;
+    GM_REQUIRE(mlog >= 1 && mlog <= 30 && sh.lg <= y_log, "matrix too large / more ranks than windows");
+    const uint64_t M = 1ull << mlog, X = 1ull << x_log, D = 1ull << d_log, ML = M / G, base = (uint64_t)sh.rank * ML;
+    void* stream = reinterpret_cast<void*>(s);
+    static const uint64_t dist_min = [] { const char* e = getenv("GM_PF_DIST_MIN"); return (uint64_t)(e && atoll(e) >= 1 ? atoll(e) : 1024); }();
+    std::vector<Fr> r(y_log + d_log + x_log), evs(3);
+    memcpy(r.data(), h_claim_point, r.size() * sizeof(Fr));
+    memcpy(evs.data(), h_claim_evs, 3 * sizeof(Fr));
+    evs[1] = fr_sub(evs[1], fr_one());  // claims.evs[1] -= 1 (pushforward.rs:641)
+
+    auto mk = [&](uint64_t n, std::shared_ptr<DevBuf>* b) -> int32_t {
+        b->reset(new DevBuf());
+        return (*b)->alloc(n * sizeof(Fr));
+    };
+    std::shared_ptr<DevBuf> c, d, ac_c, ac_d, c_pull, d_pull, c_adj, d_adj, num, den, table_c, table_d, p_sel, eqs;
+    TRY(mk(ML, &c)); TRY(mk(ML, &d)); TRY(mk(X + D, &ac_c)); TRY(mk(ML, &c_pull)); TRY(mk(ML, &d_pull));
+    {
+        // this rank's windows; its access counts are its windows' share: the global ones are the sums over the ranks
+        std::shared_ptr<DevBuf> part, parts;
+        TRY(mk(X + D, &part));
+        TRY(gm_msm_phase1_polys(plan, (uint64_t*)c->p, (uint64_t*)d->p, (uint64_t*)part->p, (uint64_t*)(part->fr() + X), stream));
+        std::vector<Fr> all;
+        TRY(pf_gather_slices(sh, part->fr(), X + D, &all, s));
+        TRY(mk((uint64_t)G * (X + D), &parts));
+        GM_HIP(hipMemcpyAsync(parts->p, all.data(), all.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pf_sum_parts, dim3(ceil_div(X + D, 256)), dim3(256), 0, s, parts->fr(), G, X + D, ac_c->fr());
+        GM_LAUNCH_CHECK();
+        GM_HIP(hipStreamSynchronize(s));   // `all` goes out of scope
+    }
+    const Fr* ac_c_p = ac_c->fr();
+    const Fr* ac_d_p = ac_c->fr() + X;
+    ac_d = ac_c;
+    TRY(gm_msm_second_phase(plan, h_claim_point, y_log, (uint64_t*)c_pull->p, (uint64_t*)d_pull->p, stream));
+
+    // challenges (pushforward.rs:684-685)
+    Fr psi, tau_c, tau_d, tau_s, gamma;
+    {
+        Fr four[4];
+        TRY(tr->challenge_vec(four, 4, 512));
+        psi = four[0]; tau_c = four[1]; tau_d = four[2]; tau_s = four[3];
+    }
+    TRY(tr->challenge(&gamma));
+    GM_REQUIRE(!fr_is_zero(tau_s) && !fr_is_zero(psi), "zero challenge (inverse().unwrap() in the reference)");
+
+    TRY(mk(ML, &c_adj)); TRY(mk(ML, &d_adj)); TRY(mk(ML, &num)); TRY(mk(ML, &den));
+    hipLaunchKernelGGL(k_pf_adj, dim3(ceil_div(ML, 256)), dim3(256), 0, s, c_pull->fr(), c->fr(), psi, tau_c, tau_s, ML, ML, c_adj->fr());
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pf_adj, dim3(ceil_div(ML, 256)), dim3(256), 0, s, d_pull->fr(), d->fr(), psi, tau_d, tau_s, ML, ML, d_adj->fr());
+    GM_LAUNCH_CHECK();
+    {
+        const Fr* in[2] = {c_adj->fr(), d_adj->fr()};
+        Fr* outp[2] = {num->fr(), den->fr()};
+        TRY(launch_dense_map(plan_of(mkfn(GM_FN_ADD_INVERSES, 1)), in, outp, ML, s));
+    }
+    // tables (pushforward.rs:725-728): small, replicated
+    TRY(mk(2 * X + 2 * D, &eqs)); TRY(mk(X, &table_c)); TRY(mk(D, &table_d));
+    {
+        Fr* eq_c = eqs->fr();
+        Fr* eq_d = eqs->fr() + 2 * X;
+        std::vector<Fr*> lv(x_log + 1);
+        for (uint32_t i = 0; i < x_log; i++) lv[i] = eq_c + X + ((1ull << i) - 1);
+        lv[x_log] = eq_c;
+        TRY(launch_eq_sequence(fr_one(), r.data() + y_log + d_log, x_log, lv.data(), s));
+        lv.assign(d_log + 1, nullptr);
+        for (uint32_t i = 0; i < d_log; i++) lv[i] = eq_d + D + ((1ull << i) - 1);
+        lv[d_log] = eq_d;
+        TRY(launch_eq_sequence(fr_one(), r.data() + y_log, d_log, lv.data(), s));
+        hipLaunchKernelGGL(k_pf_table, dim3(ceil_div(X, 256)), dim3(256), 0, s, eq_c, psi, tau_c, X, table_c->fr());
+        GM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pf_table, dim3(ceil_div(D, 256)), dim3(256), 0, s, eq_d, psi, tau_d, D, table_d->fr());
+        GM_LAUNCH_CHECK();
+    }
+    const Fr supp_total = fr_zero();   // 2 (2^mlog - matrix_size) / tau_suppression_term with matrix_size = 2^mlog
+
+    // ---- the logup tree.  A distributed array of global length L lives as slices of L / G; `split` re-spreads its halves.
+    auto split_halves = [&](const DFrac& o, DFrac* lo, DFrac* hi) -> int32_t {
+        const uint64_t L = o.len, S = L / G, H = L / 2;
+        lo->len = hi->len = H;
+        if (!o.dist) {   // replicated: the halves are views
+            *lo = o; *hi = o;
+            lo->len = hi->len = H;
+            hi->num = o.num + H; hi->den = o.den + H;
+            return GM_OK;
+        }
+        std::vector<Fr> fn, fd;
+        TRY(pf_gather_slices(sh, o.num, S, &fn, s));
+        TRY(pf_gather_slices(sh, o.den, S, &fd, s));
+        const bool stay = (H / G) >= dist_min && (H / G) >= 2;
+        const uint64_t n_out = stay ? H / G : H, off = stay ? (uint64_t)sh.rank * (H / G) : 0;
+        for (int side = 0; side < 2; side++) {
+            DFrac* t = side ? hi : lo;
+            t->dist = stay;
+            TRY(mk(n_out, &t->keep_n)); TRY(mk(n_out, &t->keep_d));
+            GM_HIP(hipMemcpyAsync(t->keep_n->p, fn.data() + (side ? H : 0) + off, n_out * sizeof(Fr), hipMemcpyHostToDevice, s));
+            GM_HIP(hipMemcpyAsync(t->keep_d->p, fd.data() + (side ? H : 0) + off, n_out * sizeof(Fr), hipMemcpyHostToDevice, s));
+            t->num = t->keep_n->fr(); t->den = t->keep_d->fr();
+        }
+        GM_HIP(hipStreamSynchronize(s));   // fn / fd go out of scope
+        return GM_OK;
+    };
+    std::vector<DFrac> layers;
+    {
+        DFrac root;
+        root.num = num->fr(); root.den = den->fr(); root.len = M; root.dist = true; root.keep_n = num; root.keep_d = den;
+        DFrac lo, hi;
+        TRY(split_halves(root, &lo, &hi));   // [left, right] of map_split_hi (pushforward.rs:719)
+        layers.push_back(lo);
+        layers.push_back(hi);
+    }
+    struct In { const Fr* num; const Fr* den; uint64_t len; std::shared_ptr<DevBuf> kn, kd; };
+    std::vector<In> inputs = {{ac_c_p, table_c->fr(), X, ac_c, table_c}, {ac_d_p, table_d->fr(), D, ac_d, table_d}};
+    std::vector<uint32_t> logsizes = {mlog - 1, mlog - 1, x_log, d_log};
+    GM_REQUIRE(mlog - 1 >= x_log && x_log >= d_log, "logsizes must be non-increasing (logup_mainphase.rs:75-77)");
+    size_t next_in = 0;
+    const SegPlan logup = plan_of(mkfn(GM_FN_LOGUP_LAYER, 1));
+    for (size_t i = 0;; i += 2) {
+        const uint64_t next_size = next_in < inputs.size() ? inputs[next_in].len : 1;
+        const uint64_t curr = layers[i].len;
+        GM_REQUIRE(layers[i].dist == layers[i + 1].dist && layers[i + 1].len == curr, "logup witness: mismatched operands");
+        const bool dist = layers[i].dist;
+        const uint64_t n_loc = dist ? curr / G : curr;
+        DFrac o;
+        o.len = curr; o.dist = dist;
+        TRY(mk(n_loc, &o.keep_n)); TRY(mk(n_loc, &o.keep_d));
+        o.num = o.keep_n->fr(); o.den = o.keep_d->fr();
+        const Fr* in[4] = {layers[i].num, layers[i].den, layers[i + 1].num, layers[i + 1].den};
+        Fr* outp[2] = {o.keep_n->fr(), o.keep_d->fr()};
+        TRY(launch_dense_map(logup, in, outp, n_loc, s));
+        if (curr == next_size) {
+            layers.push_back(o);
+            if (next_in < inputs.size()) {
+                const In& a = inputs[next_in++];
+                DFrac v;
+                v.len = a.len; v.dist = dist; v.keep_n = a.kn; v.keep_d = a.kd;
+                v.num = a.num + (dist ? (uint64_t)sh.rank * n_loc : 0);   // a replicated input seen as this rank's slice
+                v.den = a.den + (dist ? (uint64_t)sh.rank * n_loc : 0);
+                layers.push_back(v);
+            } else break;
+        } else {
+            GM_REQUIRE(curr > next_size, "logup witness: unreachable size order");
+            DFrac lo, hi;
+            TRY(split_halves(o, &lo, &hi));
+            layers.push_back(lo);
+            layers.push_back(hi);
+        }
+    }
+    DFrac top = layers.back();
+    layers.pop_back();
+    GM_REQUIRE(top.len == 1 && !top.dist, "logup witness does not end in a single replicated fraction");
+    Fr nd[2];
+    TRY(read_fr(top.num, &nd[0], s));
+    TRY(read_fr(top.den, &nd[1], s));
+    GM_REQUIRE(!fr_is_zero(nd[1]), "logup denominator is zero (logup_mainphase.rs:161)");
+    GM_REQUIRE(fr_eq(nd[0], fr_mul(nd[1], supp_total)), "logup total does not match the suppression term (logup_mainphase.rs:162)");
+    tr->write_scalars({nd[0], nd[1]});
+
+    Arena arena;
+    TRY(arena.init((size_t)32 * (5 * (ML / 2 + ML / 4) + 2 * M) + ((size_t)64 << 20)));
+    Fr* pinned = nullptr;
+    GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(pinned, 0, 16 * sizeof(Fr));
+    shared_pinned() = pinned;
+    struct Cleanup { Fr* p; ~Cleanup() { shared_pinned() = nullptr; (void)hipHostFree(p); } } cleanup{pinned};
+
+    // ---- LogupMainphaseProtocol::prove (logup_mainphase.rs:156-208)
+    uint32_t curr_log = 0;
+    Claims running;
+    running.evs = {nd[0], nd[1]};
+    std::vector<Claims> accumulated;
+    Claims last;
+    const gm_fn f_logup = mkfn(GM_FN_LOGUP_LAYER, 1);
+    for (;;) {
+        const uint32_t incoming = logsizes.back();
+        GM_REQUIRE(layers.size() >= 2, "logup witness exhausted");
+        const DFrac rr = layers.back(); layers.pop_back();
+        const DFrac ll = layers.back(); layers.pop_back();
+        GM_REQUIRE(ll.len == (1ull << curr_log) && rr.len == ll.len && ll.dist == rr.dist, "logup layer size mismatch");
+        Claims c4 = running;
+        if (curr_log == 0) {
+            Fr g0;
+            TRY(tr->challenge(&g0));
+            std::vector<Fr> v(4);
+            TRY(read_fr(ll.num, &v[0], s)); TRY(read_fr(ll.den, &v[1], s)); TRY(read_fr(rr.num, &v[2], s)); TRY(read_fr(rr.den, &v[3], s));
+            tr->write_scalars(v);
+            c4.point.clear();
+            c4.evs = v;
+        } else {
+            arena.reset();
+            ArenaScope scope(&arena);
+            const uint64_t n_loc = ll.dist ? ll.len / G : ll.len;
+            Advice adv;
+            adv.kind = Advice::DENSE;
+            adv.len = n_loc;
+            for (const Fr* ptr : {ll.num, ll.den, rr.num, rr.den}) {
+                adv.cols.emplace_back(new DevBuf());
+                adv.cols.back()->p = const_cast<Fr*>(ptr);   // borrowed view
+                adv.cols.back()->owned = false;
+                adv.cols.back()->bytes = n_loc * sizeof(Fr);
+            }
+            ShardScope shard(ll.dist ? sh : Shard());   // a distributed layer: the columns are this rank's slice of 2^curr_log elements
+            TRY(dense_deg2_prove(tr, f_logup, curr_log, &c4, adv, s));
+        }
+        if (incoming == curr_log) {
+            if (logsizes.size() == 2) { last = c4; break; }
+            running.point = c4.point;
+            running.evs = {c4.evs[0], c4.evs[1]};
+            Claims a;
+            a.point = c4.point;
+            a.evs = {c4.evs[2], c4.evs[3]};
+            accumulated.push_back(a);
+            logsizes.pop_back();
+        } else {
+            running = c4;
+            TRY(split_at_prove(tr, &running, true, 0, 2));
+            curr_log++;
+        }
+    }
+    accumulated.push_back(last);
+    std::reverse(accumulated.begin(), accumulated.end());
+    GM_REQUIRE(accumulated.size() == 3, "logup main phase must end with 3 claims");
+    Claims cd = accumulated[0];
+    *out_ac_c = accumulated[1];
+    *out_ac_d = accumulated[2];
+    TRY(split_at_prove(tr, &cd, true, 0, 2));   // SplitAt(HI(0), 2) (pushforward.rs:744-746)
+    GM_REQUIRE(cd.evs.size() == 2 && cd.point.size() == mlog, "cd claims have the wrong shape");
+
+    // ---- combined sumcheck (pushforward.rs:748-801) on this rank's slices
+    const Fr g1 = gamma, g2 = fr_mul(gamma, gamma);
+    TRY(mk(ML, &p_sel));
+    {
+        std::vector<Fr> e(1ull << y_log, fr_zero());
+        e[0] = fr_one();
+        for (uint32_t i = 0; i < y_log; i++)
+            for (uint64_t j = (1ull << i); j-- > 0;) {
+                const Fr w = e[j], m = fr_mul(r[i], w);
+                e[2 * j] = fr_sub(w, m);
+                e[2 * j + 1] = m;
+            }
+        std::shared_ptr<DevBuf> d_e;
+        TRY(mk(e.size(), &d_e));
+        GM_HIP(hipMemcpyAsync(d_e->p, e.data(), e.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pf_psel_at, dim3(ceil_div(ML, 256)), dim3(256), 0, s, reinterpret_cast<const Fr*>(d_points_xy), d_e->fr(), g1,
+                           g2, x_log, base, ML, p_sel->fr());
+        GM_LAUNCH_CHECK();
+        GM_HIP(hipStreamSynchronize(s));
+    }
+    const Fr ev_folded = fr_add(fr_add(evs[0], fr_mul(g1, evs[1])), fr_mul(g2, evs[2]));
+    Fr claim = fr_add(fr_add(cd.evs[0], fr_mul(g1, cd.evs[1])), fr_mul(g2, ev_folded));
+    arena.reset();
+    ArenaScope scope(&arena);
+    PinnedSharedScope two_objects;
+    ScHolder prod3, frac;
+    {
+        ShardScope shard(sh);
+        const uint64_t* pc[3] = {(const uint64_t*)p_sel->p, (const uint64_t*)c_pull->p, (const uint64_t*)d_pull->p};
+        TRY(gm_sc_dense_create(1, nullptr, mlog, pc, nullptr, reinterpret_cast<const uint64_t*>(&ev_folded), &prod3.so, stream));
+        const uint64_t* fc[2] = {(const uint64_t*)c_adj->p, (const uint64_t*)d_adj->p};
+        const gm_fn f_inv = mkfn(GM_FN_ADD_INVERSES, 1);
+        TRY(gm_sc_dense_deg2_create(&f_inv, mlog, fc, reinterpret_cast<const uint64_t*>(cd.point.data()),
+                                    reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(cd.evs.data()),
+                                    &frac.so, stream));
+    }
+    std::vector<Fr> out_pt;
+    for (uint32_t i = 0; i < mlog; i++) {
+        Fr pr[8], fq[8];
+        uint32_t n1 = 0, n2 = 0;
+        TRY(gm_sc_unipoly(prod3.so, reinterpret_cast<uint64_t*>(pr), &n1));
+        TRY(gm_sc_unipoly(frac.so, reinterpret_cast<uint64_t*>(fq), &n2));
+        GM_REQUIRE(n1 == 4 && n2 == 4, "combined sumcheck: responses must have 4 coefficients");
+        std::vector<Fr> comb(4);
+        for (int k = 0; k < 4; k++) comb[k] = fr_add(fq[k], fr_mul(g2, pr[k]));
+        const Fr chk = fr_add(fr_add(fr_dbl(comb[0]), comb[1]), fr_add(comb[2], comb[3]));
+        GM_REQUIRE(fr_eq(chk, claim), "combined sumcheck: round %u does not sum to the claim (pushforward.rs:789)", i);
+        tr->write_scalars({comb[0], comb[2], comb[3]});
+        Fr t;
+        TRY(tr->challenge(&t));
+        claim = evaluate_univar(comb, t);
+        out_pt.push_back(t);
+        TRY(gm_sc_bind(prod3.so, reinterpret_cast<const uint64_t*>(&t)));
+        TRY(gm_sc_bind(frac.so, reinterpret_cast<const uint64_t*>(&t)));
+        tr->rounds++;
+    }
+    std::reverse(out_pt.begin(), out_pt.end());
+    Fr pe[GM_MAX_COLS + 1], fe[GM_MAX_COLS + 1];
+    uint32_t ne = 0;
+    TRY(gm_sc_final_evals(prod3.so, reinterpret_cast<uint64_t*>(pe), &ne));
+    GM_REQUIRE(ne == 3, "prod3 final evaluations");
+    TRY(gm_sc_final_evals(frac.so, reinterpret_cast<uint64_t*>(fe), &ne));
+    GM_REQUIRE(ne == 2, "frac final evaluations");
+    const Fr p_sel_ev = pe[0], c_pull_ev = pe[1], d_pull_ev = pe[2], c_adj_ev = fe[0], d_adj_ev = fe[1];
+    const Fr eqy = eq_trunc_evaluate(y_log, y_size, r.data(), out_pt.data());
+    GM_REQUIRE(!fr_is_zero(eqy), "eq_sel_y evaluates to zero (inverse().unwrap(), pushforward.rs:808)");
+    const Fr p_folded_ev = fr_add(fr_mul(p_sel_ev, fr_inv(eqy)), gamma);
+    const Fr sel_ev = eq_sum_host(out_pt.data(), y_log, y_size);
+    const Fr tmp = fr_mul(tau_s, fr_sub(fr_one(), sel_ev));
+    const Fr psi_inv = fr_inv(psi);
+    const Fr c_ev = fr_mul(psi_inv, fr_sub(fr_add(fr_sub(c_adj_ev, c_pull_ev), fr_mul(tau_c, sel_ev)), tmp));
+    const Fr d_ev = fr_mul(psi_inv, fr_sub(fr_add(fr_sub(d_adj_ev, d_pull_ev), fr_mul(tau_d, sel_ev)), tmp));
+    out_matrix->point = out_pt;
+    out_matrix->evs = {p_folded_ev, c_pull_ev, d_pull_ev, c_ev, d_ev};
+    tr->write_scalars(out_matrix->evs);
+    *out_gamma = gamma;
+    return GM_OK;
+}
+
 int32_t put_claims(const Claims& c, uint64_t* h_point, uint64_t* h_evs) {
     if (h_point) memcpy(h_point, c.point.data(), c.point.size() * sizeof(Fr));
     if (h_evs) memcpy(h_evs, c.evs.data(), c.evs.size() * sizeof(Fr));
@@ -1177,12 +1546,19 @@ int32_t pushforward_entry(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
                           const uint64_t* h_claim_evs, const uint64_t* h_tape, uint64_t n_tape, const gm_transcript* cb,
                           uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_gamma, uint64_t* h_matrix_point,
                           uint64_t* h_matrix_evs, uint64_t* h_ac_c_point, uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point,
-                          uint64_t* h_ac_d_evs, uint64_t* tape_used, uint64_t* rounds, void* stream) {
+                          uint64_t* h_ac_d_evs, uint64_t* tape_used, uint64_t* rounds, void* stream, const gm_comm* comm = nullptr) {
     GM_REQUIRE(plan && d_points_xy && h_claim_point && h_claim_evs, "null argument");
     std::vector<Fr> msgs;
     Tape tr{h_tape, n_tape, 0, &msgs, 0, cb, 0};
     Fr gamma;
     Claims mx, acc, acd;
+    if (comm && comm->world > 1) {
+        GM_REQUIRE(comm->all_gather && comm->rank < comm->world, "bad gm_comm");
+        Shard sh;
+        sh.comm = comm; sh.rank = comm->rank; sh.world = comm->world;
+        while ((1u << sh.lg) < comm->world) sh.lg++;
+        TRY(pushforward_prove_sharded(plan, d_points_xy, y_logsize, sh, h_claim_point, h_claim_evs, &tr, &gamma, &mx, &acc, &acd, as_stream(stream)));
+    } else
     TRY(pushforward_prove(plan, d_points_xy, y_logsize, h_claim_point, h_claim_evs, &tr, &gamma, &mx, &acc, &acd, as_stream(stream)));
     if (tr.cb_rc) return set_err(GM_ERR_STATE, "transcript write_scalars callback failed with %d", tr.cb_rc);
     if (n_msgs) *n_msgs = msgs.size();
@@ -1211,6 +1587,21 @@ extern "C" int32_t gm_pushforward_prove(const gm_msm_plan* plan, const uint64_t*
     return pushforward_entry(plan, d_points_xy, y_logsize, h_claim_point, h_claim_evs, h_tape, n_tape, nullptr, h_msgs, msgs_cap,
                              n_msgs, h_gamma, h_matrix_point, h_matrix_evs, h_ac_c_point, h_ac_c_evs, h_ac_d_point, h_ac_d_evs,
                              tape_used, rounds, stream);
+}
+
+// The argument with the matrix sharded by windows: `plan` covers this rank's windows (gm_msm_plan_create(.., y_begin, y_end)), y_size =
+// the global window count = 2^y_logsize, comm->world | y_size.  Every rank runs the same transcript and obtains the messages and
+// claims of the unsharded argument.  `comm` must outlive the call.
+extern "C" int32_t gm_pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                                const gm_comm* comm, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                                const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_msgs, uint64_t msgs_cap,
+                                                uint64_t* n_msgs, uint64_t* h_gamma, uint64_t* h_matrix_point, uint64_t* h_matrix_evs,
+                                                uint64_t* h_ac_c_point, uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point,
+                                                uint64_t* h_ac_d_evs, uint64_t* tape_used, uint64_t* rounds, void* stream) {
+    GM_REQUIRE(h_tape && comm, "null tape / gm_comm");
+    return pushforward_entry(plan, d_points_xy, y_logsize, h_claim_point, h_claim_evs, h_tape, n_tape, nullptr, h_msgs, msgs_cap,
+                             n_msgs, h_gamma, h_matrix_point, h_matrix_evs, h_ac_c_point, h_ac_c_evs, h_ac_d_point, h_ac_d_evs,
+                             tape_used, rounds, stream, comm);
 }
 
 extern "C" int32_t gm_pushforward_prove_tr(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,

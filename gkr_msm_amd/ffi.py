@@ -152,6 +152,8 @@ _SIGS = {
                                         vp]),
     "gm_pushforward_prove": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, vp, vp, vp, vp, vp,
                                          u64p, u64p, vp]),
+    "gm_pushforward_prove_sharded": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(GmComm), vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp,
+                                                 vp, vp, vp, vp, vp, vp, u64p, u64p, vp]),
     "gm_pushforward_prove_tr": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, C.POINTER(GmTranscript), vp, vp, vp, vp, vp, vp, vp, u64p,
                                             u64p, vp]),
     "gm_multiopen_prove": (C.c_int32, [C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u64p, u64p, vp]),

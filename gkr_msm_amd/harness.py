@@ -375,8 +375,9 @@ class PipWitness:
                     evs=codec.from_mont_limbs(fev[:3]), tape_used=used.value, rounds=rounds.value, call_s=call_s)
 
 
-def pushforward_prove(plan, d_points, y_logsize, claim_point, claim_evs, tape, msgs_cap=1 << 16):
-    """gm_pushforward_prove -> dict(msgs, gamma, matrix=(point, evs), ac_c=(point, evs), ac_d=(point, evs), tape_used, rounds)"""
+def pushforward_prove(plan, d_points, y_logsize, claim_point, claim_evs, tape, msgs_cap=1 << 16, comm=None):
+    """gm_pushforward_prove -> dict(msgs, gamma, matrix=(point, evs), ac_c=(point, evs), ac_d=(point, evs), tape_used, rounds);
+    comm: gm_comm wrapper (dist.Comm / ShmComm) -> gm_pushforward_prove_sharded on a window-sharded plan"""
     L = ffi.lib()
     x, d = plan.x_logsize, plan.d_logsize
     cp, ce = fr_arg(claim_point), fr_arg(claim_evs)
@@ -388,10 +389,16 @@ def pushforward_prove(plan, d_points, y_logsize, claim_point, claim_evs, tape, m
     dpt, dev = np.zeros((max(d, 1), 4), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64)
     nm, used, rounds = C.c_uint64(), C.c_uint64(), C.c_uint64()
     t0 = time.perf_counter()
-    ffi.check(L.gm_pushforward_prove(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, cp.ctypes.data, ce.ctypes.data,
-                                     tp.ctypes.data, len(tape), msgs.ctypes.data, msgs_cap, C.byref(nm), g.ctypes.data,
-                                     mp.ctypes.data, me.ctypes.data, cpt.ctypes.data, cev.ctypes.data, dpt.ctypes.data,
-                                     dev.ctypes.data, C.byref(used), C.byref(rounds), cur_stream()))
+    if comm is not None:
+        ffi.check(L.gm_pushforward_prove_sharded(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, C.byref(comm.c), cp.ctypes.data,
+                                                 ce.ctypes.data, tp.ctypes.data, len(tape), msgs.ctypes.data, msgs_cap, C.byref(nm),
+                                                 g.ctypes.data, mp.ctypes.data, me.ctypes.data, cpt.ctypes.data, cev.ctypes.data,
+                                                 dpt.ctypes.data, dev.ctypes.data, C.byref(used), C.byref(rounds), cur_stream()))
+    else:
+        ffi.check(L.gm_pushforward_prove(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, cp.ctypes.data, ce.ctypes.data,
+                                         tp.ctypes.data, len(tape), msgs.ctypes.data, msgs_cap, C.byref(nm), g.ctypes.data,
+                                         mp.ctypes.data, me.ctypes.data, cpt.ctypes.data, cev.ctypes.data, dpt.ctypes.data,
+                                         dev.ctypes.data, C.byref(used), C.byref(rounds), cur_stream()))
     call_s = time.perf_counter() - t0
     f = codec.from_mont_limbs
     return dict(msgs=f(msgs[: nm.value]), gamma=f(g)[0], matrix=(f(mp), f(me)), ac_c=(f(cpt[:x]), f(cev)), ac_d=(f(dpt[:d]), f(dev)),

@@ -493,6 +493,18 @@ int32_t gm_pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_x
                              uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs, uint64_t* h_gamma, uint64_t* h_matrix_point,
                              uint64_t* h_matrix_evs, uint64_t* h_ac_c_point, uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point,
                              uint64_t* h_ac_d_evs, uint64_t* tape_used, uint64_t* rounds, void* stream);
+/* The argument with the matrix sharded by windows: `plan` covers this rank's windows only (gm_msm_plan_create(..,
+ * y_begin, y_end) after its gm_msm_run), y_size = the global window count = 2^y_logsize, comm->world | y_size.  Every array of the
+ * argument is indexed (window, point): a rank holds its windows' slice of each, the sumchecks run on the slices (round sums through
+ * `comm`, the last log2(world) rounds replicated), the access counts are summed over the ranks, and the halves of every level of the
+ * logup tree are re-spread over the ranks.  Every rank runs the same transcript and obtains the unsharded argument's messages and
+ * claims, bit for bit.  `comm` must outlive the call. */
+int32_t gm_pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                     const struct gm_comm* comm, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                     const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_msgs, uint64_t msgs_cap, uint64_t* n_msgs,
+                                     uint64_t* h_gamma, uint64_t* h_matrix_point, uint64_t* h_matrix_evs, uint64_t* h_ac_c_point,
+                                     uint64_t* h_ac_c_evs, uint64_t* h_ac_d_point, uint64_t* h_ac_d_evs, uint64_t* tape_used,
+                                     uint64_t* rounds, void* stream);
 int32_t gm_pushforward_prove_tr(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
                                 const uint64_t* h_claim_point, const uint64_t* h_claim_evs, const gm_transcript* tr,
                                 uint64_t* h_gamma, uint64_t* h_matrix_point, uint64_t* h_matrix_evs, uint64_t* h_ac_c_point,

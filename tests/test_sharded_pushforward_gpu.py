@@ -1,0 +1,88 @@
+"""GPU test of the pushforward argument with the matrix sharded by windows (gm_pushforward_prove_sharded): world_size 2
+and 4 processes share the one GPU of the box and exchange through the library's shared-memory communicator; every rank owns a
+contiguous block of windows.  The sharded run must give the unsharded argument's messages, gamma and final claims, bit for bit, on
+every rank (the unsharded argument is pinned to the oracle by tests/test_pushforward_gpu.py).  GM_PF_DIST_MIN = 2 keeps the levels of
+the logup tree distributed down to two elements per rank, so the re-spreading of the halves runs at every level of these small
+shapes; the default threshold is exercised by the larger shape."""
+import os
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q):
+    """one rank: the unsharded argument as the reference (every rank computes it: small), then the sharded one on its windows;
+    the incoming claims are the image's evaluations, as in Pippenger::prove"""
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        if dist_min:
+            os.environ["GM_PF_DIST_MIN"] = str(dist_min)
+        from gkr_msm_amd import codec, dist as gd, harness as H
+        from pyref import field as F
+        from pyref import gkr as G
+        from pyref import polys as PL
+        y_size = (nbits + d_log - 1) // d_log
+        y_log = (y_size - 1).bit_length()
+        n = 1 << x_log
+        pts = F.random_points(n, 5)
+        sc = F.random_scalars(n, nbits, 6)
+        sc[0] = 0
+        d_pts = H.to_dev(codec.points_to_mont(pts))
+        d_sc = H.to_dev(codec.ints_to_limbs(sc))
+        image, digits, counter = G.bucketing_image(pts, sc, y_size, y_log, d_log, x_log)
+        rng = F.SplitMix64(9)
+        r = [rng.next_fr() for _ in range(y_log + d_log + x_log)]
+        evs = [PL.evaluate_poly(p.to_dense(), r) for p in image]
+        tape = [rng.next_fr() for _ in range(4)] + [rng.next_bits(128) for _ in range(3000)]
+        plan = H.MsmPlan(x_log, d_log, y_size)
+        plan.run(d_pts, d_sc)
+        ref = H.pushforward_prove(plan, d_pts, y_log, r, evs, tape)
+        y0, y1 = gd.window_range(rank, world, y_size)
+        comm = gd.ShmComm("/gm-test-pf-%s" % tag, rank, world)
+        plan_s = H.MsmPlan(x_log, d_log, y_size, y0, y1)
+        plan_s.run(d_pts, d_sc)
+        got = H.pushforward_prove(plan_s, d_pts, y_log, r, evs, tape, comm=comm)
+        keys = ("msgs", "gamma", "tape_used", "rounds")
+        ok = all(got[k] == ref[k] for k in keys) and all(
+            (list(got[k][0]), list(got[k][1])) == (list(ref[k][0]), list(ref[k][1])) for k in ("matrix", "ac_c", "ac_d"))
+        q.put((rank, ok, "" if ok else "sharded argument differs (rounds %d vs %d, %d vs %d messages)" % (
+            got["rounds"], ref["rounds"], len(got["msgs"]), len(ref["msgs"])), comm.calls))
+        comm.close()
+    except Exception as e:
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc(), 0))
+
+
+def _run(target, world, x_log, d_log, nbits, dist_min):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    tag = "%d-%d-%d-%d" % (os.getpid(), world, x_log, dist_min)
+    procs = [ctx.Process(target=target, args=(r, world, tag, x_log, d_log, nbits, dist_min, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=300))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert len(res) == world
+    for rank, ok, info, calls in sorted(res):
+        assert ok is True, "rank %d: %s" % (rank, info)
+    return sorted(res)
+
+
+@pytest.mark.parametrize("world,x_log,d_log,nbits,dist_min", [(2, 4, 2, 8, 2), (4, 5, 2, 8, 2), (2, 6, 3, 24, 2), (4, 7, 4, 32, 2),
+                                                               (2, 10, 4, 16, 0)])
+def test_sharded_pushforward_matches_unsharded(world, x_log, d_log, nbits, dist_min):
+    res = _run(_claims_worker, world, x_log, d_log, nbits, dist_min)
+    for rank, ok, info, calls in res:
+        assert calls > x_log      # the round sums (and the re-spread halves) really went through the communicator
