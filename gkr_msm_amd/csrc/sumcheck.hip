@@ -1815,10 +1815,14 @@ struct RoundScratch {
         *reinterpret_cast<volatile uint32_t*>(ticket_word()) = ticket;
     }
     // small pre-enqueued folds carry their gate inside (no k_fold_gate launch) when the host can write into device memory
-    GateArgs gate_in_fold(uint32_t round, uint32_t ticket, uint64_t fold_blocks) const {
+    // (every workgroup of such a fold spins until the challenge arrives.  Ranks of a sharded proof that SHARE a device -- rehearsals,
+    // tests -- wait for each other's round sums: four ranks' spinning folds of 512 workgroups each fill the device and keep the round
+    // kernel of the rank everybody waits for from being scheduled.  Sharded objects therefore keep the inside gate to folds of <= 64
+    // workgroups; a rank with a device of its own loses a gate launch on the larger ones.)
+    GateArgs gate_in_fold(uint32_t round, uint32_t ticket, uint64_t fold_blocks, bool sharded = false) const {
         static const bool off = [] { const char* e = getenv("GM_FOLD_GATE_INSIDE"); return e && e[0] == '0'; }();
         GateArgs g;
-        g.bar_slot = (!off && bar && fold_blocks <= 512) ? bar + 12 * (round & 3) : nullptr;
+        g.bar_slot = (!off && bar && fold_blocks <= (sharded ? 64u : 512u)) ? bar + 12 * (round & 3) : nullptr;
         g.ticket = ticket;
         g.status = const_cast<uint32_t*>(reinterpret_cast<volatile uint32_t*>(ticket_word())) + 1;
         g.timeout_ticks = wait_timeout_ticks();
@@ -3075,7 +3079,7 @@ struct ScDenseDeg2 : gm_sc {
             if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
             const uint64_t n_out = npairs;
             Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
-            const GateArgs ga = rs.gate_in_fold(r, fold_ticket, (uint64_t)ceil_div(n_out, 256) * cols.k);
+            const GateArgs ga = rs.gate_in_fold(r, fold_ticket, (uint64_t)ceil_div(n_out, 256) * cols.k, sh.comm != nullptr);
             if (ga.bar_slot) {
                 hipLaunchKernelGGL(k_dense_fold_gated, dim3(ceil_div(n_out, 256), cols.k), dim3(256), 0, stream, ci, co, n_out, ga);
             } else {
@@ -3313,7 +3317,7 @@ struct ScVecVecDeg2 : gm_sc {
             fold_ticket = ++RoundScratch::ticket_counter();
             if (fold_ticket == 0) fold_ticket = ++RoundScratch::ticket_counter();
             Fr* d_t = reinterpret_cast<Fr*>(static_cast<char*>(rs.counter.p) + 64);
-            const GateArgs ga = rs.gate_in_fold(already_bound, fold_ticket, (uint64_t)ceil_div(nx_bound, SC_THREADS) * ((k + 1) / 2));
+            const GateArgs ga = rs.gate_in_fold(already_bound, fold_ticket, (uint64_t)ceil_div(nx_bound, SC_THREADS) * ((k + 1) / 2), sh.comm != nullptr);
             if (!ga.bar_slot)
                 hipLaunchKernelGGL(k_fold_gate, dim3(1), dim3(64), 0, stream, rs.t_slot(already_bound), rs.ticket_word(), fold_ticket,
                                    rs.ticket_word() + 1, d_t, wait_timeout_ticks());

@@ -368,6 +368,107 @@ def test_config_b_image_part_sharded_over_four_ranks():
     assert sharded <= 2.0 * alone, "sharded over ranks sharing one GPU: %.1f ms against %.1f ms unsharded" % (1e3 * sharded, 1e3 * alone)
 
 
+def _sharded_pf_worker(rank, world, port, x_log, d_log, nbits, q):
+    """one rank of the at-size sharded pushforward argument.  Rank 0 first runs the unsharded image part (its final claims are what the
+    argument starts from, pippenger.rs:138-160) and the unsharded argument as the reference, then hands the claims to the others."""
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for d in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+            if d not in sys.path:
+                sys.path.insert(0, d)
+        import hashlib
+        from gkr_msm_amd import dist as gd
+        y_size = (nbits + d_log - 1) // d_log
+        y_log = (y_size - 1).bit_length()
+        nv = y_log + d_log + x_log
+        d_pts, d_sc, sc = device_inputs(x_log, nbits, 0x474B524D534D)
+        pr = np.random.default_rng(7)
+        tape = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(4)] + [int.from_bytes(pr.bytes(16), "little") for _ in range(3000)]
+        comm = gd.ShmComm("/gm-at-size-pf-%d" % port, rank, world)
+        buf = np.zeros((nv + 3, 4), dtype=np.uint64)
+        info = {}
+        if rank == 0:
+            r0 = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(y_log)]
+            tape0 = [int.from_bytes(pr.bytes(16), "little") for _ in range(4000)]
+            plan = H.MsmPlan(x_log, d_log, y_size)
+            plan.run(d_pts, d_sc)
+            w = H.PipWitness(plan, d_pts, y_log)
+            outs, _ = w.outputs()
+
+            def ev(poly):
+                cur = list(poly)
+                for f in reversed(r0):
+                    cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
+                return cur[0]
+            img = w.prove_image_part(r0, [ev(o) for o in outs], tape0)
+            w.close()
+            H.pushforward_prove(plan, d_pts, y_log, img["point"], img["evs"], tape)          # warm-up (first-use allocations)
+            ref = H.pushforward_prove(plan, d_pts, y_log, img["point"], img["evs"], tape)
+            info.update(unsharded_s=ref["call_s"], ref_digest=hashlib.sha256(repr(
+                (ref["msgs"], ref["gamma"], ref["matrix"], ref["ac_c"], ref["ac_d"])).encode()).hexdigest())
+            plan.close()
+            ffi.lib().gm_release_cached_memory()
+            buf[:] = codec.to_mont_limbs(list(img["point"]) + list(img["evs"]))
+        comm.sum_fr(buf)   # the others contribute zeros: everybody has rank 0's claims
+        vals = codec.from_mont_limbs(buf)
+        r_pt, evs = vals[:nv], vals[nv:]
+        y0, y1 = gd.window_range(rank, world, y_size)
+        plan_s = H.MsmPlan(x_log, d_log, y_size, y0, y1)
+        plan_s.run(d_pts, d_sc)
+        got = H.pushforward_prove(plan_s, d_pts, y_log, r_pt, evs, tape, comm=comm)
+        info.update(sharded_s=got["call_s"], rounds=got["rounds"], exchanges=comm.calls, digest=hashlib.sha256(repr(
+            (got["msgs"], got["gamma"], got["matrix"], got["ac_c"], got["ac_d"])).encode()).hexdigest())
+        q.put((rank, True, info))
+        comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))   # everybody leaves together
+        comm.close()
+    except Exception as e:  # report instead of hanging the parent
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc()))
+
+
+def test_config_b_pushforward_sharded_over_four_ranks():
+    """the pushforward argument with the matrix sharded by windows (gm_pushforward_prove_sharded) at config B's full size, world 4 on
+    the one GPU: the messages and claims of every rank equal the unsharded argument's.  The halves of the logup tree's levels are
+    re-spread through the host here (the communicator's all-gather), which is what the time below mostly is: a functional check at
+    size, not a speed."""
+    import torch.multiprocessing as mp
+    world, x_log, d_log, nbits = 4, 20, 8, 256
+    require_host_gib(64, "config B pushforward sharded over 4 processes")
+    t_begin = time.perf_counter()
+    ffi.lib().gm_release_cached_memory()
+    torch.cuda.empty_cache()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_pf_worker, args=(r, world, port, x_log, d_log, nbits, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=900))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert len(res) == world
+    res.sort()
+    for rank, ok, info in res:
+        assert ok, "rank %d: %s" % (rank, info)
+    ref = res[0][2]["ref_digest"]
+    for rank, ok, info in res:
+        assert info["digest"] == ref, "rank %d: the sharded argument differs from the unsharded one" % rank
+    sharded = max(r[2]["sharded_s"] for r in res)
+    print("[at-size] config B pushforward argument sharded over %d ranks sharing one GPU (x_logsize %d): %d rounds, %.0f ms (host-staged "
+          "re-spreading) against %.1f ms unsharded; %d exchanges per rank; equal to the unsharded argument on every rank" % (
+              world, x_log, res[0][2]["rounds"], 1e3 * sharded, 1e3 * res[0][2]["unsharded_s"], res[0][2]["exchanges"]))
+    record("config_b_pushforward_sharded_over_four_ranks", x_logsize=x_log, world=world, rounds=res[0][2]["rounds"], transport="shm",
+           sharded_ms=round(1e3 * sharded, 1), unsharded_ms=round(1e3 * res[0][2]["unsharded_s"], 1),
+           exchanges_per_rank=res[0][2]["exchanges"], seconds=round(time.perf_counter() - t_begin, 1),
+           checked="messages, gamma and the three final claims equal to the unsharded argument on every rank")
+
+
 def test_config_e_dry_run_of_one_ranks_share_of_the_sharded_prover():
     """BASELINE.json configs[4] (x_logsize=24, bucket rows sharded 8 ways): rank 3's share -- the witness of 4 windows over 2^24
     points (twice config B's cells) and all sumcheck rounds over it -- at full size on one GPU.  A DRY RUN: the all-gather
