@@ -1178,9 +1178,10 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
 //   * the access counts are sums over the ranks' windows (one exchange of 2^x_logsize + 2^d_logsize elements);
 //   * what does NOT stay local is the WITNESS of the logup tree: map_split_hi pairs element i with element i + len / 2, so after
 //     every level the two halves are re-spread over the ranks (new rank j: l-slice from old rank j / 2, r-slice from old rank
-//     world / 2 + j / 2).  Here that goes through the communicator's all-gather on host buffers (correct with any gm_comm and what
-//     the tests run; a node's ranks would move the slices device to device -- pairwise over xGMI -- which this box cannot rehearse);
-//     below `GM_PF_DIST_MIN` elements per rank (default 1024) a level is gathered once and the tree goes on replicated.
+//     world / 2 + j / 2): device to device through gm_comm::pull_dev when the communicator has it (the shared-memory one does:
+//     HIP IPC handles, then copies between the devices -- over xGMI on a node, local between ranks that share a device), else
+//     staged through the communicator's all-gather on host buffers; below `GM_PF_DIST_MIN` elements per rank (default 1024) a
+//     level is gathered once and the tree goes on replicated.
 // Requires y_size = 2^y_logsize (as the sharded image part) and world | y_size.  Same transcript on every rank, same messages and
 // claims as the unsharded argument.
 namespace gm {
@@ -1236,6 +1237,7 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     const uint64_t M = 1ull << mlog, X = 1ull << x_log, D = 1ull << d_log, ML = M / G, base = (uint64_t)sh.rank * ML;
     void* stream = reinterpret_cast<void*>(s);
     static const uint64_t dist_min = [] { const char* e = getenv("GM_PF_DIST_MIN"); return (uint64_t)(e && atoll(e) >= 1 ? atoll(e) : 1024); }();
+    static const bool host_staged = [] { const char* e = getenv("GM_PF_HOST_STAGED"); return e && e[0] == '1'; }();   // A/B and tests: never pull_dev
     std::vector<Fr> r(y_log + d_log + x_log), evs(3);
     memcpy(r.data(), h_claim_point, r.size() * sizeof(Fr));
     memcpy(evs.data(), h_claim_evs, 3 * sizeof(Fr));
@@ -1252,13 +1254,20 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
         std::shared_ptr<DevBuf> part, parts;
         TRY(mk(X + D, &part));
         TRY(gm_msm_phase1_polys(plan, (uint64_t*)c->p, (uint64_t*)d->p, (uint64_t*)part->p, (uint64_t*)(part->fr() + X), stream));
-        std::vector<Fr> all;
-        TRY(pf_gather_slices(sh, part->fr(), X + D, &all, s));
         TRY(mk((uint64_t)G * (X + D), &parts));
-        GM_HIP(hipMemcpyAsync(parts->p, all.data(), all.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+        std::vector<Fr> all;
+        if (sh.comm->pull_dev && !host_staged) {   // device to device: every rank's share next to each other
+            std::vector<gm_pull> pc(G);
+            for (uint32_t q = 0; q < G; q++) pc[q] = gm_pull{q, 0u, 0ull, (X + D) * sizeof(Fr), parts->fr() + (uint64_t)q * (X + D)};
+            const int32_t rc = sh.comm->pull_dev(sh.comm->ctx, part->p, (X + D) * sizeof(Fr), G, pc.data(), stream);
+            if (rc) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
+        } else {
+            TRY(pf_gather_slices(sh, part->fr(), X + D, &all, s));
+            GM_HIP(hipMemcpyAsync(parts->p, all.data(), all.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+        }
         hipLaunchKernelGGL(k_pf_sum_parts, dim3(ceil_div(X + D, 256)), dim3(256), 0, s, parts->fr(), G, X + D, ac_c->fr());
         GM_LAUNCH_CHECK();
-        GM_HIP(hipStreamSynchronize(s));   // `all` goes out of scope
+        GM_HIP(hipStreamSynchronize(s));   // `all` / `part` go out of scope
     }
     const Fr* ac_c_p = ac_c->fr();
     const Fr* ac_d_p = ac_c->fr() + X;
@@ -1315,18 +1324,42 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
             hi->num = o.num + H; hi->den = o.den + H;
             return GM_OK;
         }
-        std::vector<Fr> fn, fd;
-        TRY(pf_gather_slices(sh, o.num, S, &fn, s));
-        TRY(pf_gather_slices(sh, o.den, S, &fd, s));
         const bool stay = (H / G) >= dist_min && (H / G) >= 2;
         const uint64_t n_out = stay ? H / G : H, off = stay ? (uint64_t)sh.rank * (H / G) : 0;
         for (int side = 0; side < 2; side++) {
             DFrac* t = side ? hi : lo;
             t->dist = stay;
             TRY(mk(n_out, &t->keep_n)); TRY(mk(n_out, &t->keep_d));
+            t->num = t->keep_n->fr(); t->den = t->keep_d->fr();
+        }
+        if (sh.comm->pull_dev && !host_staged) {
+            // device to device.  Staying distributed: new rank j takes its l-slice from old rank j / 2 and its r-slice from old rank
+            // G / 2 + j / 2 (the first or the second half of that rank's slice); turning replicated: every rank's whole slice.
+            for (int arr = 0; arr < 2; arr++) {
+                std::vector<gm_pull> pc;
+                Fr* dlo = arr ? lo->keep_d->fr() : lo->keep_n->fr();
+                Fr* dhi = arr ? hi->keep_d->fr() : hi->keep_n->fr();
+                if (stay) {
+                    const uint64_t half_bytes = (S / 2) * sizeof(Fr), so = (uint64_t)(sh.rank & 1u) * half_bytes;
+                    pc.push_back(gm_pull{sh.rank / 2, 0u, so, half_bytes, dlo});
+                    pc.push_back(gm_pull{G / 2 + sh.rank / 2, 0u, so, half_bytes, dhi});
+                } else {
+                    for (uint32_t q = 0; q < G; q++)
+                        pc.push_back(gm_pull{q, 0u, 0ull, S * sizeof(Fr), (q < G / 2 ? dlo : dhi) + (uint64_t)(q % (G / 2)) * S});
+                }
+                const int32_t rc = sh.comm->pull_dev(sh.comm->ctx, arr ? o.den : o.num, S * sizeof(Fr), (uint32_t)pc.size(), pc.data(),
+                                                     reinterpret_cast<void*>(s));
+                if (rc) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
+            }
+            return GM_OK;
+        }
+        std::vector<Fr> fn, fd;   // host-staged: the whole array through the communicator's all-gather
+        TRY(pf_gather_slices(sh, o.num, S, &fn, s));
+        TRY(pf_gather_slices(sh, o.den, S, &fd, s));
+        for (int side = 0; side < 2; side++) {
+            DFrac* t = side ? hi : lo;
             GM_HIP(hipMemcpyAsync(t->keep_n->p, fn.data() + (side ? H : 0) + off, n_out * sizeof(Fr), hipMemcpyHostToDevice, s));
             GM_HIP(hipMemcpyAsync(t->keep_d->p, fd.data() + (side ? H : 0) + off, n_out * sizeof(Fr), hipMemcpyHostToDevice, s));
-            t->num = t->keep_n->fr(); t->den = t->keep_d->fr();
         }
         GM_HIP(hipStreamSynchronize(s));   // fn / fd go out of scope
         return GM_OK;

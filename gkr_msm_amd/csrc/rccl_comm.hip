@@ -172,6 +172,7 @@ int32_t gm_comm_rccl_as_comm(gm_rccl* r, gm_comm* out) {
     out->world = r->world;
     out->all_gather = rccl_all_gather_host;
     out->all_gather_dev = rccl_all_gather_dev_cb;
+    out->pull_dev = nullptr;   // (pairwise ncclSend / ncclRecv would serve; this box cannot rehearse them with more than one rank)
     return GM_OK;
 }
 

@@ -25,6 +25,7 @@
 #include <chrono>
 #include <memory>
 #include <string>
+#include <vector>
 #include <thread>
 
 #include "internal.hpp"
@@ -95,6 +96,59 @@ static int32_t shm_all_gather(void* ctx, void* buf, uint64_t nbytes) {
     }
     c->calls++;
     c->payload += nbytes;
+    return 0;
+}
+
+// gm_comm::pull_dev: the bulk redistributions of the sharded pushforward argument, device to device.  Every rank publishes a HIP IPC
+// handle of the allocation its source lies in (+ the offset inside it) through the all-gather above, opens the handles of the ranks it
+// pulls from and copies its pieces with hipMemcpyAsync -- between two GPUs that is a peer copy over xGMI, between ranks that share
+// a device (the rehearsals on this box) a local copy.  Two host barriers: sources complete before anybody reads, everybody done
+// reading before a source may be reused.
+struct ShmIpcMsg {
+    hipIpcMemHandle_t handle;
+    uint64_t offset, bytes;
+};
+static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, uint32_t n, const gm_pull* pieces, void* stream) {
+    gm_shm* c = static_cast<gm_shm*>(ctx);
+    if (!c || (n && !pieces)) return 1;
+    hipStream_t s = as_stream(stream);
+    std::vector<ShmIpcMsg> msgs(c->world);
+    ShmIpcMsg& mine = msgs[c->rank];
+    memset(&mine, 0, sizeof(mine));
+    if (d_src && src_bytes) {
+        void* base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, const_cast<void*>(d_src)) != hipSuccess) return 3;
+        if (hipIpcGetMemHandle(&mine.handle, base) != hipSuccess) return 4;
+        mine.offset = (uint64_t)(static_cast<const char*>(d_src) - static_cast<const char*>(base));
+        mine.bytes = src_bytes;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return 5;   // the source is complete before its handle goes out
+    if (int32_t rc = shm_all_gather(c, msgs.data(), sizeof(ShmIpcMsg))) return rc;
+    std::vector<void*> opened(c->world, nullptr);
+    int32_t err = 0;
+    for (uint32_t k = 0; k < n && !err; k++) {
+        const gm_pull& p = pieces[k];
+        if (p.peer >= c->world || !p.d_dst || p.src_offset + p.bytes > msgs[p.peer].bytes) { err = 6; break; }
+        const char* src;
+        if (p.peer == c->rank) src = static_cast<const char*>(d_src);
+        else {
+            if (!opened[p.peer] && hipIpcOpenMemHandle(&opened[p.peer], msgs[p.peer].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { err = 7; break; }
+            src = static_cast<const char*>(opened[p.peer]) + msgs[p.peer].offset;
+        }
+        if (hipMemcpyAsync(p.d_dst, src + p.src_offset, p.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) err = 8;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess && !err) err = 9;
+    for (void* o : opened)
+        if (o) (void)hipIpcCloseMemHandle(o);
+    if (err) (void)hipGetLastError();
+    // everybody is done reading (also after an error on this rank: the others must not hang in their barrier)
+    std::vector<uint32_t> done(c->world, 0);
+    done[c->rank] = err ? 2u : 1u;
+    if (int32_t rc = shm_all_gather(c, done.data(), sizeof(uint32_t))) return rc;
+    if (err) return err;
+    for (uint32_t r = 0; r < c->world; r++)
+        if (done[r] != 1u) return 10;   // a peer failed
     return 0;
 }
 
@@ -176,6 +230,7 @@ int32_t gm_comm_shm_as_comm(gm_shm* c, gm_comm* out) {
     out->world = c->world;
     out->all_gather = shm_all_gather;
     out->all_gather_dev = nullptr;
+    out->pull_dev = shm_pull_dev;
     return GM_OK;
 }
 

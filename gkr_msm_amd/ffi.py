@@ -79,7 +79,7 @@ ALL_GATHER_DEV_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C
 class GmComm(C.Structure):
     """gm_comm: rank / world, one host-buffer all-gather and, optionally (NULL by default), the same collective on device buffers"""
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", ALL_GATHER_CB),
-                ("all_gather_dev", ALL_GATHER_DEV_CB)]
+                ("all_gather_dev", ALL_GATHER_DEV_CB), ("pull_dev", C.c_void_p)]
 
 
 _SIGS = {

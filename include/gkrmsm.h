@@ -371,6 +371,11 @@ int32_t gm_merlin_unread(const gm_merlin* t, uint64_t* n);
  *     slice is exhausted (the last log2(G) rounds of that layer run replicated).
  * all_gather: `h_buf` holds world * bytes_per_rank bytes; the caller has filled slot `rank`; on return every slot is filled.
  * Every rank must run the same sequence of calls (the provers are deterministic given the same challenges). */
+typedef struct gm_pull {
+    uint32_t peer, reserved;
+    uint64_t src_offset, bytes;
+    void* d_dst;
+} gm_pull;
 typedef struct gm_comm {
     void* ctx;
     uint32_t rank, world;   /* world: a power of two dividing y_size */
@@ -380,6 +385,12 @@ typedef struct gm_comm {
      * leave the device before they are added up: round kernel -> device slot -> this all-gather -> a one-wave sum -> ONE report
      * to the host (gm_comm_rccl_as_comm sets it: ncclAllGather). */
     int32_t (*all_gather_dev)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream);
+    /* optional (NULL: bulk redistributions are staged through `all_gather` on host buffers): device to device, collective -- every
+     * rank exposes `src_bytes` bytes at d_src and pulls n pieces, piece k = bytes [src_offset, src_offset + bytes) of rank `peer`'s
+     * d_src into d_dst (a rank may pull from itself).  Returns when this rank's pieces have arrived AND every rank has finished
+     * reading (d_src may be reused).  The sharded pushforward argument re-spreads the halves of its logup tree with it
+     * (gm_comm_shm_as_comm sets it: HIP IPC handles exchanged through the shared memory, hipMemcpyAsync between the devices). */
+    int32_t (*pull_dev)(void* ctx, const void* d_src, uint64_t src_bytes, uint32_t n, const struct gm_pull* pieces, void* stream);
 } gm_comm;
 /* host-only self-test of a gm_comm (no GPU): sums the field elements h_vals[0..n) of all ranks in place (Montgomery) */
 int32_t gm_comm_sum_fr(const gm_comm* comm, uint64_t* h_vals, uint32_t n);

@@ -429,8 +429,9 @@ def _sharded_pf_worker(rank, world, port, x_log, d_log, nbits, q):
 def test_config_b_pushforward_sharded_over_four_ranks():
     """the pushforward argument with the matrix sharded by windows (gm_pushforward_prove_sharded) at config B's full size, world 4 on
     the one GPU: the messages and claims of every rank equal the unsharded argument's.  The halves of the logup tree's levels are
-    re-spread through the host here (the communicator's all-gather), which is what the time below mostly is: a functional check at
-    size, not a speed."""
+    re-spread device to device (gm_comm::pull_dev of the shared-memory communicator: HIP IPC handles + copies between the ranks'
+    buffers; on a node those copies cross xGMI, here the four ranks share the device -- so the time is a functional check at size
+    with all four ranks' work on ONE GPU, not a speed-up)."""
     import torch.multiprocessing as mp
     world, x_log, d_log, nbits = 4, 20, 8, 256
     require_host_gib(64, "config B pushforward sharded over 4 processes")
@@ -460,11 +461,11 @@ def test_config_b_pushforward_sharded_over_four_ranks():
     for rank, ok, info in res:
         assert info["digest"] == ref, "rank %d: the sharded argument differs from the unsharded one" % rank
     sharded = max(r[2]["sharded_s"] for r in res)
-    print("[at-size] config B pushforward argument sharded over %d ranks sharing one GPU (x_logsize %d): %d rounds, %.0f ms (host-staged "
-          "re-spreading) against %.1f ms unsharded; %d exchanges per rank; equal to the unsharded argument on every rank" % (
+    print("[at-size] config B pushforward argument sharded over %d ranks sharing one GPU (x_logsize %d): %d rounds, %.0f ms (halves re-spread "
+          "device to device over HIP IPC) against %.1f ms unsharded; %d exchanges per rank; equal to the unsharded argument on every rank" % (
               world, x_log, res[0][2]["rounds"], 1e3 * sharded, 1e3 * res[0][2]["unsharded_s"], res[0][2]["exchanges"]))
-    record("config_b_pushforward_sharded_over_four_ranks", x_logsize=x_log, world=world, rounds=res[0][2]["rounds"], transport="shm",
-           sharded_ms=round(1e3 * sharded, 1), unsharded_ms=round(1e3 * res[0][2]["unsharded_s"], 1),
+    record("config_b_pushforward_sharded_over_four_ranks", x_logsize=x_log, world=world, rounds=res[0][2]["rounds"],
+           transport="shm (round sums) + HIP IPC pulls (tree halves, access counts)", sharded_ms=round(1e3 * sharded, 1), unsharded_ms=round(1e3 * res[0][2]["unsharded_s"], 1),
            exchanges_per_rank=res[0][2]["exchanges"], seconds=round(time.perf_counter() - t_begin, 1),
            checked="messages, gamma and the three final claims equal to the unsharded argument on every rank")
 

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q):
+def _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q, host_staged=False):
     """one rank: the unsharded argument as the reference (every rank computes it: small), then the sharded one on its windows;
     the incoming claims are the image's evaluations, as in Pippenger::prove"""
     try:
@@ -22,6 +22,8 @@ def _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         if dist_min:
             os.environ["GM_PF_DIST_MIN"] = str(dist_min)
+        if host_staged:
+            os.environ["GM_PF_HOST_STAGED"] = "1"
         from gkr_msm_amd import codec, dist as gd, harness as H
         from pyref import field as F
         from pyref import gkr as G
@@ -58,11 +60,11 @@ def _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q):
         q.put((rank, False, repr(e) + traceback.format_exc(), 0))
 
 
-def _run(target, world, x_log, d_log, nbits, dist_min):
+def _run(target, world, x_log, d_log, nbits, dist_min, host_staged=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    tag = "%d-%d-%d-%d" % (os.getpid(), world, x_log, dist_min)
-    procs = [ctx.Process(target=target, args=(r, world, tag, x_log, d_log, nbits, dist_min, q)) for r in range(world)]
+    tag = "%d-%d-%d-%d-%d" % (os.getpid(), world, x_log, dist_min, host_staged)
+    procs = [ctx.Process(target=target, args=(r, world, tag, x_log, d_log, nbits, dist_min, q, host_staged)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -80,9 +82,10 @@ def _run(target, world, x_log, d_log, nbits, dist_min):
     return sorted(res)
 
 
+@pytest.mark.parametrize("host_staged", [False, True])   # the halves re-spread device to device (gm_comm::pull_dev, HIP IPC) / through the host
 @pytest.mark.parametrize("world,x_log,d_log,nbits,dist_min", [(2, 4, 2, 8, 2), (4, 5, 2, 8, 2), (2, 6, 3, 24, 2), (4, 7, 4, 32, 2),
-                                                               (2, 10, 4, 16, 0)])
-def test_sharded_pushforward_matches_unsharded(world, x_log, d_log, nbits, dist_min):
-    res = _run(_claims_worker, world, x_log, d_log, nbits, dist_min)
+                                                               (2, 10, 4, 16, 0), (4, 10, 8, 64, 0)])
+def test_sharded_pushforward_matches_unsharded(world, x_log, d_log, nbits, dist_min, host_staged):
+    res = _run(_claims_worker, world, x_log, d_log, nbits, dist_min, host_staged)
     for rank, ok, info, calls in res:
         assert calls > x_log      # the round sums (and the re-spread halves) really went through the communicator
