@@ -768,6 +768,20 @@ def main():
             L.gm_sc_stage_counts(C.byref(stage1[0]), C.byref(stage1[1]))
             out["sumcheck"]["stage_kernel_launches_per_proof"] = (stage1[0].value - stage0[0].value) // 2
             out["sumcheck"]["stage_kernel_launches_left_early"] = stage1[1].value - stage0[1].value
+            # the pushforward argument on the same sharding (gm_pushforward_prove_sharded), chained after the image part as in
+            # Pippenger::prove; its tree halves move device to device through gm_comm::pull_dev (HIP IPC) when the communicator has it
+            try:
+                g_rng = np.random.default_rng(23)
+                pf_tape = [int.from_bytes(g_rng.bytes(64), "little") % P for _ in range(4)] + [int.from_bytes(g_rng.bytes(16), "little") for _ in range(3000)]
+                harness.pushforward_prove(plan, d_pts, y_log, res["point"], res["evs"], pf_tape, comm=comm)      # warmup
+                sync_all()
+                pf = harness.pushforward_prove(plan, d_pts, y_log, res["point"], res["evs"], pf_tape, comm=comm)
+                pf_dt = max_over_ranks(pf["call_s"])
+                out["sumcheck"]["pushforward_sharded"] = {"ms": round(pf_dt * 1e3, 2), "rounds": pf["rounds"],
+                                                          "rounds_per_sec": round(pf["rounds"] / pf_dt, 1),
+                                                          "redistribution": "gm_comm::pull_dev (HIP IPC, device to device)" if which == "shm" else "host all-gather"}
+            except Exception as e:
+                out["sumcheck"]["pushforward_sharded"] = {"error": repr(e)[:300]}
             w.close()
             del w
             # the unsharded prover on every GPU at once, same run: what one GPU does alone
