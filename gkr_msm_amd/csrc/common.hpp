@@ -121,7 +121,10 @@ struct DevPool {
         }
         (void)hipFree(p);
     }
+    std::atomic<uint64_t> release_epoch{0};   // bumps whenever blocks went back to the driver: peers holding HIP IPC mappings of this
+                                              // process's allocations (shm_comm.hip) drop them when they see a new value
     void release() {
+        release_epoch++;
         std::multimap<Key, void*> take;
         {
             std::lock_guard<std::mutex> g(mu);

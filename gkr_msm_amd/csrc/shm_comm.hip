@@ -52,10 +52,38 @@ struct gm_shm {
     size_t bytes = 0;
     uint64_t seq = 0;       // all_gather chunks done by this rank
     uint64_t calls = 0, payload = 0;
+    // peers' allocations opened through HIP IPC (pull_dev), kept open: the same few pool slabs / arenas come back call after call
+    // and opening one costs ~a millisecond.  Oldest first out; everything is closed with the communicator.
+    // A mapping is only as good as the peer's allocation: the peer publishes the epoch of its device pool with every handle (it moves
+    // whenever the pool gave blocks back to the driver), and a new epoch drops everything opened from that peer.
+    struct Opened { hipIpcMemHandle_t handle; void* ptr; uint32_t peer; };
+    std::vector<Opened> opened;
+    std::vector<uint64_t> peer_epoch;
+    static constexpr size_t MAX_OPENED = 32;
+    void* open_peer(uint32_t peer, const hipIpcMemHandle_t& h, uint64_t epoch) {
+        if (peer_epoch.size() != world) peer_epoch.assign(world, ~0ull);
+        if (peer_epoch[peer] != epoch) {
+            for (size_t i = 0; i < opened.size();)
+                if (opened[i].peer == peer) { (void)hipIpcCloseMemHandle(opened[i].ptr); opened.erase(opened.begin() + i); }
+                else i++;
+            peer_epoch[peer] = epoch;
+        }
+        for (const Opened& o : opened)
+            if (o.peer == peer && memcmp(&o.handle, &h, sizeof(h)) == 0) return o.ptr;
+        void* p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (opened.size() >= MAX_OPENED) {
+            (void)hipIpcCloseMemHandle(opened.front().ptr);
+            opened.erase(opened.begin());
+        }
+        opened.push_back(Opened{h, p, peer});
+        return p;
+    }
     ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
     std::atomic<uint64_t>* seq_of(uint32_t r) const { return reinterpret_cast<std::atomic<uint64_t>*>(base + 64 + (size_t)r * 64); }
     char* slot(uint32_t r, uint64_t n) const { return base + 64 + (size_t)world * 64 + ((size_t)r * 2 + (n & 1)) * SHM_SLOT; }
     ~gm_shm() {
+        for (const Opened& o : opened) (void)hipIpcCloseMemHandle(o.ptr);
         if (base) munmap(base, bytes);
     }
 };
@@ -106,7 +134,7 @@ static int32_t shm_all_gather(void* ctx, void* buf, uint64_t nbytes) {
 // reading before a source may be reused.
 struct ShmIpcMsg {
     hipIpcMemHandle_t handle;
-    uint64_t offset, bytes;
+    uint64_t offset, bytes, epoch;
 };
 static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, uint32_t n, const gm_pull* pieces, void* stream) {
     gm_shm* c = static_cast<gm_shm*>(ctx);
@@ -123,9 +151,9 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         mine.offset = (uint64_t)(static_cast<const char*>(d_src) - static_cast<const char*>(base));
         mine.bytes = src_bytes;
     }
+    mine.epoch = dev_pool().release_epoch.load();
     if (hipStreamSynchronize(s) != hipSuccess) return 5;   // the source is complete before its handle goes out
     if (int32_t rc = shm_all_gather(c, msgs.data(), sizeof(ShmIpcMsg))) return rc;
-    std::vector<void*> opened(c->world, nullptr);
     int32_t err = 0;
     for (uint32_t k = 0; k < n && !err; k++) {
         const gm_pull& p = pieces[k];
@@ -133,14 +161,13 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         const char* src;
         if (p.peer == c->rank) src = static_cast<const char*>(d_src);
         else {
-            if (!opened[p.peer] && hipIpcOpenMemHandle(&opened[p.peer], msgs[p.peer].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { err = 7; break; }
-            src = static_cast<const char*>(opened[p.peer]) + msgs[p.peer].offset;
+            void* peer_base = c->open_peer(p.peer, msgs[p.peer].handle, msgs[p.peer].epoch);
+            if (!peer_base) { err = 7; break; }
+            src = static_cast<const char*>(peer_base) + msgs[p.peer].offset;
         }
         if (hipMemcpyAsync(p.d_dst, src + p.src_offset, p.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) err = 8;
     }
     if (hipStreamSynchronize(s) != hipSuccess && !err) err = 9;
-    for (void* o : opened)
-        if (o) (void)hipIpcCloseMemHandle(o);
     if (err) (void)hipGetLastError();
     // everybody is done reading (also after an error on this rank: the others must not hang in their barrier)
     std::vector<uint32_t> done(c->world, 0);
