@@ -1421,7 +1421,9 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     tr->write_scalars({nd[0], nd[1]});
 
     Arena arena;
-    TRY(arena.init((size_t)32 * (5 * (ML / 2 + ML / 4) + 2 * M) + ((size_t)64 << 20)));
+    // workspace of the sumcheck objects: fold buffers and eq levels of this rank's slices (the sharded objects keep their slice of
+    // the eq tables), the replicated top of the tree
+    TRY(arena.init((size_t)32 * (5 * (ML / 2 + ML / 4) + 2 * ML + 8 * dist_min * G) + ((size_t)64 << 20)));
     Fr* pinned = nullptr;
     GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
     memset(pinned, 0, 16 * sizeof(Fr));

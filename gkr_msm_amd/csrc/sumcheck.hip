@@ -2766,7 +2766,16 @@ struct ScDenseDeg2 : gm_sc {
 
     Fr claim() const override { return claim_; }
     const Fr* eq_ext = nullptr;   // levels built by someone else (the VecVec object's row_eq_coefs scratch), packed like d_eq
-    const Fr* eq_level(uint32_t i) const { return (eq_ext ? eq_ext : d_eq.fr()) + ((1ull << i) - 1); }
+    // Level i of eq_poly_sequence(point) at global index `off`.  A sharded object built by gm_sc_dense_deg2_create keeps only its own
+    // slice of the levels its local rounds read (level i >= lg restricted to the rank = eq(point[0..lg), rank) x eq(point[lg..i], .):
+    // 2^loc_vars entries instead of 2^num_vars) plus the lg small top levels of the replicated last rounds.
+    bool eq_sliced = false;
+    uint32_t eq_lg = 0, eq_rank = 0;
+    const Fr* eq_at(uint32_t i, uint64_t off) const {
+        if (!eq_sliced) return (eq_ext ? eq_ext : d_eq.fr()) + ((1ull << i) - 1) + off;
+        if (i >= eq_lg) return d_eq.fr() + ((1ull << (i - eq_lg)) - 1) + (off - ((uint64_t)eq_rank << (i - eq_lg)));
+        return d_eq.fr() + ((size_t)1 << (num_vars - eq_lg)) + ((1ull << i) - 1) + off;
+    }
 
     int32_t gather_cols() {
         const int k = cols.k;
@@ -2808,7 +2817,7 @@ struct ScDenseDeg2 : gm_sc {
             if (rc) return rc;
         }
         const uint64_t npairs = 1ull << (loc_vars - 1);
-        const Fr* eq_cur = eq_level(num_vars - 1 - round_idx) + (glob_off >> 1);
+        const Fr* eq_cur = eq_at(num_vars - 1 - round_idx, glob_off >> 1);
         ColPtrs cp;
         for (int i = 0; i < cols.k; i++) cp.p[i] = cols.cur[i];
         const bool split = npairs <= SC_SPLIT_MAX_PAIRS;
@@ -2914,7 +2923,7 @@ struct ScDenseDeg2 : gm_sc {
         const int nr = (int)(num_vars - r0);
         if (nr < 1 || nr > STAGE_MAX_ROUNDS || (1ull << (nr - 1)) != npairs0) return set_err(GM_ERR_STATE, "stage rounds: inconsistent shape");
         const uint64_t g0 = glob_off >> (r0 - round_idx);   // glob_off at round r0
-        for (int q = 0; q < nr; q++) a.eq[q] = eq_level(num_vars - 1 - (r0 + q)) + (g0 >> (q + 1));
+        for (int q = 0; q < nr; q++) a.eq[q] = eq_at(num_vars - 1 - (r0 + q), g0 >> (q + 1));
         a.n_elems = (uint32_t)(2 * npairs0);
         const int hr = stage_host_rounds(sp, nr);
         a.n_dense = nr - hr;
@@ -3100,7 +3109,7 @@ struct ScDenseDeg2 : gm_sc {
             if (staged) {
                 k_enq = num_vars;
             } else {
-                const Fr* eq_next = eq_level(num_vars - 2 - r) + (glob_off >> 2);
+                const Fr* eq_next = eq_at(num_vars - 2 - r, glob_off >> 2);
                 int32_t rc = launch_small_round(cn, eq_next, npairs >> 1, r + 1);
                 if (rc) return rc;
                 k_enq = r + 2;
@@ -3769,6 +3778,28 @@ extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, co
     rc = alloc_gamma(so->gamma_pows, &so->d_gamma);
     if (rc) return rc;
     // eq_poly_sequence(point[0 .. n-1])  (dense_eq.rs:85): levels 0..n-1, level i has 2^i entries
+    if (so->sh.comm && so->sh.lg >= 1 && so->loc_vars >= 1) {
+        // sharded: this rank's slice of the levels lg .. n-1 (local levels 0 .. loc_vars-1, scaled by eq(point[0..lg), rank)) and the
+        // whole levels 0 .. lg-1 behind them
+        const uint32_t lg = so->sh.lg, lv_n = so->loc_vars;
+        so->eq_sliced = true; so->eq_lg = lg; so->eq_rank = so->sh.rank;
+        rc = so->d_eq.alloc((((size_t)1 << lv_n) + ((size_t)1 << lg)) * sizeof(Fr));
+        if (rc) return rc;
+        Fr factor = fr_one();   // eq(point[0..lg), rank): point[0] is the most significant variable
+        for (uint32_t j = 0; j < lg; j++) {
+            const Fr& q = so->point[j];
+            factor = fr_mul(factor, ((so->sh.rank >> (lg - 1 - j)) & 1u) ? q : fr_sub(fr_one(), q));
+        }
+        std::vector<Fr*> lv(lv_n);
+        for (uint32_t i = 0; i < lv_n; i++) lv[i] = so->d_eq.fr() + ((1ull << i) - 1);
+        rc = launch_eq_sequence(factor, so->point.data() + lg, lv_n - 1, lv.data(), so->stream, so->gamma_pows.data(),
+                                (uint32_t)so->gamma_pows.size(), so->d_gamma.fr());
+        if (rc) return rc;
+        std::vector<Fr*> top(lg);
+        for (uint32_t i = 0; i < lg; i++) top[i] = so->d_eq.fr() + ((size_t)1 << lv_n) + ((1ull << i) - 1);
+        rc = launch_eq_sequence(fr_one(), so->point.data(), lg - 1, top.data(), so->stream);
+        if (rc) return rc;
+    } else {
     rc = so->d_eq.alloc(((size_t)1 << num_vars) * sizeof(Fr));
     if (rc) return rc;
     std::vector<Fr*> lv(num_vars);
@@ -3776,6 +3807,7 @@ extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, co
     rc = launch_eq_sequence(fr_one(), so->point.data(), num_vars - 1, lv.data(), so->stream, so->gamma_pows.data(),
                             (uint32_t)so->gamma_pows.size(), so->d_gamma.fr());
     if (rc) return rc;
+    }
     rc = so->rs.init(so->stream);
     if (rc) return rc;
     so->inv_eq0 = batch_inv_one_minus(so->point);   // now, while the device builds the eq tables: not when the first round's sums are in
