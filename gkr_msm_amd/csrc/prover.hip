@@ -222,19 +222,39 @@ struct LayerClock {
     }
 };
 
-// GenericSumcheckProtocol::prove (sumcheck.rs:101-123)
+// Layers of a sharded proof that every rank would prove alike (the bucket-reduction GKR runs on the gathered bucket sums): ONE rank
+// -- the leader, rank 0 -- runs their sumcheck objects, the others take every round polynomial and the final evaluations from the
+// exchange (they contribute zeros to the field sum) and only drive their transcript.  Same messages everywhere; 7 of 8 GPUs do not
+// spend ~300 latency-bound rounds per proof on work whose result they can read.
+inline Shard& current_lead() {
+    static thread_local Shard s;
+    return s;
+}
+struct LeadScope {
+    Shard prev;
+    explicit LeadScope(const Shard& s) : prev(current_lead()) { current_lead() = s; }
+    ~LeadScope() { current_lead() = prev; }
+};
+inline bool lead_follower() { return current_lead().comm && current_lead().rank != 0; }
+
+// GenericSumcheckProtocol::prove (sumcheck.rs:101-123); so == nullptr on a follower (see LeadScope), n_finals = the evaluations it expects
 int32_t generic_sumcheck_prove(Tape* tr, gm_sc* so, uint32_t num_rounds, uint32_t degree, std::vector<Fr>* point,
-                               std::vector<Fr>* final_evals) {
+                               std::vector<Fr>* final_evals, uint32_t n_finals = 0) {
     std::vector<Fr> r;
     const bool clk = LayerClock::on();
     LayerClock& lc = LayerClock::get();
+    const Shard ld = current_lead();
+    const bool follower = ld.comm && ld.rank != 0;
+    if (follower != (so == nullptr)) return set_err(GM_ERR_STATE, "leader / follower mismatch");
     for (uint32_t rd = 0; rd < num_rounds; rd++) {
         Fr coeffs[8];
-        uint32_t nc = 0;
+        uint32_t nc = degree + 1;
         const double t0 = clk ? LayerClock::now() : 0;
-        TRY(gm_sc_unipoly(so, reinterpret_cast<uint64_t*>(coeffs), &nc));
-        if (clk) { lc.unipoly += LayerClock::now() - t0; lc.rounds++; }
+        if (!follower) TRY(gm_sc_unipoly(so, reinterpret_cast<uint64_t*>(coeffs), &nc));
+        else for (uint32_t i = 0; i < nc; i++) coeffs[i] = fr_zero();
         if (nc != degree + 1) return set_err(GM_ERR_STATE, "round polynomial has %u coefficients, expected %u", nc, degree + 1);
+        if (ld.comm) TRY(shard_sum_fr(ld, coeffs, (int)nc));
+        if (clk) { lc.unipoly += LayerClock::now() - t0; lc.rounds++; }
         std::vector<Fr> msg;  // compress_coefficients: drop the linear term (sumcheck.rs:27-31)
         msg.push_back(coeffs[0]);
         for (uint32_t i = 2; i < nc; i++) msg.push_back(coeffs[i]);
@@ -243,15 +263,20 @@ int32_t generic_sumcheck_prove(Tape* tr, gm_sc* so, uint32_t num_rounds, uint32_
         TRY(tr->challenge(&x));
         r.push_back(x);
         const double t1 = clk ? LayerClock::now() : 0;
-        TRY(gm_sc_bind(so, reinterpret_cast<const uint64_t*>(&x)));
+        if (!follower) TRY(gm_sc_bind(so, reinterpret_cast<const uint64_t*>(&x)));
         if (clk) lc.bind += LayerClock::now() - t1;
         tr->rounds++;
     }
     point->assign(r.rbegin(), r.rend());
     Fr ev[GM_MAX_COLS + 1];
-    uint32_t ne = 0;
+    uint32_t ne = n_finals;
     const double t2 = clk ? LayerClock::now() : 0;
-    TRY(gm_sc_final_evals(so, reinterpret_cast<uint64_t*>(ev), &ne));
+    if (!follower) TRY(gm_sc_final_evals(so, reinterpret_cast<uint64_t*>(ev), &ne));
+    else for (uint32_t i = 0; i < ne; i++) ev[i] = fr_zero();
+    if (ld.comm) {
+        if (n_finals && ne != n_finals) return set_err(GM_ERR_STATE, "leader has %u final evaluations, the followers expect %u", ne, n_finals);
+        TRY(shard_sum_fr(ld, ev, (int)ne));
+    }
     if (clk) lc.finals += LayerClock::now() - t2;
     final_evals->assign(ev, ev + ne);
     return GM_OK;
@@ -270,12 +295,13 @@ int32_t dense_deg2_prove(Tape* tr, const gm_fn& f, uint32_t num_vars, Claims* cl
     ScHolder h;
     auto ptrs = adv.col_ptrs();
     const double t0 = LayerClock::on() ? LayerClock::now() : 0;
-    TRY(gm_sc_dense_deg2_create(&f, num_vars, ptrs.data(), reinterpret_cast<const uint64_t*>(claims->point.data()),
-                                reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(claims->evs.data()),
-                                &h.so, s));
+    if (!lead_follower())
+        TRY(gm_sc_dense_deg2_create(&f, num_vars, ptrs.data(), reinterpret_cast<const uint64_t*>(claims->point.data()),
+                                    reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(claims->evs.data()),
+                                    &h.so, s));
     if (LayerClock::on()) { LayerClock::get().create += LayerClock::now() - t0; LayerClock::get().layers++; }
     std::vector<Fr> pt, evs;
-    TRY(generic_sumcheck_prove(tr, h.so, num_vars, 3, &pt, &evs));
+    TRY(generic_sumcheck_prove(tr, h.so, num_vars, 3, &pt, &evs, (uint32_t)plan_of(f).n_ins));
     tr->write_scalars(evs);
     claims->point = pt;
     claims->evs = evs;
@@ -593,7 +619,11 @@ static int32_t image_part_core(const gm_pip_witness* w, Tape* trp, Claims* cp) {
     gm_pip_witness* wm = const_cast<gm_pip_witness*>(w);
     shared_pinned() = wm->pinned;
     struct PinnedReset { ~PinnedReset() { shared_pinned() = nullptr; } } pinned_reset;
-    TRY(simple_gkr_prove(&tr, triangle_layers(multirow + bucket - 2, multirow), w->triangle_advices, &c, &wm->arena, s));
+    {   // sharded: the bucket reduction runs on the gathered bucket sums -- on the leader only (LeadScope)
+        static const bool no_lead = [] { const char* e = getenv("GM_SHARD_NO_LEADER"); return e && e[0] == '1'; }();   // A/B: every rank proves it
+        LeadScope lead((w->sh.comm && !no_lead) ? w->sh : Shard());
+        TRY(simple_gkr_prove(&tr, triangle_layers(multirow + bucket - 2, multirow), w->triangle_advices, &c, &wm->arena, s));
+    }
     TRY(split_at_prove(&tr, &c, true, multirow, 3));
     TRY(split_at_prove(&tr, &c, true, multirow, 3));
     {   // the bucket-sum tree runs over this rank's rows only when the witness is sharded
