@@ -1267,7 +1267,8 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     const uint64_t M = 1ull << mlog, X = 1ull << x_log, D = 1ull << d_log, ML = M / G, base = (uint64_t)sh.rank * ML;
     void* stream = reinterpret_cast<void*>(s);
     static const uint64_t dist_min = [] { const char* e = getenv("GM_PF_DIST_MIN"); return (uint64_t)(e && atoll(e) >= 1 ? atoll(e) : 1024); }();
-    static const bool host_staged = [] { const char* e = getenv("GM_PF_HOST_STAGED"); return e && e[0] == '1'; }();   // A/B and tests: never pull_dev
+    static const bool host_staged_env = [] { const char* e = getenv("GM_PF_HOST_STAGED"); return e && e[0] == '1'; }();   // A/B and tests: never pull_dev
+    bool host_staged = host_staged_env;   // also once the communicator reports that its device path is unavailable (100: every rank alike)
     std::vector<Fr> r(y_log + d_log + x_log), evs(3);
     memcpy(r.data(), h_claim_point, r.size() * sizeof(Fr));
     memcpy(evs.data(), h_claim_evs, 3 * sizeof(Fr));
@@ -1290,8 +1291,10 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
             std::vector<gm_pull> pc(G);
             for (uint32_t q = 0; q < G; q++) pc[q] = gm_pull{q, 0u, 0ull, (X + D) * sizeof(Fr), parts->fr() + (uint64_t)q * (X + D)};
             const int32_t rc = sh.comm->pull_dev(sh.comm->ctx, part->p, (X + D) * sizeof(Fr), G, pc.data(), stream);
-            if (rc) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
-        } else {
+            if (rc == 100) host_staged = true;
+            else if (rc) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
+        }
+        if (!sh.comm->pull_dev || host_staged) {
             TRY(pf_gather_slices(sh, part->fr(), X + D, &all, s));
             GM_HIP(hipMemcpyAsync(parts->p, all.data(), all.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
         }
@@ -1379,9 +1382,10 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
                 }
                 const int32_t rc = sh.comm->pull_dev(sh.comm->ctx, arr ? o.den : o.num, S * sizeof(Fr), (uint32_t)pc.size(), pc.data(),
                                                      reinterpret_cast<void*>(s));
+                if (rc == 100) { host_staged = true; break; }   // nothing was copied: this and the later levels through the host
                 if (rc) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
             }
-            return GM_OK;
+            if (!host_staged) return GM_OK;
         }
         std::vector<Fr> fn, fd;   // host-staged: the whole array through the communicator's all-gather
         TRY(pf_gather_slices(sh, o.num, S, &fn, s));

@@ -136,6 +136,10 @@ struct ShmIpcMsg {
     hipIpcMemHandle_t handle;
     uint64_t offset, bytes, epoch;
 };
+// Return value GM_PULL_UNAVAILABLE (100): some rank could not export or open a mapping (devices hidden from each other, IPC
+// switched off): every rank learns it in the same exchange, nothing was copied, and the caller stages this redistribution through
+// the host instead -- on every rank alike.
+#define GM_PULL_UNAVAILABLE 100
 static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, uint32_t n, const gm_pull* pieces, void* stream) {
     gm_shm* c = static_cast<gm_shm*>(ctx);
     if (!c || (n && !pieces)) return 1;
@@ -143,30 +147,48 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
     std::vector<ShmIpcMsg> msgs(c->world);
     ShmIpcMsg& mine = msgs[c->rank];
     memset(&mine, 0, sizeof(mine));
-    if (d_src && src_bytes) {
+    static const bool no_ipc = [] { const char* e = getenv("GM_SHM_NO_IPC"); return e && e[0] == '1'; }();   // tests: this rank cannot export
+    bool exported = !no_ipc;
+    if (exported && d_src && src_bytes) {
         void* base = nullptr;
         size_t size = 0;
-        if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, const_cast<void*>(d_src)) != hipSuccess) return 3;
-        if (hipIpcGetMemHandle(&mine.handle, base) != hipSuccess) return 4;
-        mine.offset = (uint64_t)(static_cast<const char*>(d_src) - static_cast<const char*>(base));
-        mine.bytes = src_bytes;
+        if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, const_cast<void*>(d_src)) != hipSuccess ||
+            hipIpcGetMemHandle(&mine.handle, base) != hipSuccess) {
+            (void)hipGetLastError();
+            exported = false;
+        } else {
+            mine.offset = (uint64_t)(static_cast<const char*>(d_src) - static_cast<const char*>(base));
+            mine.bytes = src_bytes;
+        }
     }
     mine.epoch = dev_pool().release_epoch.load();
     if (hipStreamSynchronize(s) != hipSuccess) return 5;   // the source is complete before its handle goes out
     if (int32_t rc = shm_all_gather(c, msgs.data(), sizeof(ShmIpcMsg))) return rc;
+    // open what this rank pulls from; then agree that everybody could
+    std::vector<const char*> src(n, nullptr);
     int32_t err = 0;
-    for (uint32_t k = 0; k < n && !err; k++) {
+    bool usable = exported;
+    for (uint32_t k = 0; k < n && usable; k++) {
         const gm_pull& p = pieces[k];
-        if (p.peer >= c->world || !p.d_dst || p.src_offset + p.bytes > msgs[p.peer].bytes) { err = 6; break; }
-        const char* src;
-        if (p.peer == c->rank) src = static_cast<const char*>(d_src);
+        if (p.peer >= c->world || !p.d_dst) { err = 6; break; }
+        if (p.src_offset + p.bytes > msgs[p.peer].bytes) { usable = false; break; }   // (a peer that could not export announces 0 bytes)
+        if (p.peer == c->rank) src[k] = static_cast<const char*>(d_src) + p.src_offset;
         else {
             void* peer_base = c->open_peer(p.peer, msgs[p.peer].handle, msgs[p.peer].epoch);
-            if (!peer_base) { err = 7; break; }
-            src = static_cast<const char*>(peer_base) + msgs[p.peer].offset;
+            if (!peer_base) { usable = false; break; }
+            src[k] = static_cast<const char*>(peer_base) + msgs[p.peer].offset + p.src_offset;
         }
-        if (hipMemcpyAsync(p.d_dst, src + p.src_offset, p.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) err = 8;
     }
+    std::vector<uint32_t> st(c->world, 0);
+    st[c->rank] = err ? 3u : usable ? 1u : 2u;
+    if (int32_t rc = shm_all_gather(c, st.data(), sizeof(uint32_t))) return rc;
+    if (err) return err;
+    for (uint32_t r = 0; r < c->world; r++) {
+        if (st[r] == 3u) return 10;                     // a peer failed outright
+        if (st[r] != 1u) return GM_PULL_UNAVAILABLE;    // same answer on every rank; nothing has been copied
+    }
+    for (uint32_t k = 0; k < n && !err; k++)
+        if (hipMemcpyAsync(pieces[k].d_dst, src[k], pieces[k].bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) err = 8;
     if (hipStreamSynchronize(s) != hipSuccess && !err) err = 9;
     if (err) (void)hipGetLastError();
     // everybody is done reading (also after an error on this rank: the others must not hang in their barrier)

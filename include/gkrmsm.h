@@ -388,7 +388,9 @@ typedef struct gm_comm {
     /* optional (NULL: bulk redistributions are staged through `all_gather` on host buffers): device to device, collective -- every
      * rank exposes `src_bytes` bytes at d_src and pulls n pieces, piece k = bytes [src_offset, src_offset + bytes) of rank `peer`'s
      * d_src into d_dst (a rank may pull from itself).  Returns when this rank's pieces have arrived AND every rank has finished
-     * reading (d_src may be reused).  The sharded pushforward argument re-spreads the halves of its logup tree with it
+     * reading (d_src may be reused).  Return value 100 = the device path is not available (some rank could not export or open a
+     * mapping): every rank gets the same answer from the same call, nothing was copied, the caller stages the redistribution through
+     * `all_gather` instead.  The sharded pushforward argument re-spreads the halves of its logup tree with it
      * (gm_comm_shm_as_comm sets it: HIP IPC handles exchanged through the shared memory, hipMemcpyAsync between the devices). */
     int32_t (*pull_dev)(void* ctx, const void* d_src, uint64_t src_bytes, uint32_t n, const struct gm_pull* pieces, void* stream);
 } gm_comm;

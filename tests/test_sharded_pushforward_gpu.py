@@ -22,8 +22,10 @@ def _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q, host_stag
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         if dist_min:
             os.environ["GM_PF_DIST_MIN"] = str(dist_min)
-        if host_staged:
+        if host_staged is True:
             os.environ["GM_PF_HOST_STAGED"] = "1"
+        if host_staged == "rank1-cannot-export" and rank == 1:
+            os.environ["GM_SHM_NO_IPC"] = "1"
         from gkr_msm_amd import codec, dist as gd, harness as H
         from pyref import field as F
         from pyref import gkr as G
@@ -63,7 +65,7 @@ def _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q, host_stag
 def _run(target, world, x_log, d_log, nbits, dist_min, host_staged=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    tag = "%d-%d-%d-%d-%d" % (os.getpid(), world, x_log, dist_min, host_staged)
+    tag = "%d-%d-%d-%d-%s" % (os.getpid(), world, x_log, dist_min, str(host_staged)[:5])
     procs = [ctx.Process(target=target, args=(r, world, tag, x_log, d_log, nbits, dist_min, q, host_staged)) for r in range(world)]
     for p in procs:
         p.start()
@@ -89,3 +91,9 @@ def test_sharded_pushforward_matches_unsharded(world, x_log, d_log, nbits, dist_
     res = _run(_claims_worker, world, x_log, d_log, nbits, dist_min, host_staged)
     for rank, ok, info, calls in res:
         assert calls > x_log      # the round sums (and the re-spread halves) really went through the communicator
+
+
+def test_sharded_pushforward_when_one_rank_cannot_export_its_buffers():
+    """gm_comm::pull_dev answers "unavailable" on EVERY rank when one of them cannot export (or open) an IPC mapping -- devices hidden
+    from each other, IPC switched off -- and the argument stages that redistribution through the host instead: same result, no hang"""
+    _run(_claims_worker, 4, 7, 4, 32, 2, "rank1-cannot-export")
