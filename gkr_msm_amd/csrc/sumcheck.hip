@@ -311,6 +311,27 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
             }
         }
         __syncthreads();
+        if (fc.raw && NACC <= 3) {
+            // ONE trip to the L2 (as k_stage's exchange): a returning add per (sum, limb) that also counts the contributors in the
+            // accumulator's top bits; the block whose add arrives last at an accumulator forwards that total to the host -- 8 bytes,
+            // self-validating: a 12-bit tag of the launch's sequence number (never 0) over the 52-bit total -- and leaves a zero behind.
+            // No drain, no arrival counter, no swap by a last block, no sequence word: the host waits for the 8 NACC tagged values
+            // (RoundScratch::finish_seq, which zeroes them once read) and reduces mod p.
+            if (threadIdx.x < 8 * NACC) {
+                const uint32_t a = threadIdx.x >> 3, l = threadIdx.x & 7;
+                unsigned long long v = 0;
+#pragma unroll
+                for (int w = 0; w < SC_THREADS / 64; w++) v += (unsigned long long)half[w][a][2 * l] + ((unsigned long long)half[w][a][2 * l + 1] << 16);
+                const unsigned long long prev = __hip_atomic_fetch_add(fc.acc + threadIdx.x * 16, v + (1ull << 52), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(prev >> 52) == nblk - 1) {
+                    const unsigned long long tot = (prev + v) & ((1ull << 52) - 1);
+                    const unsigned long long tag = (unsigned long long)(fc.seq % 4095u + 1u) << 52;
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(fc.out) + threadIdx.x, tag | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(fc.acc + threadIdx.x * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
         if (threadIdx.x < 8 * NACC) {   // one lane per (sum, limb): the block's integer limb sum (< 2^42) into the launch's accumulator
             const uint32_t a = threadIdx.x >> 3, l = threadIdx.x & 7;
             unsigned long long v = 0;
@@ -326,22 +347,6 @@ __device__ __forceinline__ void block_reduce_finish(Fr* acc, const FinishCtx& fc
         }
         __syncthreads();
         if (!is_last) return;
-        if (fc.raw && NACC <= 3) {   // (four sums would reach into the sequence slot)
-            // the last block forwards the limb sums unreduced (8 NACC <= 24 lanes of the first wave, 8 bytes each): no LDS hand-over, no
-            // barrier and no product on the path the host is waiting on
-            if (threadIdx.x < 8 * NACC) {
-                const unsigned long long v = __hip_atomic_exchange(fc.acc + threadIdx.x * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(fc.out) + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            if (threadIdx.x < 64) {
-                coh_drain();   // one wave: the sums have reached host memory before the sequence word is written
-                if (threadIdx.x == 0) {
-                    __hip_atomic_store(fc.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(fc.out + 7), (1ull << 32) | fc.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-            return;
-        }
         if (threadIdx.x < 8 * NACC) {
             const unsigned long long v = __hip_atomic_exchange(fc.acc + threadIdx.x * 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_lo[threadIdx.x] = (uint32_t)v;
@@ -1830,10 +1835,31 @@ struct RoundScratch {
     }
     // can_sync = false: a pre-enqueued fold is waiting in the stream for a challenge the host has not published yet, so a
     // stream synchronisation would wait for it; keep polling (bounded by wall time) instead
+    // Two result formats (block_reduce_finish): grids of <= 512 blocks send 8 nacc tagged 64-bit limb sums (tag = want % 4095 + 1 in
+    // the top 12 bits; no sequence word) which are reduced here and zeroed once read (a stale value can then never carry a valid tag);
+    // larger grids send nacc field elements and then the sequence word.
+    bool tagged_sums(uint32_t want, int nacc, Fr* out) {
+        volatile unsigned long long* raw = reinterpret_cast<volatile unsigned long long*>(h_result);
+        const unsigned long long tag = (unsigned long long)(want % 4095u + 1u);
+        if (nacc > 3) return false;
+        unsigned long long v[24];
+        for (int i = 0; i < 8 * nacc; i++) {
+            v[i] = raw[i];
+            if ((v[i] >> 52) != tag) return false;
+        }
+        for (int a = 0; a < nacc; a++) {
+            uint32_t lo[8], hi[8];
+            for (int l = 0; l < 8; l++) { const unsigned long long t = v[8 * a + l] & ((1ull << 52) - 1); lo[l] = (uint32_t)t; hi[l] = (uint32_t)(t >> 32); }
+            out[a] = limb_sums_mod_p(lo, hi);
+        }
+        for (int i = 0; i < 8 * nacc; i++) raw[i] = 0;
+        return true;
+    }
     int32_t finish_seq(uint32_t want, int nacc, hipStream_t s, Fr* out, bool can_sync = true) {
         volatile uint32_t* slot = reinterpret_cast<volatile uint32_t*>(h_result + 7);
         bool seen = false;
         for (int spin = 0; spin < 200000; spin++) {
+            if (tagged_sums(want, nacc, out)) return GM_OK;
             if (*slot == want) { seen = true; break; }
             __builtin_ia32_pause();
         }
@@ -1841,23 +1867,18 @@ struct RoundScratch {
             const auto t0 = std::chrono::steady_clock::now();
             while (!seen && std::chrono::steady_clock::now() - t0 < wait_timeout_host()) {
                 for (int spin = 0; spin < 10000 && !seen; spin++) {
+                    if (tagged_sums(want, nacc, out)) return GM_OK;
                     if (*slot == want) seen = true;
                     __builtin_ia32_pause();
                 }
             }
             if (!seen) return set_err(GM_ERR_STATE, "round kernel result did not arrive within %u ms (gm_set_wait_timeout_ms)", wait_timeout_ms().load());
         }
-        if (!seen) GM_HIP(hipStreamSynchronize(s));
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (slot[1] == 1u) {   // the launch forwarded its 64-bit limb sums (block_reduce_finish, grids of <= 512 blocks)
-            const volatile unsigned long long* raw = reinterpret_cast<const volatile unsigned long long*>(h_result);
-            for (int a = 0; a < nacc; a++) {
-                uint32_t lo[8], hi[8];
-                for (int l = 0; l < 8; l++) { const unsigned long long v = raw[8 * a + l]; lo[l] = (uint32_t)v; hi[l] = (uint32_t)(v >> 32); }
-                out[a] = limb_sums_mod_p(lo, hi);
-            }
-            return GM_OK;
+        if (!seen) {
+            GM_HIP(hipStreamSynchronize(s));
+            if (tagged_sums(want, nacc, out)) return GM_OK;
         }
+        std::atomic_thread_fence(std::memory_order_acquire);
         for (int a = 0; a < nacc; a++) out[a] = h_result[a];
         return GM_OK;
     }
