@@ -1401,6 +1401,48 @@ __global__ void __launch_bounds__(SC_THREADS, 2) k_round_deg2_lean9x2(LeanCols c
     block_reduce_finish<NACC>(acc, fc);
 }
 
+// The medium sparse rounds (<= 2^14 pairs: latency-bound) of a single-primitive layer in the same form: one (pair, evaluation point) per
+// thread, blockIdx.y = the point; the tail weight (a loop over the ROWS) runs in workgroup row y = 2 of its own instead of ahead of the
+// pairs in row 0, whose threads were the launch's critical path.  Same sums as k_round_deg2_lean_split, bit for bit.
+template <int PRIM>
+__global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean9_split(LeanCols cols, const Fr* __restrict__ eq, const Fr* __restrict__ gp,
+                                                                        VVArgs vv, FinishCtx fc) {
+    Fr acc[3] = {fr_zero(), fr_zero(), fr_zero()};
+    if (blockIdx.y == 2) {
+        for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
+            const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+        }
+        block_reduce_finish<3>(acc, fc);
+        return;
+    }
+    const bool h = blockIdx.y == 1;
+    Fr9 a = fr9_zero();   // domain 241; normalised, S grows by <= 1.5 per pair
+    uint32_t it = 0;
+    const uint64_t npairs = (uint64_t)(vv.off[vv.nrows] >> 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS, it++) {
+        const uint32_t cell0 = (uint32_t)(2 * i);
+        const uint32_t r = vv.coarse ? find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0) : find_row(vv.off, vv.nrows, cell0);
+        const Fr9 w = fr9_mul(fr9_load_raw(eq + ((cell0 - vv.off[r]) >> 1)), fr9_load_raw(vv.row_coef + r));   // domain 251, S 1.02
+        auto ld = [&](int q) -> Fr9 {
+            const Fr9 p1 = fr9_load_raw(cols.p[q] + 2 * i + 1);
+            if (!h) return p1;
+            return fr9_norm(fr9_sub8(fr9_add(p1, p1), fr9_load_raw(cols.p[q] + 2 * i)));   // 2 p1 - p0 + 8 p: S 10
+        };
+        auto lds = [&](int q) -> Fr9 {
+            const Fr9 p1 = fr9_load(cols.p[q] + 2 * i + 1);                                 // the limbs of 32 X: domain 261, S 32
+            if (!h) return p1;
+            return fr9_norm(fr9_sub64(fr9_add(p1, p1), fr9_load(cols.p[q] + 2 * i)));      // S 128, top limb < 2^29.9
+        };
+        const Fr9 t = fr9_mul(lean_gamma_eval9<PRIM>(ld, lds, gp), w);
+        a = fr9_norm(fr9_add(a, t));
+        if ((it & 15u) == 15u) a = fr9_mul(a, fr9_one());
+    }
+    a = fr9_mul(a, lean9_terms_256(PRIM) ? fr9_two271() : fr9_two276());
+    acc[h ? 1 : 0] = fr9_to_raw(a);
+    block_reduce_finish<3>(acc, fc);
+}
+
 // generic degree-3 round of F = eq * GammaWrapper(f) (same contract as k_round_generic<3, false>, kind 0); cols.p[NI] = eq
 template <int PRIM>
 __global__ void __launch_bounds__(SC_THREADS) k_round_generic3_lean(LeanCols cols, const Fr* __restrict__ gp, uint64_t npairs,
@@ -2387,6 +2429,18 @@ static bool launch_deg2_lean_split(int prim, dim3 grid, hipStream_t s, const Lea
                                    const FinishCtx& fc) {
     static const bool off = [] { const char* e = getenv("GM_LEAN_SPLIT"); return e && e[0] == '0'; }();
     if (off) return false;
+    static const bool form9 = [] { const char* e = getenv("GM_LEAN_SPLIT9"); return !(e && e[0] == '0'); }();   // A/B: the 8 x 32 form
+    if (form9) {
+        const dim3 g3(grid.x, 3);   // row 2: the tail weight
+#define GM_LS9_CASE(P) \
+    case P: hipLaunchKernelGGL((k_round_deg2_lean9_split<P>), g3, dim3(SC_THREADS), 0, s, lc, eq, gp, va, fc); return true;
+        switch (prim) {
+            GM_LS9_CASE(FN_AFF_L1) GM_LS9_CASE(FN_AFF_L2) GM_LS9_CASE(FN_AFF_L3) GM_LS9_CASE(FN_PROJ_L1) GM_LS9_CASE(FN_PROJ_L2)
+            GM_LS9_CASE(FN_PROJ_L3) GM_LS9_CASE(LEAN_AFF_L1_BC)
+            default: break;
+        }
+#undef GM_LS9_CASE
+    }
 #define GM_LS_CASE(P) \
     case P: hipLaunchKernelGGL((k_round_deg2_lean_split<P>), grid, dim3(SC_THREADS), 0, s, lc, eq, gp, va, fc); return true;
     switch (prim) {
