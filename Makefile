@@ -28,7 +28,8 @@ build/examples/%: examples/%.c include/gkrmsm.h $(LIB)
 # device-side self-checks that tests/ run on the GPU box (prebuilt here: the 14 x 28 one takes hipcc three minutes); each binary
 # carries the digest of its source + the field headers, tests/ubench_util.py rebuilds only when that digest is stale
 ubench: build/ubench/fq14_test build/ubench/fr9_mul_test
-UBENCH_HDRS := gkr_msm_amd/csrc/fq14.hip.h gkr_msm_amd/csrc/g1.hip.h gkr_msm_amd/csrc/fq.hip.h gkr_msm_amd/csrc/fr9.hip.h gkr_msm_amd/csrc/fr.hip.h
+UBENCH_HDRS := gkr_msm_amd/csrc/fq14.hip.h gkr_msm_amd/csrc/g1.hip.h gkr_msm_amd/csrc/fq.hip.h gkr_msm_amd/csrc/fr9.hip.h gkr_msm_amd/csrc/fr.hip.h \
+	gkr_msm_amd/csrc/fq14_mul_gen.inc gkr_msm_amd/csrc/fr9_mul_asm.inc gkr_msm_amd/csrc/fr9_sqr_asm.inc gkr_msm_amd/csrc/fr_mul_asm.inc
 build/ubench/%: scripts/ubench/%.hip $(HDR)
 	@mkdir -p build/ubench
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -w -mllvm -enable-misched=0 -o $@ $<

@@ -713,10 +713,31 @@ def main():
         import threading
 
         def _emit_without_prover():
-            out.setdefault("sumcheck", {})["error"] = "the sharded prover leg did not finish within its time box; line emitted by the watchdog"
-            if rank == 0:
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            # The timer thread races the main thread, which may be adding keys to `out`: serialise a snapshot, retrying if the dict
+            # changed under the copy, and ALWAYS leave through os._exit -- a watchdog that dies of an exception leaves the hang in place.
+            # Exit code 3 (not 0): a requested leg did not finish; the line is printed first, so the launcher still forwards it.
+            line = None
+            try:
+                for _ in range(20):
+                    try:
+                        snap = json.loads(json.dumps(dict(out), default=repr))
+                        snap.setdefault("sumcheck", {})
+                        if not isinstance(snap["sumcheck"], dict):
+                            snap["sumcheck"] = {"partial": snap["sumcheck"]}
+                        snap["sumcheck"]["error"] = "the sharded prover leg did not finish within its time box; line emitted by the watchdog"
+                        snap["legs_unfinished"] = ["sharded_prover"]
+                        line = json.dumps(snap)
+                        break
+                    except RuntimeError:
+                        time.sleep(0.01)
+                if line is None:
+                    line = json.dumps({"metric": out.get("metric"), "value": out.get("value"), "unit": out.get("unit"),
+                                       "n_gpus": out.get("n_gpus"), "legs_unfinished": ["sharded_prover"],
+                                       "error": "watchdog could not snapshot the full line"}, default=repr)
+                if rank == 0:
+                    print(line, flush=True)
+            finally:
+                os._exit(3)
         watchdog = threading.Timer(float(os.environ.get("GM_BENCH_PROVER_TIMEBOX_S", "240")), _emit_without_prover)
         watchdog.daemon = True
         watchdog.start()

@@ -16,6 +16,10 @@
 
 namespace gm {
 
+// per-device tables inside the library (stage-kernel budgets, pinned staging, persistent counters) hold this many devices;
+// gm_set_device refuses ids beyond it instead of aliasing slot 0
+#define GM_MAX_DEVICES 16
+
 inline char* err_buf() {
     static thread_local char buf[512] = {0};
     return buf;

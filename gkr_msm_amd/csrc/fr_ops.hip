@@ -165,7 +165,11 @@ extern "C" int32_t gm_device_count(int32_t* out_count) {
     *out_count = n;
     return GM_OK;
 }
-extern "C" int32_t gm_set_device(int32_t device) { GM_HIP(hipSetDevice(device)); return GM_OK; }
+extern "C" int32_t gm_set_device(int32_t device) {
+    GM_REQUIRE(device >= 0 && device < GM_MAX_DEVICES, "device id %d: this library's per-device tables hold %d devices", device, GM_MAX_DEVICES);
+    GM_HIP(hipSetDevice(device));
+    return GM_OK;
+}
 extern "C" int32_t gm_stream_sync(void* stream) { GM_HIP(hipStreamSynchronize(as_stream(stream))); return GM_OK; }
 extern "C" int32_t gm_malloc(void** out, size_t bytes) { GM_REQUIRE(out, "null out"); GM_HIP(hipMalloc(out, bytes ? bytes : 16)); return GM_OK; }
 extern "C" int32_t gm_free(void* p) { GM_HIP(hipFree(p)); return GM_OK; }

@@ -53,31 +53,45 @@ struct gm_shm {
     uint64_t seq = 0;       // all_gather chunks done by this rank
     uint64_t calls = 0, payload = 0;
     // peers' allocations opened through HIP IPC (pull_dev), kept open: the same few pool slabs / arenas come back call after call
-    // and opening one costs ~a millisecond.  Oldest first out; everything is closed with the communicator.
+    // and opening one costs ~a millisecond.  Least recently used first out (a hit moves to the back); a mapping a pull has resolved
+    // an address into is never closed under it: open_peer only ADDS (the cache may exceed its bound while a call runs), trim() closes
+    // the surplus after the call's "done reading" barrier, oldest first, skipping what the call touched.
     // A mapping is only as good as the peer's allocation: the peer publishes the epoch of its device pool with every handle (it moves
-    // whenever the pool gave blocks back to the driver), and a new epoch drops everything opened from that peer.
-    struct Opened { hipIpcMemHandle_t handle; void* ptr; uint32_t peer; };
+    // whenever the pool gave blocks back to the driver), and a new epoch drops everything opened from that peer -- also only between
+    // calls (the epoch is compared at the head of a pull, before any address of that call has been resolved).
+    struct Opened { hipIpcMemHandle_t handle; void* ptr; uint32_t peer; uint64_t used_in; };
     std::vector<Opened> opened;
     std::vector<uint64_t> peer_epoch;
-    static constexpr size_t MAX_OPENED = 32;
-    void* open_peer(uint32_t peer, const hipIpcMemHandle_t& h, uint64_t epoch) {
+    uint64_t pull_no = 0;          // pull_dev calls so far: the stamp of "touched by the current call"
+    uint64_t ipc_opens = 0, ipc_closes = 0;
+    size_t max_opened = [] { const char* e = getenv("GM_SHM_MAX_OPENED"); long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 32); }();
+    void sync_epoch(uint32_t peer, uint64_t epoch) {
         if (peer_epoch.size() != world) peer_epoch.assign(world, ~0ull);
-        if (peer_epoch[peer] != epoch) {
-            for (size_t i = 0; i < opened.size();)
-                if (opened[i].peer == peer) { (void)hipIpcCloseMemHandle(opened[i].ptr); opened.erase(opened.begin() + i); }
-                else i++;
-            peer_epoch[peer] = epoch;
-        }
-        for (const Opened& o : opened)
-            if (o.peer == peer && memcmp(&o.handle, &h, sizeof(h)) == 0) return o.ptr;
+        if (peer_epoch[peer] == epoch) return;
+        for (size_t i = 0; i < opened.size();)
+            if (opened[i].peer == peer) { (void)hipIpcCloseMemHandle(opened[i].ptr); ipc_closes++; opened.erase(opened.begin() + i); }
+            else i++;
+        peer_epoch[peer] = epoch;
+    }
+    void* open_peer(uint32_t peer, const hipIpcMemHandle_t& h) {
+        for (size_t i = 0; i < opened.size(); i++)
+            if (opened[i].peer == peer && memcmp(&opened[i].handle, &h, sizeof(h)) == 0) {
+                Opened o = opened[i];
+                o.used_in = pull_no;
+                opened.erase(opened.begin() + i);
+                opened.push_back(o);
+                return o.ptr;
+            }
         void* p = nullptr;
         if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (opened.size() >= MAX_OPENED) {
-            (void)hipIpcCloseMemHandle(opened.front().ptr);
-            opened.erase(opened.begin());
-        }
-        opened.push_back(Opened{h, p, peer});
+        ipc_opens++;
+        opened.push_back(Opened{h, p, peer, pull_no});
         return p;
+    }
+    void trim() {
+        for (size_t i = 0; i < opened.size() && opened.size() > max_opened;)
+            if (opened[i].used_in != pull_no) { (void)hipIpcCloseMemHandle(opened[i].ptr); ipc_closes++; opened.erase(opened.begin() + i); }
+            else i++;
     }
     ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
     std::atomic<uint64_t>* seq_of(uint32_t r) const { return reinterpret_cast<std::atomic<uint64_t>*>(base + 64 + (size_t)r * 64); }
@@ -135,6 +149,7 @@ static int32_t shm_all_gather(void* ctx, void* buf, uint64_t nbytes) {
 struct ShmIpcMsg {
     hipIpcMemHandle_t handle;
     uint64_t offset, bytes, epoch;
+    uint32_t failed, pad;     // the rank's source could not be completed (stream error): every rank returns an error, nobody waits
 };
 // Return value GM_PULL_UNAVAILABLE (100): some rank could not export or open a mapping (devices hidden from each other, IPC
 // switched off): every rank learns it in the same exchange, nothing was copied, and the caller stages this redistribution through
@@ -144,6 +159,7 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
     gm_shm* c = static_cast<gm_shm*>(ctx);
     if (!c || (n && !pieces)) return 1;
     hipStream_t s = as_stream(stream);
+    c->pull_no++;
     std::vector<ShmIpcMsg> msgs(c->world);
     ShmIpcMsg& mine = msgs[c->rank];
     memset(&mine, 0, sizeof(mine));
@@ -162,8 +178,15 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         }
     }
     mine.epoch = dev_pool().release_epoch.load();
-    if (hipStreamSynchronize(s) != hipSuccess) return 5;   // the source is complete before its handle goes out
+    // the source is complete before its handle goes out; a rank that cannot complete it says so IN the exchange (its peers would
+    // otherwise sit in the all-gather until the time-out)
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); mine.failed = 1; mine.bytes = 0; }
     if (int32_t rc = shm_all_gather(c, msgs.data(), sizeof(ShmIpcMsg))) return rc;
+    for (uint32_t r = 0; r < c->world; r++)
+        if (msgs[r].failed) return r == c->rank ? 5 : 10;
+    // mappings of a peer whose pool gave memory back are dropped now, before any address of this call is resolved
+    for (uint32_t r = 0; r < c->world; r++)
+        if (r != c->rank) c->sync_epoch(r, msgs[r].epoch);
     // open what this rank pulls from; then agree that everybody could
     std::vector<const char*> src(n, nullptr);
     int32_t err = 0;
@@ -174,7 +197,7 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         if (p.src_offset + p.bytes > msgs[p.peer].bytes) { usable = false; break; }   // (a peer that could not export announces 0 bytes)
         if (p.peer == c->rank) src[k] = static_cast<const char*>(d_src) + p.src_offset;
         else {
-            void* peer_base = c->open_peer(p.peer, msgs[p.peer].handle, msgs[p.peer].epoch);
+            void* peer_base = c->open_peer(p.peer, msgs[p.peer].handle);
             if (!peer_base) { usable = false; break; }
             src[k] = static_cast<const char*>(peer_base) + msgs[p.peer].offset + p.src_offset;
         }
@@ -195,6 +218,7 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
     std::vector<uint32_t> done(c->world, 0);
     done[c->rank] = err ? 2u : 1u;
     if (int32_t rc = shm_all_gather(c, done.data(), sizeof(uint32_t))) return rc;
+    c->trim();   // this rank's copies have completed: mappings the call did not touch may go
     if (err) return err;
     for (uint32_t r = 0; r < c->world; r++)
         if (done[r] != 1u) return 10;   // a peer failed
@@ -214,13 +238,19 @@ int32_t gm_comm_shm_create(const char* name, uint32_t rank, uint32_t world, gm_s
     const auto t0 = std::chrono::steady_clock::now();
     const auto limit = wait_timeout_host() + std::chrono::milliseconds(200);
     int fd = -1;
+    // rank 0 owns the NAME from the moment it created it: whatever way this function is left, the name is gone again (a job whose
+    // rank did not start must not leave /dev/shm/<name> behind -- 0.5 MiB per rank, and O_EXCL would refuse the next job of that name)
+    struct NameGuard {
+        const char* name = nullptr;
+        ~NameGuard() { if (name) shm_unlink(name); }
+    } name_guard;
     if (rank == 0) {
         fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0) return set_err(GM_ERR_STATE, "shm_open(%s, create) failed: %s (a stale or duplicated job name?)", name, strerror(errno));
+        name_guard.name = name;
         if (ftruncate(fd, (off_t)c->bytes) != 0) {
             const int e = errno;
             close(fd);
-            shm_unlink(name);
             return set_err(GM_ERR_STATE, "ftruncate(%s, %zu) failed: %s", name, c->bytes, strerror(e));
         }
     } else {
@@ -239,7 +269,6 @@ int32_t gm_comm_shm_create(const char* name, uint32_t rank, uint32_t world, gm_s
     void* p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) {
-        if (rank == 0) shm_unlink(name);
         return set_err(GM_ERR_STATE, "mmap(%s, %zu) failed: %s", name, c->bytes, strerror(errno));
     }
     c->base = static_cast<char*>(p);
@@ -260,8 +289,8 @@ int32_t gm_comm_shm_create(const char* name, uint32_t rank, uint32_t world, gm_s
             return set_err(GM_ERR_STATE, "only %u of %u ranks attached to %s", h->attached.load(), world, name);
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
-    // everybody holds a mapping: the name is no longer needed (and a rank that dies later leaves nothing behind in /dev/shm)
-    if (rank == 0) shm_unlink(name);
+    // everybody holds a mapping: the name is no longer needed (and a rank that dies later leaves nothing behind in /dev/shm);
+    // name_guard removes it here as on every failure path above
     *out = c.release();
     return GM_OK;
 }
@@ -287,6 +316,15 @@ int32_t gm_comm_shm_stats(const gm_shm* c, uint64_t* all_gathers, uint64_t* byte
     GM_REQUIRE(c, "null argument");
     if (all_gathers) *all_gathers = c->calls;
     if (bytes_per_rank_total) *bytes_per_rank_total = c->payload;
+    return GM_OK;
+}
+
+// HIP IPC mappings of the peers' allocations: opened / closed so far and held now (tests of the cache's bound and its eviction order)
+int32_t gm_comm_shm_ipc_stats(const gm_shm* c, uint64_t* opens, uint64_t* closes, uint64_t* held) {
+    GM_REQUIRE(c, "null argument");
+    if (opens) *opens = c->ipc_opens;
+    if (closes) *closes = c->ipc_closes;
+    if (held) *held = c->opened.size();
     return GM_OK;
 }
 

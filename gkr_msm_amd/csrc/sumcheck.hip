@@ -1762,22 +1762,60 @@ struct RoundScratch {
     // after the other; a thread that drives two streams gets two sets.
     struct Persistent { void* p = nullptr; uint32_t* bar = nullptr; };
     struct CounterView { void* p = nullptr; } counter, accbuf;
-    uint32_t* bar = nullptr;   // host-writable device words (4 challenge slots of 12 words) of this thread and device, or nullptr
+    uint32_t* bar = nullptr;   // host-writable device words (4 challenge slots of 12 words) of this object's set, or nullptr
+    std::shared_ptr<Persistent> pset;   // keeps the set out of the recycling below while this object lives
     const uint32_t* bar_slot(uint32_t round) const { return bar ? bar + 12 * (round & 3) : nullptr; }
-    static int32_t persistent(hipStream_t stream, void** counter_p, void** acc_p, uint32_t** bar_p) {
-        static thread_local std::map<std::pair<int, hipStream_t>, Persistent> sets;
+    // Sets per (host thread, device), keyed by stream.  A caller that opens a fresh stream per proof must not grow this without
+    // bound nor stall the device at every new stream: a new set is zeroed IN STREAM ORDER (no device synchronisation); the one 4 KiB
+    // page of host-writable device memory per (thread, device) -- its probe is the only synchronising step, once -- is cut into
+    // sixteen 256-byte slices, one per set (later sets run without: bar == nullptr, the pinned-memory path); and once MAX_SETS streams
+    // have been seen, the sets no live object refers to are recycled for new streams behind ONE hipDeviceSynchronize (their last
+    // kernels may still be running on streams this thread can no longer name).
+    static constexpr size_t SET_BYTES = 256 + 24 * 128;
+    static constexpr size_t MAX_SETS = 64;
+    struct PerDev {
+        uint32_t* bar_page = nullptr;
+        bool bar_tried = false;
+        uint32_t bar_slices_used = 0;
+        std::map<hipStream_t, std::shared_ptr<Persistent>> sets;
+        std::vector<std::shared_ptr<Persistent>> spare;
+    };
+    static int32_t persistent(hipStream_t stream, std::shared_ptr<Persistent>* keep) {
+        static thread_local std::map<int, PerDev> per_dev;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        Persistent& e = sets[std::make_pair(dev, stream)];
-        if (!e.p) {
-            GM_HIP(hipMalloc(&e.p, 256 + 24 * 128));
-            GM_HIP(hipMemset(e.p, 0, 256 + 24 * 128));
-            GM_HIP(hipDeviceSynchronize());   // once per thread and device: the zeros are in place before any stream uses them
-            e.bar = alloc_host_writable_device_words();
+        GM_REQUIRE(dev >= 0 && dev < GM_MAX_DEVICES, "device id %d: the per-device tables of this library hold %d devices", dev, GM_MAX_DEVICES);
+        PerDev& pd = per_dev[dev];
+        auto it = pd.sets.find(stream);
+        if (it != pd.sets.end()) { *keep = it->second; return GM_OK; }
+        if (pd.sets.size() >= MAX_SETS && pd.spare.empty()) {
+            std::vector<hipStream_t> idle;
+            for (auto& kv : pd.sets) if (kv.second.use_count() == 1) idle.push_back(kv.first);
+            if (!idle.empty()) {
+                GM_HIP(hipDeviceSynchronize());
+                for (hipStream_t st : idle) {
+                    GM_HIP(hipMemset(pd.sets[st]->p, 0, SET_BYTES));   // (kernels leave the words at zero; a killed launch may not have)
+                    pd.spare.push_back(pd.sets[st]);
+                    pd.sets.erase(st);
+                }
+            }
         }
-        *bar_p = e.bar;
-        *counter_p = e.p;
-        *acc_p = static_cast<char*>(e.p) + 256;
+        std::shared_ptr<Persistent> e;
+        if (!pd.spare.empty()) {
+            e = pd.spare.back();
+            pd.spare.pop_back();
+        } else {
+            e = std::make_shared<Persistent>();
+            GM_HIP(hipMalloc(&e->p, SET_BYTES));
+            GM_HIP(hipMemsetAsync(e->p, 0, SET_BYTES, stream));   // every use of the set is on this stream: ordered behind the zeros
+            if (!pd.bar_tried) {
+                pd.bar_tried = true;
+                pd.bar_page = alloc_host_writable_device_words();
+            }
+            if (pd.bar_page && pd.bar_slices_used < 16) e->bar = pd.bar_page + 64 * pd.bar_slices_used++;
+        }
+        pd.sets[stream] = e;
+        *keep = e;
         return GM_OK;
     }
     Fr* h_result = nullptr;  // pinned, device-visible
@@ -1787,8 +1825,11 @@ struct RoundScratch {
         if (rc) return rc;
         // counter: [0] last-block counter, [64..96) the device copy of a pre-enqueued fold's challenge; accbuf: the limb accumulators
         // of block_reduce_finish (3 sums x 8 limbs, one 128-byte line each)
-        rc = persistent(s, &counter.p, &accbuf.p, &bar);
+        rc = persistent(s, &pset);
         if (rc) return rc;
+        counter.p = pset->p;
+        accbuf.p = static_cast<char*>(pset->p) + 256;
+        bar = pset->bar;
         if (shared_pinned()) {
             h_result = shared_pinned();
             own_pinned = false;
@@ -1932,10 +1973,11 @@ struct FinalsStage {
     uint32_t seq = 0;
 };
 static int32_t gather_finals(const Fr* const* cur, int k, hipStream_t s, std::vector<Fr>* out) {
-    static thread_local FinalsStage per_dev[16];   // per (host thread, device), as TailStage
+    static thread_local FinalsStage per_dev[GM_MAX_DEVICES];   // per (host thread, device), as TailStage
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-    FinalsStage& st = per_dev[(dev_ >= 0 && dev_ < 16) ? dev_ : 0];
+    GM_REQUIRE(dev_ >= 0 && dev_ < GM_MAX_DEVICES, "device id %d: the per-device tables of this library hold %d devices", dev_, GM_MAX_DEVICES);
+    FinalsStage& st = per_dev[dev_];
     if (!st.h) {
         GM_HIP(hipHostMalloc((void**)&st.h, (GM_MAX_COLS + 1) * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
         memset(st.h, 0, (GM_MAX_COLS + 1) * sizeof(Fr));
@@ -1983,12 +2025,14 @@ struct TailStage {
     static constexpr size_t STATE_BYTES = 256 + 2 * GM_MAX_SEGS * 4 + 64;   // relay | round counters | merge counters | residency word
     static constexpr size_t ARRIVE_WORD = (256 + 2 * GM_MAX_SEGS * 4) / 4;
 };
-static inline int cur_device_slot() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < 16) ? d : 0; }
 // one per (host thread, device): a thread that drives several GPUs (gm_set_device between calls) gets device-side counters and
 // pinned staging of its own on each of them
 static int32_t tail_stage(TailStage** out) {
-    static thread_local TailStage per_dev[16];
-    TailStage& st = per_dev[cur_device_slot()];
+    static thread_local TailStage per_dev[GM_MAX_DEVICES];
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    GM_REQUIRE(dev_ >= 0 && dev_ < GM_MAX_DEVICES, "device id %d: the per-device tables of this library hold %d devices", dev_, GM_MAX_DEVICES);
+    TailStage& st = per_dev[dev_];
     if (!st.base) {
         GM_HIP(hipHostMalloc((void**)&st.base, TailStage::BYTES, hipHostMallocCoherent | hipHostMallocMapped));
         memset(st.base, 0, TailStage::BYTES);
@@ -2045,9 +2089,10 @@ struct StageSlots {
     std::condition_variable cv;
     // budget in units of 1 / (pw pn) of a compute unit, pw / pn = workgroups of the wide / narrow instance a CU holds: a wide
     // workgroup costs pn units, a narrow one pw, the device has CUs * pw * pn
-    uint32_t capacity[16] = {0}, in_flight[16] = {0}, cost_wide[16] = {0}, cost_narrow[16] = {0};
+    uint32_t capacity[GM_MAX_DEVICES] = {0}, in_flight[GM_MAX_DEVICES] = {0}, cost_wide[GM_MAX_DEVICES] = {0}, cost_narrow[GM_MAX_DEVICES] = {0};
     static StageSlots& get() { static StageSlots s; return s; }
-    static int device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < 16) ? d : 0; }
+    // (ids >= GM_MAX_DEVICES never get here: no sumcheck object can be created on such a device, RoundScratch::persistent refuses)
+    static int device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < GM_MAX_DEVICES) ? d : 0; }
     uint32_t cap(int dev) {
         std::lock_guard<std::mutex> g(mu);
         if (!capacity[dev]) {

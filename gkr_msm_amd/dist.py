@@ -164,6 +164,13 @@ class ShmComm:
         self.L.gm_comm_shm_stats(self.h, C.byref(n), C.byref(b))
         return n.value
 
+    def ipc_stats(self):
+        """(opened, closed, held now): the HIP IPC mappings of peers' allocations behind pull_dev"""
+        import ctypes as C
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.L.gm_comm_shm_ipc_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
     def sum_fr(self, vals):
         """self-test of the seam: field sums over the ranks of a list of Montgomery elements (numpy uint64 (n, 4)), in place"""
         from . import ffi

@@ -143,6 +143,7 @@ _SIGS = {
     "gm_comm_shm_destroy": (C.c_int32, [vp]),
     "gm_comm_shm_as_comm": (C.c_int32, [vp, C.POINTER(GmComm)]),
     "gm_comm_shm_stats": (C.c_int32, [vp, u64p, u64p]),
+    "gm_comm_shm_ipc_stats": (C.c_int32, [vp, u64p, u64p, u64p]),
     "gm_pip_witness_destroy": (C.c_int32, [vp]),
     "gm_pip_witness_outputs": (C.c_int32, [vp, vp, u32p, u64p, vp]),
     "gm_pip_witness_bytes": (C.c_uint64, [vp]),

@@ -9,7 +9,10 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HDRS = ("fq14.hip.h", "g1.hip.h", "fq.hip.h", "fr9.hip.h", "fr.hip.h")      # Makefile: UBENCH_HDRS, same order
+# Makefile: UBENCH_HDRS, same order.  The generated multiplier bodies (*.inc) are part of the digest: regenerating one must make the
+# prebuilt self-check stale, or the GPU tests would validate the previous multiplier.
+HDRS = ("fq14.hip.h", "g1.hip.h", "fq.hip.h", "fr9.hip.h", "fr.hip.h",
+        "fq14_mul_gen.inc", "fr9_mul_asm.inc", "fr9_sqr_asm.inc", "fr_mul_asm.inc")
 
 
 def ubench_exe(name, tmp_path, build_timeout=1200):
