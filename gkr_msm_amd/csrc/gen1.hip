@@ -215,10 +215,8 @@ static int32_t gkr_msm_prove_impl(const uint64_t* d_points_xy, const uint8_t* d_
     Arena arena;
     TRY(arena.init(arena_need + ((size_t)64 << 20)));
     Fr* pinned = nullptr;
-    GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
-    memset(pinned, 0, 16 * sizeof(Fr));
-    shared_pinned() = pinned;
-    struct Cleanup { Fr* p; ~Cleanup() { shared_pinned() = nullptr; (void)hipHostFree(p); } } cleanup{pinned};
+    TRY(thread_pinned_staging(&pinned));
+    SharedPinnedScope pinned_scope(pinned);
 
     // BintreeProver::round loop (bintree.rs:213-288): layers in reverse, one challenge per call
     for (size_t li = layers.size(); li-- > 0;) {

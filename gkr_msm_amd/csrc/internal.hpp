@@ -1,5 +1,6 @@
 // Cross-translation-unit declarations inside libgkrmsm_hip.so (not part of the ABI).
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -81,6 +82,59 @@ inline int32_t shard_sum_fr(const Shard& sh, Fr* vals, int n) {
     return GM_OK;
 }
 
+// ---- a rank's view of the KZG key (the key has 2^(x + clm + 1) - 1 points -- 51 GB at x_logsize 24, clm 4 --
+// and no rank needs it whole): the segments of kzg_basis() that are resident on this rank's device.  Every sharded G1 step asks for
+// the range it needs and fails by name when it is not there.
+inline const uint64_t* key_range(const gm_key_view* kv, uint64_t first, uint64_t count) {
+    if (!kv) return nullptr;
+    for (uint32_t i = 0; i < kv->n_segments; i++)
+        if (first >= kv->first[i] && first + count <= kv->first[i] + kv->count[i]) return kv->d_segment[i] + 12 * (first - kv->first[i]);
+    return nullptr;
+}
+#define GM_KEY_RANGE(var, kv, first, count, what)                                                                            \
+    const uint64_t* var = gm::key_range(kv, first, count);                                                                   \
+    if (!var && (count))                                                                                                     \
+        return gm::set_err(GM_ERR_INVALID, "%s: key points [%llu, %llu) are not resident on this rank (gm_key_view)", what, \
+                           (unsigned long long)(first), (unsigned long long)((first) + (count)))
+
+// The bulk moves of the sharded provers, one collective call: every rank exposes `src_elems` field elements at d_src and fetches
+// `pieces` (gm_pull: peer, byte offset into that peer's source, bytes, destination) -- device to device through gm_comm::pull_dev
+// when the communicator has it; through the host all-gather (every rank's whole source) otherwise, or once pull_dev has answered
+// "unavailable" (100: the same answer on every rank; *host_staged is sticky so that later calls do not ask again).
+inline int32_t shard_pull(const Shard& sh, const Fr* d_src, uint64_t src_elems, const std::vector<gm_pull>& pieces, bool* host_staged,
+                          hipStream_t s) {
+    if (sh.comm->pull_dev && !*host_staged) {
+        const int32_t rc = sh.comm->pull_dev(sh.comm->ctx, d_src, src_elems * sizeof(Fr), (uint32_t)pieces.size(), pieces.data(),
+                                             reinterpret_cast<void*>(s));
+        if (rc == 0) return GM_OK;
+        if (rc != 100) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
+    }
+    *host_staged = true;
+    std::vector<Fr> all((size_t)sh.world * src_elems);
+    GM_HIP(hipMemcpyAsync(all.data() + (size_t)sh.rank * src_elems, d_src, src_elems * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    const int32_t rc = sh.comm->all_gather(sh.comm->ctx, all.data(), src_elems * sizeof(Fr));
+    if (rc) return set_err(GM_ERR_STATE, "gm_comm all_gather failed with %d", rc);
+    for (const gm_pull& p : pieces)
+        GM_HIP(hipMemcpyAsync(p.d_dst, all.data() + (size_t)p.peer * src_elems + p.src_offset / sizeof(Fr), p.bytes, hipMemcpyHostToDevice, s));
+    GM_HIP(hipStreamSynchronize(s));   // `all` goes out of scope
+    return GM_OK;
+}
+
+// Read elements [lo, lo + count) of an array that is distributed over the ranks in contiguous slices of S elements (rank q holds
+// [q S, (q + 1) S)) into d_dst; indices outside [0, world * S) read as zero (lo may be negative).  Collective: every rank calls it
+// with its own slice as d_src and its own (lo, count) -- count = 0 included.
+inline int32_t dist_read(const Shard& sh, const Fr* d_src, uint64_t S, int64_t lo, uint64_t count, Fr* d_dst, bool* host_staged, hipStream_t s) {
+    if (count) GM_HIP(hipMemsetAsync(d_dst, 0, count * sizeof(Fr), s));
+    std::vector<gm_pull> pc;
+    for (uint32_t q = 0; q < sh.world; q++) {
+        const int64_t a = std::max<int64_t>(lo, (int64_t)q * (int64_t)S), b = std::min<int64_t>(lo + (int64_t)count, ((int64_t)q + 1) * (int64_t)S);
+        if (a >= b) continue;
+        pc.push_back(gm_pull{q, 0u, (uint64_t)(a - (int64_t)q * (int64_t)S) * sizeof(Fr), (uint64_t)(b - a) * sizeof(Fr), d_dst + (a - lo)});
+    }
+    return shard_pull(sh, d_src, S, pc, host_staged, s);
+}
+
 // Bump allocator over one device allocation.  The image-part prover creates ~65 short-lived sumcheck objects;
 // hipMalloc/hipFree per buffer (hipFree synchronises the device) dominated the per-round cost, so the driver opens
 // an ArenaScope around each layer and resets the arena afterwards.  DevBuf::alloc carves from the current arena
@@ -123,6 +177,27 @@ struct PinnedSharedScope {
     bool prev;
     PinnedSharedScope() : prev(pinned_exclusive()) { pinned_exclusive() = false; }
     ~PinnedSharedScope() { pinned_exclusive() = prev; }
+};
+// The round objects of a driver report through 16 field elements of pinned, device-visible host memory.  One buffer per (host thread,
+// device), allocated on first use and kept: hipHostMalloc / hipHostFree per call cost ~100 us each, and a free may wait for the whole
+// device -- including another rank-thread's kernel that is itself waiting for this thread (ranks as threads of one process).
+inline int32_t thread_pinned_staging(Fr** out) {
+    static thread_local Fr* per_dev[GM_MAX_DEVICES] = {nullptr};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= GM_MAX_DEVICES) return set_err(GM_ERR_INVALID, "device id %d: the per-device tables of this library hold %d devices", dev, GM_MAX_DEVICES);
+    if (!per_dev[dev]) {
+        hipError_t e = hipHostMalloc((void**)&per_dev[dev], 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped);
+        if (e != hipSuccess) return set_err(GM_ERR_HIP, "hipHostMalloc(pinned staging): %s", hipGetErrorString(e));
+        memset(per_dev[dev], 0, 16 * sizeof(Fr));
+    }
+    *out = per_dev[dev];
+    return GM_OK;
+}
+struct SharedPinnedScope {   // shared_pinned() = the thread's staging for the life of the scope
+    Fr* prev;
+    explicit SharedPinnedScope(Fr* p) : prev(shared_pinned()) { shared_pinned() = p; }
+    ~SharedPinnedScope() { shared_pinned() = prev; }
 };
 struct ArenaScope {
     Arena* prev;

@@ -919,8 +919,11 @@ int32_t read_fr(const Fr* d, Fr* h, hipStream_t s) {
     return GM_OK;
 }
 
-struct PfCols {  // the Fr columns of the argument, handed to the opening phase
+struct PfCols {  // the Fr columns of the argument, handed to the opening phase (sharded: this rank's slices of c, d, c_pull, d_pull;
+                 // the access counts whole on every rank, both in one buffer)
     std::shared_ptr<DevBuf> c, d, c_pull, d_pull, ac_c, ac_d;
+    const Fr* ac_c_p = nullptr;
+    const Fr* ac_d_p = nullptr;
 };
 
 int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_log, const uint64_t* h_claim_point,
@@ -1048,10 +1051,8 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     TRY(arena.init((size_t)32 * (5 * (M / 2 + M / 4) + 2 * M) + ((size_t)64 << 20)));
     pf_timer.mark("arena");
     Fr* pinned = nullptr;
-    GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
-    memset(pinned, 0, 16 * sizeof(Fr));
-    shared_pinned() = pinned;
-    struct Cleanup { Fr* p; ~Cleanup() { shared_pinned() = nullptr; (void)hipHostFree(p); } } cleanup{pinned};
+    TRY(thread_pinned_staging(&pinned));
+    SharedPinnedScope pinned_scope(pinned);
 
     // ---- LogupMainphaseProtocol::prove (logup_mainphase.rs:156-208)
     uint32_t curr_log = 0;
@@ -1193,7 +1194,10 @@ int32_t pushforward_prove(const gm_msm_plan* plan, const uint64_t* d_points_xy, 
     tr->write_scalars(out_matrix->evs);
     pf_timer.mark("combined sumcheck");
     *out_gamma = gamma;
-    if (keep) { keep->c = c; keep->d = d; keep->c_pull = c_pull; keep->d_pull = d_pull; keep->ac_c = ac_c; keep->ac_d = ac_d; }
+    if (keep) {
+        keep->c = c; keep->d = d; keep->c_pull = c_pull; keep->d_pull = d_pull; keep->ac_c = ac_c; keep->ac_d = ac_d;
+        keep->ac_c_p = ac_c->fr(); keep->ac_d_p = ac_d->fr();
+    }
     return GM_OK;
 }
 
@@ -1256,7 +1260,7 @@ struct DFrac {   // a (numerator, denominator) pair of the sharded logup tree: t
 
 int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_log, const Shard& sh,
                                   const uint64_t* h_claim_point, const uint64_t* h_claim_evs, Tape* tr, Fr* out_gamma,
-                                  Claims* out_matrix, Claims* out_ac_c, Claims* out_ac_d, hipStream_t s) {
+                                  Claims* out_matrix, Claims* out_ac_c, Claims* out_ac_d, hipStream_t s, PfCols* keep = nullptr) {
     const uint32_t x_log = plan->x_log, d_log = plan->d_log, y_size = plan->y_size, G = sh.world;
     GM_REQUIRE(sh.comm && G >= 2 && (G & (G - 1)) == 0, "bad sharding context");
     GM_REQUIRE(y_size == (1u << y_log), "the sharded pushforward argument needs y_size = 2^y_logsize");
@@ -1459,10 +1463,8 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     // the eq tables), the replicated top of the tree
     TRY(arena.init((size_t)32 * (5 * (ML / 2 + ML / 4) + 2 * ML + 8 * dist_min * G) + ((size_t)64 << 20)));
     Fr* pinned = nullptr;
-    GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
-    memset(pinned, 0, 16 * sizeof(Fr));
-    shared_pinned() = pinned;
-    struct Cleanup { Fr* p; ~Cleanup() { shared_pinned() = nullptr; (void)hipHostFree(p); } } cleanup{pinned};
+    TRY(thread_pinned_staging(&pinned));
+    SharedPinnedScope pinned_scope(pinned);
 
     // ---- LogupMainphaseProtocol::prove (logup_mainphase.rs:156-208)
     uint32_t curr_log = 0;
@@ -1602,6 +1604,10 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     out_matrix->evs = {p_folded_ev, c_pull_ev, d_pull_ev, c_ev, d_ev};
     tr->write_scalars(out_matrix->evs);
     *out_gamma = gamma;
+    if (keep) {
+        keep->c = c; keep->d = d; keep->c_pull = c_pull; keep->d_pull = d_pull; keep->ac_c = ac_c; keep->ac_d = ac_c;
+        keep->ac_c_p = ac_c_p; keep->ac_d_p = ac_d_p;
+    }
     return GM_OK;
 }
 
@@ -1690,8 +1696,10 @@ extern "C" int32_t gm_pushforward_prove_tr(const gm_msm_plan* plan, const uint64
 // sum_i gamma^i p_i(x) eq(point_i, x).  d_polys: nargs device columns of 2^nvars elements (the caller zero-pads, pippenger.rs:233);
 // h_points: nargs x nvars coordinates; h_evs: nargs evaluations.
 namespace {
+// sh.comm != nullptr: d_polys are this rank's contiguous slices of 2^nvars / world elements; the eq tables are built for the slice
+// (eq(point)[rank * n_loc + j] = eq(point[0..lg), rank) * eq(point[lg..), j)) and the sumcheck runs on the sharded dense object
 int32_t multiopen_core(Tape* trp, uint32_t nvars, uint32_t nargs, const uint64_t* const* d_polys, const uint64_t* h_points,
-                       const uint64_t* h_evs, std::vector<Fr>* out_pt, std::vector<Fr>* out_evs, hipStream_t s) {
+                       const uint64_t* h_evs, std::vector<Fr>* out_pt, std::vector<Fr>* out_evs, hipStream_t s, const Shard& sh = Shard()) {
     Tape& tr = *trp;
     void* stream = reinterpret_cast<void*>(s);
     Fr gamma;
@@ -1702,7 +1710,9 @@ int32_t multiopen_core(Tape* trp, uint32_t nvars, uint32_t nargs, const uint64_t
     Fr claim = evs[nargs - 1];
     for (uint32_t i = 1; i < nargs; i++) claim = fr_add(fr_mul(claim, gamma), evs[nargs - 1 - i]);
     // advice.extend(EqPoly(point_i).evals())
-    const uint64_t n = 1ull << nvars;
+    const uint32_t lg = sh.comm ? sh.lg : 0, lv_n = nvars - lg;
+    GM_REQUIRE(lg <= nvars, "more ranks than elements");
+    const uint64_t n = 1ull << lv_n;   // elements per column on this rank
     std::vector<std::shared_ptr<DevBuf>> eqs(nargs);
     std::vector<const uint64_t*> cols(d_polys, d_polys + nargs);
     for (uint32_t i = 0; i < nargs; i++) {
@@ -1710,21 +1720,29 @@ int32_t multiopen_core(Tape* trp, uint32_t nvars, uint32_t nargs, const uint64_t
         TRY(eqs[i]->alloc(2 * n * sizeof(Fr)));
         std::vector<Fr> pt(nvars);
         memcpy(pt.data(), h_points + 4 * (size_t)i * nvars, nvars * sizeof(Fr));
-        std::vector<Fr*> lv(nvars + 1);
-        for (uint32_t l = 0; l < nvars; l++) lv[l] = eqs[i]->fr() + n + ((1ull << l) - 1);
-        lv[nvars] = eqs[i]->fr();
-        TRY(launch_eq_sequence(fr_one(), pt.data(), nvars, lv.data(), s));
+        Fr mult = fr_one();   // eq(point[0..lg), rank): point[0] pairs with the most significant index bit
+        for (uint32_t b = 0; b < lg; b++) mult = fr_mul(mult, ((sh.rank >> (lg - 1 - b)) & 1u) ? pt[b] : fr_sub(fr_one(), pt[b]));
+        if (lv_n == 0) {
+            GM_HIP(hipMemcpyAsync(eqs[i]->p, &mult, sizeof(Fr), hipMemcpyHostToDevice, s));
+            GM_HIP(hipStreamSynchronize(s));
+        } else {
+            std::vector<Fr*> lv(lv_n + 1);
+            for (uint32_t l = 0; l < lv_n; l++) lv[l] = eqs[i]->fr() + n + ((1ull << l) - 1);
+            lv[lv_n] = eqs[i]->fr();
+            TRY(launch_eq_sequence(mult, pt.data() + lg, lv_n, lv.data(), s));
+        }
         cols.push_back(reinterpret_cast<const uint64_t*>(eqs[i]->p));
     }
     Fr* pinned = nullptr;
-    GM_HIP(hipHostMalloc((void**)&pinned, 16 * sizeof(Fr), hipHostMallocCoherent | hipHostMallocMapped));
-    memset(pinned, 0, 16 * sizeof(Fr));
-    shared_pinned() = pinned;
-    struct Cleanup { Fr* p; ~Cleanup() { shared_pinned() = nullptr; (void)hipHostFree(p); } } cleanup{pinned};
+    TRY(thread_pinned_staging(&pinned));
+    SharedPinnedScope pinned_scope(pinned);
     ScHolder h;
     gm_fn f = mkfn(GM_FN_ID, (int)nargs);
-    TRY(gm_sc_dense_create(2, &f, nvars, cols.data(), reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(&claim),
-                           &h.so, stream));
+    {
+        ShardScope scope(sh);
+        TRY(gm_sc_dense_create(2, &f, nvars, cols.data(), reinterpret_cast<const uint64_t*>(&gamma), reinterpret_cast<const uint64_t*>(&claim),
+                               &h.so, stream));
+    }
     std::vector<Fr> fin;
     TRY(generic_sumcheck_prove(&tr, h.so, nvars, 2, out_pt, &fin));
     fin.resize(nargs);   // poly_evs[..nargs] (multiopen_reduction.rs:84)
@@ -1790,6 +1808,14 @@ int32_t gm_g1_msm_nonaff(const uint64_t* d_bases_jac, const uint64_t* d_scalars,
                          uint64_t* h_out_aff, void* stream);
 int32_t gm_g1_msm_nonaff_grouped(const uint64_t* d_bases_jac, uint64_t stride, const uint32_t* h_n, uint32_t n_groups,
                                  const uint64_t* d_scalars, int32_t scalars_mont, uint32_t nbits, uint64_t* h_out_aff, void* stream);
+int32_t gm_msm_g1_outer_part(const gm_msm_plan* plan, const uint64_t* d_basis_local, const int32_t* h_slot, uint32_t clm,
+                             uint64_t* d_d_outer, uint64_t* d_c_outer, uint64_t c_outer_cap, uint32_t* c_stride, uint32_t* first_matrix,
+                             uint32_t* n_matrices, uint64_t* h_d_part_jac, uint64_t* h_c_part_jac, void* stream);
+int32_t gm_g1_combine_parts(const gm_comm* comm, const uint64_t* h_parts_jac, uint32_t n, uint64_t* h_out_aff);
+int32_t gm_knuckles_open_sharded_tr(const gm_comm* comm, const gm_key_view* key, const uint64_t* d_inverses_slice, const uint64_t* h_k,
+                                    uint32_t num_vars, const uint64_t* d_poly_slice, const uint64_t* h_point, const uint64_t* h_claimed_ev,
+                                    const uint64_t* h_commitment_aff, const gm_transcript* tr, uint64_t* h_proof, uint64_t* h_pair,
+                                    void* stream);
 int32_t gm_knuckles_open_tr(const uint64_t* d_basis_aff, const uint64_t* d_inverses, const uint64_t* h_k, uint32_t num_vars,
                             const uint64_t* d_poly, uint64_t poly_len, const uint64_t* h_point, const uint64_t* h_claimed_ev,
                             const uint64_t* h_commitment_aff, const gm_transcript* tr, uint64_t* h_proof, uint64_t* h_pair,
@@ -1834,6 +1860,43 @@ __global__ void __launch_bounds__(256) k_pp_combined(const Fr* __restrict__ c, c
     fr_store(out + i, acc);
 }
 
+// One rank's share of combined_witness from the windows [y0, y1) it holds (c, d, cp, dp: its slices, window-major from y0):
+// part[i] covers witness index a0 + i, a0 = rem0 << x_log -- rem0 = y0 mod 2^clm when the rank's windows are fewer than 2^clm
+// (each remainder then has exactly one of them), 0 otherwise.
+__global__ void __launch_bounds__(256) k_pp_combined_part(const Fr* __restrict__ c, const Fr* __restrict__ d, const Fr* __restrict__ cp,
+                                                           const Fr* __restrict__ dp, const Fr* __restrict__ multirow, Us us, uint32_t x_log,
+                                                           uint32_t y0, uint32_t y1, uint32_t clm, uint32_t rem0, uint64_t n,
+                                                           Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t x = i & ((1ull << x_log) - 1);
+    const uint32_t cm = 1u << clm, y_rem = rem0 + (uint32_t)(i >> x_log);
+    Fr acc = fr_zero();
+    for (uint32_t y = y0 + ((y_rem - y0) & (cm - 1)); y < y1; y += cm) {
+        const uint64_t idx = x + ((uint64_t)(y - y0) << x_log);
+        Fr v = fr_load(c + idx);
+        v = fr_add(v, fr_mul(fr_load(d + idx), us.u[1]));
+        v = fr_add(v, fr_mul(fr_load(cp + idx), us.u[2]));
+        v = fr_add(v, fr_mul(fr_load(dp + idx), us.u[3]));
+        acc = fr_add(acc, fr_mul(fr_load(multirow + (y >> clm)), v));
+    }
+    fr_store(out + i, acc);
+}
+
+// this rank's slice [base, base + n) of a short replicated column zero-padded to the witness length: out[i] = src[base + i] below len
+__global__ void __launch_bounds__(256) k_pp_pad_slice(const Fr* __restrict__ src, uint64_t len, uint64_t base, uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(out + i, base + i < len ? fr_load(src + base + i) : fr_zero());
+}
+// the same for p_0 + gamma p_1
+__global__ void __launch_bounds__(256) k_pp_axpy_slice(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr g, uint64_t len, uint64_t base,
+                                                        uint64_t n, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_store(out + i, base + i < len ? fr_add(fr_load(a + base + i), fr_mul(g, fr_load(b + base + i))) : fr_zero());
+}
+
 // out[i] = sum_j q[j] w_j[i]  (the folded opening witness, pippenger.rs:269-275)
 struct Cols4 { const Fr* p[4]; };
 __global__ void __launch_bounds__(256) k_pp_fold4(Cols4 w, Us q, uint64_t n, Fr* __restrict__ out) {
@@ -1858,6 +1921,13 @@ struct gm_pippenger_wg {
     std::vector<uint32_t> c_upper;                 // c_upper_bound of every matrix (pushforward.rs:431): its longest bucket row
     uint64_t comm_p0[12], comm_p1[12], comm_ac_c[12], comm_ac_d[12];
     hipStream_t stream = nullptr;
+    // sharded (gm_pippenger_wg_create_sharded): this rank's windows; d_outer / c_outer are its PARTIAL outer buckets of the matrices
+    // m0 .. m0 + n_mat_loc - 1 its windows touch; the commitments above are the combined (global) ones on every rank
+    Shard sh;
+    uint32_t m0 = 0, n_mat_loc = 0;
+    std::vector<const uint64_t*> key_seg;
+    std::vector<uint64_t> key_first, key_count;
+    gm_key_view key{0, 0, nullptr, nullptr, nullptr};
     ~gm_pippenger_wg() { delete w; }
 };
 
@@ -2125,6 +2195,374 @@ extern "C" int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_
     return GM_OK;
 }
 
+
+// =================================================================================================================
+// The whole gen-2 prover with the matrix sharded by windows (BASELINE.json configs[4]).  What the unsharded calls above
+// do with the whole KZG key, a rank does with the key ranges it holds (gm_key_view) -- every G1 step of the protocol is linear in
+// the committed column, so a commitment is the ranks' partial MSMs combined (gm_g1_combine_parts: one group element per rank):
+//   c / d commitments, phase-2 commitments   partial outer buckets of the rank's windows (gm_msm_g1_outer_part)
+//   p_0, p_1, ac_c, ac_d                     columns every rank holds whole: rank r commits entries [r L / G, (r + 1) L / G)
+//   the opening                              the four witnesses as contiguous slices of 2^(x + clm) / G, the multi-open reduction on the
+//                                            sharded dense object, the Knuckles opening on slices (knuckles.hip)
+// Every rank runs the same transcript and ends with the same proof and pairing pair as the unsharded prover.
+namespace {
+
+int32_t sharded_access_counts(const gm_msm_plan* plan, const Shard& sh, Fr* d_c, Fr* d_d, Fr* d_ac, bool* host_staged, hipStream_t s) {
+    const uint64_t X = 1ull << plan->x_log, D = 1ull << plan->d_log, L = X + D;
+    const uint32_t G = sh.world;
+    DevBuf part, parts;
+    TRY(part.alloc(L * sizeof(Fr)));
+    TRY(gm_msm_phase1_polys(plan, (uint64_t*)d_c, (uint64_t*)d_d, (uint64_t*)part.p, (uint64_t*)(part.fr() + X), reinterpret_cast<void*>(s)));
+    TRY(parts.alloc((uint64_t)G * L * sizeof(Fr)));
+    std::vector<gm_pull> pc(G);
+    for (uint32_t q = 0; q < G; q++) pc[q] = gm_pull{q, 0u, 0ull, L * sizeof(Fr), parts.fr() + (uint64_t)q * L};
+    TRY(shard_pull(sh, part.fr(), L, pc, host_staged, s));
+    hipLaunchKernelGGL(k_pf_sum_parts, dim3(ceil_div(L, 256)), dim3(256), 0, s, parts.fr(), G, L, d_ac);
+    GM_LAUNCH_CHECK();
+    GM_HIP(hipStreamSynchronize(s));   // part / parts go out of scope
+    return GM_OK;
+}
+
+// this rank's share of the commitment of a column every rank holds whole
+int32_t commit_replicated_part(const gm_pippenger_wg* st, const Fr* d_col, uint64_t L, uint32_t nbits, G1Jac* part, const char* what, void* stream) {
+    const uint32_t G = st->sh.world;
+    uint64_t lo = 0, cnt = st->sh.rank == 0 ? L : 0;
+    if (L >= G) { cnt = L / G; lo = (uint64_t)st->sh.rank * cnt; }
+    *part = g1_inf();
+    if (!cnt) return GM_OK;
+    GM_KEY_RANGE(kp, &st->key, lo, cnt, what);
+    uint64_t a12[12];
+    TRY(gm_g1_msm(kp, reinterpret_cast<const uint64_t*>(d_col + lo), cnt, 1, nbits, a12, stream));
+    *part = pp_aff_in(a12);
+    return GM_OK;
+}
+
+int32_t pippenger_prove_sharded(const gm_pippenger_wg* st, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
+                                const uint64_t* d_kn_inverses_slice, const uint64_t* h_k, Tape* tr, uint64_t* h_pair) {
+    const gm_msm_plan* plan = st->plan;
+    const Shard& sh = st->sh;
+    const uint32_t x_log = plan->x_log, d_log = plan->d_log, y_log = st->y_log, clm = st->clm, G = sh.world;
+    const uint32_t n_mat = st->n_mat, cm = 1u << clm;
+    hipStream_t s = st->stream;
+    void* stream = reinterpret_cast<void*>(s);
+    GM_REQUIRE(y_log >= clm, "commitment_log_multiplicity exceeds y_logsize");
+    StageTimer timer("prove (sharded)", s);
+    auto stage = [&](const char* name) { timer.mark(name); };
+    tr->write_points(st->comm_c.data(), n_mat);
+    tr->write_points(st->comm_d.data(), n_mat);
+    tr->write_points(st->comm_p0, 1);
+    tr->write_points(st->comm_p1, 1);
+    tr->write_points(st->comm_ac_c, 1);
+    tr->write_points(st->comm_ac_d, 1);
+    Claims c;
+    c.point.resize(y_log);
+    memcpy(c.point.data(), h_claim_point, 32 * (size_t)y_log);
+    c.evs.resize(3 * (d_log + 1));
+    memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
+    TRY(image_part_core(st->w, tr, &c));
+    stage("image part");
+    // commit phase 2: the eq-weighted MSMs over this rank's PARTIAL outer buckets, combined
+    std::vector<uint64_t> comm_cp(12 * (size_t)n_mat), comm_dp(12 * (size_t)n_mat);
+    {
+        const uint64_t X = 1ull << x_log, D = 1ull << d_log;
+        DevBuf eqs;
+        TRY(eqs.alloc((2 * X + 2 * D) * sizeof(Fr)));
+        Fr* eq_c = eqs.fr();
+        Fr* eq_d = eqs.fr() + 2 * X;
+        std::vector<Fr*> lv(x_log + 1);
+        for (uint32_t i = 0; i < x_log; i++) lv[i] = eq_c + X + ((1ull << i) - 1);
+        lv[x_log] = eq_c;
+        TRY(launch_eq_sequence(fr_one(), c.point.data() + y_log + d_log, x_log, lv.data(), s));
+        lv.assign(d_log + 1, nullptr);
+        for (uint32_t i = 0; i < d_log; i++) lv[i] = eq_d + D + ((1ull << i) - 1);
+        lv[d_log] = eq_d;
+        TRY(launch_eq_sequence(fr_one(), c.point.data() + y_log, d_log, lv.data(), s));
+        const uint32_t nl = st->n_mat_loc;
+        std::vector<uint32_t> nd_all(nl, (uint32_t)D);
+        std::vector<uint64_t> loc_d(12 * (size_t)nl), loc_c(12 * (size_t)nl);
+        TRY(gm_g1_msm_nonaff_grouped(reinterpret_cast<const uint64_t*>(st->d_outer->p), D, nd_all.data(), nl,
+                                     reinterpret_cast<const uint64_t*>(eq_d), 1, 255, loc_d.data(), stream));
+        TRY(gm_g1_msm_nonaff_grouped(reinterpret_cast<const uint64_t*>(st->c_outer->p), st->c_stride, st->c_upper.data(), nl,
+                                     reinterpret_cast<const uint64_t*>(eq_c), 1, 255, loc_c.data(), stream));
+        std::vector<G1Jac> parts(2 * (size_t)n_mat, g1_inf());
+        for (uint32_t i = 0; i < nl; i++) {
+            parts[st->m0 + i] = pp_aff_in(loc_c.data() + 12 * (size_t)i);
+            parts[n_mat + st->m0 + i] = pp_aff_in(loc_d.data() + 12 * (size_t)i);
+        }
+        std::vector<uint64_t> both(24 * (size_t)n_mat);
+        TRY(gm_g1_combine_parts(sh.comm, reinterpret_cast<const uint64_t*>(parts.data()), 2 * n_mat, both.data()));
+        memcpy(comm_cp.data(), both.data(), 96 * (size_t)n_mat);
+        memcpy(comm_dp.data(), both.data() + 12 * (size_t)n_mat, 96 * (size_t)n_mat);
+    }
+    tr->write_points(comm_cp.data(), n_mat);
+    tr->write_points(comm_dp.data(), n_mat);
+    stage("phase-2 commitments");
+    Fr gamma;
+    Claims mx, acc, acd;
+    PfCols cols;
+    TRY(pushforward_prove_sharded(plan, st->d_points_xy, y_log, sh, reinterpret_cast<const uint64_t*>(c.point.data()),
+                                  reinterpret_cast<const uint64_t*>(c.evs.data()), tr, &gamma, &mx, &acc, &acd, s, &cols));
+    stage("pushforward");
+    // ---- open (pippenger.rs:162-286) on slices
+    const Fr p_folded_ev = mx.evs[0], c_pull_ev = mx.evs[1], d_pull_ev = mx.evs[2], c_ev = mx.evs[3], d_ev = mx.evs[4];
+    const uint32_t nv = x_log + clm;
+    GM_REQUIRE(nv >= sh.lg, "more ranks than opening-witness entries");
+    const uint64_t n = 1ull << nv, X = 1ull << x_log, D = 1ull << d_log, SL = n / G, base = (uint64_t)sh.rank * SL;
+    std::vector<Fr> pts(4 * (size_t)nv, fr_zero());
+    for (uint32_t i = 0; i < x_log; i++) pts[0 * nv + clm + i] = mx.point[y_log + i];
+    for (uint32_t i = 0; i < x_log; i++) pts[1 * nv + clm + i] = acc.point[i];
+    for (uint32_t i = 0; i < d_log; i++) pts[2 * nv + (nv - d_log) + i] = acd.point[i];
+    for (uint32_t i = 0; i < nv; i++) pts[3 * nv + i] = mx.point[y_log - clm + i];
+    std::vector<Fr> multirow(1ull << (y_log - clm), fr_zero());
+    multirow[0] = fr_one();
+    for (uint32_t i = 0; i < y_log - clm; i++)
+        for (uint64_t j = (1ull << i); j-- > 0;) {
+            const Fr w = multirow[j], m = fr_mul(mx.point[i], w);
+            multirow[2 * j] = fr_sub(w, m);
+            multirow[2 * j + 1] = m;
+        }
+    // sum_m multirow_evs[m] * commitment[m]: n_mat <= 2^(y_log - clm) points, the same small MSM on every rank
+    const uint32_t n_comb = n_mat < multirow.size() ? n_mat : (uint32_t)multirow.size();
+    DevBuf d_mr, d_cs;
+    TRY(d_mr.alloc(n_comb * sizeof(Fr)));
+    TRY(d_cs.alloc((size_t)n_comb * sizeof(G1Aff)));
+    GM_HIP(hipMemcpyAsync(d_mr.p, multirow.data(), n_comb * sizeof(Fr), hipMemcpyHostToDevice, s));
+    auto comb = [&](const uint64_t* cs, G1Jac* out) -> int32_t {
+        uint64_t r12[12];
+        GM_HIP(hipMemcpyAsync(d_cs.p, cs, (size_t)n_comb * sizeof(G1Aff), hipMemcpyHostToDevice, s));
+        const int32_t rc = gm_g1_msm((const uint64_t*)d_cs.p, (const uint64_t*)d_mr.p, n_comb, 1, 255, r12, stream);
+        if (rc) return rc;
+        *out = pp_aff_in(r12);
+        return GM_OK;
+    };
+    G1Jac c_comb, d_comb, cp_comb, dp_comb;
+    TRY(comb(st->comm_c.data(), &c_comb));
+    TRY(comb(st->comm_d.data(), &d_comb));
+    TRY(comb(comm_cp.data(), &cp_comb));
+    TRY(comb(comm_dp.data(), &dp_comb));
+    Fr u;
+    TRY(tr->challenge(&u, 512));
+    Us us;
+    us.u[0] = fr_one(); us.u[1] = u; us.u[2] = fr_mul(u, u); us.u[3] = fr_mul(us.u[2], u);
+    const G1Jac combined_comm = g1_add(g1_add(c_comb, pp_mul(d_comb, us.u[1])), g1_add(pp_mul(cp_comb, us.u[2]), pp_mul(dp_comb, us.u[3])));
+    const Fr combined_ev = fr_add(fr_add(c_ev, fr_mul(d_ev, us.u[1])), fr_add(fr_mul(c_pull_ev, us.u[2]), fr_mul(d_pull_ev, us.u[3])));
+    // the four opening witnesses: this rank's slice [base, base + SL) of each (zero-padded to 2^nv)
+    DevBuf w0, w1, w2, w3, d_multirow, folded;
+    TRY(w0.alloc(SL * sizeof(Fr))); TRY(w1.alloc(SL * sizeof(Fr))); TRY(w2.alloc(SL * sizeof(Fr))); TRY(w3.alloc(SL * sizeof(Fr)));
+    TRY(folded.alloc(SL * sizeof(Fr)));
+    hipLaunchKernelGGL(k_pp_axpy_slice, dim3(ceil_div(SL, 256)), dim3(256), 0, s, st->p0->fr(), st->p1->fr(), gamma, X, base, SL, w0.fr());
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pp_pad_slice, dim3(ceil_div(SL, 256)), dim3(256), 0, s, cols.ac_c_p, X, base, SL, w1.fr());
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pp_pad_slice, dim3(ceil_div(SL, 256)), dim3(256), 0, s, cols.ac_d_p, D, base, SL, w2.fr());
+    GM_LAUNCH_CHECK();
+    TRY(d_multirow.alloc(multirow.size() * sizeof(Fr)));
+    GM_HIP(hipMemcpyAsync(d_multirow.p, multirow.data(), multirow.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+    bool host_staged = false;
+    {
+        // combined_witness (pippenger.rs:208-222): a rank's windows give it a share over a contiguous index range of the witness --
+        // [ (y0 mod cm) X, + W X ) for W = y_size / G < cm windows per rank, the whole of it otherwise -- and the slice of rank r
+        // is the sum of the shares that cover it (y_size / cm of them, or all G): pulled side by side, then added.
+        const uint32_t W = plan->nwin;
+        const bool narrow = W < cm;
+        const uint32_t rem0 = narrow ? (plan->y0 & (cm - 1)) : 0;
+        const uint64_t len_g = (uint64_t)(narrow ? W : cm) << x_log;
+        DevBuf share, stage_buf;
+        TRY(share.alloc(len_g * sizeof(Fr)));
+        hipLaunchKernelGGL(k_pp_combined_part, dim3(ceil_div(len_g, 256)), dim3(256), 0, s, cols.c->fr(), cols.d->fr(), cols.c_pull->fr(),
+                           cols.d_pull->fr(), d_multirow.fr(), us, x_log, plan->y0, plan->y1, clm, rem0, len_g, share.fr());
+        GM_LAUNCH_CHECK();
+        std::vector<gm_pull> pc;
+        std::vector<uint32_t> from;
+        for (uint32_t g = 0; g < G; g++) {
+            const uint64_t a_g = narrow ? ((uint64_t)((g * W) & (cm - 1)) << x_log) : 0;
+            if (a_g <= base && base + SL <= a_g + len_g) from.push_back(g);
+        }
+        GM_REQUIRE(!from.empty(), "no rank covers this rank's slice of the combined witness");
+        TRY(stage_buf.alloc((uint64_t)from.size() * SL * sizeof(Fr)));
+        for (size_t k = 0; k < from.size(); k++) {
+            const uint32_t g = from[k];
+            const uint64_t a_g = narrow ? ((uint64_t)((g * W) & (cm - 1)) << x_log) : 0;
+            pc.push_back(gm_pull{g, 0u, (base - a_g) * sizeof(Fr), SL * sizeof(Fr), stage_buf.fr() + k * SL});
+        }
+        TRY(shard_pull(sh, share.fr(), len_g, pc, &host_staged, s));
+        hipLaunchKernelGGL(k_pf_sum_parts, dim3(ceil_div(SL, 256)), dim3(256), 0, s, stage_buf.fr(), (uint32_t)from.size(), SL, w3.fr());
+        GM_LAUNCH_CHECK();
+        GM_HIP(hipStreamSynchronize(s));   // share / stage_buf go out of scope; multirow (host) is consumed
+    }
+    stage("opening witnesses");
+    std::vector<Fr> mo_evs = {fr_sub(p_folded_ev, fr_mul(gamma, gamma)), acc.evs[0], acd.evs[0], combined_ev};
+    const uint64_t* wcols[4] = {(const uint64_t*)w0.p, (const uint64_t*)w1.p, (const uint64_t*)w2.p, (const uint64_t*)w3.p};
+    std::vector<Fr> mo_pt, mo_out;
+    TRY(multiopen_core(tr, nv, 4, wcols, reinterpret_cast<const uint64_t*>(pts.data()), reinterpret_cast<const uint64_t*>(mo_evs.data()),
+                       &mo_pt, &mo_out, s, sh));
+    stage("multi-open reduction");
+    Fr q;
+    TRY(tr->challenge(&q));
+    Us qs;
+    qs.u[0] = fr_one(); qs.u[1] = q; qs.u[2] = fr_mul(q, q); qs.u[3] = fr_mul(qs.u[2], q);
+    const G1Jac parts[4] = {g1_add(pp_aff_in(st->comm_p0), pp_mul(pp_aff_in(st->comm_p1), gamma)), pp_aff_in(st->comm_ac_c),
+                            pp_aff_in(st->comm_ac_d), combined_comm};
+    G1Jac folded_comm = g1_inf();
+    for (int j = 0; j < 4; j++) folded_comm = g1_add(folded_comm, pp_mul(parts[j], qs.u[j]));
+    Cols4 c4;
+    c4.p[0] = w0.fr(); c4.p[1] = w1.fr(); c4.p[2] = w2.fr(); c4.p[3] = w3.fr();
+    hipLaunchKernelGGL(k_pp_fold4, dim3(ceil_div(SL, 256)), dim3(256), 0, s, c4, qs, SL, folded.fr());
+    GM_LAUNCH_CHECK();
+    Fr open_ev = mo_out[3];
+    for (int j = 2; j >= 0; j--) open_ev = fr_add(fr_mul(open_ev, q), mo_out[j]);
+    uint64_t fc_aff[12], proof[48];
+    pp_aff_out(fc_aff, folded_comm);
+    gm_transcript adapter{tr, tape_ws, tape_ch, tape_wp};
+    TRY(gm_knuckles_open_sharded_tr(sh.comm, &st->key, d_kn_inverses_slice, h_k, nv, reinterpret_cast<const uint64_t*>(folded.p),
+                                    reinterpret_cast<const uint64_t*>(mo_pt.data()), reinterpret_cast<const uint64_t*>(&open_ev), fc_aff,
+                                    &adapter, proof, h_pair, stream));
+    stage("knuckles open");
+    if (tr->cb_rc) return set_err(GM_ERR_STATE, "transcript callback failed with %d", tr->cb_rc);
+    return GM_OK;
+}
+
+}  // namespace
+
+// PippengerWG::new for one rank of a window-sharded proof (collective).  plan: this rank's windows (gm_msm_plan_create(.., y_begin,
+// y_end), after gm_msm_run); key: the ranges of kzg_basis() resident on this rank -- gm_pippenger_sharded_key_ranges lists what it
+// must cover; comm must outlive the handle.  The commitments the handle carries are the combined ones, equal on every rank to those
+// of gm_pippenger_wg_create over the whole key.
+extern "C" int32_t gm_pippenger_wg_create_sharded(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                                  uint32_t commitment_log_multiplicity, const gm_key_view* key, const gm_comm* comm,
+                                                  gm_pippenger_wg** out, void* stream) {
+    GM_REQUIRE(plan && d_points_xy && key && comm && out, "null argument");
+    GM_REQUIRE(commitment_log_multiplicity <= y_logsize && commitment_log_multiplicity <= 8, "bad commitment_log_multiplicity");
+    GM_REQUIRE(comm->world >= 2, "a sharded proof needs at least two ranks (gm_pippenger_wg_create otherwise)");
+    GM_REQUIRE(key->n_segments >= 1 && key->d_segment && key->first && key->count, "empty gm_key_view");
+    hipStream_t s = as_stream(stream);
+    std::unique_ptr<gm_pippenger_wg> st(new gm_pippenger_wg());
+    st->plan = plan; st->d_points_xy = d_points_xy; st->d_basis = nullptr; st->y_log = y_logsize;
+    st->clm = commitment_log_multiplicity; st->stream = s;
+    for (uint32_t i = 0; i < key->n_segments; i++) {
+        st->key_seg.push_back(key->d_segment[i]); st->key_first.push_back(key->first[i]); st->key_count.push_back(key->count[i]);
+    }
+    st->key = gm_key_view{key->n_segments, 0, st->key_seg.data(), st->key_first.data(), st->key_count.data()};
+    const uint32_t clm = st->clm, cm = 1u << clm, d_log = plan->d_log;
+    st->n_mat = (plan->y_size + cm - 1) / cm;
+    StageTimer wt("wg::new (sharded)", s);
+    TRY(pip_witness_create(plan, d_points_xy, y_logsize, comm, &st->w, stream));
+    st->sh = st->w->sh;
+    const Shard& sh = st->sh;
+    const uint32_t G = sh.world;
+    const uint64_t X = plan->N, D = 1ull << d_log;
+    GM_REQUIRE(X >= G, "fewer points than ranks");
+    wt.mark("witness");
+    {   // partial outer buckets of this rank's windows + its share of the c / d commitments
+        st->m0 = plan->y0 >> clm;
+        st->n_mat_loc = ((plan->y1 - 1) >> clm) - st->m0 + 1;
+        std::vector<uint32_t> rl(plan->nrows);
+        GM_HIP(hipMemcpyAsync(rl.data(), plan->row_len, (size_t)plan->nrows * 4, hipMemcpyDeviceToHost, s));
+        GM_HIP(hipStreamSynchronize(s));
+        uint32_t cmax = 1;
+        for (uint32_t v : rl) cmax = v > cmax ? v : cmax;
+        st->c_upper.assign(st->n_mat_loc, 1);
+        for (uint32_t r = 0; r < plan->nrows; r++) {
+            const uint32_t m = ((plan->y0 + (r >> d_log)) >> clm) - st->m0;
+            if (rl[r] > st->c_upper[m]) st->c_upper[m] = rl[r];
+        }
+        // the key slices of the rank's windows: slice s = kzg_basis[s X, (s + 1) X) for s = y mod 2^clm; all in ONE resident segment,
+        // at whole-slice distances from its start (gm_msm_g1_outer_part addresses them as slots of one buffer)
+        int32_t h_slot[256];
+        for (int i = 0; i < 256; i++) h_slot[i] = -1;
+        const uint64_t* seg_ptr = nullptr;
+        uint64_t seg_first = 0;
+        for (uint32_t y = plan->y0; y < plan->y1; y++) {
+            const uint32_t sl = y & (cm - 1);
+            if (h_slot[sl] >= 0) continue;
+            uint32_t found = key->n_segments;
+            for (uint32_t i = 0; i < key->n_segments; i++)
+                if ((uint64_t)sl * X >= key->first[i] && ((uint64_t)sl + 1) * X <= key->first[i] + key->count[i]) { found = i; break; }
+            GM_REQUIRE(found < key->n_segments, "outer buckets: key slice %u (points [%llu, %llu)) is not resident on rank %u", sl,
+                       (unsigned long long)((uint64_t)sl * X), (unsigned long long)(((uint64_t)sl + 1) * X), sh.rank);
+            if (!seg_ptr) { seg_ptr = key->d_segment[found]; seg_first = key->first[found]; }
+            GM_REQUIRE(key->d_segment[found] == seg_ptr, "outer buckets: the key slices of a rank's windows must lie in one segment");
+            GM_REQUIRE(((uint64_t)sl * X - seg_first) % X == 0 && ((uint64_t)sl * X - seg_first) / X < 256,
+                       "outer buckets: the segment must start at a multiple of 2^x_logsize points from its slices");
+            h_slot[sl] = (int32_t)(((uint64_t)sl * X - seg_first) / X);
+        }
+        st->d_outer.reset(new DevBuf());
+        st->c_outer.reset(new DevBuf());
+        TRY(st->d_outer->alloc(((size_t)st->n_mat_loc << d_log) * sizeof(G1Jac)));
+        TRY(st->c_outer->alloc((size_t)st->n_mat_loc * cmax * sizeof(G1Jac)));
+        std::vector<G1Jac> dpart(st->n_mat_loc), cpart(st->n_mat_loc);
+        uint32_t m0 = 0, nml = 0;
+        TRY(gm_msm_g1_outer_part(plan, seg_ptr, h_slot, clm, (uint64_t*)st->d_outer->p, (uint64_t*)st->c_outer->p,
+                                 (uint64_t)st->n_mat_loc * cmax, &st->c_stride, &m0, &nml, reinterpret_cast<uint64_t*>(dpart.data()),
+                                 reinterpret_cast<uint64_t*>(cpart.data()), stream));
+        GM_REQUIRE(m0 == st->m0 && nml == st->n_mat_loc, "outer buckets: unexpected matrix range");
+        std::vector<G1Jac> parts(2 * (size_t)st->n_mat, g1_inf());
+        for (uint32_t i = 0; i < nml; i++) {
+            parts[st->m0 + i] = cpart[i];
+            parts[st->n_mat + st->m0 + i] = dpart[i];
+        }
+        std::vector<uint64_t> both(24 * (size_t)st->n_mat);
+        TRY(gm_g1_combine_parts(sh.comm, reinterpret_cast<const uint64_t*>(parts.data()), 2 * st->n_mat, both.data()));
+        st->comm_c.assign(both.begin(), both.begin() + 12 * (size_t)st->n_mat);
+        st->comm_d.assign(both.begin() + 12 * (size_t)st->n_mat, both.end());
+    }
+    wt.mark("outer buckets + c/d comm");
+    st->p0.reset(new DevBuf());
+    st->p1.reset(new DevBuf());
+    TRY(st->p0->alloc(X * sizeof(Fr)));
+    TRY(st->p1->alloc(X * sizeof(Fr)));
+    hipLaunchKernelGGL(k_pp_split_xy, dim3(ceil_div(X, 256)), dim3(256), 0, s, reinterpret_cast<const Fr*>(d_points_xy), X, st->p0->fr(),
+                       st->p1->fr());
+    GM_LAUNCH_CHECK();
+    {
+        DevBuf c, d, ac;
+        const uint64_t ML = (uint64_t)plan->nwin * X;
+        TRY(c.alloc(ML * sizeof(Fr))); TRY(d.alloc(ML * sizeof(Fr))); TRY(ac.alloc((X + D) * sizeof(Fr)));
+        bool host_staged = false;
+        TRY(sharded_access_counts(plan, sh, c.fr(), d.fr(), ac.fr(), &host_staged, s));
+        wt.mark("access counts");
+        // ac_c / ac_d are negated access counts (pushforward.rs:507-508): the MSMs run over the 32-bit counts, the results are negated
+        TRY(gm_fr_batch(3, (const uint64_t*)ac.p, nullptr, (uint64_t*)ac.p, X + D, stream));
+        G1Jac four[4];
+        TRY(commit_replicated_part(st.get(), st->p0->fr(), X, 255, &four[0], "p_0 commitment", stream));
+        TRY(commit_replicated_part(st.get(), st->p1->fr(), X, 255, &four[1], "p_1 commitment", stream));
+        TRY(commit_replicated_part(st.get(), ac.fr(), X, 32, &four[2], "ac_c commitment", stream));
+        TRY(commit_replicated_part(st.get(), ac.fr() + X, D, 32, &four[3], "ac_d commitment", stream));
+        uint64_t out4[48];
+        TRY(gm_g1_combine_parts(sh.comm, reinterpret_cast<const uint64_t*>(four), 4, out4));
+        for (int j = 2; j < 4; j++) {
+            G1Aff a;
+            memcpy(&a, out4 + 12 * j, sizeof(G1Aff));
+            if (!g1_aff_is_inf(a)) a = g1_aff_neg(a);
+            memcpy(out4 + 12 * j, &a, sizeof(G1Aff));
+        }
+        memcpy(st->comm_p0, out4, 96); memcpy(st->comm_p1, out4 + 12, 96); memcpy(st->comm_ac_c, out4 + 24, 96); memcpy(st->comm_ac_d, out4 + 36, 96);
+        wt.mark("p_0, p_1, ac_c, ac_d commitments");
+    }
+    *out = st.release();
+    return GM_OK;
+}
+
+// What rank `rank` of `world` reads of kzg_basis() in a sharded proof of this shape: up to 4 ranges (first, count), for the caller to
+// size its gm_key_view.  [0] the key slices of its windows' outer buckets (one contiguous run when its windows are), [1] its share of
+// the short commitments (p_0, p_1, ac_c), [2] of ac_d, [3] its range of the opening (t and the two quotients).
+extern "C" int32_t gm_pippenger_sharded_key_ranges(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_logsize,
+                                                   uint32_t commitment_log_multiplicity, uint32_t rank, uint32_t world, uint64_t* first4,
+                                                   uint64_t* count4) {
+    GM_REQUIRE(first4 && count4 && world >= 2 && (world & (world - 1)) == 0 && rank < world, "bad argument");
+    GM_REQUIRE(commitment_log_multiplicity <= y_logsize && (1u << y_logsize) >= world, "bad shape");
+    const uint64_t X = 1ull << x_logsize, D = 1ull << d_logsize, cm = 1ull << commitment_log_multiplicity;
+    const uint64_t W = (1ull << y_logsize) / world, y0 = rank * W;
+    if (W >= cm) { first4[0] = 0; count4[0] = cm * X; }
+    else { first4[0] = (y0 & (cm - 1)) * X; count4[0] = W * X; }
+    if (X >= world) { first4[1] = rank * (X / world); count4[1] = X / world; } else { first4[1] = 0; count4[1] = rank == 0 ? X : 0; }
+    if (D >= world) { first4[2] = rank * (D / world); count4[2] = D / world; } else { first4[2] = 0; count4[2] = rank == 0 ? D : 0; }
+    const uint64_t N = cm * X, total = 2 * N - 1, S = 2 * N / world, b = rank * S;
+    first4[3] = b;
+    count4[3] = b >= total ? 0 : (total - b < S ? total - b : S);
+    return GM_OK;
+}
+
 extern "C" int32_t gm_pippenger_wg_destroy(gm_pippenger_wg* st) {
     delete st;
     return GM_OK;
@@ -2146,7 +2584,8 @@ extern "C" int32_t gm_pippenger_prove(const gm_pippenger_wg* st, const uint64_t*
     std::vector<uint64_t> points;
     Tape tr{h_tape, n_tape, 0, &msgs, 0, nullptr, 0};
     tr.points = &points;
-    TRY(pippenger_prove(st, h_claim_point, h_claim_evs, d_knuckles_inverses, h_k, &tr, h_pair));
+    if (st->sh.comm) TRY(pippenger_prove_sharded(st, h_claim_point, h_claim_evs, d_knuckles_inverses, h_k, &tr, h_pair));
+    else TRY(pippenger_prove(st, h_claim_point, h_claim_evs, d_knuckles_inverses, h_k, &tr, h_pair));
     if (n_msgs) *n_msgs = msgs.size();
     if (h_msgs) {
         GM_REQUIRE(msgs.size() <= msgs_cap, "message buffer too small: %zu > %llu", msgs.size(), (unsigned long long)msgs_cap);
@@ -2168,7 +2607,8 @@ extern "C" int32_t gm_pippenger_prove_tr(const gm_pippenger_wg* st, const uint64
     GM_REQUIRE(st && h_claim_point && h_claim_evs && d_knuckles_inverses && h_k && tr && tr->challenge && h_pair, "null argument");
     std::vector<Fr> msgs;
     Tape t{nullptr, 0, 0, &msgs, 0, tr, 0};
-    TRY(pippenger_prove(st, h_claim_point, h_claim_evs, d_knuckles_inverses, h_k, &t, h_pair));
+    if (st->sh.comm) TRY(pippenger_prove_sharded(st, h_claim_point, h_claim_evs, d_knuckles_inverses, h_k, &t, h_pair));
+    else TRY(pippenger_prove(st, h_claim_point, h_claim_evs, d_knuckles_inverses, h_k, &t, h_pair));
     if (n_challenges) *n_challenges = t.pos;
     if (rounds) *rounds = t.rounds;
     return GM_OK;

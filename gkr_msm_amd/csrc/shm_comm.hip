@@ -150,6 +150,9 @@ struct ShmIpcMsg {
     hipIpcMemHandle_t handle;
     uint64_t offset, bytes, epoch;
     uint32_t failed, pad;     // the rank's source could not be completed (stream error): every rank returns an error, nobody waits
+    uint64_t pid, raw;        // ranks that are THREADS of one process (one process driving several GPUs, or the shared-GPU rehearsals
+                              // of more ranks than the box allows processes) share an address space: the source pointer itself serves,
+                              // no IPC mapping (a process cannot open its own export)
 };
 // Return value GM_PULL_UNAVAILABLE (100): some rank could not export or open a mapping (devices hidden from each other, IPC
 // switched off): every rank learns it in the same exchange, nothing was copied, and the caller stages this redistribution through
@@ -178,6 +181,8 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         }
     }
     mine.epoch = dev_pool().release_epoch.load();
+    mine.pid = (uint64_t)getpid();
+    mine.raw = exported ? (uint64_t)(uintptr_t)d_src : 0;
     // the source is complete before its handle goes out; a rank that cannot complete it says so IN the exchange (its peers would
     // otherwise sit in the all-gather until the time-out)
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); mine.failed = 1; mine.bytes = 0; }
@@ -186,7 +191,7 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         if (msgs[r].failed) return r == c->rank ? 5 : 10;
     // mappings of a peer whose pool gave memory back are dropped now, before any address of this call is resolved
     for (uint32_t r = 0; r < c->world; r++)
-        if (r != c->rank) c->sync_epoch(r, msgs[r].epoch);
+        if (r != c->rank && msgs[r].pid != mine.pid) c->sync_epoch(r, msgs[r].epoch);
     // open what this rank pulls from; then agree that everybody could
     std::vector<const char*> src(n, nullptr);
     int32_t err = 0;
@@ -196,7 +201,10 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         if (p.peer >= c->world || !p.d_dst) { err = 6; break; }
         if (p.src_offset + p.bytes > msgs[p.peer].bytes) { usable = false; break; }   // (a peer that could not export announces 0 bytes)
         if (p.peer == c->rank) src[k] = static_cast<const char*>(d_src) + p.src_offset;
-        else {
+        else if (msgs[p.peer].pid == mine.pid) {
+            if (!msgs[p.peer].raw) { usable = false; break; }
+            src[k] = reinterpret_cast<const char*>((uintptr_t)msgs[p.peer].raw) + p.src_offset;
+        } else {
             void* peer_base = c->open_peer(p.peer, msgs[p.peer].handle);
             if (!peer_base) { usable = false; break; }
             src[k] = static_cast<const char*>(peer_base) + msgs[p.peer].offset + p.src_offset;

@@ -1737,7 +1737,9 @@ static uint32_t* alloc_host_writable_device_words() {
     if (!off && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_) == hipSuccess && large_bar) {
         uint32_t* p = nullptr;
         if (hipExtMallocWithFlags((void**)&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && p) {
-            bool good = hipMemset(p, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            // (the NULL stream only, not the device: another rank-thread of this process may have a kernel in flight that waits for
+            // a challenge its host will publish only after an exchange with THIS thread)
+            bool good = hipMemset(p, 0, 4096) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
             if (good) {
                 reinterpret_cast<volatile uint32_t*>(p)[1000] = 0x5eed1234u;   // probe: a host store the device must see
                 _mm_sfence();
@@ -3375,9 +3377,12 @@ struct ScVecVecDeg2 : gm_sc {
         // and everybody runs the layer's remaining rounds as ordinary kernels.
         const bool deciding = shard_host && !stage_decided && cur_max_len == 2 && stage_shape_ok();
         if (!stage_active && k_enq <= already_bound && cur_max_len == 2 && stage_ok() && (!shard_host || deciding)) {
-            // every row is down to one pair: this round, the rest of the sparse stage and the whole dense stage run in one launch
-            int32_t rc = launch_stage(cur.data(), off_cur, already_bound);
-            if (rc) return rc;
+            // every row is down to one pair: this round, the rest of the sparse stage and the whole dense stage run in one launch.
+            // A sharded launch only TRIES for its share of the device's co-residency budget: ranks that are threads of one process
+            // share that budget, and the rank holding it waits for this one's round sums -- waiting here would close the cycle.
+            // "Busy" is one more way of "could not" for the agreement below.
+            int32_t rc = launch_stage(cur.data(), off_cur, already_bound, !shard_host);
+            if (rc && !(shard_host && rc == GM_STAGE_BUSY)) return rc;
         }
         bool healthy = false;
         if (stage_active) {

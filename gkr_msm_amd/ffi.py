@@ -76,6 +76,11 @@ class GmScProfileRow(C.Structure):
 ALL_GATHER_DEV_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
+class GmKeyView(C.Structure):
+    _fields_ = [("n_segments", C.c_uint32), ("reserved", C.c_uint32), ("d_segment", C.POINTER(C.c_void_p)),
+                ("first", C.POINTER(C.c_uint64)), ("count", C.POINTER(C.c_uint64))]
+
+
 class GmComm(C.Structure):
     """gm_comm: rank / world, one host-buffer all-gather and, optionally (NULL by default), the same collective on device buffers"""
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", ALL_GATHER_CB),
@@ -183,6 +188,13 @@ _SIGS = {
     "gm_merlin_unread": (C.c_int32, [vp, u64p]),
     "gm_kzg_div_by_linear": (C.c_int32, [vp, C.c_uint64, vp, vp, vp, vp]),
     "gm_knuckles_setup": (C.c_int32, [vp, C.c_uint32, vp, vp]),
+    "gm_knuckles_setup_range": (C.c_int32, [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]),
+    "gm_knuckles_open_sharded": (C.c_int32, [C.POINTER(GmComm), C.POINTER(GmKeyView), vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64,
+                                             vp, vp, vp]),
+    "gm_knuckles_open_sharded_tr": (C.c_int32, [C.POINTER(GmComm), C.POINTER(GmKeyView), vp, vp, C.c_uint32, vp, vp, vp, vp,
+                                                C.POINTER(GmTranscript), vp, vp, vp]),
+    "gm_pippenger_wg_create_sharded": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(GmKeyView), C.POINTER(GmComm), C.POINTER(vp), vp]),
+    "gm_pippenger_sharded_key_ranges": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p]),
     "gm_knuckles_open": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]),
     "gm_knuckles_open_tr": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, C.POINTER(GmTranscript), vp, vp, vp]),
     "gm_gkr_msm_prove": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u32p, vp,

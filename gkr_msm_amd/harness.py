@@ -489,6 +489,83 @@ class PippengerWG:
                     pair=tuple(codec.g1_aff_from_limbs(pair)), tape_used=used.value, rounds=rounds.value)
 
 
+class KeyView:
+    """gm_key_view over device tensors: segments = [(tensor of affine points, index of its first point in kzg_basis(), count)]"""
+
+    def __init__(self, segments):
+        self.keep = [t for t, _, _ in segments]
+        n = len(segments)
+        self.ptrs = (C.c_void_p * n)(*[t.data_ptr() for t, _, _ in segments])
+        self.first = (C.c_uint64 * n)(*[f for _, f, _ in segments])
+        self.count = (C.c_uint64 * n)(*[c for _, _, c in segments])
+        self.c = ffi.GmKeyView(n, 0, self.ptrs, self.first, self.count)
+
+    @staticmethod
+    def whole(d_basis_aff, n_points):
+        return KeyView([(d_basis_aff, 0, n_points)])
+
+    @staticmethod
+    def ranges_for(x_log, d_log, y_log, clm, rank, world):
+        """[(first, count)] x 4: what gm_pippenger_sharded_key_ranges says this rank reads"""
+        f4, c4 = (C.c_uint64 * 4)(), (C.c_uint64 * 4)()
+        ffi.check(ffi.lib().gm_pippenger_sharded_key_ranges(x_log, d_log, y_log, clm, rank, world, f4, c4))
+        return [(f4[i], c4[i]) for i in range(4)]
+
+    @staticmethod
+    def minimal(d_basis_aff, x_log, d_log, y_log, clm, rank, world):
+        """only what the rank reads: the four ranges, merged where they touch or overlap, each copied out of the whole key
+        (a device tensor, 12 words per point) into an allocation of its own -- what a deployment would upload per rank"""
+        rg = sorted((f, f + c) for f, c in KeyView.ranges_for(x_log, d_log, y_log, clm, rank, world) if c)
+        merged = []
+        for a, b in rg:
+            if merged and a <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], b)
+            else:
+                merged.append([a, b])
+        return KeyView([(d_basis_aff[12 * a: 12 * b].clone(), a, b - a) for a, b in merged])
+
+
+def knuckles_setup_range(k, num_vars, first, count):
+    d_inv = dev_empty(4 * max(count, 1))
+    ffi.check(ffi.lib().gm_knuckles_setup_range(fr_arg([k]).ctypes.data, num_vars, first, count, _p(d_inv), cur_stream()))
+    return d_inv
+
+
+def knuckles_slice_of(num_vars, rank, world):
+    """(first, count) of the inverses table / key range rank `rank` holds in a sharded opening"""
+    n2 = 2 << num_vars
+    s = n2 // world
+    first = rank * s
+    return first, max(0, min(s, n2 - 1 - first))
+
+
+def knuckles_open_sharded(comm, key, d_inverses_slice, k, num_vars, d_poly_slice, point, claimed_ev, commitment, tape):
+    kk, pt, ev = fr_arg([k]), fr_arg(point), fr_arg([claimed_ev])
+    cm = codec.g1_aff_to_limbs([commitment])
+    tp = codec.ints_to_limbs(tape)
+    proof = np.zeros(48, dtype=np.uint64)
+    pair = np.zeros(24, dtype=np.uint64)
+    ffi.check(ffi.lib().gm_knuckles_open_sharded(C.byref(comm.c), C.byref(key.c), _p(d_inverses_slice), kk.ctypes.data, num_vars,
+                                                 _p(d_poly_slice), pt.ctypes.data, ev.ctypes.data, cm.ctypes.data, tp.ctypes.data,
+                                                 len(tape), proof.ctypes.data, pair.ctypes.data, cur_stream()))
+    f, g = codec.from_mont_limbs, codec.g1_aff_from_limbs
+    pr = dict(t_comm=g(proof[0:12])[0], t_x=f(proof[12:16])[0], p_x=f(proof[16:20])[0], p_lt_x_proof=g(proof[20:32])[0],
+              t_kx=f(proof[32:36])[0], t_kx_proof=g(proof[36:48])[0])
+    return pr, tuple(g(pair))
+
+
+class PippengerWGSharded(PippengerWG):
+    """one rank of gm_pippenger_wg_create_sharded: `plan` covers the rank's windows, `key` (KeyView) the key ranges resident here"""
+
+    def __init__(self, plan, d_points, y_logsize, clm, key, comm):
+        self.L = ffi.lib()
+        self.plan, self.y_logsize, self.clm = plan, y_logsize, clm
+        self.keep = (d_points, key, comm)
+        self.h = C.c_void_p()
+        ffi.check(self.L.gm_pippenger_wg_create_sharded(plan.h, _p(d_points), y_logsize, clm, C.byref(key.c), C.byref(comm.c),
+                                                        C.byref(self.h), cur_stream()))
+
+
 class LiveTranscript:
     """A gm_transcript whose callbacks run Python code: `on_write(list of canonical ints)` and `draw() -> int`.
     Stands in for the Rust shim's wrappers over ProofTranscript2 (tests drive it from a tape or a hash)."""

@@ -394,6 +394,18 @@ typedef struct gm_comm {
      * (gm_comm_shm_as_comm sets it: HIP IPC handles exchanged through the shared memory, hipMemcpyAsync between the devices). */
     int32_t (*pull_dev)(void* ctx, const void* d_src, uint64_t src_bytes, uint32_t n, const struct gm_pull* pieces, void* stream);
 } gm_comm;
+/* A rank's view of the KZG proving key (kzg_pk.ptau_1, kzg.rs:123-132) in a sharded proof: the segments of the key that are
+ * resident on this rank's device, as (device pointer, index of the first point, number of points), affine wire form.  With
+ * commitment_log_multiplicity = clm the key has 2^(x_logsize + clm + 1) - 1 points (pippenger.rs:475-480: 51 GB at x_logsize 24,
+ * clm 4) and no rank needs it whole; gm_pippenger_sharded_key_ranges lists what a rank reads.  A step whose range is not resident
+ * fails with GM_ERR_INVALID naming the range.  One segment covering the whole key is the small-shape / test form. */
+typedef struct gm_key_view {
+    uint32_t n_segments, reserved;
+    const uint64_t* const* d_segment;
+    const uint64_t* first;
+    const uint64_t* count;
+} gm_key_view;
+
 /* host-only self-test of a gm_comm (no GPU): sums the field elements h_vals[0..n) of all ranks in place (Montgomery) */
 int32_t gm_comm_sum_fr(const gm_comm* comm, uint64_t* h_vals, uint32_t n);
 
@@ -561,6 +573,24 @@ int32_t gm_knuckles_open_tr(const uint64_t* d_basis_aff, const uint64_t* d_inver
                             const uint64_t* d_poly, uint64_t poly_len, const uint64_t* h_point, const uint64_t* h_claimed_ev,
                             const uint64_t* h_commitment_aff, const gm_transcript* tr, uint64_t* h_proof, uint64_t* h_pair,
                             void* stream);
+/* The opening with polynomial, key and inverses distributed over the ranks of a gm_comm (config E: 2^28 coefficients, a
+ * 51 GB key, a 16 GiB table t).  Collective; rank r of G holds, with N = 2^num_vars and S = 2N / G:
+ *   d_poly_slice      coefficients [r N / G, (r + 1) N / G) of the zero-padded polynomial
+ *   d_inverses_slice  entries [r S, (r + 1) S) of the inverses table that exist (2N - 1 in all): gm_knuckles_setup_range
+ *   key               must hold points [r S, (r + 1) S) that exist (and point 0 on rank 0)
+ * compute_t's passes (knuckles.rs:131-146) read a halo from the lower neighbour (gm_comm::pull_dev, or its host fall-back),
+ * evaluations and quotients (kzg.rs:73-81, 142-150) chain one value per rank, every commitment (kzg.rs:123-132) is the rank's MSM
+ * over its key range combined by gm_g1_combine_parts.  Same proof and pair on every rank as gm_knuckles_open over the whole. */
+int32_t gm_knuckles_setup_range(const uint64_t* h_k, uint32_t num_vars, uint64_t first, uint64_t count, uint64_t* d_inverses,
+                                void* stream);
+int32_t gm_knuckles_open_sharded(const gm_comm* comm, const gm_key_view* key, const uint64_t* d_inverses_slice, const uint64_t* h_k,
+                                 uint32_t num_vars, const uint64_t* d_poly_slice, const uint64_t* h_point, const uint64_t* h_claimed_ev,
+                                 const uint64_t* h_commitment_aff, const uint64_t* h_tape, uint64_t n_tape, uint64_t* h_proof,
+                                 uint64_t* h_pair, void* stream);
+int32_t gm_knuckles_open_sharded_tr(const gm_comm* comm, const gm_key_view* key, const uint64_t* d_inverses_slice, const uint64_t* h_k,
+                                    uint32_t num_vars, const uint64_t* d_poly_slice, const uint64_t* h_point, const uint64_t* h_claimed_ev,
+                                    const uint64_t* h_commitment_aff, const gm_transcript* tr, uint64_t* h_proof, uint64_t* h_pair,
+                                    void* stream);
 
 /* ---------------------------------------------------------------- the whole gen-2 prover
  * PippengerWG::new (cleanup/protocols/pippenger.rs:37-70) and Pippenger::prove (pippenger.rs:118-290) behind two calls; pure
@@ -577,6 +607,22 @@ typedef struct gm_pippenger_wg gm_pippenger_wg;
 int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
                                uint32_t commitment_log_multiplicity, const uint64_t* d_kzg_basis_aff, gm_pippenger_wg** out,
                                void* stream);
+/* The same for one rank of a window-sharded proof (BASELINE.json configs[4]).  Collective: every rank calls it with the
+ * plan of ITS windows, the same shape and clm, a gm_key_view of the key ranges resident on its device and the communicator (which
+ * must outlive the handle).  PippengerWG::new's G1 work is linear in the committed columns (pushforward.rs:417-420, 504-524;
+ * kzg.rs:123-132): a rank commits what its windows / its index range contribute, one group element per commitment crosses the
+ * communicator, and the handle carries the COMBINED commitments -- equal on every rank to gm_pippenger_wg_create's over the whole
+ * key.  gm_pippenger_prove(_tr) on such a handle runs Pippenger::prove sharded (image part, pushforward argument, the opening
+ * witnesses and MultiOpenReduction on slices, gm_knuckles_open_sharded); there d_knuckles_inverses is the rank's
+ * gm_knuckles_setup_range slice.  Every rank obtains the proof and pairing pair of the unsharded prover.
+ * gm_pippenger_sharded_key_ranges: the <= 4 ranges of kzg_basis() a rank reads ([0] the key slices of its windows' outer buckets,
+ * which must lie in ONE segment of the view; [1] its share of p_0 / p_1 / ac_c; [2] of ac_d; [3] its range of the opening). */
+int32_t gm_pippenger_wg_create_sharded(const gm_msm_plan* plan, const uint64_t* d_points_xy, uint32_t y_logsize,
+                                       uint32_t commitment_log_multiplicity, const gm_key_view* key, const gm_comm* comm,
+                                       gm_pippenger_wg** out, void* stream);
+int32_t gm_pippenger_sharded_key_ranges(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_logsize,
+                                        uint32_t commitment_log_multiplicity, uint32_t rank, uint32_t world, uint64_t* first4,
+                                        uint64_t* count4);
 int32_t gm_pippenger_wg_destroy(gm_pippenger_wg* wg);
 int32_t gm_pippenger_wg_witness(const gm_pippenger_wg* wg, const gm_pip_witness** w);
 int32_t gm_pippenger_prove(const gm_pippenger_wg* wg, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
