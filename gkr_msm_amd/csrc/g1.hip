@@ -1287,7 +1287,7 @@ extern "C" int32_t gm_g1_combine_parts(const gm_comm* comm, const uint64_t* h_pa
     const size_t bytes = (size_t)n * sizeof(G1Jac);
     std::vector<char> all((size_t)comm->world * bytes, 0);
     memcpy(all.data() + (size_t)comm->rank * bytes, h_parts_jac, bytes);
-    const int32_t rc = comm->all_gather(comm->ctx, all.data(), bytes);
+    const int32_t rc = comm_all_gather(comm, all.data(), bytes);
     if (rc) return set_err(GM_ERR_STATE, "gm_comm all_gather failed with %d", rc);
     const G1Jac* a = reinterpret_cast<const G1Jac*>(all.data());
     for (uint32_t i = 0; i < n; i++) {

@@ -47,6 +47,36 @@ inline std::atomic<uint32_t>& wait_timeout_ms() {
 inline uint64_t wait_timeout_ticks() { return (uint64_t)wait_timeout_ms().load() * 100000ull; }
 inline std::chrono::milliseconds wait_timeout_host() { return std::chrono::milliseconds(wait_timeout_ms().load()); }
 
+// Where the wall time of a sharded call goes on this rank's host thread (thread-local; gm_shard_clock reads / resets it):
+// `small` = host all-gathers of <= 4 KiB (the per-round sums, agreement words, group elements: mostly WAITING for the slowest rank),
+// `bulk` = larger host all-gathers (bucket sums, host-staged redistributions), `pull` = gm_comm::pull_dev calls (device to device).
+struct ShardClock {
+    double small_us = 0, bulk_us = 0, pull_us = 0;
+    uint64_t small_n = 0, bulk_n = 0, pull_n = 0, bulk_bytes = 0, pull_bytes = 0;
+    static ShardClock& get() { static thread_local ShardClock c; return c; }
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void gather(double t0, uint64_t bytes) {
+        const double dt = now() - t0;
+        if (bytes <= 4096) { small_us += dt; small_n++; } else { bulk_us += dt; bulk_n++; bulk_bytes += bytes; }
+    }
+    void pulled(double t0, uint64_t bytes) { pull_us += now() - t0; pull_n++; pull_bytes += bytes; }
+};
+// every call of a gm_comm's collectives inside the library goes through these two
+inline int32_t comm_all_gather(const gm_comm* c, void* h_buf, uint64_t bytes_per_rank) {
+    const double t0 = ShardClock::now();
+    const int32_t rc = c->all_gather(c->ctx, h_buf, bytes_per_rank);
+    ShardClock::get().gather(t0, bytes_per_rank);
+    return rc;
+}
+inline int32_t comm_pull_dev(const gm_comm* c, const void* d_src, uint64_t src_bytes, uint32_t n, const gm_pull* pieces, void* stream) {
+    const double t0 = ShardClock::now();
+    const int32_t rc = c->pull_dev(c->ctx, d_src, src_bytes, n, pieces, stream);
+    uint64_t b = 0;
+    for (uint32_t i = 0; i < n; i++) b += pieces[i].bytes;
+    ShardClock::get().pulled(t0, b);
+    return rc;
+}
+
 struct Shard {
     const gm_comm* comm = nullptr;  // nullptr: unsharded
     uint32_t rank = 0, world = 1, lg = 0;
@@ -64,7 +94,7 @@ struct ShardScope {
 inline int32_t shard_all_gather(const Shard& sh, const void* mine, size_t bytes, std::vector<char>* all) {
     all->assign((size_t)sh.world * bytes, 0);
     memcpy(all->data() + (size_t)sh.rank * bytes, mine, bytes);
-    const int32_t rc = sh.comm->all_gather(sh.comm->ctx, all->data(), bytes);
+    const int32_t rc = comm_all_gather(sh.comm, all->data(), bytes);
     if (rc) return set_err(GM_ERR_STATE, "gm_comm all_gather failed with %d", rc);
     return GM_OK;
 }
@@ -104,8 +134,7 @@ inline const uint64_t* key_range(const gm_key_view* kv, uint64_t first, uint64_t
 inline int32_t shard_pull(const Shard& sh, const Fr* d_src, uint64_t src_elems, const std::vector<gm_pull>& pieces, bool* host_staged,
                           hipStream_t s) {
     if (sh.comm->pull_dev && !*host_staged) {
-        const int32_t rc = sh.comm->pull_dev(sh.comm->ctx, d_src, src_elems * sizeof(Fr), (uint32_t)pieces.size(), pieces.data(),
-                                             reinterpret_cast<void*>(s));
+        const int32_t rc = comm_pull_dev(sh.comm, d_src, src_elems * sizeof(Fr), (uint32_t)pieces.size(), pieces.data(), reinterpret_cast<void*>(s));
         if (rc == 0) return GM_OK;
         if (rc != 100) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
     }
@@ -113,7 +142,7 @@ inline int32_t shard_pull(const Shard& sh, const Fr* d_src, uint64_t src_elems, 
     std::vector<Fr> all((size_t)sh.world * src_elems);
     GM_HIP(hipMemcpyAsync(all.data() + (size_t)sh.rank * src_elems, d_src, src_elems * sizeof(Fr), hipMemcpyDeviceToHost, s));
     GM_HIP(hipStreamSynchronize(s));
-    const int32_t rc = sh.comm->all_gather(sh.comm->ctx, all.data(), src_elems * sizeof(Fr));
+    const int32_t rc = comm_all_gather(sh.comm, all.data(), src_elems * sizeof(Fr));
     if (rc) return set_err(GM_ERR_STATE, "gm_comm all_gather failed with %d", rc);
     for (const gm_pull& p : pieces)
         GM_HIP(hipMemcpyAsync(p.d_dst, all.data() + (size_t)p.peer * src_elems + p.src_offset / sizeof(Fr), p.bytes, hipMemcpyHostToDevice, s));

@@ -550,6 +550,18 @@ extern "C" int32_t gm_comm_sum_fr(const gm_comm* comm, uint64_t* h_vals, uint32_
     return shard_sum_fr(sh, reinterpret_cast<Fr*>(h_vals), (int)n);
 }
 
+// Where the wall time of the calling thread's sharded calls went since the last reset (ShardClock, internal.hpp):
+// out8 = {small all-gathers: microseconds, count; bulk all-gathers: microseconds, count, bytes; pull_dev: microseconds, count, bytes}
+extern "C" int32_t gm_shard_clock(int32_t reset, double* out8) {
+    ShardClock& c = ShardClock::get();
+    if (out8) {
+        out8[0] = c.small_us; out8[1] = (double)c.small_n; out8[2] = c.bulk_us; out8[3] = (double)c.bulk_n; out8[4] = (double)c.bulk_bytes;
+        out8[5] = c.pull_us; out8[6] = (double)c.pull_n; out8[7] = (double)c.pull_bytes;
+    }
+    if (reset) c = ShardClock();
+    return GM_OK;
+}
+
 extern "C" int32_t gm_pip_witness_destroy(gm_pip_witness* w) {
     delete w;
     return GM_OK;
@@ -1245,8 +1257,26 @@ int32_t pf_gather_slices(const Shard& sh, const Fr* d_slice, uint64_t n_loc, std
     all->resize((size_t)sh.world * n_loc);
     GM_HIP(hipMemcpyAsync(all->data() + (size_t)sh.rank * n_loc, d_slice, n_loc * sizeof(Fr), hipMemcpyDeviceToHost, s));
     GM_HIP(hipStreamSynchronize(s));
-    const int32_t rc = sh.comm->all_gather(sh.comm->ctx, all->data(), n_loc * sizeof(Fr));
+    const int32_t rc = comm_all_gather(sh.comm, all->data(), n_loc * sizeof(Fr));
     if (rc) return set_err(GM_ERR_STATE, "gm_comm all_gather failed with %d", rc);
+    return GM_OK;
+}
+
+// the global access counts (sums over the ranks' windows) on every rank: ac[0..X) = ac_c, ac[X..X+D) = ac_d; d_c / d_d: this rank's
+// slices of the c and d columns (phase-1 polynomials of its windows)
+int32_t sharded_access_counts(const gm_msm_plan* plan, const Shard& sh, Fr* d_c, Fr* d_d, Fr* d_ac, bool* host_staged, hipStream_t s) {
+    const uint64_t X = 1ull << plan->x_log, D = 1ull << plan->d_log, L = X + D;
+    const uint32_t G = sh.world;
+    DevBuf part, parts;
+    TRY(part.alloc(L * sizeof(Fr)));
+    TRY(gm_msm_phase1_polys(plan, (uint64_t*)d_c, (uint64_t*)d_d, (uint64_t*)part.p, (uint64_t*)(part.fr() + X), reinterpret_cast<void*>(s)));
+    TRY(parts.alloc((uint64_t)G * L * sizeof(Fr)));
+    std::vector<gm_pull> pc(G);
+    for (uint32_t q = 0; q < G; q++) pc[q] = gm_pull{q, 0u, 0ull, L * sizeof(Fr), parts.fr() + (uint64_t)q * L};
+    TRY(shard_pull(sh, part.fr(), L, pc, host_staged, s));
+    hipLaunchKernelGGL(k_pf_sum_parts, dim3(ceil_div(L, 256)), dim3(256), 0, s, parts.fr(), G, L, d_ac);
+    GM_LAUNCH_CHECK();
+    GM_HIP(hipStreamSynchronize(s));   // part / parts go out of scope
     return GM_OK;
 }
 
@@ -1277,40 +1307,44 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     memcpy(r.data(), h_claim_point, r.size() * sizeof(Fr));
     memcpy(evs.data(), h_claim_evs, 3 * sizeof(Fr));
     evs[1] = fr_sub(evs[1], fr_one());  // claims.evs[1] -= 1 (pushforward.rs:641)
+    StageTimer pf_timer("pushforward (sharded)", s);
 
     auto mk = [&](uint64_t n, std::shared_ptr<DevBuf>* b) -> int32_t {
         b->reset(new DevBuf());
         return (*b)->alloc(n * sizeof(Fr));
     };
+    // The SMALL distributed levels of the logup tree come out of one slab: gm_comm::pull_dev exports the allocation a source lies in
+    // (one HIP IPC handle, ~0.7 ms to open on the other side; the mappings are cached, and the pool hands the same blocks back proof
+    // after proof, so a process opens each of them once) -- a slab makes that one handle per peer for all the levels below 1/8 of
+    // it instead of three per level.  The slab is capped at 1 GiB: exporting a 2.2 GiB slab with every level in it hung the
+    // first pull at config B (four processes on one device, ROCm 7.2; not understood, not pursued -- GM_PF_NO_SLAB=1 switches the
+    // slab off altogether).  Buffers that do not fit are pool blocks of their own, as before.
+    static const bool no_slab = [] { const char* e = getenv("GM_PF_NO_SLAB"); return e && e[0] == '1'; }();
+    Arena tree_arena;
+    const size_t slab_want = (size_t)32 * (2 * ML + 16 * dist_min * G) + ((size_t)1 << 18), slab_cap = (size_t)1 << 30;
+    const size_t slab_bytes = no_slab ? 0 : (slab_want < slab_cap ? slab_want : slab_cap);
+    if (slab_bytes) TRY(tree_arena.init(slab_bytes));
+    auto mk_tree = [&](uint64_t n, std::shared_ptr<DevBuf>* b) -> int32_t {
+        b->reset(new DevBuf());
+        if (slab_bytes && n * sizeof(Fr) <= slab_bytes / 8) {
+            if (void* p = tree_arena.carve(n * sizeof(Fr))) {
+                (*b)->p = p; (*b)->bytes = n * sizeof(Fr); (*b)->owned = false;
+                return GM_OK;
+            }
+        }
+        return (*b)->alloc(n * sizeof(Fr));
+    };
     std::shared_ptr<DevBuf> c, d, ac_c, ac_d, c_pull, d_pull, c_adj, d_adj, num, den, table_c, table_d, p_sel, eqs;
     TRY(mk(ML, &c)); TRY(mk(ML, &d)); TRY(mk(X + D, &ac_c)); TRY(mk(ML, &c_pull)); TRY(mk(ML, &d_pull));
-    {
-        // this rank's windows; its access counts are its windows' share: the global ones are the sums over the ranks
-        std::shared_ptr<DevBuf> part, parts;
-        TRY(mk(X + D, &part));
-        TRY(gm_msm_phase1_polys(plan, (uint64_t*)c->p, (uint64_t*)d->p, (uint64_t*)part->p, (uint64_t*)(part->fr() + X), stream));
-        TRY(mk((uint64_t)G * (X + D), &parts));
-        std::vector<Fr> all;
-        if (sh.comm->pull_dev && !host_staged) {   // device to device: every rank's share next to each other
-            std::vector<gm_pull> pc(G);
-            for (uint32_t q = 0; q < G; q++) pc[q] = gm_pull{q, 0u, 0ull, (X + D) * sizeof(Fr), parts->fr() + (uint64_t)q * (X + D)};
-            const int32_t rc = sh.comm->pull_dev(sh.comm->ctx, part->p, (X + D) * sizeof(Fr), G, pc.data(), stream);
-            if (rc == 100) host_staged = true;
-            else if (rc) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
-        }
-        if (!sh.comm->pull_dev || host_staged) {
-            TRY(pf_gather_slices(sh, part->fr(), X + D, &all, s));
-            GM_HIP(hipMemcpyAsync(parts->p, all.data(), all.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
-        }
-        hipLaunchKernelGGL(k_pf_sum_parts, dim3(ceil_div(X + D, 256)), dim3(256), 0, s, parts->fr(), G, X + D, ac_c->fr());
-        GM_LAUNCH_CHECK();
-        GM_HIP(hipStreamSynchronize(s));   // `all` / `part` go out of scope
-    }
+    // this rank's windows; its access counts are its windows' share: the global ones are the sums over the ranks
+    TRY(sharded_access_counts(plan, sh, c->fr(), d->fr(), ac_c->fr(), &host_staged, s));
+    pf_timer.mark("phase-1 polys + access counts");
     const Fr* ac_c_p = ac_c->fr();
     const Fr* ac_d_p = ac_c->fr() + X;
     ac_d = ac_c;
     TRY(gm_msm_second_phase(plan, h_claim_point, y_log, (uint64_t*)c_pull->p, (uint64_t*)d_pull->p, stream));
 
+    pf_timer.mark("second phase");
     // challenges (pushforward.rs:684-685)
     Fr psi, tau_c, tau_d, tau_s, gamma;
     {
@@ -1321,14 +1355,16 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     TRY(tr->challenge(&gamma));
     GM_REQUIRE(!fr_is_zero(tau_s) && !fr_is_zero(psi), "zero challenge (inverse().unwrap() in the reference)");
 
-    TRY(mk(ML, &c_adj)); TRY(mk(ML, &d_adj)); TRY(mk(ML, &num)); TRY(mk(ML, &den));
+    // (numerator, denominator) pairs of the tree live in ONE allocation each, den = num + local length: a level's re-spread is then
+    // a single pull_dev (one source buffer per call) instead of two
+    TRY(mk(ML, &c_adj)); TRY(mk(ML, &d_adj)); TRY(mk_tree(2 * ML, &num)); den = num;
     hipLaunchKernelGGL(k_pf_adj, dim3(ceil_div(ML, 256)), dim3(256), 0, s, c_pull->fr(), c->fr(), psi, tau_c, tau_s, ML, ML, c_adj->fr());
     GM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pf_adj, dim3(ceil_div(ML, 256)), dim3(256), 0, s, d_pull->fr(), d->fr(), psi, tau_d, tau_s, ML, ML, d_adj->fr());
     GM_LAUNCH_CHECK();
     {
         const Fr* in[2] = {c_adj->fr(), d_adj->fr()};
-        Fr* outp[2] = {num->fr(), den->fr()};
+        Fr* outp[2] = {num->fr(), num->fr() + ML};
         TRY(launch_dense_map(plan_of(mkfn(GM_FN_ADD_INVERSES, 1)), in, outp, ML, s));
     }
     // tables (pushforward.rs:725-728): small, replicated
@@ -1349,6 +1385,7 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
         hipLaunchKernelGGL(k_pf_table, dim3(ceil_div(D, 256)), dim3(256), 0, s, eq_d, psi, tau_d, D, table_d->fr());
         GM_LAUNCH_CHECK();
     }
+    pf_timer.mark("adj + tables");
     const Fr supp_total = fr_zero();   // 2 (2^mlog - matrix_size) / tau_suppression_term with matrix_size = 2^mlog
 
     // ---- the logup tree.  A distributed array of global length L lives as slices of L / G; `split` re-spreads its halves.
@@ -1366,38 +1403,41 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
         for (int side = 0; side < 2; side++) {
             DFrac* t = side ? hi : lo;
             t->dist = stay;
-            TRY(mk(n_out, &t->keep_n)); TRY(mk(n_out, &t->keep_d));
-            t->num = t->keep_n->fr(); t->den = t->keep_d->fr();
+            TRY(mk_tree(2 * n_out, &t->keep_n));
+            t->keep_d = t->keep_n;
+            t->num = t->keep_n->fr(); t->den = t->keep_n->fr() + n_out;
         }
         if (sh.comm->pull_dev && !host_staged) {
             // device to device.  Staying distributed: new rank j takes its l-slice from old rank j / 2 and its r-slice from old rank
             // G / 2 + j / 2 (the first or the second half of that rank's slice); turning replicated: every rank's whole slice.
+            // The source is the rank's [num | den] buffer of 2 S elements: both arrays in one call.
+            GM_REQUIRE(o.den == o.num + S, "logup tree: numerator and denominator are not one buffer");
+            std::vector<gm_pull> pc;
             for (int arr = 0; arr < 2; arr++) {
-                std::vector<gm_pull> pc;
-                Fr* dlo = arr ? lo->keep_d->fr() : lo->keep_n->fr();
-                Fr* dhi = arr ? hi->keep_d->fr() : hi->keep_n->fr();
+                Fr* dlo = const_cast<Fr*>(arr ? lo->den : lo->num);
+                Fr* dhi = const_cast<Fr*>(arr ? hi->den : hi->num);
+                const uint64_t ab = (uint64_t)arr * S * sizeof(Fr);
                 if (stay) {
                     const uint64_t half_bytes = (S / 2) * sizeof(Fr), so = (uint64_t)(sh.rank & 1u) * half_bytes;
-                    pc.push_back(gm_pull{sh.rank / 2, 0u, so, half_bytes, dlo});
-                    pc.push_back(gm_pull{G / 2 + sh.rank / 2, 0u, so, half_bytes, dhi});
+                    pc.push_back(gm_pull{sh.rank / 2, 0u, ab + so, half_bytes, dlo});
+                    pc.push_back(gm_pull{G / 2 + sh.rank / 2, 0u, ab + so, half_bytes, dhi});
                 } else {
                     for (uint32_t q = 0; q < G; q++)
-                        pc.push_back(gm_pull{q, 0u, 0ull, S * sizeof(Fr), (q < G / 2 ? dlo : dhi) + (uint64_t)(q % (G / 2)) * S});
+                        pc.push_back(gm_pull{q, 0u, ab, S * sizeof(Fr), (q < G / 2 ? dlo : dhi) + (uint64_t)(q % (G / 2)) * S});
                 }
-                const int32_t rc = sh.comm->pull_dev(sh.comm->ctx, arr ? o.den : o.num, S * sizeof(Fr), (uint32_t)pc.size(), pc.data(),
-                                                     reinterpret_cast<void*>(s));
-                if (rc == 100) { host_staged = true; break; }   // nothing was copied: this and the later levels through the host
-                if (rc) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
             }
-            if (!host_staged) return GM_OK;
+            const int32_t rc = comm_pull_dev(sh.comm, o.num, 2 * S * sizeof(Fr), (uint32_t)pc.size(), pc.data(), reinterpret_cast<void*>(s));
+            if (rc == 0) return GM_OK;
+            if (rc != 100) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
+            host_staged = true;   // nothing was copied: this and the later levels through the host
         }
         std::vector<Fr> fn, fd;   // host-staged: the whole array through the communicator's all-gather
         TRY(pf_gather_slices(sh, o.num, S, &fn, s));
         TRY(pf_gather_slices(sh, o.den, S, &fd, s));
         for (int side = 0; side < 2; side++) {
             DFrac* t = side ? hi : lo;
-            GM_HIP(hipMemcpyAsync(t->keep_n->p, fn.data() + (side ? H : 0) + off, n_out * sizeof(Fr), hipMemcpyHostToDevice, s));
-            GM_HIP(hipMemcpyAsync(t->keep_d->p, fd.data() + (side ? H : 0) + off, n_out * sizeof(Fr), hipMemcpyHostToDevice, s));
+            GM_HIP(hipMemcpyAsync(const_cast<Fr*>(t->num), fn.data() + (side ? H : 0) + off, n_out * sizeof(Fr), hipMemcpyHostToDevice, s));
+            GM_HIP(hipMemcpyAsync(const_cast<Fr*>(t->den), fd.data() + (side ? H : 0) + off, n_out * sizeof(Fr), hipMemcpyHostToDevice, s));
         }
         GM_HIP(hipStreamSynchronize(s));   // fn / fd go out of scope
         return GM_OK;
@@ -1405,7 +1445,7 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     std::vector<DFrac> layers;
     {
         DFrac root;
-        root.num = num->fr(); root.den = den->fr(); root.len = M; root.dist = true; root.keep_n = num; root.keep_d = den;
+        root.num = num->fr(); root.den = num->fr() + ML; root.len = M; root.dist = true; root.keep_n = num; root.keep_d = num;
         DFrac lo, hi;
         TRY(split_halves(root, &lo, &hi));   // [left, right] of map_split_hi (pushforward.rs:719)
         layers.push_back(lo);
@@ -1425,10 +1465,11 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
         const uint64_t n_loc = dist ? curr / G : curr;
         DFrac o;
         o.len = curr; o.dist = dist;
-        TRY(mk(n_loc, &o.keep_n)); TRY(mk(n_loc, &o.keep_d));
-        o.num = o.keep_n->fr(); o.den = o.keep_d->fr();
+        TRY(mk_tree(2 * n_loc, &o.keep_n));
+        o.keep_d = o.keep_n;
+        o.num = o.keep_n->fr(); o.den = o.keep_n->fr() + n_loc;
         const Fr* in[4] = {layers[i].num, layers[i].den, layers[i + 1].num, layers[i + 1].den};
-        Fr* outp[2] = {o.keep_n->fr(), o.keep_d->fr()};
+        Fr* outp[2] = {const_cast<Fr*>(o.num), const_cast<Fr*>(o.den)};
         TRY(launch_dense_map(logup, in, outp, n_loc, s));
         if (curr == next_size) {
             layers.push_back(o);
@@ -1458,6 +1499,7 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     GM_REQUIRE(fr_eq(nd[0], fr_mul(nd[1], supp_total)), "logup total does not match the suppression term (logup_mainphase.rs:162)");
     tr->write_scalars({nd[0], nd[1]});
 
+    pf_timer.mark("logup witness + re-spreads");
     Arena arena;
     // workspace of the sumcheck objects: fold buffers and eq levels of this rank's slices (the sharded objects keep their slice of
     // the eq tables), the replicated top of the tree
@@ -1502,6 +1544,10 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
                 adv.cols.back()->bytes = n_loc * sizeof(Fr);
             }
             ShardScope shard(ll.dist ? sh : Shard());   // a distributed layer: the columns are this rank's slice of 2^curr_log elements
+            // a replicated layer (the top of the tree, below GM_PF_DIST_MIN elements per rank): every rank would prove it alike -- the
+            // leader does, the others read its round polynomials from the exchange (LeadScope, as the bucket-reduction layers)
+            static const bool no_lead = [] { const char* e = getenv("GM_SHARD_NO_LEADER"); return e && e[0] == '1'; }();
+            LeadScope lead((!ll.dist && !no_lead) ? sh : Shard());
             TRY(dense_deg2_prove(tr, f_logup, curr_log, &c4, adv, s));
         }
         if (incoming == curr_log) {
@@ -1528,6 +1574,7 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     TRY(split_at_prove(tr, &cd, true, 0, 2));   // SplitAt(HI(0), 2) (pushforward.rs:744-746)
     GM_REQUIRE(cd.evs.size() == 2 && cd.point.size() == mlog, "cd claims have the wrong shape");
 
+    pf_timer.mark("logup prove");
     // ---- combined sumcheck (pushforward.rs:748-801) on this rank's slices
     const Fr g1 = gamma, g2 = fr_mul(gamma, gamma);
     TRY(mk(ML, &p_sel));
@@ -1603,6 +1650,7 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     out_matrix->point = out_pt;
     out_matrix->evs = {p_folded_ev, c_pull_ev, d_pull_ev, c_ev, d_ev};
     tr->write_scalars(out_matrix->evs);
+    pf_timer.mark("combined sumcheck");
     *out_gamma = gamma;
     if (keep) {
         keep->c = c; keep->d = d; keep->c_pull = c_pull; keep->d_pull = d_pull; keep->ac_c = ac_c; keep->ac_d = ac_c;
@@ -2206,22 +2254,6 @@ extern "C" int32_t gm_pippenger_wg_create(const gm_msm_plan* plan, const uint64_
 //                                            sharded dense object, the Knuckles opening on slices (knuckles.hip)
 // Every rank runs the same transcript and ends with the same proof and pairing pair as the unsharded prover.
 namespace {
-
-int32_t sharded_access_counts(const gm_msm_plan* plan, const Shard& sh, Fr* d_c, Fr* d_d, Fr* d_ac, bool* host_staged, hipStream_t s) {
-    const uint64_t X = 1ull << plan->x_log, D = 1ull << plan->d_log, L = X + D;
-    const uint32_t G = sh.world;
-    DevBuf part, parts;
-    TRY(part.alloc(L * sizeof(Fr)));
-    TRY(gm_msm_phase1_polys(plan, (uint64_t*)d_c, (uint64_t*)d_d, (uint64_t*)part.p, (uint64_t*)(part.fr() + X), reinterpret_cast<void*>(s)));
-    TRY(parts.alloc((uint64_t)G * L * sizeof(Fr)));
-    std::vector<gm_pull> pc(G);
-    for (uint32_t q = 0; q < G; q++) pc[q] = gm_pull{q, 0u, 0ull, L * sizeof(Fr), parts.fr() + (uint64_t)q * L};
-    TRY(shard_pull(sh, part.fr(), L, pc, host_staged, s));
-    hipLaunchKernelGGL(k_pf_sum_parts, dim3(ceil_div(L, 256)), dim3(256), 0, s, parts.fr(), G, L, d_ac);
-    GM_LAUNCH_CHECK();
-    GM_HIP(hipStreamSynchronize(s));   // part / parts go out of scope
-    return GM_OK;
-}
 
 // this rank's share of the commitment of a column every rank holds whole
 int32_t commit_replicated_part(const gm_pippenger_wg* st, const Fr* d_col, uint64_t L, uint32_t nbits, G1Jac* part, const char* what, void* stream) {

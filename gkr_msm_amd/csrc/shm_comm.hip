@@ -45,6 +45,11 @@ static_assert(sizeof(ShmHeader) <= 64, "header fits its line");
 size_t shm_bytes(uint32_t world) { return 64 + (size_t)world * 64 + (size_t)world * 2 * SHM_SLOT; }
 }  // namespace
 
+// same-device copies of pull_dev (see ShmIpcMsg::bus): 16 bytes per lane and step, grid-stride
+__global__ void __launch_bounds__(256) k_shm_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 struct gm_shm {
     std::string name;
     uint32_t rank = 0, world = 1;
@@ -64,7 +69,7 @@ struct gm_shm {
     std::vector<uint64_t> peer_epoch;
     uint64_t pull_no = 0;          // pull_dev calls so far: the stamp of "touched by the current call"
     uint64_t ipc_opens = 0, ipc_closes = 0;
-    size_t max_opened = [] { const char* e = getenv("GM_SHM_MAX_OPENED"); long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 32); }();
+    size_t max_opened = [] { const char* e = getenv("GM_SHM_MAX_OPENED"); long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 128); }();
     void sync_epoch(uint32_t peer, uint64_t epoch) {
         if (peer_epoch.size() != world) peer_epoch.assign(world, ~0ull);
         if (peer_epoch[peer] == epoch) return;
@@ -150,6 +155,9 @@ struct ShmIpcMsg {
     hipIpcMemHandle_t handle;
     uint64_t offset, bytes, epoch;
     uint32_t failed, pad;     // the rank's source could not be completed (stream error): every rank returns an error, nobody waits
+    char bus[16];             // PCI bus id of the rank's device: a peer on the SAME device (ranks sharing a GPU: the one-box rehearsals) is
+                              // copied from by a kernel -- hipMemcpyAsync from an IPC mapping takes the SDMA path, ~55 GB/s, where
+                              // the device copies itself at TB/s; between two GPUs the copy stays a peer hipMemcpyAsync over xGMI
     uint64_t pid, raw;        // ranks that are THREADS of one process (one process driving several GPUs, or the shared-GPU rehearsals
                               // of more ranks than the box allows processes) share an address space: the source pointer itself serves,
                               // no IPC mapping (a process cannot open its own export)
@@ -181,6 +189,13 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         }
     }
     mine.epoch = dev_pool().release_epoch.load();
+    {
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        char busid[64] = {0};
+        if (hipDeviceGetPCIBusId(busid, sizeof(busid), dev_) != hipSuccess) { (void)hipGetLastError(); busid[0] = 0; }
+        strncpy(mine.bus, busid, sizeof(mine.bus) - 1);
+    }
     mine.pid = (uint64_t)getpid();
     mine.raw = exported ? (uint64_t)(uintptr_t)d_src : 0;
     // the source is complete before its handle goes out; a rank that cannot complete it says so IN the exchange (its peers would
@@ -218,8 +233,19 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         if (st[r] == 3u) return 10;                     // a peer failed outright
         if (st[r] != 1u) return GM_PULL_UNAVAILABLE;    // same answer on every rank; nothing has been copied
     }
-    for (uint32_t k = 0; k < n && !err; k++)
-        if (hipMemcpyAsync(pieces[k].d_dst, src[k], pieces[k].bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) err = 8;
+    static const bool no_kernel_copy = [] { const char* e = getenv("GM_SHM_NO_KERNEL_COPY"); return e && e[0] == '1'; }();   // A/B
+    for (uint32_t k = 0; k < n && !err; k++) {
+        const gm_pull& p = pieces[k];
+        const bool same_dev = mine.bus[0] && memcmp(mine.bus, msgs[p.peer].bus, sizeof(mine.bus)) == 0;
+        if (same_dev && !no_kernel_copy && p.bytes >= 4096 && p.bytes % 16 == 0 && ((uintptr_t)p.d_dst | (uintptr_t)src[k]) % 16 == 0) {
+            const uint64_t n16 = p.bytes / 16;
+            uint64_t blocks = (n16 + 1023) / 1024;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(k_shm_copy16, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src[k]),
+                               reinterpret_cast<uint4*>(p.d_dst), n16);
+            if (hipGetLastError() != hipSuccess) err = 8;
+        } else if (hipMemcpyAsync(p.d_dst, src[k], p.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) err = 8;
+    }
     if (hipStreamSynchronize(s) != hipSuccess && !err) err = 9;
     if (err) (void)hipGetLastError();
     // everybody is done reading (also after an error on this rank: the others must not hang in their barrier)

@@ -131,6 +131,16 @@ class RcclComm:
         return np.ascontiguousarray(np.transpose(raw, (1, 0, 2, 3)).reshape(ncols, self.world * wpr, 4))
 
 
+def shard_clock(reset=True):
+    """gm_shard_clock of the calling thread as a dict (ms)"""
+    import ctypes as C
+    from . import ffi
+    o = (C.c_double * 8)()
+    ffi.check(ffi.lib().gm_shard_clock(1 if reset else 0, o))
+    return dict(small_gather_ms=round(o[0] / 1e3, 2), small_gathers=int(o[1]), bulk_gather_ms=round(o[2] / 1e3, 2), bulk_gathers=int(o[3]),
+                bulk_MB_per_rank=round(o[4] / 1e6, 2), pull_ms=round(o[5] / 1e3, 2), pulls=int(o[6]), pulled_MB=round(o[7] / 1e6, 2))
+
+
 class ShmComm:
     """The library's one-node communicator over POSIX shared memory (gm_comm_shm_*, csrc/shm_comm.hip): the ranks' host threads
     exchange the per-round sums of a sharded proof directly -- no device collective, no Python on the path.  `name` ("/gm-...")

@@ -134,6 +134,7 @@ _SIGS = {
     "gm_pip_witness_create": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(vp), vp]),
     "gm_pip_witness_create_sharded": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(GmComm), C.POINTER(vp), vp]),
     "gm_comm_sum_fr": (C.c_int32, [C.POINTER(GmComm), vp, C.c_uint32]),
+    "gm_shard_clock": (C.c_int32, [C.c_int32, C.POINTER(C.c_double)]),
     "gm_msm_g1_outer_part": (C.c_int32, [vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, u32p, u32p, u32p, vp, vp, vp]),
     "gm_g1_combine_parts": (C.c_int32, [C.POINTER(GmComm), vp, C.c_uint32, vp]),
     "gm_comm_rccl_unique_id": (C.c_int32, [vp]),

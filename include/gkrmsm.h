@@ -406,6 +406,10 @@ typedef struct gm_key_view {
     const uint64_t* count;
 } gm_key_view;
 
+/* Diagnosis of a sharded run: where the calling thread's time inside the communicator went since the last reset.  out8 = {small
+ * host all-gathers (<= 4 KiB: round sums, agreement words, group elements -- mostly waiting for the slowest rank): microseconds,
+ * count; larger host all-gathers: microseconds, count, bytes per rank; pull_dev: microseconds, count, bytes pulled}. */
+int32_t gm_shard_clock(int32_t reset, double* out8);
 /* host-only self-test of a gm_comm (no GPU): sums the field elements h_vals[0..n) of all ranks in place (Montgomery) */
 int32_t gm_comm_sum_fr(const gm_comm* comm, uint64_t* h_vals, uint32_t n);
 
@@ -444,7 +448,7 @@ int32_t gm_comm_shm_create(const char* name, uint32_t rank, uint32_t world, gm_s
 int32_t gm_comm_shm_destroy(gm_shm* c);
 int32_t gm_comm_shm_as_comm(gm_shm* c, gm_comm* out);
 int32_t gm_comm_shm_stats(const gm_shm* c, uint64_t* all_gathers, uint64_t* bytes_per_rank_total);
-/* pull_dev's cache of opened peer allocations (HIP IPC): least recently used first out, bounded by GM_SHM_MAX_OPENED (default 32)
+/* pull_dev's cache of opened peer allocations (HIP IPC): least recently used first out, bounded by GM_SHM_MAX_OPENED (default 128)
  * BETWEEN calls -- a mapping the running call resolved an address into is never closed under it.  Counters for tests / diagnosis. */
 int32_t gm_comm_shm_ipc_stats(const gm_shm* c, uint64_t* opens, uint64_t* closes, uint64_t* held);
 

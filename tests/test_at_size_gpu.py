@@ -295,8 +295,10 @@ def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
         a0, b0 = C.c_uint64(), C.c_uint64()
         ffi.lib().gm_sc_stage_counts(C.byref(a0), C.byref(b0))
         ws.prove_image_part(r_pt, evs, tape)            # warm-up (first-use allocations)
+        gd.shard_clock()
         got = ws.prove_image_part(r_pt, evs, tape)
         dt = got["call_s"]
+        clock = gd.shard_clock()
         a1, b1 = C.c_uint64(), C.c_uint64()
         ffi.lib().gm_sc_stage_counts(C.byref(a1), C.byref(b1))
         ok = (outs_s == outs and bs_s == bs and got["msgs"] == ref["msgs"] and got["point"] == ref["point"] and
@@ -305,6 +307,31 @@ def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
         ws.close()
         plan_s.close()
         ffi.lib().gm_release_cached_memory()
+        # The comparison that separates the cost of SHARDING from the cost of FOUR PROCESSES SHARING ONE GPU: every rank proves, at the
+        # same time as the others and with no exchange at all, an independent unsharded image part of its share's size (the first
+        # y_size / world windows: the same bucket rows per process, a few rounds fewer because y_logsize is smaller).
+        yq = y_size // world
+        yq_log = (yq - 1).bit_length()
+        plan_q = H.MsmPlan(x_log, d_log, yq)
+        plan_q.run(d_pts, d_sc)
+        wq = H.PipWitness(plan_q, d_pts, yq_log)
+        outs_q, _ = wq.outputs()
+        rq = r_pt[:yq_log]
+
+        def evq(poly):
+            cur = list(poly)
+            for f in reversed(rq):
+                cur = [(cur[2 * i] + f * (cur[2 * i + 1] - cur[2 * i])) % P for i in range(len(cur) // 2)]
+            return cur[0]
+        evs_q = [evq(o) for o in outs_q]
+        wq.prove_image_part(rq, evs_q, tape)
+        comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))   # start together
+        gq = [wq.prove_image_part(rq, evs_q, tape) for _ in range(2)]
+        indep = dict(ms=round(1e3 * min(g_["call_s"] for g_ in gq), 1), rounds=gq[0]["rounds"])
+        wq.close()
+        plan_q.close()
+        ffi.lib().gm_release_cached_memory()
+        comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))
         one = None
         if rank == 0:
             # the unsharded proof timed ALONE on the GPU: the other ranks are done (they wait in the exchange below without touching it)
@@ -317,7 +344,7 @@ def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
             plan.close()
         comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))   # everybody leaves together
         q.put((rank, ok, dict(exchanges=calls, sharded_s=dt, unsharded_alone_s=one, stage_launches=(a1.value - a0.value) // 2,
-                              stage_left=b1.value - b0.value), got["rounds"]))
+                              stage_left=b1.value - b0.value, clock=clock, indep=indep), got["rounds"]))
         comm.close()
     except Exception as e:  # report instead of hanging the parent
         import traceback
@@ -363,6 +390,10 @@ def test_config_b_image_part_sharded_over_four_ranks():
            sharded_ms=round(1e3 * sharded, 1), unsharded_alone_ms=round(1e3 * alone, 1), ratio=round(sharded / alone, 2),
            stage_launches_per_rank=res[0][2]["stage_launches"], stage_left_early=sum(r[2]["stage_left"] for r in res),
            exchanges_per_rank=res[0][2]["exchanges"],
+           time_inside_the_communicator_per_rank=[r[2]["clock"] for r in res], per_rank_ms=[round(1e3 * r[2]["sharded_s"], 1) for r in res],
+           four_independent_share_sized_proofs_at_once=dict(what="every process proves an unsharded image part over y_size / world windows at the "
+                                                            "same time, no exchange: what sharing ONE GPU between the processes costs by itself",
+                                                            ms_per_process=[r[2]["indep"]["ms"] for r in res], rounds=res[0][2]["indep"]["rounds"]),
            seconds=round(time.perf_counter() - t_begin, 1), checked="every message equal to the unsharded proof on every rank")
     assert res[0][2]["stage_launches"] >= 30, "the sharded bintree layers did not run in the stage kernel"
     assert sharded <= 2.0 * alone, "sharded over ranks sharing one GPU: %.1f ms against %.1f ms unsharded" % (1e3 * sharded, 1e3 * alone)
@@ -415,8 +446,10 @@ def _sharded_pf_worker(rank, world, port, x_log, d_log, nbits, q):
         y0, y1 = gd.window_range(rank, world, y_size)
         plan_s = H.MsmPlan(x_log, d_log, y_size, y0, y1)
         plan_s.run(d_pts, d_sc)
+        H.pushforward_prove(plan_s, d_pts, y_log, r_pt, evs, tape, comm=comm)      # warm-up: first-use allocations, IPC mappings
+        gd.shard_clock()
         got = H.pushforward_prove(plan_s, d_pts, y_log, r_pt, evs, tape, comm=comm)
-        info.update(sharded_s=got["call_s"], rounds=got["rounds"], exchanges=comm.calls, digest=hashlib.sha256(repr(
+        info.update(sharded_s=got["call_s"], rounds=got["rounds"], exchanges=comm.calls, clock=gd.shard_clock(), ipc=comm.ipc_stats(), digest=hashlib.sha256(repr(
             (got["msgs"], got["gamma"], got["matrix"], got["ac_c"], got["ac_d"])).encode()).hexdigest())
         q.put((rank, True, info))
         comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))   # everybody leaves together
@@ -467,6 +500,8 @@ def test_config_b_pushforward_sharded_over_four_ranks():
     record("config_b_pushforward_sharded_over_four_ranks", x_logsize=x_log, world=world, rounds=res[0][2]["rounds"],
            transport="shm (round sums) + HIP IPC pulls (tree halves, access counts)", sharded_ms=round(1e3 * sharded, 1), unsharded_ms=round(1e3 * res[0][2]["unsharded_s"], 1),
            exchanges_per_rank=res[0][2]["exchanges"], seconds=round(time.perf_counter() - t_begin, 1),
+           time_inside_the_communicator_per_rank=[r[2]["clock"] for r in res], per_rank_ms=[round(1e3 * r[2]["sharded_s"], 1) for r in res],
+           ipc_mappings_opened_closed_held=[r[2]["ipc"] for r in res],
            checked="messages, gamma and the three final claims equal to the unsharded argument on every rank")
 
 

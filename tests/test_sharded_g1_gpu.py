@@ -13,14 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, x_log, d_log, nbits, clm, q):
+def _worker(rank, world, port, x_log, d_log, nbits, clm, q, transport="gloo"):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist = None
+        if transport == "gloo":
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         from gkr_msm_amd import codec, dist as gd, harness as H
         from pyref import field as F
         y_size = (nbits + d_log - 1) // d_log
@@ -43,13 +45,14 @@ def _worker(rank, world, port, x_log, d_log, nbits, clm, q):
         plan_s = H.MsmPlan(x_log, d_log, y_size, y0, y1)
         plan_s.run(d_pts, d_sc)
         part = H.msm_g1_outer_part(plan_s, d_local, slot, clm, n)
-        comm = gd.Comm(dist, rank, world)
+        comm = gd.Comm(dist, rank, world) if dist is not None else gd.ShmComm("/gm-test-g1-%d" % port, rank, world)
         got_d = H.g1_combine_parts(comm, part["d_part"], n_mat, part["first_matrix"])
         got_c = H.g1_combine_parts(comm, part["c_part"], n_mat, part["first_matrix"])
         ok = got_d == d_comm and got_c == c_comm and part["n_matrices"] == ((y1 - 1) >> clm) - (y0 >> clm) + 1
         q.put((rank, ok, "slices held %s of %d; matrices %d..%d" % (need, cm, part["first_matrix"], part["first_matrix"] + part["n_matrices"] - 1)))
-        dist.barrier()
-        dist.destroy_process_group()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
     except Exception as e:  # report instead of hanging the parent
         import traceback
         q.put((rank, False, repr(e) + traceback.format_exc()))
@@ -75,3 +78,15 @@ def test_sharded_outer_commitments_match_unsharded(world, x_log, d_log, nbits, c
     assert len(res) == world
     for rank, ok, info in sorted(res):
         assert ok is True, "rank %d: %s" % (rank, info)
+
+
+def _worker_q(rank, world, q, port, x_log, d_log, nbits, clm):
+    _worker(rank, world, port, x_log, d_log, nbits, clm, q, "shm")
+
+
+def test_sharded_outer_commitments_world_8():
+    """config E's structure: 32 windows, commitment_log_multiplicity 4, 8 ranks x 4 windows -- matrix 0 spans ranks 0-3, matrix 1
+    ranks 4-7; each rank holds 4 of the 16 key slices (4 processes x 2 rank threads, the shared-memory communicator)"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rank_threads import run_ranks
+    run_ranks(_worker_q, 8, (36900 + os.getpid() % 2000, 4, 2, 64, 4), threads_per_proc=2)

@@ -108,6 +108,21 @@ def test_sharded_prove_image_part_matches_unsharded(world, x_log, d_log, nbits, 
         assert sharded >= 1 and left == 0, "rank %d: %d stage launches unsharded, %d sharded, %d left early" % (rank, unsharded, sharded, left)
 
 
+def _worker_q(rank, world, q, port, x_log, d_log, nbits):
+    _worker(rank, world, port, x_log, d_log, nbits, q, "shm")
+
+
+def test_sharded_prove_image_part_world_8():
+    """the target machine's rank count: 8 ranks x 2 windows (4 processes x 2 rank threads share the GPU, tests/rank_threads.py): the
+    last log2(8) = 3 rounds of every dense stage run replicated, the leader proves the bucket reduction for seven followers, the stage
+    kernel's agreement word is exchanged between 8"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rank_threads import run_ranks
+    res = run_ranks(_worker_q, 8, (35100 + os.getpid() % 2000, 6, 2, 32), threads_per_proc=2)
+    for rank, ok, calls, rounds, (unsharded, sharded, left) in res:
+        assert calls > rounds // 2
+
+
 def test_sharded_ranks_agree_when_one_cannot_run_the_stage_kernel():
     """rank 1's stage launches never become resident (forced): every rank must leave its launch of that layer and run ordinary rounds
     -- same messages as the unsharded proof, no hang"""

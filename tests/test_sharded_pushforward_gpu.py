@@ -93,6 +93,21 @@ def test_sharded_pushforward_matches_unsharded(world, x_log, d_log, nbits, dist_
         assert calls > x_log      # the round sums (and the re-spread halves) really went through the communicator
 
 
+def _claims_worker_q(rank, world, q, tag, x_log, d_log, nbits, dist_min):
+    _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q)
+
+
+@pytest.mark.parametrize("x_log,d_log,nbits,dist_min", [(6, 2, 32, 2), (8, 4, 64, 0)])
+def test_sharded_pushforward_world_8(x_log, d_log, nbits, dist_min):
+    """8 ranks x 2 windows as 4 processes x 2 rank threads (tests/rank_threads.py): the halves of every logup-tree level cross both
+    kinds of peers -- threads of the same process (reached by address) and other processes (HIP IPC)"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rank_threads import run_ranks
+    res = run_ranks(_claims_worker_q, 8, ("w8-%d-%d" % (os.getpid(), x_log), x_log, d_log, nbits, dist_min), threads_per_proc=2)
+    for rank, ok, info, calls in res:
+        assert calls > x_log
+
+
 def test_sharded_pushforward_when_one_rank_cannot_export_its_buffers():
     """gm_comm::pull_dev answers "unavailable" on EVERY rank when one of them cannot export (or open) an IPC mapping -- devices hidden
     from each other, IPC switched off -- and the argument stages that redistribution through the host instead: same result, no hang"""

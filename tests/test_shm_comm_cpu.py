@@ -44,7 +44,7 @@ def _worker(rank, world, name, q):
         q.put((rank, repr(e) + traceback.format_exc(), False, 0))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_shm_comm_field_sums_and_large_gather(world):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from pyref import field as F
@@ -74,6 +74,41 @@ def test_shm_comm_field_sums_and_large_gather(world):
         for it, got in sums:
             assert got == want[it], "rank %d, call %d" % (rank, it)
     assert not os.path.exists("/dev/shm" + name), "the name is removed once every rank has attached"
+
+
+def test_shm_comm_ranks_as_threads_of_one_process():
+    """8 ranks as threads of this process (one process driving every GPU of a node): every thread attaches under its own rank"""
+    import queue
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    q = queue.Queue()
+    name = "/gm-test-thr-%d" % os.getpid()
+    th = [threading.Thread(target=_worker, args=(r, 8, name, q)) for r in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    res = sorted(q.get_nowait() for _ in range(8))
+    for rank, sums, ok_big, calls in res:
+        assert isinstance(sums, list), "rank %d: %s" % (rank, sums)
+        assert ok_big and calls == 301
+    assert all(res[r][1] == res[0][1] for r in range(8))
+
+
+def test_shm_comm_leaves_no_name_behind_when_a_rank_never_attaches():
+    """advisor r03: rank 0 created the object, rank 1 never came -- the failure path must remove /dev/shm/<name> (O_EXCL would
+    refuse the next job of that name otherwise)"""
+    sys.path.insert(0, ROOT)
+    from gkr_msm_amd import dist as gd, ffi
+    name = "/gm-test-orphan-%d" % os.getpid()
+    ffi.lib().gm_set_wait_timeout_ms(200)
+    try:
+        with pytest.raises(Exception) as e:
+            gd.ShmComm(name, 0, 2)
+        assert "attached" in str(e.value)
+        assert not os.path.exists("/dev/shm" + name)
+    finally:
+        ffi.lib().gm_set_wait_timeout_ms(20000)
 
 
 def _lonely(name, q):
