@@ -499,6 +499,49 @@ __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* _
     }
 }
 
+// bintree levels 0 AND 1 in one pass: a lane gathers up to four affine points, adds the two pairs (level 0) and adds their sums (level
+// 1), and writes ONE level-1 cell.  The level-0 cells never go to memory: the unfused pair writes 2^(x + 5) of them (108 bytes each)
+// and reads them back -- 3.6 of the 9.3 GB the level kernels move per step at config B.  Same operations on the same operands in
+// the same order as k_add_level0 followed by k_add_level: the same field elements.
+//   off0: layout of the cells (level-0 input), off1: level-0 output = level-1 input, off2: level-1 output; br: block rows of off2
+__global__ void __launch_bounds__(128) k_add_level01(const Fr* __restrict__ points_xy, const uint32_t* __restrict__ cells,
+                                                      const uint32_t* __restrict__ off0, const uint32_t* __restrict__ off1,
+                                                      const uint32_t* __restrict__ off2, uint32_t nrows, uint32_t* __restrict__ ox,
+                                                      uint32_t* __restrict__ oy, uint32_t* __restrict__ oz, const uint32_t* __restrict__ br) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = off2[nrows];
+    if (j >= total) return;
+    const uint32_t r = find_row_tab(off2, nrows, br, j);
+    const uint32_t q = j - off2[r];
+    const uint32_t half1 = (off1[r + 1] - off1[r]) >> 1;
+    if (q >= half1) {
+        pt9_store_raw9(ox, oy, oz, j, pt9_identity());
+        return;
+    }
+    const uint32_t in0 = off0[r], half0 = (off0[r + 1] - in0) >> 1;
+    Point9 pq[2];
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        const uint32_t c = 2 * q + h;   // level-0 output cell of this row
+        if (c < half0) {
+            const uint32_t i0 = cells[(uint64_t)in0 + 2 * c], i1 = cells[(uint64_t)in0 + 2 * c + 1];
+            const Fr9 x1 = fr9_load(points_xy + 2ull * i0), y1 = fr9_load(points_xy + 2ull * i0 + 1);
+            Fr9 x2, y2;
+            if (i1 != PAD_IDX) {
+                x2 = fr9_load(points_xy + 2ull * i1);
+                y2 = fr9_load(points_xy + 2ull * i1 + 1);
+            } else {
+                x2 = fr9_zero();
+                y2 = fr9_one();
+            }
+            pq[h] = aff_add9(x1, y1, x2, y2);
+        } else {
+            pq[h] = pt9_identity();
+        }
+    }
+    pt9_store_raw9(ox, oy, oz, j, proj_add9(pq[0], pq[1]));
+}
+
 // bintree level >= 1
 __global__ void __launch_bounds__(128) k_add_level(const uint32_t* __restrict__ ix, const uint32_t* __restrict__ iy, const uint32_t* __restrict__ iz,
                             const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
@@ -1076,13 +1119,6 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
                            p->bsum[1], p->bsum[2]);
         GM_LAUNCH_CHECK();
     } else {
-        STAGE_MARK(4);
-        hipLaunchKernelGGL(k_add_level0, dim3(ceil_div(cap_out, 128)), dim3(128), 0, s, pts, p->cells, p->off[0],
-                           p->off[0] + stride, nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2], p->blk_row + p->blk_first[0]);
-        GM_LAUNCH_CHECK();
-        STAGE_MARK(5);
-        // (A first row-owned kernel for the trailing levels, one workgroup per row, was measured and dropped in round 1: its lanes
-        // idled.  k_add_tail gives every LANE a row and adds the identity with 5 multiplications instead of 12.)
         // levels tail_L0 .. x_log - 1 by the row-owned tail kernel (k_add_tail) when at least three levels are left for it
         static const bool no_tail = [] { const char* e = getenv("GM_MSM_NO_TAIL"); return e && e[0] == '1'; }();
         uint32_t tail_L0 = 0;
@@ -1092,9 +1128,26 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
             if (tail_L0 > p->x_log - 4) tail_L0 = p->x_log - 4;
         }
         const uint32_t tail_level = tail_L0 ? tail_L0 : p->x_log - 1;
-        int cur_lvl = 0;
-        uint64_t cells_cur = cap_out;
-        for (uint32_t level = 1; level < tail_level; level++) {
+        // levels 0 and 1 fused (k_add_level01) whenever level 1 is a flat launch of its own; GM_MSM_FUSE01=0: the two launches (A/B)
+        static const bool fuse01_on = [] { const char* e = getenv("GM_MSM_FUSE01"); return !(e && e[0] == '0'); }();
+        const bool fuse01 = fuse01_on && tail_level >= 2 && p->blk_nlev >= 2;
+        p->fused01 = fuse01;
+        STAGE_MARK(4);
+        if (fuse01) {
+            const uint64_t cells1 = cap_out / 2 + nrows + 2;
+            hipLaunchKernelGGL(k_add_level01, dim3(ceil_div(cells1, 128)), dim3(128), 0, s, pts, p->cells, p->off[0], p->off[0] + stride,
+                               p->off[0] + 2ull * stride, nrows, p->lvl[1][0], p->lvl[1][1], p->lvl[1][2], p->blk_row + p->blk_first[1]);
+        } else {
+            hipLaunchKernelGGL(k_add_level0, dim3(ceil_div(cap_out, 128)), dim3(128), 0, s, pts, p->cells, p->off[0],
+                               p->off[0] + stride, nrows, p->lvl[0][0], p->lvl[0][1], p->lvl[0][2], p->blk_row + p->blk_first[0]);
+        }
+        GM_LAUNCH_CHECK();
+        STAGE_MARK(5);
+        // (A first row-owned kernel for the trailing levels, one workgroup per row, was measured and dropped in round 1: its lanes
+        // idled.  k_add_tail gives every LANE a row and adds the identity with 5 multiplications instead of 12.)
+        int cur_lvl = fuse01 ? 1 : 0;
+        uint64_t cells_cur = fuse01 ? cap_out / 2 + nrows + 2 : cap_out;
+        for (uint32_t level = fuse01 ? 2 : 1; level < tail_level; level++) {
             const uint64_t cells_next = cells_cur / 2 + nrows + 2;
             hipLaunchKernelGGL(k_add_level, dim3(ceil_div(cells_next, 128)), dim3(128), 0, s, p->lvl[cur_lvl][0],
                                p->lvl[cur_lvl][1], p->lvl[cur_lvl][2], p->off[0] + (uint64_t)level * stride,

@@ -24,6 +24,7 @@ struct gm_msm_plan {
     Fr* win_pts = nullptr;
     Fr* tri_scratch = nullptr;
     uint64_t cap0, cap1;  // cell capacity of level buffers
+    bool fused01 = false;  // the last run added levels 0 and 1 in one launch (k_add_level01)
     size_t bytes = 0;
     // stage timing (bench only): events bracket the stages of gm_msm_run on the launch stream
     int prof_mode = 0;  // 0 off, 1 dominant kernel only (level-0 add), 2 all stages

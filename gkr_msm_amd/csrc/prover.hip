@@ -2017,6 +2017,18 @@ int32_t tape_wp(void* ctx, const uint64_t* aff, uint64_t n) {
     return t->cb_rc;
 }
 
+// The reference's tracing spans of Pippenger::prove (pippenger.rs:121-159: "prove image part", the phase-2 commitments, "prove
+// pushforward", "open") of the calling thread's last proof, in milliseconds of host wall time; every span ends with results on the
+// host, so no extra synchronisation is needed to attribute it.  [0] image part, [1] phase-2 commitments, [2] pushforward,
+// [3] opening witnesses + commitment combinations, [4] MultiOpenReduction, [5] Knuckles opening.
+struct ProveSpans {
+    double ms[8] = {0};
+    double t = 0;
+    static ProveSpans& get() { static thread_local ProveSpans s; return s; }
+    void start() { for (double& v : ms) v = 0; t = LayerClock::now(); }
+    void end(int i) { const double n = LayerClock::now(); ms[i] += (n - t) / 1e3; t = n; }
+};
+
 int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
                         const uint64_t* d_kn_inverses, const uint64_t* h_k, Tape* tr, uint64_t* h_pair) {
     const gm_msm_plan* plan = st->plan;
@@ -2027,6 +2039,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     GM_REQUIRE(y_log >= clm, "commitment_log_multiplicity exceeds y_logsize");
     StageTimer timer("prove", s);
     auto stage = [&](const char* name) { timer.mark(name); };
+    ProveSpans::get().start();
     // phase-1 commitments onto the transcript (pippenger.rs:131-136)
     tr->write_points(st->comm_c.data(), n_mat);
     tr->write_points(st->comm_d.data(), n_mat);
@@ -2042,6 +2055,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
     TRY(image_part_core(st->w, tr, &c));
     stage("image part");
+    ProveSpans::get().end(0);
     // commit phase 2 (second_phase, pushforward.rs:596-605): msm_nonaff of the outer buckets with the eq tables
     std::vector<uint64_t> comm_cp(12 * (size_t)n_mat), comm_dp(12 * (size_t)n_mat);
     {
@@ -2069,6 +2083,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     tr->write_points(comm_cp.data(), n_mat);
     tr->write_points(comm_dp.data(), n_mat);
     stage("phase-2 commitments");
+    ProveSpans::get().end(1);
     // prove pushforward
     Fr gamma;
     Claims mx, acc, acd;
@@ -2076,6 +2091,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     TRY(pushforward_prove(plan, st->d_points_xy, y_log, reinterpret_cast<const uint64_t*>(c.point.data()),
                           reinterpret_cast<const uint64_t*>(c.evs.data()), tr, &gamma, &mx, &acc, &acd, s, &cols));
     stage("pushforward");
+    ProveSpans::get().end(2);
     // ---- open (pippenger.rs:162-286)
     const Fr p_folded_ev = mx.evs[0], c_pull_ev = mx.evs[1], d_pull_ev = mx.evs[2], c_ev = mx.evs[3], d_ev = mx.evs[4];
     const uint32_t nv = x_log + clm;
@@ -2135,6 +2151,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     GM_LAUNCH_CHECK();
     GM_HIP(hipStreamSynchronize(s));  // multirow (host) is consumed
     stage("opening witnesses");
+    ProveSpans::get().end(3);
     // MultiOpenReduction (pippenger.rs:224-258)
     std::vector<Fr> mo_evs = {fr_sub(p_folded_ev, fr_mul(gamma, gamma)), acc.evs[0], acd.evs[0], combined_ev};
     const uint64_t* wcols[4] = {(const uint64_t*)w0.p, (const uint64_t*)w1.p, (const uint64_t*)w2.p, (const uint64_t*)w3.p};
@@ -2142,6 +2159,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
     TRY(multiopen_core(tr, nv, 4, wcols, reinterpret_cast<const uint64_t*>(pts.data()), reinterpret_cast<const uint64_t*>(mo_evs.data()),
                        &mo_pt, &mo_out, s));
     stage("multi-open reduction");
+    ProveSpans::get().end(4);
     Fr q;
     TRY(tr->challenge(&q));
     Us qs;
@@ -2164,6 +2182,7 @@ int32_t pippenger_prove(const gm_pippenger_wg* st, const uint64_t* h_claim_point
                             reinterpret_cast<const uint64_t*>(mo_pt.data()), reinterpret_cast<const uint64_t*>(&open_ev), fc_aff,
                             &adapter, proof, h_pair, stream));
     stage("knuckles open");
+    ProveSpans::get().end(5);
     if (tr->cb_rc) return set_err(GM_ERR_STATE, "transcript callback failed with %d", tr->cb_rc);
     return GM_OK;
 }
@@ -2280,6 +2299,7 @@ int32_t pippenger_prove_sharded(const gm_pippenger_wg* st, const uint64_t* h_cla
     GM_REQUIRE(y_log >= clm, "commitment_log_multiplicity exceeds y_logsize");
     StageTimer timer("prove (sharded)", s);
     auto stage = [&](const char* name) { timer.mark(name); };
+    ProveSpans::get().start();
     tr->write_points(st->comm_c.data(), n_mat);
     tr->write_points(st->comm_d.data(), n_mat);
     tr->write_points(st->comm_p0, 1);
@@ -2293,6 +2313,7 @@ int32_t pippenger_prove_sharded(const gm_pippenger_wg* st, const uint64_t* h_cla
     memcpy(c.evs.data(), h_claim_evs, 32 * c.evs.size());
     TRY(image_part_core(st->w, tr, &c));
     stage("image part");
+    ProveSpans::get().end(0);
     // commit phase 2: the eq-weighted MSMs over this rank's PARTIAL outer buckets, combined
     std::vector<uint64_t> comm_cp(12 * (size_t)n_mat), comm_dp(12 * (size_t)n_mat);
     {
@@ -2329,12 +2350,14 @@ int32_t pippenger_prove_sharded(const gm_pippenger_wg* st, const uint64_t* h_cla
     tr->write_points(comm_cp.data(), n_mat);
     tr->write_points(comm_dp.data(), n_mat);
     stage("phase-2 commitments");
+    ProveSpans::get().end(1);
     Fr gamma;
     Claims mx, acc, acd;
     PfCols cols;
     TRY(pushforward_prove_sharded(plan, st->d_points_xy, y_log, sh, reinterpret_cast<const uint64_t*>(c.point.data()),
                                   reinterpret_cast<const uint64_t*>(c.evs.data()), tr, &gamma, &mx, &acc, &acd, s, &cols));
     stage("pushforward");
+    ProveSpans::get().end(2);
     // ---- open (pippenger.rs:162-286) on slices
     const Fr p_folded_ev = mx.evs[0], c_pull_ev = mx.evs[1], d_pull_ev = mx.evs[2], c_ev = mx.evs[3], d_ev = mx.evs[4];
     const uint32_t nv = x_log + clm;
@@ -2423,12 +2446,14 @@ int32_t pippenger_prove_sharded(const gm_pippenger_wg* st, const uint64_t* h_cla
         GM_HIP(hipStreamSynchronize(s));   // share / stage_buf go out of scope; multirow (host) is consumed
     }
     stage("opening witnesses");
+    ProveSpans::get().end(3);
     std::vector<Fr> mo_evs = {fr_sub(p_folded_ev, fr_mul(gamma, gamma)), acc.evs[0], acd.evs[0], combined_ev};
     const uint64_t* wcols[4] = {(const uint64_t*)w0.p, (const uint64_t*)w1.p, (const uint64_t*)w2.p, (const uint64_t*)w3.p};
     std::vector<Fr> mo_pt, mo_out;
     TRY(multiopen_core(tr, nv, 4, wcols, reinterpret_cast<const uint64_t*>(pts.data()), reinterpret_cast<const uint64_t*>(mo_evs.data()),
                        &mo_pt, &mo_out, s, sh));
     stage("multi-open reduction");
+    ProveSpans::get().end(4);
     Fr q;
     TRY(tr->challenge(&q));
     Us qs;
@@ -2450,6 +2475,7 @@ int32_t pippenger_prove_sharded(const gm_pippenger_wg* st, const uint64_t* h_cla
                                     reinterpret_cast<const uint64_t*>(mo_pt.data()), reinterpret_cast<const uint64_t*>(&open_ev), fc_aff,
                                     &adapter, proof, h_pair, stream));
     stage("knuckles open");
+    ProveSpans::get().end(5);
     if (tr->cb_rc) return set_err(GM_ERR_STATE, "transcript callback failed with %d", tr->cb_rc);
     return GM_OK;
 }
@@ -2592,6 +2618,12 @@ extern "C" int32_t gm_pippenger_sharded_key_ranges(uint32_t x_logsize, uint32_t 
     const uint64_t N = cm * X, total = 2 * N - 1, S = 2 * N / world, b = rank * S;
     first4[3] = b;
     count4[3] = b >= total ? 0 : (total - b < S ? total - b : S);
+    return GM_OK;
+}
+
+extern "C" int32_t gm_pippenger_last_spans(double* out8) {
+    GM_REQUIRE(out8, "null argument");
+    memcpy(out8, ProveSpans::get().ms, 8 * sizeof(double));
     return GM_OK;
 }
 

@@ -165,6 +165,7 @@ _SIGS = {
                                             u64p, vp]),
     "gm_multiopen_prove": (C.c_int32, [C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, u64p, u64p, vp]),
     "gm_multiopen_prove_tr": (C.c_int32, [C.c_uint32, C.c_uint32, vp, vp, vp, C.POINTER(GmTranscript), vp, vp, u64p, u64p, vp]),
+    "gm_pippenger_last_spans": (C.c_int32, [C.POINTER(C.c_double)]),
     "gm_pippenger_wg_create": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(vp), vp]),
     "gm_pippenger_wg_destroy": (C.c_int32, [vp]),
     "gm_pippenger_wg_witness": (C.c_int32, [vp, C.POINTER(vp)]),

@@ -566,6 +566,17 @@ class PippengerWGSharded(PippengerWG):
                                                         C.byref(self.h), cur_stream()))
 
 
+def pippenger_prove_tr(wg, claim_point, claim_evs, d_kn_inverses, k, transcript):
+    """gm_pippenger_prove_tr on a PippengerWG (sharded or not) -> dict(pair, rounds, n_challenges, call_s)"""
+    cp, ce, kk = fr_arg(claim_point), fr_arg(claim_evs), fr_arg([k])
+    pair = np.zeros(24, dtype=np.uint64)
+    used, rounds = C.c_uint64(), C.c_uint64()
+    t0 = time.perf_counter()
+    ffi.check(wg.L.gm_pippenger_prove_tr(wg.h, cp.ctypes.data, ce.ctypes.data, _p(d_kn_inverses), kk.ctypes.data, C.byref(transcript.c),
+                                         pair.ctypes.data, C.byref(used), C.byref(rounds)))
+    return dict(pair=tuple(codec.g1_aff_from_limbs(pair)), rounds=rounds.value, n_challenges=used.value, call_s=time.perf_counter() - t0)
+
+
 class LiveTranscript:
     """A gm_transcript whose callbacks run Python code: `on_write(list of canonical ints)` and `draw() -> int`.
     Stands in for the Rust shim's wrappers over ProofTranscript2 (tests drive it from a tape or a hash)."""
@@ -604,15 +615,73 @@ class LiveTranscript:
         self.c = ffi.GmTranscript(None, self._w, self._c, self._pt)
 
 
+class MerlinTranscript:
+    """The library's ProofTranscript2 clone (gm_merlin_*, csrc/merlin.hip) as a gm_transcript: real Fiat-Shamir -- every message is
+    absorbed into STROBE-128 / Keccak-f[1600] and every challenge squeezed from it, inside the prover's round loop, with no Python
+    on the path (the callbacks are the library's own functions)"""
+
+    def __init__(self, label=b"gkr-msm"):
+        self.L = ffi.lib()
+        self.h = C.c_void_p()
+        ffi.check(self.L.gm_merlin_create(label, len(label), C.byref(self.h)))
+        self.c = ffi.GmTranscript()
+        ffi.check(self.L.gm_merlin_transcript(self.h, C.byref(self.c)))
+
+    def proof(self):
+        pp, pn = C.c_void_p(), C.c_uint64()
+        ffi.check(self.L.gm_merlin_proof(self.h, C.byref(pp), C.byref(pn)))
+        return C.string_at(pp, pn.value)
+
+    def close(self):
+        if self.h:
+            self.L.gm_merlin_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def prove_image_part_tr(w, claim_point, claim_evs, transcript):
     cp, ce = fr_arg(claim_point), fr_arg(claim_evs)
     fpt = np.zeros((64, 4), dtype=np.uint64)
     fev = np.zeros((8, 4), dtype=np.uint64)
     used, rounds, npt = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    t0 = time.perf_counter()
     ffi.check(w.L.gm_pip_prove_image_part_tr(w.h, cp.ctypes.data, ce.ctypes.data, C.byref(transcript.c), fpt.ctypes.data,
                                              C.byref(npt), fev.ctypes.data, C.byref(used), C.byref(rounds)))
+    call_s = time.perf_counter() - t0
     return dict(point=codec.from_mont_limbs(fpt[: npt.value]), evs=codec.from_mont_limbs(fev[:3]), n_challenges=used.value,
-                rounds=rounds.value)
+                rounds=rounds.value, call_s=call_s)
+
+
+def pushforward_prove_tr(plan, d_points, y_logsize, claim_point, claim_evs, transcript):
+    """gm_pushforward_prove_tr: the argument under the caller's live transcript -> dict(rounds, n_challenges, call_s)"""
+    L = ffi.lib()
+    x, d = plan.x_logsize, plan.d_logsize
+    cp, ce = fr_arg(claim_point), fr_arg(claim_evs)
+    g = np.zeros((1, 4), dtype=np.uint64)
+    mp, me = np.zeros((x + y_logsize, 4), dtype=np.uint64), np.zeros((5, 4), dtype=np.uint64)
+    cpt, cev = np.zeros((max(x, 1), 4), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64)
+    dpt, dev = np.zeros((max(d, 1), 4), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64)
+    used, rounds = C.c_uint64(), C.c_uint64()
+    t0 = time.perf_counter()
+    ffi.check(L.gm_pushforward_prove_tr(plan.h, C.c_void_p(d_points.data_ptr()), y_logsize, cp.ctypes.data, ce.ctypes.data,
+                                        C.byref(transcript.c), g.ctypes.data, mp.ctypes.data, me.ctypes.data, cpt.ctypes.data,
+                                        cev.ctypes.data, dpt.ctypes.data, dev.ctypes.data, C.byref(used), C.byref(rounds), cur_stream()))
+    return dict(rounds=rounds.value, n_challenges=used.value, call_s=time.perf_counter() - t0)
+
+
+def pippenger_last_spans():
+    """wall time of the calling thread's last gm_pippenger_prove(_tr) by the reference's tracing spans (pippenger.rs:121-159), ms"""
+    o = (C.c_double * 8)()
+    ffi.check(ffi.lib().gm_pippenger_last_spans(o))
+    names = ("prove_image_part_ms", "commit_phase_2_ms", "prove_pushforward_ms", "open_witnesses_ms", "open_multiopen_ms", "open_knuckles_ms")
+    d = {k: round(o[i], 2) for i, k in enumerate(names)}
+    d["open_ms"] = round(o[3] + o[4] + o[5], 2)
+    return d
 
 
 def gkr_msm_prove_tr(d_points, d_bits_u8, log_num_points, log_num_scalar_bits, transcript):
@@ -622,12 +691,14 @@ def gkr_msm_prove_tr(d_points, d_bits_u8, log_num_points, log_num_scalar_bits, t
     fpt = np.zeros((64, 4), dtype=np.uint64)
     fev = np.zeros((8, 4), dtype=np.uint64)
     used, rounds, npt = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    t0 = time.perf_counter()
     ffi.check(L.gm_gkr_msm_prove_tr(C.c_void_p(d_points.data_ptr()), C.c_void_p(d_bits_u8.data_ptr()), log_num_points,
                                     log_num_scalar_bits, C.byref(transcript.c), outp.ctypes.data, fpt.ctypes.data,
                                     C.byref(npt), fev.ctypes.data, C.byref(used), C.byref(rounds), cur_stream()))
+    call_s = time.perf_counter() - t0
     return dict(output=[codec.from_mont_limbs(outp[c * nout:(c + 1) * nout]) for c in range(3)],
                 point=codec.from_mont_limbs(fpt[: npt.value]), evs=codec.from_mont_limbs(fev[:3]), n_challenges=used.value,
-                rounds=rounds.value)
+                rounds=rounds.value, call_s=call_s)
 
 
 def gkr_msm_prove(d_points, d_bits_u8, log_num_points, log_num_scalar_bits, tape, msgs_cap=1 << 18):

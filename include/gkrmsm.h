@@ -627,6 +627,10 @@ int32_t gm_pippenger_wg_create_sharded(const gm_msm_plan* plan, const uint64_t* 
 int32_t gm_pippenger_sharded_key_ranges(uint32_t x_logsize, uint32_t d_logsize, uint32_t y_logsize,
                                         uint32_t commitment_log_multiplicity, uint32_t rank, uint32_t world, uint64_t* first4,
                                         uint64_t* count4);
+/* The calling thread's last gm_pippenger_prove(_tr) by the reference's tracing spans (pippenger.rs:121-159), milliseconds of host
+ * wall time: out8 = {prove image part, phase-2 commitments, prove pushforward, open: witnesses + commitment combinations, open:
+ * MultiOpenReduction, open: Knuckles, 0, 0}. */
+int32_t gm_pippenger_last_spans(double* out8);
 int32_t gm_pippenger_wg_destroy(gm_pippenger_wg* wg);
 int32_t gm_pippenger_wg_witness(const gm_pippenger_wg* wg, const gm_pip_witness** w);
 int32_t gm_pippenger_prove(const gm_pippenger_wg* wg, const uint64_t* h_claim_point, const uint64_t* h_claim_evs,
