@@ -118,11 +118,12 @@ SEED = 0x474B524D534D      # "GKRMSM"
 
 # HBM traffic per launch of the dominant kernels at config B from the committed PMC passes (profiles/r03/*_pmc_hbm.csv:
 # (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction); None for any other shape
+PMC_FETCH_FACTOR_GATHER = 1    # 64-byte gathers: FETCH_SIZE reads the bytes exactly (scripts/ubench/fetch_size_gather.hip, profiles/r04)
 PMC_TRAFFIC_MSM_B = None
 PMC_TRAFFIC_GE1_B = None   # bytes per step of all k_add_level + k_add_tail launches together
 PMC_TRAFFIC_SC_B = {}      # kernel name -> bytes per launch (profiles/r03/prover_pmc_per_launch.json, written by scripts/summarise_profiles.py)
 try:
-    _pj = [os.path.join(ROOT, "profiles", r_, "prover_pmc_per_launch.json") for r_ in ("r03", "r02")]
+    _pj = [os.path.join(ROOT, "profiles", r_, "prover_pmc_per_launch.json") for r_ in ("r04", "r03", "r02")]
     with open([p_ for p_ in _pj if os.path.exists(p_)][0]) as _f:
         PMC_TRAFFIC_SC_B = json.load(_f)
     PMC_TRAFFIC_MSM_B = PMC_TRAFFIC_SC_B.get("k_add_level0")
@@ -424,6 +425,8 @@ def main():
         ffi.check(L.gm_msm_profile(plan.h, 2))
         step()
         ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
+        # ("add_level0" / "add_levels_ge1" keep their names: with levels 0 and 1 fused -- the default, see roofline.kernel -- the first
+        # is the fused launch and the second the levels from 2 on)
         stages = dict(zip(["digits", "histogram", "chunk_scan_offsets", "scatter", "add_level0", "add_levels_ge1", "triangle"],
                           [round(float(v), 4) for v in prof]))
         ffi.check(L.gm_msm_profile(plan.h, 0))
@@ -433,15 +436,46 @@ def main():
         # (2 x 4 B), one projective point written (96 B); cells = windows * N / 2.  Field multiplications: 8 per level-0 add,
         # 12 per add above (shared sub-products; the layer-by-layer evaluation needs 9 / 13).
         cells0 = wpr * n // 2
-        alg_bytes = cells0 * (128 + 8 + 96)
-        fr_mul0 = cells0 * 8
         fr_mul_step = cells0 * 8 + (cells0 - (wpr << d_log)) * 12 if cells0 > (wpr << d_log) else cells0 * 8
+        fz = C.c_int32(0)
+        ffi.check(L.gm_msm_run_info(plan.h, C.byref(fz)))
+        fused = bool(fz.value)
+        try:
+            cells = (C.c_uint64 * (x_log + 1))()
+            ffi.check(L.gm_msm_level_cells(plan.h, cells, x_log + 1, harness.cur_stream()))
+            adds = [int(cells[l]) // 2 for l in range(1, x_log)]     # adds[0] = additions of level 1, ...
+        except Exception:
+            adds = []
+        if fused and adds:
+            # k_add_level01: bintree levels 0 and 1 in one launch.  Algorithmic bytes per launch (SURVEY 8(d) units): every level-0 addition
+            # gathers two affine points (2 x 64 B) and two cell indices (2 x 4 B); the level-0 cells never exist; every level-1 cell is one
+            # projective point written (96 B; 108 as stored, in the 9 x 29 cell form).  8 field multiplications per level-0 addition, 12 per
+            # level-1 addition.
+            dom_name = "k_add_level01 (bintree levels 0 + 1 fused)"
+            alg_bytes = cells0 * (128 + 8) + int(cells[2]) * 96
+            fr_mul0 = cells0 * 8 + adds[0] * 12
+            first_ge = 2
+            traffic_dom = PMC_TRAFFIC_SC_B.get("k_add_level01")
+            traffic_rest = PMC_TRAFFIC_SC_B.get("k_add_levels_ge2_per_step")
+        else:
+            # algorithmic bytes of one k_add_level0 launch: per output cell 2 gathered affine points (2 x 64 B), 2 cell indices
+            # (2 x 4 B), one projective point written (96 B); cells = windows * N / 2.  Field multiplications: 8 per level-0 add,
+            # 12 per add above (shared sub-products; the layer-by-layer evaluation needs 9 / 13).
+            dom_name = "k_add_level0"
+            alg_bytes = cells0 * (128 + 8 + 96)
+            fr_mul0 = cells0 * 8
+            first_ge = 1
+            traffic_dom = PMC_TRAFFIC_MSM_B
+            traffic_rest = PMC_TRAFFIC_GE1_B
         roofline = None
         if dom:
             ach = alg_bytes / (dom * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_add_level0", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": PMC_TRAFFIC_MSM_B if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None,
+                        "traffic": traffic_dom if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None,
+                        "traffic_note": "PMC bytes per launch = (FETCH_SIZE x %s + WRITE_SIZE) x 1024: this kernel's reads are 64-byte gathers, for which "
+                                        "FETCH_SIZE reads the bytes exactly (profiles/r04/fetch_size_gather_factors.json: factor 1.00-1.06; the x 2 of "
+                                        "the guide is for 16 B / lane coalesced streams)" % PMC_FETCH_FACTOR_GATHER,
                         "avg_launch_ms": round(dom, 4), "algorithmic_bytes_per_launch": alg_bytes, "fr_mul_per_launch": fr_mul0,
                         "fr_mul_per_s": round(fr_mul0 / (dom * 1e-3), 1),
                         "valu_frac_of_measured_ceiling": round(fr_mul0 / (dom * 1e-3) / FR9_MUL_CEILING, 3)}
@@ -454,28 +488,26 @@ def main():
                                             "frac": round(alg_bytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                             "fr_mul_per_s": round(fr_mul0 / (alone * 1e-3), 1),
                                             "valu_frac_of_measured_ceiling": round(fr_mul0 / (alone * 1e-3) / FR9_MUL_CEILING, 3)}
-        # the level kernels above level 0 (k_add_level on the flat levels, k_add_tail on the late ones), summed over their launches of
-        # one step: by time they are the largest stage.  Algorithmic bytes per addition as SURVEY 8(d): two projective points read
-        # (2 x 96 B), one written (96 B); 12 field multiplications.  Exact pair counts from the row layouts of the run.
+        # the level kernels above (k_add_level on the flat levels, k_add_tail on the late ones), summed over their launches of one step.
+        # Algorithmic bytes per addition as SURVEY 8(d): two projective points read (2 x 96 B), one written (96 B); 12 field
+        # multiplications.  Exact pair counts from the row layouts of the run.
         roofline_ge1 = None
         try:
-            cells = (C.c_uint64 * (x_log + 1))()
-            ffi.check(L.gm_msm_level_cells(plan.h, cells, x_log + 1, harness.cur_stream()))
-            adds = [int(cells[l]) // 2 for l in range(1, x_log)]
+            rest = adds[first_ge - 1:]
             t_ge1 = stages["add_levels_ge1"]
-            if t_ge1 > 0 and adds:
-                tot_adds = sum(adds)
+            if t_ge1 > 0 and rest:
+                tot_adds = sum(rest)
                 b_ge1 = tot_adds * 288
                 m_ge1 = tot_adds * 12
                 ach1 = b_ge1 / (t_ge1 * 1e-3) / 1e9
-                roofline_ge1 = {"bound": "hbm", "kernel": "k_add_level (levels 1..%d) + k_add_tail (the late levels)" % (x_log - 1),
+                roofline_ge1 = {"bound": "hbm", "kernel": "k_add_level (levels %d..) + k_add_tail (the late levels, to %d)" % (first_ge, x_log - 1),
                                 "achieved": round(ach1, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach1 / HBM_PEAK_GBS, 4),
-                                "traffic": PMC_TRAFFIC_GE1_B if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None,
+                                "traffic": traffic_rest if (x_log, d_log, nbits, wpr) == (20, 8, 256, 32) else None,
                                 "ms_per_step": round(t_ge1, 4), "additions_per_step": tot_adds, "algorithmic_bytes_per_step": b_ge1,
                                 "fr_mul_per_step": m_ge1, "fr_mul_per_s": round(m_ge1 / (t_ge1 * 1e-3), 1),
                                 "valu_frac_of_measured_ceiling": round(m_ge1 / (t_ge1 * 1e-3) / FR9_MUL_CEILING, 3),
-                                "largest_levels_additions": adds[:4],
-                                "note": "unoverlapped (the untimed stage-breakdown pass); launches: levels 1..L0-1 flat, one k_add_tail for the rest"}
+                                "largest_levels_additions": rest[:4],
+                                "note": "unoverlapped (the untimed stage-breakdown pass); flat launches up to level x - d - 3, one k_add_tail for the rest"}
         except Exception as e:
             roofline_ge1 = {"error": repr(e)[:200]}
         res = {"x_logsize": x_log, "value": round(n * steps / dt, 1), "ms_per_step": round(ms_per_step, 4), "roofline_levels_ge1": roofline_ge1,

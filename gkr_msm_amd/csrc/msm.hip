@@ -1043,6 +1043,14 @@ extern "C" int32_t gm_msm_profile_read(gm_msm_plan* p, float* h_ms, int32_t n) {
 
 extern "C" size_t gm_msm_plan_workspace_bytes(const gm_msm_plan* p) { return p ? p->bytes : 0; }
 
+// how the plan's last gm_msm_run was launched: *fused01 = 1 when bintree levels 0 and 1 ran as one kernel (k_add_level01: stage
+// "add_level0" of gm_msm_profile_read then covers both levels and "add_levels_ge1" the levels from 2 on)
+extern "C" int32_t gm_msm_run_info(const gm_msm_plan* p, int32_t* fused01) {
+    GM_REQUIRE(p && fused01, "null argument");
+    *fused01 = p->fused01 ? 1 : 0;
+    return GM_OK;
+}
+
 extern "C" int32_t gm_msm_level_cells(const gm_msm_plan* p, uint64_t* h_cells, uint32_t n, void* stream) {
     GM_REQUIRE(p && h_cells && n >= p->x_log + 1, "need x_logsize + 1 counts");
     std::vector<uint32_t> v(p->x_log + 1, 0u);
@@ -1161,9 +1169,9 @@ extern "C" int32_t gm_msm_run(gm_msm_plan* p, const uint64_t* d_points_xy, const
         // (a row-owned workgroup per row spent 86 us here with one busy lane in 64)
         if (tail_L0) {
             LvlBufs lb;
+            // level l reads buffer (l - 1) & 1: that is cur_lvl here (level 0 wrote buffer 0; the fused first launch wrote level 1's buffer)
             for (int b = 0; b < 2; b++)
                 for (int c = 0; c < 3; c++) lb.c[b][c] = p->lvl[b][c];
-            // level l reads buffer (l - 1) & 1: that is cur_lvl here (level 0 wrote buffer 0)
             const uint32_t n_thin = ceil_div(nrows, 64);
             hipLaunchKernelGGL(k_add_tail, dim3(n_thin + GM_TAIL_FAT_WAVES), dim3(64), 0, s, lb, p->off[0], nrows, tail_L0, p->x_log, n_thin,
                                p->bsum[0], p->bsum[1], p->bsum[2]);

@@ -211,6 +211,7 @@ _SIGS = {
     "gm_msm_phase1_polys": (C.c_int32, [vp, vp, vp, vp, vp, vp]),
     "gm_msm_second_phase": (C.c_int32, [vp, vp, C.c_uint32, vp, vp, vp]),
     "gm_msm_profile": (C.c_int32, [vp, C.c_int32]),
+    "gm_msm_run_info": (C.c_int32, [vp, C.POINTER(C.c_int32)]),
     "gm_msm_profile_read": (C.c_int32, [vp, C.POINTER(C.c_float), C.c_int32]),
     "gm_msm_level_cells": (C.c_int32, [vp, u64p, C.c_uint32, vp]),
     "gm_msm_combine_host": (C.c_int32, [vp, C.c_uint32, C.c_uint32, vp]),

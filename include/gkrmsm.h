@@ -253,6 +253,9 @@ int32_t gm_msm_second_phase(const gm_msm_plan* plan, const uint64_t* h_r, uint32
  * offsets, scatter, level-0 add, levels >= 1, bucket reduction; -1 where not recorded). */
 int32_t gm_msm_profile(gm_msm_plan* plan, int32_t mode);
 int32_t gm_msm_profile_read(gm_msm_plan* plan, float* h_ms, int32_t n);
+/* how the last gm_msm_run was launched: *fused01 = 1 when bintree levels 0 and 1 ran as ONE kernel (k_add_level01; GM_MSM_FUSE01=0
+ * switches that off): stage 4 of gm_msm_profile_read then covers both levels, stage 5 the levels from 2 on. */
+int32_t gm_msm_run_info(const gm_msm_plan* p, int32_t* fused01);
 /* cells of the row layout of every level of the LAST run (x_logsize + 1 counts: level l's input layout, pad cells included;
  * level l >= 1 adds h_cells[l] / 2 pairs); synchronises the stream.  Bench accounting of the level kernels' bytes and products. */
 int32_t gm_msm_level_cells(const gm_msm_plan* plan, uint64_t* h_cells, uint32_t n, void* stream);
