@@ -355,7 +355,9 @@ def main():
         # Depth: 2 steps in flight when a step is milliseconds of large kernels; 4 when a rank's share is small (x_logsize 20 over
         # 8 ranks: ~25 launches of 10-200 us, a 0.93 ms dependency chain for 0.5 ms of work -- measured on one GPU with
         # scripts/quick_rank_share_time.py: 0.97 ms unpipelined, 0.66 ms at depth 2, 0.55 ms at depth 4).
-        depth = int(os.environ.get("GM_BENCH_DEPTH", "0")) or (4 if (world > 1 and wpr * n <= (1 << 24)) else 2)
+        # (round 4, same script, with levels 0 + 1 fused: 8 ranks' share 0.472 ms at depth 4, 0.402 at 6, 0.391 at 8 against 2.86 / 8 = 0.358
+        # for perfect scaling of the one-GPU step; 4 ranks' share 0.776 / 0.719 / 0.720; 2 ranks' 1.50 / 1.38 / 1.37)
+        depth = int(os.environ.get("GM_BENCH_DEPTH", "0")) or (2 if world == 1 or wpr * n > (1 << 24) else (8 if wpr * n <= (1 << 22) else 6))
         plans = [plan] + [harness.MsmPlan(x_log, d_log, y_size, y0, y1) for _ in range(depth - 1)]
         streams = [torch.cuda.Stream() for _ in range(depth)]
         recv = [torch.empty(world * ncols * wpr * 4, dtype=torch.int64, device="cuda") for _ in range(depth)] if rcomm is not None else None

@@ -43,7 +43,7 @@ ffi.check(L.gm_msm_profile_read(plan.h, prof, 7))
 print(dict(zip(["digits", "histogram", "chunk_scan_offsets", "scatter", "add_level0", "add_levels_ge1", "triangle"], [round(float(v), 4) for v in prof])))
 
 # pipelined over `depth` plans / streams, as bench.py's timed loop (without the all-gather)
-for depth in (2, 3, 4):
+for depth in (2, 4, 6, 8):
     plans = [plan] + [harness.MsmPlan(x_log, d_log, y_size, y0, y1) for _ in range(depth - 1)]
     streams = [torch.cuda.Stream() for _ in range(depth)]
     for pl, st in zip(plans, streams):
