@@ -11,6 +11,7 @@
 #include <tuple>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "../../include/gkrmsm.h"
 
@@ -71,6 +72,68 @@ struct DevPool {
     size_t idle_bytes = 0;
     uint64_t n_driver_allocs = 0, driver_alloc_bytes = 0;  // pool misses (diagnostics)
     static constexpr size_t SMALL = (size_t)1 << 20;
+    // ---- reserved slabs (gm_reserve): memory taken from the driver ONCE, at set-up time, that the pool cuts its blocks from.  The
+    // driver hands out memory at ~25-40 GiB/s (a gen-1 proof at 2^20 x 2^8 allocates 120 GiB: 5 s on its first call against 0.33 s
+    // in steady state; the whole gen-2 proof 0.2 s against 0.18), so a prover that proves ONCE pays several times its proving time
+    // for allocation unless the cost moves to where the SRS load already is.  First fit over a list of free ranges per slab; blocks
+    // go back to their slab only in release() (behind a device synchronisation, as hipFree implies one) -- between releases a freed
+    // block idles under its (device, thread, class) key exactly like a driver block.
+    struct Slab {
+        char* base = nullptr;
+        size_t bytes = 0;
+        int dev = 0;
+        std::map<size_t, size_t> free_;   // offset -> length
+    };
+    std::vector<Slab> slabs;
+    std::unordered_map<void*, int> slab_of;   // blocks cut from a slab (live or idle) -> slab index
+    size_t slab_bytes = 0, slab_used = 0;
+    uint64_t n_slab_cuts = 0;
+    static bool& no_slab() { static thread_local bool v = false; return v; }   // ExportableScope: allocations that must be driver blocks
+    hipError_t reserve(size_t bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        Slab sl;
+        bytes = (bytes + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc((void**)&sl.base, bytes);
+        if (e != hipSuccess) return e;
+        sl.bytes = bytes; sl.dev = dev; sl.free_[0] = bytes;
+        std::lock_guard<std::mutex> g(mu);
+        slabs.push_back(sl);
+        slab_bytes += bytes;
+        return hipSuccess;
+    }
+    void* slab_cut(int dev, size_t b) {   // mu held; b is a multiple of 256
+        for (size_t i = 0; i < slabs.size(); i++) {
+            Slab& sl = slabs[i];
+            if (sl.dev != dev) continue;
+            for (auto it = sl.free_.begin(); it != sl.free_.end(); ++it) {
+                if (it->second < b) continue;
+                const size_t off = it->first, len = it->second;
+                sl.free_.erase(it);
+                if (len > b) sl.free_[off + b] = len - b;
+                void* p = sl.base + off;
+                slab_of[p] = (int)i;
+                slab_used += b;
+                n_slab_cuts++;
+                return p;
+            }
+        }
+        return nullptr;
+    }
+    void slab_return(void* p, size_t b) {   // mu held
+        auto so = slab_of.find(p);
+        Slab& sl = slabs[so->second];
+        size_t off = (size_t)(static_cast<char*>(p) - sl.base), len = b;
+        auto nx = sl.free_.lower_bound(off);
+        if (nx != sl.free_.end() && off + len == nx->first) { len += nx->second; nx = sl.free_.erase(nx); }
+        if (nx != sl.free_.begin()) {
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == off) { off = pv->first; len += pv->second; sl.free_.erase(pv); }
+        }
+        sl.free_[off] = len;
+        slab_used -= b;
+        slab_of.erase(so);
+    }
     hipError_t alloc(void** out, size_t b) {
         // small blocks: power-of-two classes from 256 bytes (the provers create and drop hundreds of few-KiB buffers per
         // proof; hipMalloc costs tens of microseconds and hipFree synchronises the device); large ones: 2 MiB granules
@@ -96,6 +159,13 @@ struct DevPool {
                 idle_bytes -= b;
                 idle.erase(it);
                 return hipSuccess;
+            }
+            if (!slabs.empty() && !no_slab()) {
+                if (void* p = slab_cut(dev, b)) {
+                    *out = p;
+                    live[p] = Block{b, dev};
+                    return hipSuccess;
+                }
             }
         }
         hipError_t e = hipMalloc(out, b);
@@ -135,8 +205,38 @@ struct DevPool {
             take.swap(idle);
             idle_bytes = 0;
         }
+        std::vector<std::pair<void*, size_t>> to_slab;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (auto it = take.begin(); it != take.end();) {
+                if (slab_of.count(it->second)) { to_slab.emplace_back(it->second, std::get<2>(it->first)); it = take.erase(it); }
+                else ++it;
+            }
+        }
+        if (!to_slab.empty()) {
+            (void)hipDeviceSynchronize();   // back into a slab: the next cut may hand the range to another thread / stream
+            std::lock_guard<std::mutex> g(mu);
+            for (auto& pb : to_slab) slab_return(pb.first, pb.second);
+        }
         for (auto& kv : take) (void)hipFree(kv.second);
     }
+    // give the slabs back to the driver; false when blocks cut from them are still live
+    bool unreserve() {
+        release();
+        std::lock_guard<std::mutex> g(mu);
+        if (!slab_of.empty()) return false;
+        for (Slab& sl : slabs) (void)hipFree(sl.base);
+        slabs.clear();
+        slab_bytes = slab_used = 0;
+        return true;
+    }
+};
+// allocations made inside the scope are driver blocks of their own even when slabs are reserved: buffers a rank EXPORTS to its
+// peers (gm_comm::pull_dev opens the allocation a source lies in: a slab would export everything in it)
+struct ExportableScope {
+    bool prev;
+    ExportableScope() : prev(DevPool::no_slab()) { DevPool::no_slab() = true; }
+    ~ExportableScope() { DevPool::no_slab() = prev; }
 };
 inline DevPool& dev_pool() {
     static DevPool p;

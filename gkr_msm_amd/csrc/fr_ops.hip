@@ -174,6 +174,28 @@ extern "C" int32_t gm_stream_sync(void* stream) { GM_HIP(hipStreamSynchronize(as
 extern "C" int32_t gm_malloc(void** out, size_t bytes) { GM_REQUIRE(out, "null out"); GM_HIP(hipMalloc(out, bytes ? bytes : 16)); return GM_OK; }
 extern "C" int32_t gm_free(void* p) { GM_HIP(hipFree(p)); return GM_OK; }
 extern "C" int32_t gm_release_cached_memory(void) { gm::dev_pool().release(); return GM_OK; }
+// Take `bytes` of device memory from the driver NOW (set-up time, like loading the SRS) for the library's pool to cut its blocks
+// from: the first proof then allocates at pool speed instead of the driver's ~25-40 GiB/s (DevPool, common.hpp).  Per device
+// (gm_set_device); may be called more than once; requests the slabs cannot serve fall back to the driver.
+extern "C" int32_t gm_reserve(uint64_t bytes) {
+    GM_REQUIRE(bytes >= 256, "nothing to reserve");
+    hipError_t e = gm::dev_pool().reserve((size_t)bytes);
+    if (e != hipSuccess) return gm::set_err(GM_ERR_HIP, "gm_reserve(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return GM_OK;
+}
+extern "C" int32_t gm_unreserve(void) {
+    if (!gm::dev_pool().unreserve()) return gm::set_err(GM_ERR_STATE, "gm_unreserve: blocks cut from the reserved memory are still in use (destroy the handles first)");
+    return GM_OK;
+}
+// out8 = {driver allocations so far, their bytes, bytes idling in the pool, bytes reserved, of which cut, blocks cut from the reserve so far, 0, 0}
+extern "C" int32_t gm_memory_stats(uint64_t* out8) {
+    GM_REQUIRE(out8, "null argument");
+    gm::DevPool& p = gm::dev_pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    out8[0] = p.n_driver_allocs; out8[1] = p.driver_alloc_bytes; out8[2] = p.idle_bytes; out8[3] = p.slab_bytes; out8[4] = p.slab_used;
+    out8[5] = p.n_slab_cuts; out8[6] = out8[7] = 0;
+    return GM_OK;
+}
 extern "C" int32_t gm_memcpy_h2d(void* d, const void* h, size_t bytes, void* stream) {
     GM_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, as_stream(stream)));
     GM_HIP(hipStreamSynchronize(as_stream(stream)));

@@ -451,7 +451,11 @@ int32_t knuckles_open_sharded(const Shard& sh, const gm_key_view* key, const uin
 
     // the polynomial, re-spread from slices of N / G to this rank's S = 2 (N / G) entries of the 2N array (zeros from N on)
     DevBuf ta, tb, halo, pol, quo;
-    TRY(ta.alloc(S * sizeof(Fr))); TRY(tb.alloc(S * sizeof(Fr))); TRY(halo.alloc(S * sizeof(Fr))); TRY(pol.alloc(S * sizeof(Fr)));
+    {
+        ExportableScope exported;   // the passes read halos of each other's ta / tb (dist_read)
+        TRY(ta.alloc(S * sizeof(Fr))); TRY(tb.alloc(S * sizeof(Fr)));
+    }
+    TRY(halo.alloc(S * sizeof(Fr))); TRY(pol.alloc(S * sizeof(Fr)));
     TRY(dist_read(sh, reinterpret_cast<const Fr*>(d_poly_slice), SL, (int64_t)base, S, pol.fr(), &host_staged, s));
     GM_HIP(hipMemcpyAsync(ta.p, pol.p, S * sizeof(Fr), hipMemcpyDeviceToDevice, s));
     // ---- compute_t (knuckles.rs:111-154)

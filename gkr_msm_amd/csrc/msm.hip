@@ -499,6 +499,23 @@ __global__ void k_add_level0(const Fr* __restrict__ points_xy, const uint32_t* _
     }
 }
 
+// level-0 output cell c of a row (cells in0 .., `half0` pairs): the sum of its two gathered points, or the image of the row pad
+__device__ __forceinline__ Point9 level0_cell(const Fr* __restrict__ points_xy, const uint32_t* __restrict__ cells, uint32_t in0,
+                                              uint32_t half0, uint32_t c) {
+    if (c >= half0) return pt9_identity();
+    const uint32_t i0 = cells[(uint64_t)in0 + 2 * c], i1 = cells[(uint64_t)in0 + 2 * c + 1];
+    const Fr9 x1 = fr9_load(points_xy + 2ull * i0), y1 = fr9_load(points_xy + 2ull * i0 + 1);
+    Fr9 x2, y2;
+    if (i1 != PAD_IDX) {
+        x2 = fr9_load(points_xy + 2ull * i1);
+        y2 = fr9_load(points_xy + 2ull * i1 + 1);
+    } else {
+        x2 = fr9_zero();
+        y2 = fr9_one();
+    }
+    return aff_add9(x1, y1, x2, y2);
+}
+
 // bintree levels 0 AND 1 in one pass: a lane gathers up to four affine points, adds the two pairs (level 0) and adds their sums (level
 // 1), and writes ONE level-1 cell.  The level-0 cells never go to memory: the unfused pair writes 2^(x + 5) of them (108 bytes each)
 // and reads them back -- 3.6 of the 9.3 GB the level kernels move per step at config B.  Same operations on the same operands in
@@ -519,27 +536,11 @@ __global__ void __launch_bounds__(128) k_add_level01(const Fr* __restrict__ poin
         return;
     }
     const uint32_t in0 = off0[r], half0 = (off0[r + 1] - in0) >> 1;
-    Point9 pq[2];
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
-        const uint32_t c = 2 * q + h;   // level-0 output cell of this row
-        if (c < half0) {
-            const uint32_t i0 = cells[(uint64_t)in0 + 2 * c], i1 = cells[(uint64_t)in0 + 2 * c + 1];
-            const Fr9 x1 = fr9_load(points_xy + 2ull * i0), y1 = fr9_load(points_xy + 2ull * i0 + 1);
-            Fr9 x2, y2;
-            if (i1 != PAD_IDX) {
-                x2 = fr9_load(points_xy + 2ull * i1);
-                y2 = fr9_load(points_xy + 2ull * i1 + 1);
-            } else {
-                x2 = fr9_zero();
-                y2 = fr9_one();
-            }
-            pq[h] = aff_add9(x1, y1, x2, y2);
-        } else {
-            pq[h] = pt9_identity();
-        }
-    }
-    pt9_store_raw9(ox, oy, oz, j, proj_add9(pq[0], pq[1]));
+    // (two calls of one inlined helper, NOT a loop over an array of two points: indexed by the loop variable the array lived in
+    // scratch memory -- 216 bytes per lane written and read back, WRITE_SIZE 2.72 GB per launch for 0.92 GB of cells: profiles/r04)
+    const Point9 p0 = level0_cell(points_xy, cells, in0, half0, 2 * q);
+    const Point9 p1 = level0_cell(points_xy, cells, in0, half0, 2 * q + 1);
+    pt9_store_raw9(ox, oy, oz, j, proj_add9(p0, p1));
 }
 
 // bintree level >= 1

@@ -1268,7 +1268,10 @@ int32_t sharded_access_counts(const gm_msm_plan* plan, const Shard& sh, Fr* d_c,
     const uint64_t X = 1ull << plan->x_log, D = 1ull << plan->d_log, L = X + D;
     const uint32_t G = sh.world;
     DevBuf part, parts;
-    TRY(part.alloc(L * sizeof(Fr)));
+    {
+        ExportableScope exported;   // a pull source: a driver block of its own, not a cut of a reserved slab
+        TRY(part.alloc(L * sizeof(Fr)));
+    }
     TRY(gm_msm_phase1_polys(plan, (uint64_t*)d_c, (uint64_t*)d_d, (uint64_t*)part.p, (uint64_t*)(part.fr() + X), reinterpret_cast<void*>(s)));
     TRY(parts.alloc((uint64_t)G * L * sizeof(Fr)));
     std::vector<gm_pull> pc(G);
@@ -1323,8 +1326,12 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     Arena tree_arena;
     const size_t slab_want = (size_t)32 * (2 * ML + 16 * dist_min * G) + ((size_t)1 << 18), slab_cap = (size_t)1 << 30;
     const size_t slab_bytes = no_slab ? 0 : (slab_want < slab_cap ? slab_want : slab_cap);
-    if (slab_bytes) TRY(tree_arena.init(slab_bytes));
+    if (slab_bytes) {
+        ExportableScope exported;
+        TRY(tree_arena.init(slab_bytes));
+    }
     auto mk_tree = [&](uint64_t n, std::shared_ptr<DevBuf>* b) -> int32_t {
+        ExportableScope exported;   // every level of the tree is a pull source
         b->reset(new DevBuf());
         if (slab_bytes && n * sizeof(Fr) <= slab_bytes / 8) {
             if (void* p = tree_arena.carve(n * sizeof(Fr))) {
@@ -2404,7 +2411,10 @@ int32_t pippenger_prove_sharded(const gm_pippenger_wg* st, const uint64_t* h_cla
     // the four opening witnesses: this rank's slice [base, base + SL) of each (zero-padded to 2^nv)
     DevBuf w0, w1, w2, w3, d_multirow, folded;
     TRY(w0.alloc(SL * sizeof(Fr))); TRY(w1.alloc(SL * sizeof(Fr))); TRY(w2.alloc(SL * sizeof(Fr))); TRY(w3.alloc(SL * sizeof(Fr)));
-    TRY(folded.alloc(SL * sizeof(Fr)));
+    {
+        ExportableScope exported;   // the Knuckles opening re-spreads it over the ranks (dist_read)
+        TRY(folded.alloc(SL * sizeof(Fr)));
+    }
     hipLaunchKernelGGL(k_pp_axpy_slice, dim3(ceil_div(SL, 256)), dim3(256), 0, s, st->p0->fr(), st->p1->fr(), gamma, X, base, SL, w0.fr());
     GM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pp_pad_slice, dim3(ceil_div(SL, 256)), dim3(256), 0, s, cols.ac_c_p, X, base, SL, w1.fr());
@@ -2423,7 +2433,10 @@ int32_t pippenger_prove_sharded(const gm_pippenger_wg* st, const uint64_t* h_cla
         const uint32_t rem0 = narrow ? (plan->y0 & (cm - 1)) : 0;
         const uint64_t len_g = (uint64_t)(narrow ? W : cm) << x_log;
         DevBuf share, stage_buf;
-        TRY(share.alloc(len_g * sizeof(Fr)));
+        {
+            ExportableScope exported;
+            TRY(share.alloc(len_g * sizeof(Fr)));
+        }
         hipLaunchKernelGGL(k_pp_combined_part, dim3(ceil_div(len_g, 256)), dim3(256), 0, s, cols.c->fr(), cols.d->fr(), cols.c_pull->fr(),
                            cols.d_pull->fr(), d_multirow.fr(), us, x_log, plan->y0, plan->y1, clm, rem0, len_g, share.fr());
         GM_LAUNCH_CHECK();

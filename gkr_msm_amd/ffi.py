@@ -96,6 +96,9 @@ _SIGS = {
     "gm_malloc": (C.c_int32, [C.POINTER(vp), C.c_size_t]),
     "gm_free": (C.c_int32, [vp]),
     "gm_release_cached_memory": (C.c_int32, []),
+    "gm_reserve": (C.c_int32, [C.c_uint64]),
+    "gm_unreserve": (C.c_int32, []),
+    "gm_memory_stats": (C.c_int32, [u64p]),
     "gm_set_wait_timeout_ms": (C.c_int32, [C.c_uint32]),
     "gm_stage_slots": (C.c_int32, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gm_sc_profile": (C.c_int32, [C.c_int32]),

@@ -49,6 +49,15 @@ int32_t gm_free(void* d_ptr);
 /* Handles and workspaces keep the large device blocks they free on an idle list (re-allocating freshly freed HBM is slow
  * and hipFree synchronises); this returns the idle blocks to the driver. */
 int32_t gm_release_cached_memory(void);
+/* gm_reserve: take `bytes` of device memory from the driver now -- set-up time, next to the SRS load -- for the library's pool to cut
+ * its blocks from.  The driver hands memory out at ~25-40 GiB/s, so a process's FIRST proof otherwise pays for every byte of its
+ * trace (gen-1 at 2^20 x 2^8: 5.0 s against 0.33 s in steady state).  Per device; additive; what the reserve cannot serve still
+ * comes from the driver.  gm_unreserve gives the reserve back (GM_ERR_STATE while handles hold blocks of it).
+ * gm_memory_stats: out8 = {driver allocations so far, their bytes, bytes idling in the pool, bytes reserved, of which in use, blocks
+ * cut from the reserve so far, 0, 0}. */
+int32_t gm_reserve(uint64_t bytes);
+int32_t gm_unreserve(void);
+int32_t gm_memory_stats(uint64_t* out8);
 /* Small sumcheck rounds keep kernels WAITING on the device for the caller's next challenge (a one-wave gate in front of a
  * pre-enqueued fold; the persistent tail-round kernel), and the host waits for their results.  Every such wait is bounded: after
  * `ms` milliseconds (default 20000; 0 restores the default) the waiting kernel flags a status word and leaves, and the call in

@@ -4,7 +4,7 @@
 # scripts/summarise_profiles.py turns them into profiles/rNN/*.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/${1:-r03_prof}
+OUT=$R/gpurun_out/${1:-r04_prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_kt -- python3 $R/bench.py > $OUT/bench_profiled_run.json 2> $OUT/bench_kt.log || exit 1
