@@ -678,31 +678,43 @@ struct StageArgs {
     uint64_t* d_dbg;                   // development aid: phase time stamps (nullptr normally)
 };
 
+// The stage kernel's products.  k_stage<3> is 51 000 instructions (400 KB) with every product inlined, and blocks of different segments
+// / parts share an instruction cache; ONE out-of-line copy of the multiplier (-DGM_STAGE_MUL_OUTLINE: a call costs a handful of
+// instructions against the product's 302) was measured in round 4 and LOSES: image part 49.9-50.8 ms against 48.7-49.0 inlined (best of
+// 8, same box) -- the calls' argument moves sit on every round's dependent chain, and a non-inlined function in the module costs the
+// medium-round kernels a wave of occupancy.  Inlined it stays.
+#ifdef GM_STAGE_MUL_OUTLINE
+__device__ __attribute__((noinline)) Fr fr_mul_s(Fr a, Fr b) { return fr_mul(a, b); }
+#else
+__device__ __forceinline__ Fr fr_mul_s(const Fr& a, const Fr& b) { return fr_mul(a, b); }
+#endif
+__device__ __forceinline__ Fr fr_mul_by_d_s(const Fr& x) { return fr_mul_s(x, fr_coeff_d()); }
+
 // one part of a split segment (segfn.hip.h): its share of sum_o gamma^o f_o; G(k, x) = gamma^(out0 + k) x
 __device__ __forceinline__ Fr stage_part_eval(int prim, int out0, const Fr* v, const Fr* __restrict__ gp) {
-    auto G = [&](int k, const Fr& x) -> Fr { return out0 + k == 0 ? x : fr_mul(fr_load(gp + out0 + k), x); };
+    auto G = [&](int k, const Fr& x) -> Fr { return out0 + k == 0 ? x : fr_mul_s(fr_load(gp + out0 + k), x); };
     auto x5 = [](const Fr& x) -> Fr { return fr_add(fr_dbl(fr_dbl(x)), x); };   // -a x, a = -5
     switch (prim) {
-        case FN_P_PROJ_L1_A: return fr_mul(v[0], fr_add(G(0, v[2]), x5(G(2, v[1]))));          // v0, v3, v4
-        case FN_P_PROJ_L1_B: return fr_mul(v[0], fr_add(G(1, v[1]), G(2, v[2])));              // v1, v3, v4
-        case FN_P_PROJ_L1_C: return G(3, fr_mul(v[0], v[1]));                                  // v2, v5
-        case FN_P_PROJ_L2_A: return fr_add(G(0, fr_mul(fr_add(v[0], v[1]), v[2])), G(3, fr_mul(v[0], v[1])));   // v0, v1, v3
-        case FN_P_PROJ_L2_B: return fr_mul(v[1], fr_add(G(1, v[0]), G(2, v[1])));              // v2, v3
-        case FN_P_PROJ_L3_A: return G(0, fr_mul(fr_sub(v[1], fr_mul_by_d(v[2])), v[0]));       // v0, v2, v3
-        case FN_P_PROJ_L3_B: return G(1, fr_mul(fr_add(v[1], fr_mul_by_d(v[2])), v[0]));       // v1, v2, v3
+        case FN_P_PROJ_L1_A: return fr_mul_s(v[0], fr_add(G(0, v[2]), x5(G(2, v[1]))));          // v0, v3, v4
+        case FN_P_PROJ_L1_B: return fr_mul_s(v[0], fr_add(G(1, v[1]), G(2, v[2])));              // v1, v3, v4
+        case FN_P_PROJ_L1_C: return G(3, fr_mul_s(v[0], v[1]));                                  // v2, v5
+        case FN_P_PROJ_L2_A: return fr_add(G(0, fr_mul_s(fr_add(v[0], v[1]), v[2])), G(3, fr_mul_s(v[0], v[1])));   // v0, v1, v3
+        case FN_P_PROJ_L2_B: return fr_mul_s(v[1], fr_add(G(1, v[0]), G(2, v[1])));              // v2, v3
+        case FN_P_PROJ_L3_A: return G(0, fr_mul_s(fr_sub(v[1], fr_mul_by_d_s(v[2])), v[0]));       // v0, v2, v3
+        case FN_P_PROJ_L3_B: return G(1, fr_mul_s(fr_add(v[1], fr_mul_by_d_s(v[2])), v[0]));       // v1, v2, v3
         case FN_P_PROJ_L3_C: {                                                                 // v2, v3
-            const Fr dxy = fr_mul_by_d(v[1]);
-            return G(2, fr_mul(fr_sub(v[0], dxy), fr_add(v[0], dxy)));
+            const Fr dxy = fr_mul_by_d_s(v[1]);
+            return G(2, fr_mul_s(fr_sub(v[0], dxy), fr_add(v[0], dxy)));
         }
-        case FN_P_AFF_L1_A: return fr_mul(v[0], fr_add(G(0, v[2]), x5(G(2, v[1]))));           // v0, v2, v3
-        case FN_P_AFF_L1_B: return fr_mul(v[0], fr_add(G(1, v[1]), G(2, v[2])));               // v1, v2, v3
-        case FN_P_LOGUP_A: return fr_mul(v[2], fr_add(G(0, v[0]), G(1, v[1])));                // v0, v1, v3
-        case FN_P_LOGUP_B: return G(0, fr_mul(v[0], v[1]));                                    // v1, v2
-        case FN_P_AFF_L3_A: return G(0, fr_mul(fr_sub(fr_one(), fr_mul_by_d(v[1])), v[0]));    // v0, v2
-        case FN_P_AFF_L3_B: return G(1, fr_mul(fr_add(fr_one(), fr_mul_by_d(v[1])), v[0]));    // v1, v2
+        case FN_P_AFF_L1_A: return fr_mul_s(v[0], fr_add(G(0, v[2]), x5(G(2, v[1]))));           // v0, v2, v3
+        case FN_P_AFF_L1_B: return fr_mul_s(v[0], fr_add(G(1, v[1]), G(2, v[2])));               // v1, v2, v3
+        case FN_P_LOGUP_A: return fr_mul_s(v[2], fr_add(G(0, v[0]), G(1, v[1])));                // v0, v1, v3
+        case FN_P_LOGUP_B: return G(0, fr_mul_s(v[0], v[1]));                                    // v1, v2
+        case FN_P_AFF_L3_A: return G(0, fr_mul_s(fr_sub(fr_one(), fr_mul_by_d_s(v[1])), v[0]));    // v0, v2
+        case FN_P_AFF_L3_B: return G(1, fr_mul_s(fr_add(fr_one(), fr_mul_by_d_s(v[1])), v[0]));    // v1, v2
         default: {                                                                             // FN_P_AFF_L3_C: v2
-            const Fr dxy = fr_mul_by_d(v[0]);
-            return G(2, fr_mul(fr_sub(fr_one(), dxy), fr_add(fr_one(), dxy)));
+            const Fr dxy = fr_mul_by_d_s(v[0]);
+            return G(2, fr_mul_s(fr_sub(fr_one(), dxy), fr_add(fr_one(), dxy)));
         }
     }
 }
@@ -747,7 +759,7 @@ __device__ __forceinline__ Fr stage_eval(const Seg& g, const Fr* p0, const Fr* p
     for (int q = 0; q < 4; q++)
         if (q < g.n_out) {
             const int oc = g.out0 + q;
-            A = fr_add(A, oc == 0 ? o[q] : fr_mul(fr_load(gp + oc), o[q]));
+            A = fr_add(A, oc == 0 ? o[q] : fr_mul_s(fr_load(gp + oc), o[q]));
         }
     return A;
 }
@@ -920,15 +932,15 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
             STAGE_STAMP(0);
             const Fr e0 = fr_load(a.thin_eq[tr]);
             Fr acc = fr_zero(), accw = fr_zero();
-            if (have) acc = fr_mul(stage_eval<MAXIN>(g, p0, p1, gp, h), fr_mul(e0, coef));
+            if (have) acc = fr_mul_s(stage_eval<MAXIN>(g, p0, p1, gp, h), fr_mul_s(e0, coef));
             // the tail weight W = sum_r coef[r] (1 - sum_{idx < seg_r} eq[idx]), get_trailing_sum (vecvec.rs:144-146): once per slice
-            if (blockIdx.x == 0 && r < a.nrows) accw = have ? fr_mul(coef, fr_sub(fr_one(), e0)) : coef;
+            if (blockIdx.x == 0 && r < a.nrows) accw = have ? fr_mul_s(coef, fr_sub(fr_one(), e0)) : coef;
             if (!exchange(acc, accw, blockIdx.x == 0, nsl * gridDim.x)) return;
             if (have) {   // bind_21 on a row of one pair: [p0 + t (p1 - p0), row_pad]
                 const Fr t = ts;
 #pragma unroll
                 for (int q = 0; q < MAXIN; q++)
-                    if (q < g.n_in) { p0[q] = fr_add(p0[q], fr_mul(t, fr_sub(p1[q], p0[q]))); p1[q] = a.row_pad.v[g.in[q]]; }
+                    if (q < g.n_in) { p0[q] = fr_add(p0[q], fr_mul_s(t, fr_sub(p1[q], p0[q]))); p1[q] = a.row_pad.v[g.in[q]]; }
             }
         }
         // bind_into_dense: the last fold above left the row's value in p0; absent cells are row_pad, absent rows col_pad
@@ -959,13 +971,13 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
     for (int dr = 0; dr < a.n_dense; dr++, round++) {
         STAGE_STAMP(0);
         Fr acc = fr_zero();
-        if (i < np) acc = fr_mul(stage_eval<MAXIN>(g, p0, p1, gp, h), fr_load(a.eq[dr] + (uint64_t)my_slice * np + i));
+        if (i < np) acc = fr_mul_s(stage_eval<MAXIN>(g, p0, p1, gp, h), fr_load(a.eq[dr] + (uint64_t)my_slice * np + i));
         if (!exchange(acc, fr_zero(), false, (merged || nsl == 1) ? gridDim.x : nsl * gridDim.x)) return;
         const Fr t = ts;
         if (i < np) {
 #pragma unroll
             for (int q = 0; q < MAXIN; q++)
-                if (q < g.n_in) xch[q][i] = fr_add(p0[q], fr_mul(t, fr_sub(p1[q], p0[q])));
+                if (q < g.n_in) xch[q][i] = fr_add(p0[q], fr_mul_s(t, fr_sub(p1[q], p0[q])));
         }
         __syncthreads();
         n_left = np;
@@ -1038,7 +1050,7 @@ __global__ void __launch_bounds__(256) k_dense_fold_gated(ColPtrs in, ColPtrsMut
     if (i >= n_out) return;
     const Fr* src = in.p[blockIdx.y];
     const Fr p0 = fr_load(src + 2 * i), p1 = fr_load(src + 2 * i + 1);
-    fr_store(out.p[blockIdx.y] + i, fr_add(p0, fr_mul(t, fr_sub(p1, p0))));
+    fr_store(out.p[blockIdx.y] + i, fr_add(p0, fr_mul_s(t, fr_sub(p1, p0))));
 }
 
 // ------------------------------------------------------------------------------------------ lean large-round kernels
@@ -1061,42 +1073,42 @@ __device__ __forceinline__ Fr lean_gamma_eval(const Fr* v, const Fr* __restrict_
     // the same re-association as lean_gamma_eval9 (every gamma power multiplies an input once): exact identities
     if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
         const Fr g2 = fr_load(g + 2);
-        const Fr g2v2 = fr_mul(g2, v[2]);
+        const Fr g2v2 = fr_mul_s(g2, v[2]);
         const Fr t1 = fr_add(v[3], fr_add(fr_dbl(fr_dbl(g2v2)), g2v2));                   // v3 + 5 g2 v2   (-a = 5)
-        const Fr t2 = fr_add(fr_mul(fr_load(g + 1), v[2]), fr_mul(g2, v[3]));
-        Fr A = fr_add(fr_mul(v[0], t1), fr_mul(v[1], t2));
+        const Fr t2 = fr_add(fr_mul_s(fr_load(g + 1), v[2]), fr_mul_s(g2, v[3]));
+        Fr A = fr_add(fr_mul_s(v[0], t1), fr_mul_s(v[1], t2));
         if (PRIM == LEAN_AFF_L1_BC) {
-            A = fr_add(A, fr_mul(fr_load(g + 3), fr_sub(fr_sqr(v[4]), v[4])));
-            A = fr_add(A, fr_mul(fr_load(g + 4), fr_sub(fr_sqr(v[5]), v[5])));
+            A = fr_add(A, fr_mul_s(fr_load(g + 3), fr_sub(fr_sqr(v[4]), v[4])));
+            A = fr_add(A, fr_mul_s(fr_load(g + 4), fr_sub(fr_sqr(v[5]), v[5])));
         }
         return A;
     } else if (PRIM == FN_AFF_L2) {
         Fr A = fr_add(v[0], v[1]);
-        A = fr_add(A, fr_mul(fr_load(g + 1), v[2]));
-        return fr_add(A, fr_mul(fr_mul(fr_load(g + 2), v[0]), v[1]));
+        A = fr_add(A, fr_mul_s(fr_load(g + 1), v[2]));
+        return fr_add(A, fr_mul_s(fr_mul_s(fr_load(g + 2), v[0]), v[1]));
     } else if (PRIM == FN_AFF_L3 || PRIM == FN_PROJ_L3) {
         const Fr dxy = fr_mul_by_d(v[PRIM == FN_AFF_L3 ? 2 : 3]);
         const Fr base = PRIM == FN_AFF_L3 ? fr_one() : v[2];
         const Fr m = fr_sub(base, dxy), q = fr_add(base, dxy);
-        const Fr A = fr_mul(m, fr_add(v[0], fr_mul(fr_load(g + 2), q)));
-        return fr_add(A, fr_mul(fr_load(g + 1), fr_mul(q, v[1])));
+        const Fr A = fr_mul_s(m, fr_add(v[0], fr_mul_s(fr_load(g + 2), q)));
+        return fr_add(A, fr_mul_s(fr_load(g + 1), fr_mul_s(q, v[1])));
     } else if (PRIM == FN_PROJ_L1) {
         const Fr g2 = fr_load(g + 2);
-        const Fr g2v3 = fr_mul(g2, v[3]);
+        const Fr g2v3 = fr_mul_s(g2, v[3]);
         const Fr t1 = fr_add(v[4], fr_add(fr_dbl(fr_dbl(g2v3)), g2v3));                   // v4 + 5 g2 v3
-        const Fr t2 = fr_add(fr_mul(fr_load(g + 1), v[3]), fr_mul(g2, v[4]));
-        const Fr A = fr_add(fr_mul(v[0], t1), fr_mul(v[1], t2));
-        return fr_add(A, fr_mul(fr_load(g + 3), fr_mul(v[2], v[5])));
+        const Fr t2 = fr_add(fr_mul_s(fr_load(g + 1), v[3]), fr_mul_s(g2, v[4]));
+        const Fr A = fr_add(fr_mul_s(v[0], t1), fr_mul_s(v[1], t2));
+        return fr_add(A, fr_mul_s(fr_load(g + 3), fr_mul_s(v[2], v[5])));
     } else if (PRIM == FN_PROJ_L2) {
-        const Fr u = fr_add(fr_add(v[0], v[1]), fr_add(fr_mul(fr_load(g + 1), v[2]), fr_mul(fr_load(g + 2), v[3])));
-        return fr_add(fr_mul(v[3], u), fr_mul(fr_load(g + 3), fr_mul(v[0], v[1])));
+        const Fr u = fr_add(fr_add(v[0], v[1]), fr_add(fr_mul_s(fr_load(g + 1), v[2]), fr_mul_s(fr_load(g + 2), v[3])));
+        return fr_add(fr_mul_s(v[3], u), fr_mul_s(fr_load(g + 3), fr_mul_s(v[0], v[1])));
     } else if (PRIM == FN_ADD_INVERSES) {
-        return fr_add(fr_add(v[0], v[1]), fr_mul(fr_mul(fr_load(g + 1), v[0]), v[1]));
+        return fr_add(fr_add(v[0], v[1]), fr_mul_s(fr_mul_s(fr_load(g + 1), v[0]), v[1]));
     } else if (PRIM == FN_LOGUP_LAYER) {
-        return fr_add(fr_mul(v[3], fr_add(v[0], fr_mul(fr_load(g + 1), v[1]))), fr_mul(v[1], v[2]));
+        return fr_add(fr_mul_s(v[3], fr_add(v[0], fr_mul_s(fr_load(g + 1), v[1]))), fr_mul_s(v[1], v[2]));
     } else {  // FN_PT_BIT_CHOICE: (b, x, y) -> (b x, b (y - 1) + 1): b (x + g1 (y - 1)) + g1
         const Fr g1 = fr_load(g + 1);
-        return fr_add(fr_mul(v[0], fr_add(v[1], fr_mul(g1, fr_sub(v[2], fr_one())))), g1);
+        return fr_add(fr_mul_s(v[0], fr_add(v[1], fr_mul_s(g1, fr_sub(v[2], fr_one())))), g1);
     }
 }
 
@@ -1114,7 +1126,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
     if (VECVEC) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
     }
     const uint64_t npairs = VECVEC ? (uint64_t)(vv.off[vv.nrows] >> 1) : npairs_dense;
@@ -1125,7 +1137,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
             // 13 dependent loads of a full binary search per pair stall the few resident waves; the coarse table brackets the
             // row to the rows that intersect one 256-cell block (one or two for long rows)
             const uint32_t r = vv.coarse ? find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0) : find_row(vv.off, vv.nrows, cell0);
-            w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
+            w = fr_mul_s(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
         } else {
             w = fr_load(eq + i);
         }
@@ -1137,7 +1149,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
                 const Fr p1 = fr_load(cols.p[q] + 2 * i + 1);
                 v[q] = h ? fr_sub(fr_dbl(p1), fr_load(cols.p[q] + 2 * i)) : p1;
             }
-            const Fr t = fr_mul(lean_gamma_eval<PRIM>(v, gp), w);
+            const Fr t = fr_mul_s(lean_gamma_eval<PRIM>(v, gp), w);
             if (h == 0) acc[0] = fr_add(acc[0], t); else acc[1] = fr_add(acc[1], t);
         }
     }
@@ -1155,7 +1167,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean_split(LeanCols c
     if (blockIdx.y == 0) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
     }
     const uint64_t npairs = (uint64_t)(vv.off[vv.nrows] >> 1);
@@ -1163,14 +1175,14 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean_split(LeanCols c
     for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
         const uint32_t cell0 = (uint32_t)(2 * i);
         const uint32_t r = vv.coarse ? find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0) : find_row(vv.off, vv.nrows, cell0);
-        const Fr w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
+        const Fr w = fr_mul_s(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
         Fr v[NI];
 #pragma unroll
         for (int q = 0; q < NI; q++) {
             const Fr p1 = fr_load(cols.p[q] + 2 * i + 1);
             v[q] = h ? fr_sub(fr_dbl(p1), fr_load(cols.p[q] + 2 * i)) : p1;
         }
-        acc[h] = fr_add(acc[h], fr_mul(lean_gamma_eval<PRIM>(v, gp), w));
+        acc[h] = fr_add(acc[h], fr_mul_s(lean_gamma_eval<PRIM>(v, gp), w));
     }
     block_reduce_finish<3>(acc, fc);
 }
@@ -1311,7 +1323,7 @@ __global__ void __launch_bounds__(SC_THREADS, 3) k_round_deg2_lean9(LeanCols col
     if (VECVEC) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
     }
     Fr9 a0 = fr9_zero(), a1 = fr9_zero();   // domain 241 (VecVec) / 246 (dense); normalised, S grows by <= 1.5 per pair
@@ -1367,7 +1379,7 @@ __global__ void __launch_bounds__(SC_THREADS, 2) k_round_deg2_lean9x2(LeanCols c
     if (VECVEC) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
     }
     Fr9x2 a = Fr9x2(fr9_zero());   // domain 241 (VecVec) / 246 (dense); normalised, S grows by <= 1.5 per pair
@@ -1411,7 +1423,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean9_split(LeanCols 
     if (blockIdx.y == 2) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
         block_reduce_finish<3>(acc, fc);
         return;
@@ -1463,7 +1475,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic3_lean(LeanCols col
                     v[q] = fr_add(p1, s == 1 ? d : fr_dbl(d));
                 }
             }
-            const Fr t = fr_mul(lean_gamma_eval<PRIM>(v, gp), v[NI]);
+            const Fr t = fr_mul_s(lean_gamma_eval<PRIM>(v, gp), v[NI]);
             if (s == 0) acc[0] = fr_add(acc[0], t);
             else if (s == 1) acc[1] = fr_add(acc[1], t);
             else acc[2] = fr_add(acc[2], t);
@@ -1488,7 +1500,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_prod3_lean(LeanCols cols, 
                     v[q] = fr_add(p1, s == 1 ? d : fr_dbl(d));
                 }
             }
-            const Fr t = fr_mul(fr_mul(v[0], v[1]), v[2]);
+            const Fr t = fr_mul_s(fr_mul_s(v[0], v[1]), v[2]);
             if (s == 0) acc[0] = fr_add(acc[0], t);
             else if (s == 1) acc[1] = fr_add(acc[1], t);
             else acc[2] = fr_add(acc[2], t);
@@ -1510,12 +1522,12 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_folded_prod(FoldedCols col
         for (int q = 0; q < nargs; q++) {
             const Fr a0 = fr_load(cols.p[q] + 2 * i), a1 = fr_load(cols.p[q] + 2 * i + 1);
             const Fr e0 = fr_load(cols.p[nargs + q] + 2 * i), e1 = fr_load(cols.p[nargs + q] + 2 * i + 1);
-            Fr t0 = fr_mul(a1, e1);
-            Fr t1 = fr_mul(fr_sub(fr_dbl(a1), a0), fr_sub(fr_dbl(e1), e0));
+            Fr t0 = fr_mul_s(a1, e1);
+            Fr t1 = fr_mul_s(fr_sub(fr_dbl(a1), a0), fr_sub(fr_dbl(e1), e0));
             if (q) {
                 const Fr g = fr_load(gp + q);
-                t0 = fr_mul(t0, g);
-                t1 = fr_mul(t1, g);
+                t0 = fr_mul_s(t0, g);
+                t1 = fr_mul_s(t1, g);
             }
             acc[0] = fr_add(acc[0], t0);
             acc[1] = fr_add(acc[1], t1);
@@ -1603,8 +1615,8 @@ __global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut o
         const Fr a0 = fr_load(in.p[c0] + in0 + 2 * p), a1 = fr_load(in.p[c0] + in0 + 2 * p + 1);
         Fr b0 = a0, b1 = a1;
         if (has1) { b0 = fr_load(in.p[c1] + in0 + 2 * p); b1 = fr_load(in.p[c1] + in0 + 2 * p + 1); }
-        fr_store(out.p[c0] + j, fr_add(a0, fr_mul(t, fr_sub(a1, a0))));
-        if (has1) fr_store(out.p[c1] + j, fr_add(b0, fr_mul(t, fr_sub(b1, b0))));
+        fr_store(out.p[c0] + j, fr_add(a0, fr_mul_s(t, fr_sub(a1, a0))));
+        if (has1) fr_store(out.p[c1] + j, fr_add(b0, fr_mul_s(t, fr_sub(b1, b0))));
     } else {
         fr_store(out.p[c0] + j, pad.v[c0]);
         if (has1) fr_store(out.p[c1] + j, pad.v[c1]);
@@ -1625,7 +1637,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_vv_fold_to_dense(ColPtrs in, Col
         if (len == 0) v = row_pad.v[c];
         else {
             const Fr p0 = fr_load(in.p[c] + in0), p1 = fr_load(in.p[c] + in0 + 1);
-            v = fr_add(p0, fr_mul(t, fr_sub(p1, p0)));
+            v = fr_add(p0, fr_mul_s(t, fr_sub(p1, p0)));
         }
     }
     fr_store(out.p[c] + r, v);
@@ -1655,7 +1667,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan 
 #pragma unroll
                     for (int q = 0; q < 3; q++) a[q] = fr_add(a[q], d[q]);
                 }
-                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul(fr_mul(a[0], a[1]), a[2]));
+                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul_s(fr_mul_s(a[0], a[1]), a[2]));
             }
         } else {
             const Fr e0 = fr_load(cols.p[ncols - 1] + 2 * i), e1 = fr_load(cols.p[ncols - 1] + 2 * i + 1);
@@ -1687,14 +1699,14 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan 
                     for (int q = 0; q < 4; q++)
                         if (q < g.n_out) {
                             const int oc = g.out0 + q;
-                            G[s] = fr_add(G[s], oc == 0 ? o[q] : fr_mul(fr_load(gp + oc), o[q]));
+                            G[s] = fr_add(G[s], oc == 0 ? o[q] : fr_mul_s(fr_load(gp + oc), o[q]));
                         }
                 }
             }
             Fr e = e1;
             for (int s = 0; s < s_hi; s++) {
                 if (s) e = fr_add(e, ed);
-                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul(G[s], e));
+                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul_s(G[s], e));
             }
         }
     }

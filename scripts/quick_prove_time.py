@@ -42,10 +42,15 @@ def ev(poly, pt):
     return cur[0]
 evs = [ev(o, r) for o in outs]
 tape = [int.from_bytes(pr.bytes(16), "little") for _ in range(4000)]
-for it in range(2):
+reps = int(os.environ.get("GM_QUICK_REPS", "2"))
+best = 1e9
+for it in range(reps):
     torch.cuda.synchronize()
-    t = time.time()
     res = w.prove_image_part(r, evs, tape)
-    dt = time.time() - t
-    print("prove image part %.1f ms: %d rounds, %d challenges, %d msgs -> %.0f rounds/s" % (
-        dt * 1e3, res["rounds"], res["tape_used"], len(res["msgs"]), res["rounds"] / dt))
+    dt = res["call_s"]
+    best = min(best, dt)
+    if it < 2 or it == reps - 1:
+        print("prove image part %.1f ms: %d rounds, %d challenges, %d msgs -> %.0f rounds/s" % (
+            dt * 1e3, res["rounds"], res["tape_used"], len(res["msgs"]), res["rounds"] / dt))
+if reps > 2:
+    print("best of %d: %.2f ms" % (reps, best * 1e3))
