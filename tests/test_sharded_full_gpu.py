@@ -65,6 +65,7 @@ def _proc(ranks, world, tag, shape, q, key_mode, env):
         assert ref["pair"][0] == G.mul(ref["pair"][1], tau), "the unsharded proof does not verify"
         torch.cuda.synchronize()
         results = {}
+        prove_ms = {}
 
         def run_rank(rank):
             try:
@@ -80,8 +81,11 @@ def _proc(ranks, world, tag, shape, q, key_mode, env):
                     wgs = H.PippengerWGSharded(plan_s, d_pts, y_log, clm, key, comm)
                     first, cnt = H.knuckles_slice_of(nv, rank, world)
                     d_inv_s = H.knuckles_setup_range(k, nv, first, cnt)
+                    import time as _t
+                    t0 = _t.perf_counter()
                     got = wgs.prove(claims[0], claims[1], d_inv_s, k, tape)
                     stream.synchronize()
+                    prove_ms[rank] = 1e3 * (_t.perf_counter() - t0)
                     bad = [kk for kk in ("msgs", "points", "pair", "tape_used", "rounds") if got[kk] != ref[kk]]
                     results[rank] = (not bad, "differs from the unsharded proof in %s" % bad if bad else "",
                                      sum(c for _, _, c in zip(key.keep, key.first, key.count)), comm.ipc_stats())
@@ -98,6 +102,9 @@ def _proc(ranks, world, tag, shape, q, key_mode, env):
             t.join()
         for rk in ranks:
             q.put((rk,) + results.get(rk, (False, "no result", 0, (0, 0, 0))) + (n_key,))
+        if os.environ.get("GM_TEST_SAY_TIMES"):
+            print("[sharded whole proof] ranks %s: prove %s ms (incl. Python marshalling), rounds %d, %d transcript scalars, %d points" % (
+                ranks, [round(prove_ms.get(rk, -1), 1) for rk in ranks], ref["rounds"], len(ref["msgs"]), len(ref["points"])), flush=True)
     except Exception as e:
         import traceback
         for rk in ranks:
@@ -164,3 +171,13 @@ def test_sharded_whole_proof_with_a_one_entry_ipc_cache_and_host_staging():
     assert any(ipc[1] > 0 for _, _, _, _, ipc, _ in res), "no mapping was ever evicted: the bound was not exercised"
     assert all(ipc[2] <= 2 for _, _, _, _, ipc, _ in res)      # what one call touched may stay, nothing more
     _run(4, (4, 2, 16, 2), "minimal", env={"GM_SHM_NO_IPC": "1"})
+
+
+def test_config_e_structure_at_x_logsize_14_over_eight_ranks():
+    """BASELINE.json configs[4]'s structure -- 32 windows of 8 bits, commitment_log_multiplicity 4, 8 ranks x 4 windows, every rank
+    holding only its key ranges -- at x_logsize 14 (2^19 matrix entries, 2^18-coefficient opening, a 2^19-point key): large enough for
+    the logup tree to stay distributed over several levels, for the opening's compute_t passes to read halos AND whole slices, and
+    for the stage kernel to run sharded; 4 processes x 2 rank threads on the one GPU.  The whole transcript and the pairing pair equal
+    the unsharded prover's on every rank."""
+    res = _run(8, (14, 8, 256, 4), "minimal", threads_per_proc=2, env=dict(MANY_QUEUES, GM_TEST_SAY_TIMES="1"))
+    assert all(kp < n_key for _, _, _, kp, _, n_key in res)
