@@ -85,7 +85,7 @@ for tag in ("msm", "prover", "g1"):
             if tot < 1e7:
                 continue
             out.write("%s,%d,%d,%d,%d,%d,%s\n" % (k, n, f1, w1, raw, cor, ("%.0f" % (tot / secs / 1e9)) if secs > 0 else ""))
-            if tag != "g1":
+            if tag != "g1" and k not in per_launch:   # (the prover's run also launches the MSM once: the MSM's own pass comes first and stays)
                 per_launch[k] = int(cor)
                 launches_of[k] = n
 
