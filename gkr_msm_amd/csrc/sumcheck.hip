@@ -680,9 +680,8 @@ struct StageArgs {
 
 // The stage kernel's products.  k_stage<3> is 51 000 instructions (400 KB) with every product inlined, and blocks of different segments
 // / parts share an instruction cache; ONE out-of-line copy of the multiplier (-DGM_STAGE_MUL_OUTLINE: a call costs a handful of
-// instructions against the product's 302) was measured in round 4 and LOSES: image part 49.9-50.8 ms against 48.7-49.0 inlined (best of
-// 8, same box) -- the calls' argument moves sit on every round's dependent chain, and a non-inlined function in the module costs the
-// medium-round kernels a wave of occupancy.  Inlined it stays.
+// instructions against the product's 302) was measured in round 4 and changes nothing: image part 49.1-49.9 ms against 48.8-50.3
+// inlined (best of 8, three alternating runs, same box) -- the instruction cache is not what a stage round waits for.  Inlined it stays.
 #ifdef GM_STAGE_MUL_OUTLINE
 __device__ __attribute__((noinline)) Fr fr_mul_s(Fr a, Fr b) { return fr_mul(a, b); }
 #else
@@ -1050,7 +1049,7 @@ __global__ void __launch_bounds__(256) k_dense_fold_gated(ColPtrs in, ColPtrsMut
     if (i >= n_out) return;
     const Fr* src = in.p[blockIdx.y];
     const Fr p0 = fr_load(src + 2 * i), p1 = fr_load(src + 2 * i + 1);
-    fr_store(out.p[blockIdx.y] + i, fr_add(p0, fr_mul_s(t, fr_sub(p1, p0))));
+    fr_store(out.p[blockIdx.y] + i, fr_add(p0, fr_mul(t, fr_sub(p1, p0))));
 }
 
 // ------------------------------------------------------------------------------------------ lean large-round kernels
@@ -1073,42 +1072,42 @@ __device__ __forceinline__ Fr lean_gamma_eval(const Fr* v, const Fr* __restrict_
     // the same re-association as lean_gamma_eval9 (every gamma power multiplies an input once): exact identities
     if (PRIM == FN_AFF_L1 || PRIM == LEAN_AFF_L1_BC) {
         const Fr g2 = fr_load(g + 2);
-        const Fr g2v2 = fr_mul_s(g2, v[2]);
+        const Fr g2v2 = fr_mul(g2, v[2]);
         const Fr t1 = fr_add(v[3], fr_add(fr_dbl(fr_dbl(g2v2)), g2v2));                   // v3 + 5 g2 v2   (-a = 5)
-        const Fr t2 = fr_add(fr_mul_s(fr_load(g + 1), v[2]), fr_mul_s(g2, v[3]));
-        Fr A = fr_add(fr_mul_s(v[0], t1), fr_mul_s(v[1], t2));
+        const Fr t2 = fr_add(fr_mul(fr_load(g + 1), v[2]), fr_mul(g2, v[3]));
+        Fr A = fr_add(fr_mul(v[0], t1), fr_mul(v[1], t2));
         if (PRIM == LEAN_AFF_L1_BC) {
-            A = fr_add(A, fr_mul_s(fr_load(g + 3), fr_sub(fr_sqr(v[4]), v[4])));
-            A = fr_add(A, fr_mul_s(fr_load(g + 4), fr_sub(fr_sqr(v[5]), v[5])));
+            A = fr_add(A, fr_mul(fr_load(g + 3), fr_sub(fr_sqr(v[4]), v[4])));
+            A = fr_add(A, fr_mul(fr_load(g + 4), fr_sub(fr_sqr(v[5]), v[5])));
         }
         return A;
     } else if (PRIM == FN_AFF_L2) {
         Fr A = fr_add(v[0], v[1]);
-        A = fr_add(A, fr_mul_s(fr_load(g + 1), v[2]));
-        return fr_add(A, fr_mul_s(fr_mul_s(fr_load(g + 2), v[0]), v[1]));
+        A = fr_add(A, fr_mul(fr_load(g + 1), v[2]));
+        return fr_add(A, fr_mul(fr_mul(fr_load(g + 2), v[0]), v[1]));
     } else if (PRIM == FN_AFF_L3 || PRIM == FN_PROJ_L3) {
         const Fr dxy = fr_mul_by_d(v[PRIM == FN_AFF_L3 ? 2 : 3]);
         const Fr base = PRIM == FN_AFF_L3 ? fr_one() : v[2];
         const Fr m = fr_sub(base, dxy), q = fr_add(base, dxy);
-        const Fr A = fr_mul_s(m, fr_add(v[0], fr_mul_s(fr_load(g + 2), q)));
-        return fr_add(A, fr_mul_s(fr_load(g + 1), fr_mul_s(q, v[1])));
+        const Fr A = fr_mul(m, fr_add(v[0], fr_mul(fr_load(g + 2), q)));
+        return fr_add(A, fr_mul(fr_load(g + 1), fr_mul(q, v[1])));
     } else if (PRIM == FN_PROJ_L1) {
         const Fr g2 = fr_load(g + 2);
-        const Fr g2v3 = fr_mul_s(g2, v[3]);
+        const Fr g2v3 = fr_mul(g2, v[3]);
         const Fr t1 = fr_add(v[4], fr_add(fr_dbl(fr_dbl(g2v3)), g2v3));                   // v4 + 5 g2 v3
-        const Fr t2 = fr_add(fr_mul_s(fr_load(g + 1), v[3]), fr_mul_s(g2, v[4]));
-        const Fr A = fr_add(fr_mul_s(v[0], t1), fr_mul_s(v[1], t2));
-        return fr_add(A, fr_mul_s(fr_load(g + 3), fr_mul_s(v[2], v[5])));
+        const Fr t2 = fr_add(fr_mul(fr_load(g + 1), v[3]), fr_mul(g2, v[4]));
+        const Fr A = fr_add(fr_mul(v[0], t1), fr_mul(v[1], t2));
+        return fr_add(A, fr_mul(fr_load(g + 3), fr_mul(v[2], v[5])));
     } else if (PRIM == FN_PROJ_L2) {
-        const Fr u = fr_add(fr_add(v[0], v[1]), fr_add(fr_mul_s(fr_load(g + 1), v[2]), fr_mul_s(fr_load(g + 2), v[3])));
-        return fr_add(fr_mul_s(v[3], u), fr_mul_s(fr_load(g + 3), fr_mul_s(v[0], v[1])));
+        const Fr u = fr_add(fr_add(v[0], v[1]), fr_add(fr_mul(fr_load(g + 1), v[2]), fr_mul(fr_load(g + 2), v[3])));
+        return fr_add(fr_mul(v[3], u), fr_mul(fr_load(g + 3), fr_mul(v[0], v[1])));
     } else if (PRIM == FN_ADD_INVERSES) {
-        return fr_add(fr_add(v[0], v[1]), fr_mul_s(fr_mul_s(fr_load(g + 1), v[0]), v[1]));
+        return fr_add(fr_add(v[0], v[1]), fr_mul(fr_mul(fr_load(g + 1), v[0]), v[1]));
     } else if (PRIM == FN_LOGUP_LAYER) {
-        return fr_add(fr_mul_s(v[3], fr_add(v[0], fr_mul_s(fr_load(g + 1), v[1]))), fr_mul_s(v[1], v[2]));
+        return fr_add(fr_mul(v[3], fr_add(v[0], fr_mul(fr_load(g + 1), v[1]))), fr_mul(v[1], v[2]));
     } else {  // FN_PT_BIT_CHOICE: (b, x, y) -> (b x, b (y - 1) + 1): b (x + g1 (y - 1)) + g1
         const Fr g1 = fr_load(g + 1);
-        return fr_add(fr_mul_s(v[0], fr_add(v[1], fr_mul_s(g1, fr_sub(v[2], fr_one())))), g1);
+        return fr_add(fr_mul(v[0], fr_add(v[1], fr_mul(g1, fr_sub(v[2], fr_one())))), g1);
     }
 }
 
@@ -1126,7 +1125,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
     if (VECVEC) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
     }
     const uint64_t npairs = VECVEC ? (uint64_t)(vv.off[vv.nrows] >> 1) : npairs_dense;
@@ -1137,7 +1136,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
             // 13 dependent loads of a full binary search per pair stall the few resident waves; the coarse table brackets the
             // row to the rows that intersect one 256-cell block (one or two for long rows)
             const uint32_t r = vv.coarse ? find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0) : find_row(vv.off, vv.nrows, cell0);
-            w = fr_mul_s(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
+            w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
         } else {
             w = fr_load(eq + i);
         }
@@ -1149,7 +1148,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean(LeanCols cols, c
                 const Fr p1 = fr_load(cols.p[q] + 2 * i + 1);
                 v[q] = h ? fr_sub(fr_dbl(p1), fr_load(cols.p[q] + 2 * i)) : p1;
             }
-            const Fr t = fr_mul_s(lean_gamma_eval<PRIM>(v, gp), w);
+            const Fr t = fr_mul(lean_gamma_eval<PRIM>(v, gp), w);
             if (h == 0) acc[0] = fr_add(acc[0], t); else acc[1] = fr_add(acc[1], t);
         }
     }
@@ -1167,7 +1166,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean_split(LeanCols c
     if (blockIdx.y == 0) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
     }
     const uint64_t npairs = (uint64_t)(vv.off[vv.nrows] >> 1);
@@ -1175,14 +1174,14 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean_split(LeanCols c
     for (uint64_t i = (uint64_t)blockIdx.x * SC_THREADS + threadIdx.x; i < npairs; i += (uint64_t)gridDim.x * SC_THREADS) {
         const uint32_t cell0 = (uint32_t)(2 * i);
         const uint32_t r = vv.coarse ? find_row_coarse(vv.off, vv.nrows, vv.coarse, cell0) : find_row(vv.off, vv.nrows, cell0);
-        const Fr w = fr_mul_s(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
+        const Fr w = fr_mul(fr_load(eq + ((cell0 - vv.off[r]) >> 1)), fr_load(vv.row_coef + r));
         Fr v[NI];
 #pragma unroll
         for (int q = 0; q < NI; q++) {
             const Fr p1 = fr_load(cols.p[q] + 2 * i + 1);
             v[q] = h ? fr_sub(fr_dbl(p1), fr_load(cols.p[q] + 2 * i)) : p1;
         }
-        acc[h] = fr_add(acc[h], fr_mul_s(lean_gamma_eval<PRIM>(v, gp), w));
+        acc[h] = fr_add(acc[h], fr_mul(lean_gamma_eval<PRIM>(v, gp), w));
     }
     block_reduce_finish<3>(acc, fc);
 }
@@ -1323,7 +1322,7 @@ __global__ void __launch_bounds__(SC_THREADS, 3) k_round_deg2_lean9(LeanCols col
     if (VECVEC) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
     }
     Fr9 a0 = fr9_zero(), a1 = fr9_zero();   // domain 241 (VecVec) / 246 (dense); normalised, S grows by <= 1.5 per pair
@@ -1379,7 +1378,7 @@ __global__ void __launch_bounds__(SC_THREADS, 2) k_round_deg2_lean9x2(LeanCols c
     if (VECVEC) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
     }
     Fr9x2 a = Fr9x2(fr9_zero());   // domain 241 (VecVec) / 246 (dense); normalised, S grows by <= 1.5 per pair
@@ -1423,7 +1422,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_deg2_lean9_split(LeanCols 
     if (blockIdx.y == 2) {
         for (uint32_t r = blockIdx.x * SC_THREADS + threadIdx.x; r < vv.nrows; r += gridDim.x * SC_THREADS) {
             const uint32_t seg = (vv.off[r + 1] - vv.off[r]) >> 1;
-            acc[2] = fr_add(acc[2], fr_mul_s(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
+            acc[2] = fr_add(acc[2], fr_mul(fr_load(vv.row_coef + r), fr_sub(fr_one(), fr_load(vv.eq_prefix + seg))));
         }
         block_reduce_finish<3>(acc, fc);
         return;
@@ -1475,7 +1474,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic3_lean(LeanCols col
                     v[q] = fr_add(p1, s == 1 ? d : fr_dbl(d));
                 }
             }
-            const Fr t = fr_mul_s(lean_gamma_eval<PRIM>(v, gp), v[NI]);
+            const Fr t = fr_mul(lean_gamma_eval<PRIM>(v, gp), v[NI]);
             if (s == 0) acc[0] = fr_add(acc[0], t);
             else if (s == 1) acc[1] = fr_add(acc[1], t);
             else acc[2] = fr_add(acc[2], t);
@@ -1500,7 +1499,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_prod3_lean(LeanCols cols, 
                     v[q] = fr_add(p1, s == 1 ? d : fr_dbl(d));
                 }
             }
-            const Fr t = fr_mul_s(fr_mul_s(v[0], v[1]), v[2]);
+            const Fr t = fr_mul(fr_mul(v[0], v[1]), v[2]);
             if (s == 0) acc[0] = fr_add(acc[0], t);
             else if (s == 1) acc[1] = fr_add(acc[1], t);
             else acc[2] = fr_add(acc[2], t);
@@ -1522,12 +1521,12 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_folded_prod(FoldedCols col
         for (int q = 0; q < nargs; q++) {
             const Fr a0 = fr_load(cols.p[q] + 2 * i), a1 = fr_load(cols.p[q] + 2 * i + 1);
             const Fr e0 = fr_load(cols.p[nargs + q] + 2 * i), e1 = fr_load(cols.p[nargs + q] + 2 * i + 1);
-            Fr t0 = fr_mul_s(a1, e1);
-            Fr t1 = fr_mul_s(fr_sub(fr_dbl(a1), a0), fr_sub(fr_dbl(e1), e0));
+            Fr t0 = fr_mul(a1, e1);
+            Fr t1 = fr_mul(fr_sub(fr_dbl(a1), a0), fr_sub(fr_dbl(e1), e0));
             if (q) {
                 const Fr g = fr_load(gp + q);
-                t0 = fr_mul_s(t0, g);
-                t1 = fr_mul_s(t1, g);
+                t0 = fr_mul(t0, g);
+                t1 = fr_mul(t1, g);
             }
             acc[0] = fr_add(acc[0], t0);
             acc[1] = fr_add(acc[1], t1);
@@ -1615,8 +1614,8 @@ __global__ void __launch_bounds__(SC_THREADS) k_vv_fold(ColPtrs in, ColPtrsMut o
         const Fr a0 = fr_load(in.p[c0] + in0 + 2 * p), a1 = fr_load(in.p[c0] + in0 + 2 * p + 1);
         Fr b0 = a0, b1 = a1;
         if (has1) { b0 = fr_load(in.p[c1] + in0 + 2 * p); b1 = fr_load(in.p[c1] + in0 + 2 * p + 1); }
-        fr_store(out.p[c0] + j, fr_add(a0, fr_mul_s(t, fr_sub(a1, a0))));
-        if (has1) fr_store(out.p[c1] + j, fr_add(b0, fr_mul_s(t, fr_sub(b1, b0))));
+        fr_store(out.p[c0] + j, fr_add(a0, fr_mul(t, fr_sub(a1, a0))));
+        if (has1) fr_store(out.p[c1] + j, fr_add(b0, fr_mul(t, fr_sub(b1, b0))));
     } else {
         fr_store(out.p[c0] + j, pad.v[c0]);
         if (has1) fr_store(out.p[c1] + j, pad.v[c1]);
@@ -1637,7 +1636,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_vv_fold_to_dense(ColPtrs in, Col
         if (len == 0) v = row_pad.v[c];
         else {
             const Fr p0 = fr_load(in.p[c] + in0), p1 = fr_load(in.p[c] + in0 + 1);
-            v = fr_add(p0, fr_mul_s(t, fr_sub(p1, p0)));
+            v = fr_add(p0, fr_mul(t, fr_sub(p1, p0)));
         }
     }
     fr_store(out.p[c] + r, v);
@@ -1667,7 +1666,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan 
 #pragma unroll
                     for (int q = 0; q < 3; q++) a[q] = fr_add(a[q], d[q]);
                 }
-                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul_s(fr_mul_s(a[0], a[1]), a[2]));
+                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul(fr_mul(a[0], a[1]), a[2]));
             }
         } else {
             const Fr e0 = fr_load(cols.p[ncols - 1] + 2 * i), e1 = fr_load(cols.p[ncols - 1] + 2 * i + 1);
@@ -1699,14 +1698,14 @@ __global__ void __launch_bounds__(SC_THREADS) k_round_generic(int kind, SegPlan 
                     for (int q = 0; q < 4; q++)
                         if (q < g.n_out) {
                             const int oc = g.out0 + q;
-                            G[s] = fr_add(G[s], oc == 0 ? o[q] : fr_mul_s(fr_load(gp + oc), o[q]));
+                            G[s] = fr_add(G[s], oc == 0 ? o[q] : fr_mul(fr_load(gp + oc), o[q]));
                         }
                 }
             }
             Fr e = e1;
             for (int s = 0; s < s_hi; s++) {
                 if (s) e = fr_add(e, ed);
-                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul_s(G[s], e));
+                if (s >= s_lo) acc[s] = fr_add(acc[s], fr_mul(G[s], e));
             }
         }
     }
