@@ -2667,6 +2667,43 @@ static std::vector<Fr> make_gamma_pows(const Fr& gamma, int count) {
 }
 
 // ---- DenseSumcheckObjectSO (sumcheck.rs:237-347) ------------------------------------------------
+// Sharded dense objects: once a rank's slice is down to 2^SHARD_GATHER_LOG elements the ranks exchange their slices
+// (k columns x 2^T elements x 32 B per rank: 40 KB at T = 8, one host all-gather) and every rank finishes the remaining T + lg rounds
+// on the whole 2^(T + lg) elements, unsharded: no exchange per round any more, and the persistent tail launch serves them (a sharded
+// object runs ordinary pre-enqueued rounds: ~30 us each where the tail launch needs ~11).  T = 0 is the old behaviour (gather when
+// one element per rank is left).  GM_SC_SHARD_GATHER_LOG overrides.
+static uint32_t shard_gather_log() {
+    static const uint32_t v = [] { const char* e = getenv("GM_SC_SHARD_GATHER_LOG"); return (uint32_t)(e ? atoi(e) : 8); }();
+    return v > 12 ? 12u : v;
+}
+// all ranks' slices of n_loc elements per column, in rank (= global) order, as new device columns
+static int32_t shard_gather_columns(const Shard& sh, const Fr* const* cur, int k, uint64_t n_loc, hipStream_t stream,
+                                    std::vector<std::unique_ptr<DevBuf>>* owned, std::vector<const Fr*>* ptrs) {
+    std::vector<Fr> mine((size_t)k * n_loc);
+    for (int i = 0; i < k; i++) GM_HIP(hipMemcpyAsync(mine.data() + (size_t)i * n_loc, cur[i], n_loc * sizeof(Fr), hipMemcpyDeviceToHost, stream));
+    GM_HIP(hipStreamSynchronize(stream));
+    std::vector<char> all;
+    int32_t rc = shard_all_gather(sh, mine.data(), mine.size() * sizeof(Fr), &all);
+    if (rc) return rc;
+    const Fr* a = reinterpret_cast<const Fr*>(all.data());
+    std::vector<Fr> col((size_t)sh.world * n_loc);
+    for (int i = 0; i < k; i++) {
+        for (uint32_t r = 0; r < sh.world; r++) memcpy(col.data() + (size_t)r * n_loc, a + ((size_t)r * k + i) * n_loc, n_loc * sizeof(Fr));
+        owned->emplace_back(new DevBuf());
+        rc = owned->back()->alloc(col.size() * sizeof(Fr));
+        if (rc) return rc;
+        if (col.size() <= 48) {
+            rc = upload_small(col.data(), col.size(), owned->back()->fr(), stream);
+            if (rc) return rc;
+        } else {
+            GM_HIP(hipMemcpyAsync(owned->back()->p, col.data(), col.size() * sizeof(Fr), hipMemcpyHostToDevice, stream));
+            GM_HIP(hipStreamSynchronize(stream));   // col is reused
+        }
+        ptrs->push_back(owned->back()->fr());
+    }
+    return GM_OK;
+}
+
 struct ScDensePipe {
     static bool enabled() {
         static const bool v = [] { const char* e = getenv("GM_SC_NO_PIPELINE"); return !(e && e[0] == '1'); }();
@@ -2695,28 +2732,14 @@ struct ScDense : gm_sc {
 
     int32_t gather_cols() {
         const int k = cols.k;
-        std::vector<Fr> mine(k);
-        for (int i = 0; i < k; i++) GM_HIP(hipMemcpyAsync(&mine[i], cols.cur[i], sizeof(Fr), hipMemcpyDeviceToHost, stream));
-        GM_HIP(hipStreamSynchronize(stream));
-        std::vector<char> all;
-        int32_t rc = shard_all_gather(sh, mine.data(), (size_t)k * sizeof(Fr), &all);
-        if (rc) return rc;
-        const Fr* a = reinterpret_cast<const Fr*>(all.data());
         std::vector<const Fr*> ptrs;
-        for (int i = 0; i < k; i++) {
-            std::vector<Fr> col(sh.world);
-            for (uint32_t r = 0; r < sh.world; r++) col[r] = a[(size_t)r * k + i];
-            owned.emplace_back(new DevBuf());
-            rc = owned.back()->alloc((size_t)sh.world * sizeof(Fr));
-            if (rc) return rc;
-            rc = upload_small(col.data(), col.size(), owned.back()->fr(), stream);
-            if (rc) return rc;
-            ptrs.push_back(owned.back()->fr());
-        }
-        cols = FoldCols();
-        rc = cols.init(k, ptrs.data(), sh.world);
+        int32_t rc = shard_gather_columns(sh, cols.cur.data(), k, 1ull << loc_vars, stream, &owned, &ptrs);
         if (rc) return rc;
-        loc_vars = sh.lg;
+        const uint64_t n_all = (uint64_t)sh.world << loc_vars;
+        cols = FoldCols();
+        rc = cols.init(k, ptrs.data(), n_all);
+        if (rc) return rc;
+        loc_vars += sh.lg;
         sh = Shard();
         return GM_OK;
     }
@@ -2788,7 +2811,7 @@ struct ScDense : gm_sc {
     int32_t unipoly(std::vector<Fr>* coeffs) override {
         if (round_idx >= num_vars) return set_err(GM_ERR_STATE, "the protocol has already ended (sumcheck.rs:279)");
         if (!has_cached) {
-            if (sh.comm && loc_vars == 0) {
+            if (sh.comm && loc_vars <= shard_gather_log()) {
                 int32_t rc = gather_cols();
                 if (rc) return rc;
             }
@@ -2902,38 +2925,26 @@ struct ScDenseDeg2 : gm_sc {
     // Level i of eq_poly_sequence(point) at global index `off`.  A sharded object built by gm_sc_dense_deg2_create keeps only its own
     // slice of the levels its local rounds read (level i >= lg restricted to the rank = eq(point[0..lg), rank) x eq(point[lg..i], .):
     // 2^loc_vars entries instead of 2^num_vars) plus the lg small top levels of the replicated last rounds.
+    // The whole levels kept are 0 .. eq_top - 1 with eq_top = lg + the early-gather threshold (shard_gather_log): the rounds every rank
+    // finishes on the gathered columns read them.
     bool eq_sliced = false;
-    uint32_t eq_lg = 0, eq_rank = 0;
+    uint32_t eq_lg = 0, eq_rank = 0, eq_top = 0;
     const Fr* eq_at(uint32_t i, uint64_t off) const {
         if (!eq_sliced) return (eq_ext ? eq_ext : d_eq.fr()) + ((1ull << i) - 1) + off;
-        if (i >= eq_lg) return d_eq.fr() + ((1ull << (i - eq_lg)) - 1) + (off - ((uint64_t)eq_rank << (i - eq_lg)));
+        if (i >= eq_top) return d_eq.fr() + ((1ull << (i - eq_lg)) - 1) + (off - ((uint64_t)eq_rank << (i - eq_lg)));
         return d_eq.fr() + ((size_t)1 << (num_vars - eq_lg)) + ((1ull << i) - 1) + off;
     }
 
     int32_t gather_cols() {
         const int k = cols.k;
-        std::vector<Fr> mine(k);
-        for (int i = 0; i < k; i++) GM_HIP(hipMemcpyAsync(&mine[i], cols.cur[i], sizeof(Fr), hipMemcpyDeviceToHost, stream));
-        GM_HIP(hipStreamSynchronize(stream));
-        std::vector<char> all;
-        int32_t rc = shard_all_gather(sh, mine.data(), (size_t)k * sizeof(Fr), &all);
-        if (rc) return rc;
-        const Fr* a = reinterpret_cast<const Fr*>(all.data());
         std::vector<const Fr*> ptrs;
-        for (int i = 0; i < k; i++) {
-            std::vector<Fr> col(sh.world);
-            for (uint32_t r = 0; r < sh.world; r++) col[r] = a[(size_t)r * k + i];
-            owned.emplace_back(new DevBuf());
-            rc = owned.back()->alloc((size_t)sh.world * sizeof(Fr));
-            if (rc) return rc;
-            rc = upload_small(col.data(), col.size(), owned.back()->fr(), stream);
-            if (rc) return rc;
-            ptrs.push_back(owned.back()->fr());
-        }
-        cols = FoldCols();
-        rc = cols.init(k, ptrs.data(), sh.world);
+        int32_t rc = shard_gather_columns(sh, cols.cur.data(), k, 1ull << loc_vars, stream, &owned, &ptrs);
         if (rc) return rc;
-        loc_vars = sh.lg;
+        const uint64_t n_all = (uint64_t)sh.world << loc_vars;
+        cols = FoldCols();
+        rc = cols.init(k, ptrs.data(), n_all);
+        if (rc) return rc;
+        loc_vars += sh.lg;   // (the eq levels these rounds read, 0 .. loc_vars - 1 < eq_top, are whole: eq_at)
         glob_off = 0;
         sh = Shard();
         return GM_OK;
@@ -2945,7 +2956,7 @@ struct ScDenseDeg2 : gm_sc {
         // rounds inside a running tail launch (its first round goes through unipoly_pipelined, which handles a launch that left at the
         // residency barrier; a launch adopted from a VecVec object has been running for rounds)
         if (tail_active && round_idx >= tail_r0 && (round_idx > tail_r0 || stage_adopted)) return unipoly_tail(coeffs);
-        if (sh.comm && loc_vars == 0) {
+        if (sh.comm && loc_vars <= shard_gather_log() && !fold_pending) {
             int32_t rc = gather_cols();
             if (rc) return rc;
         }
@@ -3210,7 +3221,8 @@ struct ScDenseDeg2 : gm_sc {
             if (rc) return rc;
             k_enq = r + 1;
         }
-        if (!fold_pending && loc_vars >= 2 && k_enq == r + 1) {   // (sharded: the round after this rank's last local one needs a gather first)
+        // (sharded: the round at which the ranks gather their slices is not enqueued ahead -- its kernel runs on the gathered columns)
+        if (!fold_pending && (sh.comm ? loc_vars > shard_gather_log() + 1 : loc_vars >= 2) && k_enq == r + 1) {
             // enqueue fold r (waiting for t_r) and round kernel r + 1 while round r is still running
             cols.next(&fold_dst);
             ColPtrs ci;
@@ -3918,8 +3930,9 @@ extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, co
         // sharded: this rank's slice of the levels lg .. n-1 (local levels 0 .. loc_vars-1, scaled by eq(point[0..lg), rank)) and the
         // whole levels 0 .. lg-1 behind them
         const uint32_t lg = so->sh.lg, lv_n = so->loc_vars;
-        so->eq_sliced = true; so->eq_lg = lg; so->eq_rank = so->sh.rank;
-        rc = so->d_eq.alloc((((size_t)1 << lv_n) + ((size_t)1 << lg)) * sizeof(Fr));
+        const uint32_t top_n = (lg + shard_gather_log() < num_vars) ? lg + shard_gather_log() : num_vars;   // whole levels 0 .. top_n - 1
+        so->eq_sliced = true; so->eq_lg = lg; so->eq_rank = so->sh.rank; so->eq_top = top_n;
+        rc = so->d_eq.alloc((((size_t)1 << lv_n) + ((size_t)1 << top_n)) * sizeof(Fr));
         if (rc) return rc;
         Fr factor = fr_one();   // eq(point[0..lg), rank): point[0] is the most significant variable
         for (uint32_t j = 0; j < lg; j++) {
@@ -3931,9 +3944,9 @@ extern "C" int32_t gm_sc_dense_deg2_create(const gm_fn* f, uint32_t num_vars, co
         rc = launch_eq_sequence(factor, so->point.data() + lg, lv_n - 1, lv.data(), so->stream, so->gamma_pows.data(),
                                 (uint32_t)so->gamma_pows.size(), so->d_gamma.fr());
         if (rc) return rc;
-        std::vector<Fr*> top(lg);
-        for (uint32_t i = 0; i < lg; i++) top[i] = so->d_eq.fr() + ((size_t)1 << lv_n) + ((1ull << i) - 1);
-        rc = launch_eq_sequence(fr_one(), so->point.data(), lg - 1, top.data(), so->stream);
+        std::vector<Fr*> top(top_n);
+        for (uint32_t i = 0; i < top_n; i++) top[i] = so->d_eq.fr() + ((size_t)1 << lv_n) + ((1ull << i) - 1);
+        rc = launch_eq_sequence(fr_one(), so->point.data(), top_n - 1, top.data(), so->stream);
         if (rc) return rc;
     } else {
     rc = so->d_eq.alloc(((size_t)1 << num_vars) * sizeof(Fr));

@@ -52,8 +52,27 @@ def worker(rank, world, tag, x_log, d_log, nbits, q):
 
 if __name__ == "__main__":
     import torch.multiprocessing as mp
-    a = [int(v) for v in sys.argv[1:]]
+    threads = "--threads" in sys.argv     # the ranks as threads of ONE process (no switching between processes on the shared GPU)
+    a = [int(v) for v in sys.argv[1:] if not v.startswith("--")]
     x_log, d_log, nbits, world = (a + [20, 8, 256, 4][len(a):])[:4]
+    if threads:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        import queue
+        import threading
+        import torch
+        q = queue.Queue()
+
+        def go(r):
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                worker(r, world, "thr%d" % os.getpid(), x_log, d_log, nbits, q)
+        th = [threading.Thread(target=go, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        print(sorted(q.get_nowait() for _ in range(world)))
+        sys.exit(0)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=worker, args=(r, world, str(os.getpid()), x_log, d_log, nbits, q)) for r in range(world)]

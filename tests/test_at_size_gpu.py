@@ -254,6 +254,14 @@ def test_config_d_one_ranks_share_of_the_window_sharded_msm():
     torch.cuda.empty_cache()
 
 
+def _release_unless_rank_thread():
+    """gm_release_cached_memory gives EVERY thread's idle blocks back to the driver and hipFree waits for the device: a rank thread must
+    not do that while its sibling ranks have kernels in flight that wait for it"""
+    import threading
+    if threading.current_thread() is threading.main_thread():
+        ffi.lib().gm_release_cached_memory()
+
+
 def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
     """one rank of the at-size sharded proof: operands from gm_gen_points / numpy (identical on every rank), the unsharded
     proof as the reference (pinned to the oracle by test_config_b_msm_and_image_part_at_full_size).  The ranks exchange through the
@@ -285,7 +293,7 @@ def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
         ref = w.prove_image_part(r_pt, evs, tape)
         w.close()
         plan.close()
-        ffi.lib().gm_release_cached_memory()
+        _release_unless_rank_thread()
         y0, y1 = gd.window_range(rank, world, y_size)
         comm = gd.ShmComm("/gm-at-size-%d" % port, rank, world)
         plan_s = H.MsmPlan(x_log, d_log, y_size, y0, y1)
@@ -306,7 +314,7 @@ def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
         calls = comm.calls
         ws.close()
         plan_s.close()
-        ffi.lib().gm_release_cached_memory()
+        _release_unless_rank_thread()
         # The comparison that separates the cost of SHARDING from the cost of FOUR PROCESSES SHARING ONE GPU: every rank proves, at the
         # same time as the others and with no exchange at all, an independent unsharded image part of its share's size (the first
         # y_size / world windows: the same bucket rows per process, a few rounds fewer because y_logsize is smaller).
@@ -330,7 +338,7 @@ def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
         indep = dict(ms=round(1e3 * min(g_["call_s"] for g_ in gq), 1), rounds=gq[0]["rounds"])
         wq.close()
         plan_q.close()
-        ffi.lib().gm_release_cached_memory()
+        _release_unless_rank_thread()
         comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))
         one = None
         if rank == 0:
@@ -360,7 +368,7 @@ def test_config_b_image_part_sharded_over_four_ranks():
     world, x_log, d_log, nbits = 4, 20, 8, 256
     require_host_gib(64, "config B sharded over 4 processes")
     t_begin = time.perf_counter()
-    ffi.lib().gm_release_cached_memory()
+    _release_unless_rank_thread()
     torch.cuda.empty_cache()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -438,7 +446,7 @@ def _sharded_pf_worker(rank, world, port, x_log, d_log, nbits, q):
             info.update(unsharded_s=ref["call_s"], ref_digest=hashlib.sha256(repr(
                 (ref["msgs"], ref["gamma"], ref["matrix"], ref["ac_c"], ref["ac_d"])).encode()).hexdigest())
             plan.close()
-            ffi.lib().gm_release_cached_memory()
+            _release_unless_rank_thread()
             buf[:] = codec.to_mont_limbs(list(img["point"]) + list(img["evs"]))
         comm.sum_fr(buf)   # the others contribute zeros: everybody has rank 0's claims
         vals = codec.from_mont_limbs(buf)
@@ -469,7 +477,7 @@ def test_config_b_pushforward_sharded_over_four_ranks():
     world, x_log, d_log, nbits = 4, 20, 8, 256
     require_host_gib(64, "config B pushforward sharded over 4 processes")
     t_begin = time.perf_counter()
-    ffi.lib().gm_release_cached_memory()
+    _release_unless_rank_thread()
     torch.cuda.empty_cache()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -503,6 +511,50 @@ def test_config_b_pushforward_sharded_over_four_ranks():
            time_inside_the_communicator_per_rank=[r[2]["clock"] for r in res], per_rank_ms=[round(1e3 * r[2]["sharded_s"], 1) for r in res],
            ipc_mappings_opened_closed_held=[r[2]["ipc"] for r in res],
            checked="messages, gamma and the three final claims equal to the unsharded argument on every rank")
+
+
+def _sharded_worker_q(rank, world, q, port, x_log, d_log, nbits):
+    _sharded_worker(rank, world, port, x_log, d_log, nbits, q)
+
+
+def _sharded_pf_worker_q(rank, world, q, port, x_log, d_log, nbits):
+    _sharded_pf_worker(rank, world, port, x_log, d_log, nbits, q)
+
+
+def test_config_b_sharded_over_four_rank_threads_of_one_process():
+    """The same two sharded provers with the four ranks as THREADS of one process (tests/rank_threads.py): the device then runs ONE
+    process's queues and does not switch between four -- the switching is what most of the "sharding overhead" of the four-process
+    rehearsals above is (a one-GPU artefact: with a GPU per rank there is nothing to switch).  Same checks: every rank's proof equals the
+    unsharded one."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rank_threads import run_ranks
+    world, x_log, d_log, nbits = 4, 20, 8, 256
+    require_host_gib(64, "config B sharded over 4 rank threads")
+    t_begin = time.perf_counter()
+    ffi.lib().gm_release_cached_memory()
+    torch.cuda.empty_cache()
+    res = run_ranks(_sharded_worker_q, world, (37500 + os.getpid() % 2000, x_log, d_log, nbits), threads_per_proc=4, timeout=600)
+    sharded = max(r[2]["sharded_s"] for r in res)
+    alone = res[0][2]["unsharded_alone_s"]
+    resp = run_ranks(_sharded_pf_worker_q, world, (38500 + os.getpid() % 2000, x_log, d_log, nbits), threads_per_proc=4, timeout=900)
+    ref = resp[0][2]["ref_digest"]
+    for rank, ok, info in resp:
+        assert info["digest"] == ref, "rank %d: the sharded argument differs from the unsharded one" % rank
+    pf_sharded = max(r[2]["sharded_s"] for r in resp)
+    pf_alone = resp[0][2]["unsharded_s"]
+    print("[at-size] config B over 4 rank THREADS of one process on one GPU: image part %.1f ms against %.1f unsharded alone = %.2fx "
+          "(four independent share-sized proofs at once: %s ms); pushforward %.1f ms against %.1f = %.2fx" % (
+              1e3 * sharded, 1e3 * alone, sharded / alone, [r[2]["indep"]["ms"] for r in res], 1e3 * pf_sharded, 1e3 * pf_alone, pf_sharded / pf_alone))
+    record("config_b_sharded_over_four_rank_threads", x_logsize=x_log, world=world, image_part_sharded_ms=round(1e3 * sharded, 1),
+           image_part_unsharded_alone_ms=round(1e3 * alone, 1), image_part_ratio=round(sharded / alone, 2),
+           image_part_four_independent_share_sized_proofs_ms=[r[2]["indep"]["ms"] for r in res],
+           image_part_time_inside_the_communicator_per_rank=[r[2]["clock"] for r in res],
+           pushforward_sharded_ms=round(1e3 * pf_sharded, 1), pushforward_unsharded_ms=round(1e3 * pf_alone, 1),
+           pushforward_ratio=round(pf_sharded / pf_alone, 2),
+           pushforward_time_inside_the_communicator_per_rank=[r[2]["clock"] for r in resp],
+           seconds=round(time.perf_counter() - t_begin, 1),
+           checked="every rank's image-part proof and pushforward argument equal the unsharded ones")
+    assert sharded <= 1.6 * alone and pf_sharded <= 1.6 * pf_alone
 
 
 def test_config_e_dry_run_of_one_ranks_share_of_the_sharded_prover():

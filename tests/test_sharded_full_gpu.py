@@ -149,13 +149,15 @@ def test_sharded_whole_proof_equals_the_unsharded_one(world, shape, key_mode):
         assert all(kp < n_key for _, _, _, kp, _, n_key in res)
 
 
-@pytest.mark.parametrize("shape", [
-    (4, 2, 32, 2),     # 16 windows, 2 per rank, matrices of 4 windows
-    (5, 2, 64, 4),     # config E's structure at x_logsize 5: 32 windows, commitment_log_multiplicity 4, 8 ranks x 4 windows
+@pytest.mark.parametrize("shape,gather_log", [
+    ((4, 2, 32, 2), "8"),     # 16 windows, 2 per rank, matrices of 4 windows
+    ((5, 2, 64, 4), "8"),     # config E's structure at x_logsize 5: 32 windows, commitment_log_multiplicity 4, 8 ranks x 4 windows
+    ((5, 2, 64, 4), "0"),     # ... with the sharded dense objects exchanging round sums down to one element per rank, and with
+    ((5, 2, 64, 4), "2"),     # ... the slices gathered at four elements per rank
 ])
-def test_sharded_whole_proof_world_8(shape):
+def test_sharded_whole_proof_world_8(shape, gather_log):
     """8 ranks = 4 processes x 2 rank threads sharing the GPU"""
-    _run(8, shape, "minimal", threads_per_proc=2, env=MANY_QUEUES)
+    _run(8, shape, "minimal", threads_per_proc=2, env=dict(MANY_QUEUES, GM_SC_SHARD_GATHER_LOG=gather_log, GM_PF_DIST_MIN="2"))
 
 
 def test_sharded_whole_proof_world_8_all_ranks_threads_of_one_process():
@@ -167,7 +169,7 @@ def test_sharded_whole_proof_with_a_one_entry_ipc_cache_and_host_staging():
     """GM_SHM_MAX_OPENED=1: every pull that touches two peers overflows the cache -- mappings are closed only after the pull's last
     barrier (advisor r03: an eviction under the running call read a closed mapping); then the same proof with every bulk move staged
     through the host all-gather"""
-    res = _run(4, (4, 2, 16, 2), "minimal", env={"GM_SHM_MAX_OPENED": "1"})
+    res = _run(4, (4, 2, 16, 2), "minimal", env={"GM_SHM_MAX_OPENED": "1", "GM_SC_SHARD_GATHER_LOG": "0", "GM_PF_DIST_MIN": "2"})
     assert any(ipc[1] > 0 for _, _, _, _, ipc, _ in res), "no mapping was ever evicted: the bound was not exercised"
     assert all(ipc[2] <= 2 for _, _, _, _, ipc, _ in res)      # what one call touched may stay, nothing more
     _run(4, (4, 2, 16, 2), "minimal", env={"GM_SHM_NO_IPC": "1"})

@@ -24,6 +24,9 @@ def _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q, host_stag
             os.environ["GM_PF_DIST_MIN"] = str(dist_min)
         if host_staged is True:
             os.environ["GM_PF_HOST_STAGED"] = "1"
+            # ... and the sharded dense objects exchange round sums down to ONE element per rank (the default gathers the slices once
+            # they are down to 2^8 elements and finishes unsharded: at these small shapes that would be every round)
+            os.environ["GM_SC_SHARD_GATHER_LOG"] = "0"
         if host_staged == "rank1-cannot-export" and rank == 1:
             os.environ["GM_SHM_NO_IPC"] = "1"
         from gkr_msm_amd import codec, dist as gd, harness as H
