@@ -827,9 +827,10 @@ def main():
             exchanges = {}
             out["sumcheck"] = {"metric": "sumcheck_rounds_per_sec", "exchanges": exchanges,
                                "workload": "prove image part (triangle + bintree GKR) x_logsize=%d d_logsize=%d nbits=%d" % (x_log, d_log, nbits)}
-            r_pt = r_evs = tape = None
-            best = None
-            for which in order:
+            state = {"r_pt": None, "r_evs": None, "tape": None, "best": None}
+
+            def run_exchange(which):
+                r_pt, r_evs, tape, best = state["r_pt"], state["r_evs"], state["tape"], state["best"]
                 ex = exchanges.setdefault(which, {})
                 try:
                     if which == "shm":
@@ -891,6 +892,13 @@ def main():
                         comm.close()
                 except Exception as e:
                     ex["error"] = repr(e)[:300]
+                state.update(r_pt=r_pt, r_evs=r_evs, tape=tape, best=best)
+
+            # the shared-memory exchange first (rehearsed at world 2, 4, 8); the device-side RCCL exchange -- which has never run with more
+            # than one rank anywhere -- LAST, after every other leg, so that a stall there (the watchdog ends the run) costs nothing else
+            run_exchange(order[0])
+            best = state["best"]
+            r_pt, r_evs, tape = state["r_pt"], state["r_evs"], state["tape"]
             if best is None:
                 raise RuntimeError("no exchange finished: %s" % {k: v.get("error") for k, v in exchanges.items()})
             p_dt, which, res = best
@@ -960,6 +968,14 @@ def main():
                     del d_basis, key
                 except Exception as e:
                     out["full_gen2_prover_sharded"] = {"error": repr(e)[:400]}
+            for which_late in order[1:]:
+                run_exchange(which_late)
+                if state["best"] is not None and state["best"][1] == which_late:      # the late exchange was the faster one: it is the headline
+                    p_dt, which, res = state["best"]
+                    out["sumcheck"].update({"value": exchanges[which]["value"], "prove_ms": exchanges[which]["prove_ms"],
+                                            "transport": "%s (the faster of %s in this run)" % (exchanges[which]["transport"], order),
+                                            "witness_build_ms": exchanges[which]["witness_build_ms"]})
+                    out.setdefault("per_gpu_efficiency", {})["sharded_prover"] = round(u_dt / p_dt / world, 4)
         except Exception as e:  # keep the MSM line even if the sharded prover leg fails on this node
             out.setdefault("sumcheck", {})["error"] = repr(e)[:300]
         watchdog.cancel()

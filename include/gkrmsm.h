@@ -379,8 +379,8 @@ int32_t gm_merlin_unread(const gm_merlin* t, uint64_t* n);
  * back it with anything):
  *   - per sumcheck round: all-gather of the 2-3 partial round sums (<= 96 bytes per rank), added mod p by every rank;
  *   - once per proof: all-gather of the bucket sums (3 * 2^(y_logsize + d_logsize) field elements in total), after which the
- *     bucket-reduction (triangle) GKR runs replicated, and of one element per column when a dense layer's local
- *     slice is exhausted (the last log2(G) rounds of that layer run replicated).
+ *     bucket-reduction (triangle) GKR runs replicated, and of a dense layer's slices once they are down to 2^8 elements per
+ *     column and rank (GM_SC_SHARD_GATHER_LOG): the remaining 8 + log2(G) rounds of that layer run replicated, unsharded.
  * all_gather: `h_buf` holds world * bytes_per_rank bytes; the caller has filled slot `rank`; on return every slot is filled.
  * Every rank must run the same sequence of calls (the provers are deterministic given the same challenges). */
 typedef struct gm_pull {
