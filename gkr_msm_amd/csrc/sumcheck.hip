@@ -676,6 +676,7 @@ struct StageArgs {
     uint32_t arrive_target;            // ... value it has once every block of THIS launch is resident
     uint64_t resident_ticks;           // ... how long a block waits for the others before the launch is abandoned (100 MHz ticks)
     uint64_t* d_dbg;                   // development aid: phase time stamps (nullptr normally)
+    uint32_t par_fold;                 // dense rounds: fold by (input, pair) lanes instead of by pair lanes (GM_STAGE_PAR_FOLD=0: off)
 };
 
 // The stage kernel's products.  k_stage<3> is 51 000 instructions (400 KB) with every product inlined, and blocks of different segments
@@ -768,6 +769,10 @@ __device__ __forceinline__ Fr stage_eval(const Seg& g, const Fr* p0, const Fr* p
 template <int MAXIN>
 __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const Fr* __restrict__ gp, StageArgs a) {
     __shared__ Fr xch[MAXIN][256];
+    // the UNFOLDED pairs of a dense round, staged while the block waits for the challenge: the fold is then one product per (input, pair)
+    // lane -- every lane of the block busy for one product -- instead of n_in dependent-issue products per pair lane (a lone wave per SIMD
+    // issues ~one instruction per 7 cycles: three products of a fold are ~3.6 us, one is ~1.2)
+    __shared__ Fr pre0[MAXIN][128], pre1[MAXIN][128];
     __shared__ uint32_t half[4][2][16];
     __shared__ Fr ts;
     __shared__ int ok;
@@ -817,6 +822,7 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
     // false = give up.  Blocks publish their partial in device memory; the block that arrives last (agent-scope release /
     // acquire around the round's own counter) adds them up per evaluation point and writes ONE report to pinned host memory:
     // with up to 192 blocks, per-block reports cost ~45 us per round in PCIe write transactions alone.
+    uint32_t stage_np = 0;   // > 0: exchange() stages this many pairs (p0 / p1 of the calling lane) before it waits
     auto exchange = [&](Fr s0, Fr s1, bool with_w, uint32_t nrep) -> bool {
         STAGE_STAMP(1);
         {   // integer limb sums over the wave (see wave_half_sums): the block's share goes into the accumulators unreduced
@@ -865,6 +871,11 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
             }
         }
         STAGE_STAMP(3);
+        if (stage_np && i < stage_np) {   // off the critical path: the sums are on their way, the challenge is not back yet
+#pragma unroll
+            for (int q = 0; q < MAXIN; q++)
+                if (q < g.n_in) { pre0[q][i] = p0[q]; pre1[q][i] = p1[q]; }
+        }
         STAGE_STAMP(4);
         if (i == 0) {
             int good = 0;
@@ -971,9 +982,20 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
         STAGE_STAMP(0);
         Fr acc = fr_zero();
         if (i < np) acc = fr_mul_s(stage_eval<MAXIN>(g, p0, p1, gp, h), fr_load(a.eq[dr] + (uint64_t)my_slice * np + i));
+        const bool pf = a.par_fold && np <= 128;
+        stage_np = pf ? np : 0;
         if (!exchange(acc, fr_zero(), false, (merged || nsl == 1) ? gridDim.x : nsl * gridDim.x)) return;
+        stage_np = 0;
         const Fr t = ts;
-        if (i < np) {
+        if (pf) {
+            // (the barrier at the end of exchange() orders the staging stores before these loads)
+            const uint32_t nf = (uint32_t)g.n_in * np;
+            for (uint32_t T = i; T < nf; T += 256) {
+                const uint32_t q = T / np, j = T - q * np;
+                const Fr a0 = pre0[q][j], a1 = pre1[q][j];
+                xch[q][j] = fr_add(a0, fr_mul_s(t, fr_sub(a1, a0)));
+            }
+        } else if (i < np) {
 #pragma unroll
             for (int q = 0; q < MAXIN; q++)
                 if (q < g.n_in) xch[q][i] = fr_add(p0[q], fr_mul_s(t, fr_sub(p1[q], p0[q])));
@@ -2262,6 +2284,10 @@ struct StageRun {
         }
         a.ticket0 = ticket0;
         a.timeout_ticks = wait_timeout_ticks();
+        {
+            static const bool pf_off = [] { const char* e = getenv("GM_STAGE_PAR_FOLD"); return e && e[0] == '0'; }();   // A/B
+            a.par_fold = pf_off ? 0u : 1u;
+        }
         // the staging outlives this launch (one per host thread): a timeout flagged by an earlier launch must not fail this one
         *reinterpret_cast<volatile uint32_t*>(st->status()) = 0;
         slot_dev = StageSlots::device();
