@@ -940,12 +940,16 @@ __global__ void __launch_bounds__(256) k_stage(SegPlan sp, ColPtrs cols, const F
         }
         for (int tr = 0; tr < a.n_thin; tr++, round++) {
             STAGE_STAMP(0);
-            const Fr e0 = fr_load(a.thin_eq[tr]);
+            // The weight of a row's pair in thin round tr is coef[r] e0, e0 = entry 0 of that round's eq level: ONE scalar per round.  The
+            // host multiplies the round's sums by it (StageRun::thin_e0) -- on the device it was a product per row and round on every
+            // block's critical path.  Likewise the tail weight W = sum_r coef[r] (1 - sum_{idx < seg_r} eq[idx]) (get_trailing_sum,
+            // vecvec.rs:144-146) = C_all - e0 C_have with C_have = sum of coef over the rows that hold a pair -- the same rows in every
+            // thin round (a folded row is re-padded to one pair): reported ONCE, in the launch's first round, with no product at all.
             Fr acc = fr_zero(), accw = fr_zero();
-            if (have) acc = fr_mul_s(stage_eval<MAXIN>(g, p0, p1, gp, h), fr_mul_s(e0, coef));
-            // the tail weight W = sum_r coef[r] (1 - sum_{idx < seg_r} eq[idx]), get_trailing_sum (vecvec.rs:144-146): once per slice
-            if (blockIdx.x == 0 && r < a.nrows) accw = have ? fr_mul_s(coef, fr_sub(fr_one(), e0)) : coef;
-            if (!exchange(acc, accw, blockIdx.x == 0, nsl * gridDim.x)) return;
+            if (have) acc = fr_mul_s(stage_eval<MAXIN>(g, p0, p1, gp, h), coef);
+            const bool with_c = blockIdx.x == 0 && tr == 0;
+            if (with_c && have) accw = coef;
+            if (!exchange(acc, accw, with_c, nsl * gridDim.x)) return;
             if (have) {   // bind_21 on a row of one pair: [p0 + t (p1 - p0), row_pad]
                 const Fr t = ts;
 #pragma unroll
@@ -2332,7 +2336,7 @@ struct StageRun {
         const volatile uint32_t* rep = st->rep() + 96 * (r & 1);
         Fr v[3];
         // 24 chunks of {low word, high word, -, tag}: the limb sums of the three values; valid once every chunk carries the round's tag
-        const int nchunks = r < n_thin ? 24 : 16;   // the tail weight is reported in the thin rounds only
+        const int nchunks = (r == 0 && n_thin > 0) ? 24 : 16;   // the launch's first thin round also reports C_have (see k_stage)
         auto all = [&] {
             uint32_t lo[24] = {0}, hi[24] = {0};
             for (int c = 0; c < nchunks; c++)
@@ -2375,12 +2379,25 @@ struct StageRun {
             st->d_state_dirty = true;
             return set_err(GM_ERR_STATE, "stage round result did not arrive in time (gm_set_wait_timeout_ms)");
         }
+        if (r < n_thin) {
+            // thin round: the device summed eval x coef; the round's eq scalar and the tail weight are applied here (see k_stage)
+            if (r == 0) c_have = v[2];
+            if ((size_t)r >= thin_e0.size()) return set_err(GM_ERR_STATE, "stage round %d has no eq scalar", r);
+            const Fr e0 = thin_e0[r];
+            v[0] = fr_mul(v[0], e0);
+            v[1] = fr_mul(v[1], e0);
+            v[2] = fr_sub(c_all, fr_mul(e0, c_have));
+        }
         *s1 = v[0];
         *s2 = v[1];
         if (w) *w = v[2];
         if (debug()) t_sums = std::chrono::steady_clock::now();
         return GM_OK;
     }
+    // thin rounds (see k_stage): entry 0 of every thin round's eq level, the sum of row_coef over this launch's rows, and -- from the
+    // first round's report -- over the rows that hold a pair
+    std::vector<Fr> thin_e0;
+    Fr c_all = fr_zero(), c_have = fr_zero();
     // development aid (GM_STAGE_DEBUG=1): the host's turn-around, from a round's sums seen to its challenge written
     std::chrono::steady_clock::time_point t_sums;
     double host_us = 0;
@@ -3614,6 +3631,19 @@ struct ScVecVecDeg2 : gm_sc {
         ColPtrs cp;
         for (int i = 0; i < k; i++) cp.p[i] = cols_now[i];
         stage.reset(new StageRun());
+        {   // what the host applies to the thin rounds' sums (see k_stage): entry 0 of round tr's eq level = prod_{j < level} (1 - pt[j]) over
+            // the row variables (padded_eq_poly_sequence, utils.rs:189-220), and the sum of row_eq_coefs over this object's rows
+            const Fr* pt = point.data() + col_logsize;
+            stage->thin_e0.resize(n_thin);
+            for (int tr = 0; tr < n_thin; tr++) {
+                const uint32_t level = (uint32_t)eq_level_len.size() - 1 - (ab0 + (uint32_t)tr);
+                Fr e0 = fr_one();
+                for (uint32_t j = 0; j < level; j++) e0 = fr_mul(e0, fr_sub(fr_one(), pt[j]));
+                stage->thin_e0[tr] = e0;
+            }
+            stage->c_all = fr_sub(eq_sum_host(point.data(), col_logsize, (uint64_t)row_base + nrows),
+                                  eq_sum_host(point.data(), col_logsize, row_base));
+        }
         int32_t rc = stage->launch(sp, cp, d_gamma.fr(), a, stream, may_wait);
         if (rc) { stage.reset(); return rc; }
         for (int tr = 0; tr < n_thin; tr++) { prof_small_round(64.0 * k * (double)nrows); prof_fold(96.0 * k * (double)nrows); }
