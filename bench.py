@@ -1248,7 +1248,8 @@ def main():
                 # the timed figure: the same proof under the live merlin transcript (gm_pippenger_prove_tr)
                 mt = harness.MerlinTranscript(b"bench-full")
                 fm = harness.pippenger_prove_tr(wgf, r_f, evs_f, d_inv, 2, mt)
-                proof_len_f = len(mt.proof())
+                proof_f = bytes(mt.proof())
+                proof_len_f = len(proof_f)
                 mt.close()
                 t_p = fm["call_s"]
                 spans = harness.pippenger_last_spans()
@@ -1282,6 +1283,61 @@ def main():
                        "key (3.2 GB) in %.2f s" % (x_log + 1, srs_s, fbk_s),
                 "verified": "accepted by gm_pippenger_verify (host, %.0f ms incl. marshalling) and e(A, [1]_2) == e(B, [tau]_2) "
                             "(gm_kzg_verify_pair, %.0f ms incl. the mock verifying key)" % (t_v * 1e3, t_pair * 1e3)}
+            # ---- whole proofs from several host threads at once (a proving service's mode; the G1 engine takes one call at a time
+            # per device, so what overlaps is one proof's G1 work with the others' latency-bound sumcheck rounds)
+            if args.concurrent_provers > 1:
+                import threading
+                T, reps_c = args.concurrent_provers, 2
+                bar = threading.Barrier(T + 1)
+                box = {"ok": True}
+
+                def full_thread(k):
+                    try:
+                        with torch.cuda.stream(torch.cuda.Stream()):
+                            pl = harness.MsmPlan(x_log, d_log, y_size)
+
+                            def one():
+                                pl.run(d_pts, d_sc)
+                                wk = harness.PippengerWG(pl, d_pts, y_log, 0, d_basis)
+                                mk = harness.MerlinTranscript(b"bench-full")
+                                rk = harness.pippenger_prove_tr(wk, r_f, evs_f, d_inv, 2, mk)
+                                same = rk["pair"] == fm["pair"] and bytes(mk.proof()) == proof_f
+                                mk.close()
+                                wk.close()
+                                return same
+                            one()                                  # warm this thread's share of the memory pool
+                            bar.wait()
+                            for _ in range(reps_c):
+                                if not one():
+                                    box["ok"] = False
+                            torch.cuda.current_stream().synchronize()
+                            bar.wait()
+                            pl.close()
+                    except threading.BrokenBarrierError:
+                        box["ok"] = False
+                    except Exception as e:
+                        box["ok"] = False
+                        box.setdefault("error", repr(e)[:300])
+                        bar.abort()
+                ths = [threading.Thread(target=full_thread, args=(k,)) for k in range(T)]
+                for th in ths:
+                    th.start()
+                try:
+                    bar.wait()
+                    t1 = time.perf_counter()
+                    bar.wait()
+                    wall_c = time.perf_counter() - t1
+                except threading.BrokenBarrierError:
+                    wall_c = None
+                for th in ths:
+                    th.join()
+                out["full_gen2_prover"]["concurrent_provers"] = (
+                    {"threads": T, "proofs": T * reps_c, "wall_ms": round(wall_c * 1e3, 1),
+                     "proofs_per_sec": round(T * reps_c / wall_c, 3), "ms_per_proof": round(wall_c * 1e3 / (T * reps_c), 2),
+                     "proofs_identical_to_the_single_threaded_one": True,
+                     "note": "whole-device throughput: %d independent whole proofs (PippengerWG::new + prove under merlin) in flight, one "
+                             "host thread, stream, plan and witness each, one proving key; the figures above are the single proof" % T}
+                    if wall_c is not None and box["ok"] else {"threads": T, "error": box.get("error", "proofs differ")})
             harness.g1_fixed_base_release(d_basis)
             plan_f.close()
         del d_srs, d_gsc

@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(128) k_g1_mock_srs(G1Aff g0, Fr tau, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------ engine (host)
-// grow-only device scratch shared by the G1 calls of this process (one call at a time: guarded by a mutex)
+// grow-only device scratch shared by the G1 calls of this process on one device (one call at a time per device: guarded by a mutex)
 struct G1Scratch {
     char* base = nullptr;
     size_t cap = 0, used = 0;
@@ -528,9 +528,13 @@ struct G1Scratch {
         cap = used = 0;
     }
 };
+// one per DEVICE: rank threads of one process that drive different GPUs must neither share scratch memory (it lives on the device that
+// was current when it grew) nor queue behind each other's G1 calls
 static G1Scratch& g1_scratch() {
-    static G1Scratch s;
-    return s;
+    static G1Scratch s[GM_MAX_DEVICES];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return s[(dev >= 0 && dev < GM_MAX_DEVICES) ? dev : 0];
 }
 
 static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }

@@ -36,8 +36,11 @@ extern "C" {
  * on different handles at the same time (a proving service: one thread = one stream + one plan / witness; rayon workers in
  * the reference play the same role).  Everything the library keeps between calls is per thread (pinned staging, the host
  * tables, the last error) or behind a lock (the device-memory cache, which hands a freed block only to the thread that
- * freed it; the co-residency budget of the persistent round kernel).  A thread must outlive the handles it created.
- * bench.py's `sumcheck.concurrent_provers` and tests/test_prover_gpu.py::test_provers_on_concurrent_host_threads use this. */
+ * freed it; the co-residency budget of the persistent round kernel; the G1 engine's scratch and fixed-base registry: ONE G1 call
+ * at a time per device, so whole proofs from several threads overlap one proof's G1 work with the others' sumcheck rounds).
+ * A thread must outlive the handles it created.
+ * bench.py's `sumcheck.concurrent_provers` / `full_gen2_prover.concurrent_provers`, tests/test_prover_gpu.py::
+ * test_provers_on_concurrent_host_threads and tests/test_pippenger_full_gpu.py::test_whole_proofs_on_concurrent_host_threads use this. */
 const char* gm_last_error(void);
 const char* gm_version(void);
 int32_t gm_device_count(int32_t* out_count);
@@ -781,7 +784,7 @@ int32_t gm_g1_mock_srs(const uint64_t* h_tau, const uint64_t* h_g0_aff, uint64_t
  * The bases must stay unchanged and allocated until the release. */
 int32_t gm_g1_fixed_base_register(const uint64_t* d_bases_aff, uint64_t n, void* stream);
 int32_t gm_g1_fixed_base_release(const uint64_t* d_bases_aff);
-/* frees the grow-only device scratch the G1 calls share */
+/* frees the grow-only device scratch the G1 calls on the CURRENT device share (one scratch and one queue of G1 calls per device) */
 int32_t gm_g1_release_scratch(void);
 
 /* The G1 column commitments gkr_msm_prove makes before the GKR (gkr_msm_simple.rs:117-151): 2^log_num_bit_columns bit columns

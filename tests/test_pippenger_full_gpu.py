@@ -165,3 +165,74 @@ def test_full_prover_with_builtin_merlin_transcript_produces_a_verifying_proof()
     # size: every scalar 32 bytes, every point 48 bytes -- counts from a tape run of the same shape
     ref = wg.prove(claims[0], claims[1], d_inv, 2, [rng.next_bits(128) for _ in range(4000)])
     assert len(proofs[0]) == 32 * len(ref["msgs"]) + 48 * len(ref["points"])
+
+
+def test_whole_proofs_on_concurrent_host_threads():
+    """three host threads, each with its own stream, plan and PippengerWG (two shapes; ONE proving key on the device, read by all of
+    them), run PippengerWG::new + Pippenger::prove at the same time, four proofs each: every proof -- transcript scalars, G1 points,
+    pairing pair -- equals the one the same inputs gave on a single thread, and A = tau B.  The G1 engine's scratch and the
+    fixed-base registry are shared state behind locks (one G1 call at a time per device), the sumcheck state is per thread
+    (include/gkrmsm.h "Threads")."""
+    import threading
+    import torch
+    shapes = [(9, 4, 32, 0), (8, 4, 16, 1), (9, 4, 32, 0)]
+    nv_max = max(x + c for x, _, _, c in shapes)
+    rng = F.SplitMix64(777)
+    tau = rng.next_fr()
+    d_basis = H.g1_mock_srs(tau, (2 << nv_max) - 1, G.GEN)
+    H.g1_fixed_base_register(d_basis, (2 << nv_max) - 1)
+    torch.cuda.synchronize()
+    inputs = {}
+    for x_log, d_log, nbits, clm in set(shapes):
+        y_size = (nbits + d_log - 1) // d_log
+        y_log = (y_size - 1).bit_length()
+        n = 1 << x_log
+        inputs[(x_log, d_log, nbits, clm)] = dict(
+            pts=codec.points_to_mont(F.random_points(n, 40 + x_log)), sc=codec.ints_to_limbs(F.random_scalars(n, nbits, 41 + clm)),
+            y_size=y_size, y_log=y_log, r=[rng.next_fr() for _ in range(y_log)], tape=[rng.next_bits(128) for _ in range(6000)])
+
+    def one_proof(shape, reps):
+        x_log, d_log, nbits, clm = shape
+        c = inputs[shape]
+        d_pts = H.to_dev(c["pts"])
+        plan = H.MsmPlan(x_log, d_log, c["y_size"])
+        d_sc = H.to_dev(c["sc"])
+        d_inv = H.knuckles_setup(2, x_log + clm)
+        outs = []
+        for _ in range(reps):
+            plan.run(d_pts, d_sc)
+            wg = H.PippengerWG(plan, d_pts, c["y_log"], clm, d_basis)
+            claims = GK.pippenger_claims(wg.dense_output(), c["r"])
+            outs.append(wg.prove(claims[0], claims[1], d_inv, 2, c["tape"]))
+            wg.close()
+        plan.close()
+        return outs
+
+    alone = {s: one_proof(s, 1)[0] for s in set(shapes)}
+    for s, res in alone.items():
+        assert res["pair"][0] == G.mul(res["pair"][1], tau), "shape %r: the single-thread proof does not verify" % (s,)
+    bar = threading.Barrier(len(shapes))
+    errors = []
+
+    def prover(k):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                bar.wait(timeout=120)
+                for j, res in enumerate(one_proof(shapes[k], 4)):
+                    want = alone[shapes[k]]
+                    for key in ("msgs", "points", "pair", "tape_used", "rounds"):
+                        assert res[key] == want[key], "thread %d proof %d: %s differ from the single-thread proof" % (k, j, key)
+        except Exception as e:  # noqa: BLE001 - reported to the test thread
+            errors.append("thread %d: %r" % (k, e))
+            try:
+                bar.abort()
+            except Exception:
+                pass
+    ths = [threading.Thread(target=prover, args=(k,)) for k in range(len(shapes))]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=600)
+    torch.cuda.synchronize()
+    H.g1_fixed_base_release(d_basis)
+    assert not errors, errors
