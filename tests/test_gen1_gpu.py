@@ -29,6 +29,30 @@ def test_gkr_msm_prove_matches_oracle(lp, lb):
     assert [G1.evaluate(b, res["point"]) for b in base] == res["evs"]
 
 
+@pytest.mark.parametrize("kind", ["zeros", "ones", "identities"])
+def test_gkr_msm_prove_on_degenerate_inputs(kind):
+    """all-zero and all-one bit columns (every scalar 0 / 2^(2^lb) - 1) and identity points: the layer functions see (0, 1, 1) cells and
+    doublings of equal operands; outputs and every message as the oracle's"""
+    lp, lb = 3, 2
+    pts = F.random_points(1 << lp, 5)
+    rng = F.SplitMix64(41)
+    bits = [[bool(rng.next() & 1) for _ in range(1 << lb)] for _ in range(1 << lp)]
+    if kind == "zeros":
+        bits = [[False] * (1 << lb) for _ in range(1 << lp)]
+    elif kind == "ones":
+        bits = [[True] * (1 << lb) for _ in range(1 << lp)]
+    else:
+        pts = [(0, 1)] * (1 << lp)
+    tape = [rng.next_fr() for _ in range(4000)]
+    claim, out, tr = G1.gkr_msm_prove(bits, pts, lp, lb, tape)
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    d_bits = torch.from_numpy(np.array([[1 if b else 0 for b in s] for s in bits], dtype=np.uint8).reshape(-1)).cuda()
+    res = H.gkr_msm_prove(d_pts, d_bits, lp, lb, tape)
+    assert res["output"] == out
+    assert res["msgs"] == tr.msgs
+    assert res["point"] == claim[0] and res["evs"] == claim[1]
+
+
 def test_gen1_live_transcript_matches_tape():
     lp, lb = 4, 2
     pts = F.random_points(1 << lp, 9)

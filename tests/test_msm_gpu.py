@@ -62,6 +62,65 @@ def test_msm_matches_oracle(x_log, d_log, nbits):
     plan.close()
 
 
+@pytest.mark.parametrize("kind", ["all_equal", "negated_pairs", "identities", "max_scalars", "zero_scalars"])
+def test_msm_on_degenerate_inputs(kind):
+    """inputs that put P + P, P + (-P) and the identity into the bucket additions, and scalars whose every digit is 2^d - 1 / 0 (one
+    bucket per window takes every point): the twisted-Edwards bucket sums are the reference's unified projective formulas in its
+    association order, so the stored (X, Y, Z) must still equal the oracle's limb for limb, and the final point the naive sum"""
+    x_log, d_log, nbits = 6, 3, 24
+    y_size = nbits // d_log
+    y_log = log2_exact(y_size)
+    n = 1 << x_log
+    pts = F.random_points(n, 555)
+    sc = F.random_scalars(n, nbits, 556)
+    if kind == "all_equal":
+        pts = [pts[0]] * n
+    elif kind == "negated_pairs":
+        for i in range(0, n, 2):
+            pts[i + 1] = F.te_neg(pts[i])
+            sc[i + 1] = sc[i]               # same buckets: every bucket sum passes through P + (-P)
+    elif kind == "identities":
+        for i in range(0, n, 3):
+            pts[i] = (0, 1)
+    elif kind == "max_scalars":
+        sc = [(1 << nbits) - 1] * n
+    else:
+        sc = [0] * n
+    image, digits, counter, wg = G.pippenger_witness(pts, sc, y_size, y_log, d_log, x_log)
+    out = G.pippenger_dense_output(wg, y_log, d_log)
+    d_pts = harness.to_dev(codec.points_to_mont(pts))
+    plan = harness.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, harness.to_dev(codec.ints_to_limbs(sc)))
+    dg, ct, _ = plan.digits_counter_rowlen()
+    assert dg.tolist() == digits and ct.tolist() == counter
+    bs = plan.bucket_sums()
+    for c in range(3):
+        assert bs[c] == wg.bucket_sums[c][: y_size << d_log], "bucket sums col %d" % c
+    wp = plan.window_points()
+    for c in range(3 * (d_log + 1)):
+        assert wp[c] == out[c][:y_size], "window points col %d" % c
+    got = harness.combine_host(plan.window_points_raw(), d_log)
+    assert got == G.pippenger_final_point(out, d_log)
+    acc = (0, 1)
+    for p_, s_ in zip(pts, sc):
+        acc = F.te_add_affine(acc, F.te_mul_affine(p_, s_))
+    assert got == acc
+    # the image-part prover on the same witness (its layer functions see the same degenerate cells)
+    from gkr_msm_amd.harness import PipWitness
+    rng = F.SplitMix64(9)
+    r = [rng.next_fr() for _ in range(y_log)]
+    claims = G.pippenger_claims(out, r)
+    tape = [rng.next_bits(128) for _ in range(4000)]
+    from pyref.sumcheck import TapeTranscript
+    tr = TapeTranscript(tape)
+    G.prove_image_part(tr, y_log, d_log, x_log, claims, wg)
+    w = PipWitness(plan, d_pts, y_log)
+    res = w.prove_image_part(claims[0], claims[1], tape)
+    assert res["msgs"] == [v for m in tr.msgs for v in m]
+    w.close()
+    plan.close()
+
+
 def test_window_sharding_matches_full():
     x_log, d_log, nbits = 8, 4, 32
     y_size = 8

@@ -17,6 +17,17 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("x_log,d_log,nbits,clm", [(3, 2, 8, 0), (3, 2, 8, 1), (4, 2, 6, 0), (4, 3, 12, 2),
                                                   (3, 2, 40, 4)])   # clm = 4 (BASELINE.json configs[4]): 16 windows per commitment matrix, the last matrix partial
 def test_full_prover_matches_oracle_and_verifies(x_log, d_log, nbits, clm):
+    _full_prover_against_oracle(x_log, d_log, nbits, clm, None)
+
+
+@pytest.mark.parametrize("kind", ["all_same", "zero"])
+def test_full_prover_with_every_point_in_one_bucket_per_window(kind):
+    """every scalar equal: ONE outer bucket per window holds every key point (a G1 row of 2^x_logsize points beside empty rows),
+    the counter column reaches X - 1, the access counts are X in one place: commitments, messages and the pairing pair as the oracle's"""
+    _full_prover_against_oracle(3, 2, 8, 1, [0b10011011] * 8 if kind == "all_same" else [0] * 8)
+
+
+def _full_prover_against_oracle(x_log, d_log, nbits, clm, scalars):
     y_size = (nbits + d_log - 1) // d_log
     y_log = (y_size - 1).bit_length()
     n = 1 << x_log
@@ -24,6 +35,8 @@ def test_full_prover_matches_oracle_and_verifies(x_log, d_log, nbits, clm):
     pts = F.random_points(n, 2)
     sc = F.random_scalars(n, nbits, 3)
     sc[0] = 0
+    if scalars is not None:
+        sc = list(scalars)
     nv = x_log + clm
     N = 1 << nv
     tau, k = rng.next_fr(), 2

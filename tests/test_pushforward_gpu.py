@@ -46,6 +46,39 @@ def test_pushforward_matches_oracle(x_log, d_log, nbits):
     assert got["rounds"] == sum(range(x_log + y_log)) + x_log + d_log + x_log + y_log
 
 
+@pytest.mark.parametrize("kind", ["all_same", "zero", "max"])
+def test_pushforward_with_every_point_in_one_bucket_per_window(kind):
+    """collisions at their maximum: every scalar equal, so one bucket per window holds all 2^x_logsize points -- the counter column
+    reaches X - 1, the access counts are one entry of X and zeros elsewhere (the logup fractions of the untouched rows)"""
+    x_log, d_log, nbits = 4, 2, 6
+    y_size = (nbits + d_log - 1) // d_log
+    y_log = (y_size - 1).bit_length()
+    n = 1 << x_log
+    pts = F.random_points(n, 77)
+    sc = {"all_same": [0b100111] * n, "zero": [0] * n, "max": [(1 << nbits) - 1] * n}[kind]
+    image, digits, counter = G.bucketing_image(pts, sc, y_size, y_log, d_log, x_log)
+    assert max(max(c) for c in counter) == n - 1
+    rng = F.SplitMix64(31)
+    r = [rng.next_fr() for _ in range(y_log + d_log + x_log)]
+    evs = [PL.evaluate_poly(p.to_dense(), r) for p in image]
+    tape = [rng.next_bits(512) % F.P for _ in range(3000)]
+    tr = TapeTranscript(tape)
+    p1 = PF.phase1_data(pts, digits, counter, x_log, d_log)
+    p2 = PF.phase2_data(digits, counter, r, y_log, d_log, x_log)
+    want = PF.pushforward_prove(tr, x_log, y_log, y_size, d_log, (r, evs), p1, p2)
+    d_pts = H.to_dev(codec.points_to_mont(pts))
+    plan = H.MsmPlan(x_log, d_log, y_size)
+    plan.run(d_pts, H.to_dev(codec.ints_to_limbs(sc)))
+    got = H.pushforward_prove(plan, d_pts, y_log, r, evs, _device_tape(tape, tr))
+    assert got["tape_used"] == tr.pos
+    assert got["msgs"] == [v for m in tr.msgs for v in m]
+    assert got["gamma"] == want["gamma"]
+    assert (list(got["matrix"][0]), list(got["matrix"][1])) == (want["matrix"][0], want["matrix"][1])
+    assert (list(got["ac_c"][0]), list(got["ac_c"][1])) == (list(want["ac_c"][0]), list(want["ac_c"][1]))
+    assert (list(got["ac_d"][0]), list(got["ac_d"][1])) == (list(want["ac_d"][0]), list(want["ac_d"][1]))
+    plan.close()
+
+
 def _device_tape(tape, tr):
     """the challenges as the oracle consumed them (4 x 512-bit reduced mod p, then 128-bit truncations)"""
     return [t % F.P if i < 4 else t & ((1 << 128) - 1) for i, t in enumerate(tape[: tr.pos])] + [0] * 8
