@@ -47,6 +47,8 @@ def _proc(ranks, world, tag, shape, q, key_mode, env):
         pts = F.random_points(n, 21)
         sc = F.random_scalars(n, nbits, 22)
         sc[0] = 0
+        if os.environ.get("GM_TEST_SCALARS") == "all_same":   # every point in ONE bucket per window (a zero digit among them)
+            sc = [0x9B1B9B1B9B1B9B1B & ((1 << nbits) - 1)] * n
         tau, k = rng.next_fr(), 2
         d_pts = H.to_dev(codec.points_to_mont(pts))
         d_sc = H.to_dev(codec.ints_to_limbs(sc))
@@ -173,6 +175,12 @@ def test_sharded_whole_proof_with_a_one_entry_ipc_cache_and_host_staging():
     assert any(ipc[1] > 0 for _, _, _, _, ipc, _ in res), "no mapping was ever evicted: the bound was not exercised"
     assert all(ipc[2] <= 2 for _, _, _, _, ipc, _ in res)      # what one call touched may stay, nothing more
     _run(4, (4, 2, 16, 2), "minimal", env={"GM_SHM_NO_IPC": "1"})
+
+
+def test_sharded_whole_proof_with_every_point_in_one_bucket_per_window():
+    """collisions at their maximum on the sharded path: every scalar equal, so a rank's windows hold one full bucket each and empty
+    rows otherwise; the access counts a rank contributes are X in one place per window"""
+    _run(4, (4, 2, 16, 2), "minimal", env={"GM_TEST_SCALARS": "all_same"})
 
 
 def test_config_e_structure_at_x_logsize_14_over_eight_ranks():
