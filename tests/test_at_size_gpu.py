@@ -72,9 +72,12 @@ def device_inputs(x_log, nbits, seed):
     return d_pts, H.to_dev(sc), sc
 
 
-def check_msm(x_log, d_log, nbits, seed):
+def check_msm(x_log, d_log, nbits, seed, scalars=None):
     y_size = (nbits + d_log - 1) // d_log
     d_pts, d_sc, sc = device_inputs(x_log, nbits, seed)
+    if scalars is not None:
+        sc = np.ascontiguousarray(scalars, dtype=np.uint64)
+        d_sc = H.to_dev(sc)
     pts_host = H.to_host(d_pts).reshape(-1, 8)
     plan = H.MsmPlan(x_log, d_log, y_size)
     plan.run(d_pts, d_sc)
@@ -754,6 +757,44 @@ def test_config_c_whole_gen2_proof_at_x_logsize_20():
     del s
     ffi.lib().gm_release_cached_memory()
     ffi.check(ffi.lib().gm_g1_release_scratch())
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind", ["all_same", "half_in_one_bucket", "zero"])
+def test_whole_proof_with_skewed_buckets_at_x_logsize_16(kind):
+    """collisions at size: every scalar equal (one bucket of 2^16 points per window: a bintree row 16 levels deep beside 255 empty
+    rows, the counter column up to X - 1), half of the points in one bucket, every scalar zero -- whole proof under merlin, library
+    verifier, pairing.  The ragged trees, the thin rounds and the access counts see their most skewed shapes."""
+    from test_verifier_gpu import _prove_merlin, _setup
+    from gkr_msm_amd import verifier as VF
+    from pyref import g1 as G
+    from pyref import pairing as PR
+    x_log, d_log, nbits = 16, 8, 64
+    n = 1 << x_log
+    t_begin = time.perf_counter()
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    if kind == "all_same":
+        sc[:, 0] = np.uint64(0x9B1B00FF5A3C7E01)
+    elif kind == "half_in_one_bucket":
+        sc[:, 0] = np.random.default_rng(5).integers(0, 2**63, size=n, dtype=np.uint64)
+        sc[::2, 0] = np.uint64(0x0101010101010101)
+    # every MSM stage and every message of the image-part prover against the C oracle first
+    plan, d_pts, d_sc, pts_host, sc_h = check_msm(x_log, d_log, nbits, 99, scalars=sc)
+    check_image_part(plan, d_pts, pts_host, sc_h, x_log, d_log, nbits, 8)
+    plan.close()
+    del d_pts, d_sc
+    s = _setup(x_log, d_log, nbits, 0, 31, device_srs=True, scalars_u64x4=sc)
+    t0 = time.perf_counter()
+    proof, pair = _prove_merlin(s, b"skew")
+    prove_s = time.perf_counter() - t0
+    got = VF.pippenger_verify_merlin(*s["shape"], s["claims"][0], s["claims"][1], G.GEN, 2, b"skew", proof)
+    assert got == pair
+    assert VF.kzg_verify_pair(got, PR.G2_GEN, PR.g2_mul(PR.G2_GEN, s["tau"]))
+    record("whole_proof_skewed_buckets_" + kind, x_logsize=x_log, d_logsize=d_log, nbits=nbits, prove_ms=round(prove_s * 1e3, 1),
+           seconds=round(time.perf_counter() - t_begin, 1),
+           checked="MSM stages + image-part messages bit-exact vs the C oracle; merlin proof bytes -> library verifier -> pairing accepts")
+    del s
+    ffi.lib().gm_release_cached_memory()
     torch.cuda.empty_cache()
 
 

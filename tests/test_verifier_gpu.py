@@ -16,7 +16,7 @@ from pyref import pairing as PR
 pytestmark = pytest.mark.gpu
 
 
-def _setup(x_log, d_log, nbits, clm, seed, device_srs=False):
+def _setup(x_log, d_log, nbits, clm, seed, device_srs=False, scalars_u64x4=None):
     y_size = (nbits + d_log - 1) // d_log
     y_log = (y_size - 1).bit_length()
     n = 1 << x_log
@@ -31,6 +31,8 @@ def _setup(x_log, d_log, nbits, clm, seed, device_srs=False):
         for w in range(4):   # nbits bits
             lo = max(0, min(64, nbits - 64 * w))
             sc[:, w] &= np.uint64((1 << lo) - 1) if lo < 64 else np.uint64(2**64 - 1)
+        if scalars_u64x4 is not None:
+            sc = np.ascontiguousarray(scalars_u64x4, dtype=np.uint64).reshape(n, 4)
         d_sc = H.to_dev(sc)
         d_basis = H.g1_mock_srs(tau, (2 << nv) - 1, G.GEN)
     else:
