@@ -703,7 +703,7 @@ __device__ __forceinline__ Point9 pt9_shfl(const Point9& v, int from) {
 
 #define GM_TAIL_FAT_WAVES 64
 // grid: ceil(nrows / 64) "thin" blocks (thread = row; rows of at most 16 cells), then GM_TAIL_FAT_WAVES blocks that look for the
-// longer rows (row % GM_TAIL_FAT_WAVES == its index) and take each of them with all 64 lanes.
+// longer rows (one row per group of GM_TAIL_FAT_WAVES consecutive rows each) and take each of them with all 64 lanes.
 // Code size matters here: an addition is ~2 700 instructions (22 KB) and a lone wave that runs straight-line code fetches every
 // line of it from L2 (the first version, 13 inlined additions, took 620 us for 50 us of arithmetic).  Both paths are therefore
 // LOOPS around ONE proj_add9 and ONE add_identity9 site; which operands a step takes is decided by moves around them.
@@ -772,10 +772,14 @@ __global__ void __launch_bounds__(64) k_add_tail(LvlBufs lb, const uint32_t* __r
         fr_store(oz + r, fr9_to(T.z));
         return;
     }
-    // ---- a fat wave: rows w, w + F, w + 2 F, ... ; every long one among them with all 64 lanes
+    // ---- a fat wave: one row of every group of F = 64 consecutive rows; every long one among them with all 64 lanes.  WHICH row of
+    // group hi is mixed with hi: with "row % F == w" the 32 rows (window y, digit 0) of an all-zero scalar vector -- rows 256 y -- all
+    // fell to fat wave 0, which then added 32 rows of 1 024 cells one after the other (4.6 ms for a 3 ms MSM step; uniform scalars
+    // have no long rows at all).  Rows y 2^d + const now spread over min(y_size, 64) waves for every d.
     const uint32_t w = blockIdx.x - n_thin_blocks;
-    for (uint32_t base = w; base < nrows; base += 64u * GM_TAIL_FAT_WAVES) {
-        const uint32_t rr = base + lane * GM_TAIL_FAT_WAVES;
+    for (uint32_t hb = 0; hb * GM_TAIL_FAT_WAVES < nrows; hb += 64u) {
+        const uint32_t hi = hb + lane;
+        const uint32_t rr = hi * GM_TAIL_FAT_WAVES + ((w ^ hi ^ (hi >> 6) ^ (hi >> 12)) & (GM_TAIL_FAT_WAVES - 1u));
         const uint32_t cc = rr < nrows ? off0[rr + 1] - off0[rr] : 0u;
         uint64_t fat = __ballot(cc > 16);
         while (fat) {
