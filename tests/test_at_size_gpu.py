@@ -769,7 +769,7 @@ def test_whole_proof_with_skewed_buckets_at_x_logsize_16(kind):
     from gkr_msm_amd import verifier as VF
     from pyref import g1 as G
     from pyref import pairing as PR
-    x_log, d_log, nbits = 16, 8, 64
+    x_log, d_log, nbits = int(os.environ.get("GM_TEST_SKEW_XLOG", "16")), 8, 64
     n = 1 << x_log
     t_begin = time.perf_counter()
     sc = np.zeros((n, 4), dtype=np.uint64)
