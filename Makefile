@@ -20,10 +20,10 @@ oracle:
 	$(MAKE) -s -C oracle
 
 # plain C callers of the C ABI (no HIP headers, no C++): gcc only
-examples: build/examples/pippenger build/examples/gkr_msm_simple
+examples: build/examples/pippenger build/examples/gkr_msm_simple build/examples/pippenger_sharded
 build/examples/%: examples/%.c include/gkrmsm.h $(LIB)
 	@mkdir -p build/examples
-	gcc -std=c11 -O2 -Wall -Wextra -D_POSIX_C_SOURCE=199309L -Iinclude $< -o $@ -Lgkr_msm_amd -lgkrmsm_hip -Wl,-rpath,'$$ORIGIN/../../gkr_msm_amd'
+	gcc -std=c11 -O2 -Wall -Wextra -pthread -D_POSIX_C_SOURCE=200809L -Iinclude $< -o $@ -Lgkr_msm_amd -lgkrmsm_hip -Wl,-rpath,'$$ORIGIN/../../gkr_msm_amd'
 
 # device-side self-checks that tests/ run on the GPU box (prebuilt here: the 14 x 28 one takes hipcc three minutes); each binary
 # carries the digest of its source + the field headers, tests/ubench_util.py rebuilds only when that digest is stale

@@ -171,6 +171,19 @@ extern "C" int32_t gm_set_device(int32_t device) {
     return GM_OK;
 }
 extern "C" int32_t gm_stream_sync(void* stream) { GM_HIP(hipStreamSynchronize(as_stream(stream))); return GM_OK; }
+// a stream of the current device for callers without the HIP runtime of their own (plain C, the Rust shim): non-blocking, i.e. it does
+// not synchronise with the device's default stream -- rank threads that share a device must not (their gate kernels wait for each other's hosts)
+extern "C" int32_t gm_stream_create(void** out) {
+    GM_REQUIRE(out, "null argument");
+    hipStream_t s = nullptr;
+    GM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = s;
+    return GM_OK;
+}
+extern "C" int32_t gm_stream_destroy(void* stream) {
+    if (stream) GM_HIP(hipStreamDestroy(as_stream(stream)));
+    return GM_OK;
+}
 extern "C" int32_t gm_malloc(void** out, size_t bytes) { GM_REQUIRE(out, "null out"); GM_HIP(hipMalloc(out, bytes ? bytes : 16)); return GM_OK; }
 extern "C" int32_t gm_free(void* p) { GM_HIP(hipFree(p)); return GM_OK; }
 extern "C" int32_t gm_release_cached_memory(void) { gm::dev_pool().release(); return GM_OK; }

@@ -93,6 +93,8 @@ _SIGS = {
     "gm_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "gm_set_device": (C.c_int32, [C.c_int32]),
     "gm_stream_sync": (C.c_int32, [vp]),
+    "gm_stream_create": (C.c_int32, [C.POINTER(vp)]),
+    "gm_stream_destroy": (C.c_int32, [vp]),
     "gm_malloc": (C.c_int32, [C.POINTER(vp), C.c_size_t]),
     "gm_free": (C.c_int32, [vp]),
     "gm_release_cached_memory": (C.c_int32, []),

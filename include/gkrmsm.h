@@ -46,6 +46,11 @@ const char* gm_version(void);
 int32_t gm_device_count(int32_t* out_count);
 int32_t gm_set_device(int32_t device);
 int32_t gm_stream_sync(void* stream);
+/* a hipStream_t of the current device for callers that do not link the HIP runtime themselves (plain C, the Rust shim); created
+ * non-blocking: it never synchronises with the default stream.  Every `void* stream` argument of this header takes it (or any
+ * hipStream_t of the caller's; NULL = the default stream). */
+int32_t gm_stream_create(void** out_stream);
+int32_t gm_stream_destroy(void* stream);
 /* plain device memory helpers for non-torch callers (the Rust shim) */
 int32_t gm_malloc(void** out_d_ptr, size_t bytes);
 int32_t gm_free(void* d_ptr);

@@ -191,3 +191,22 @@ def test_config_e_structure_at_x_logsize_14_over_eight_ranks():
     the unsharded prover's on every rank."""
     res = _run(8, (14, 8, 256, 4), "minimal", threads_per_proc=2, env=dict(MANY_QUEUES, GM_TEST_SAY_TIMES="1"))
     assert all(kp < n_key for _, _, _, kp, _, n_key in res)
+
+
+@pytest.mark.parametrize("ranks,shape", [(2, (8, 4, 32, 1)), (4, (6, 2, 16, 2)), (8, (5, 2, 64, 4))])
+def test_c_example_of_the_sharded_proof(ranks, shape):
+    """examples/pippenger_sharded.c: one process, one host thread per rank, plain C against include/gkrmsm.h (gm_stream_create, the
+    shared-memory communicator, key views INTO the SRS by gm_pippenger_sharded_key_ranges, gm_knuckles_setup_range) -- every rank ends
+    with the same merlin proof bytes, the host verifier and the pairing accept them; the last shape is config E's structure (32 windows,
+    clm 4, 8 ranks x 4 windows) at x_logsize 5"""
+    import subprocess
+    exe = os.path.join(ROOT, "build", "examples", "pippenger_sharded")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", ROOT, "examples"])
+    x_log, d_log, nbits, clm = shape
+    r = subprocess.run([exe, "--ranks", str(ranks), "--x-logsize", str(x_log), "--d-logsize", str(d_log), "--nbits", str(nbits),
+                        "--commitment-log-multiplicity", str(clm)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, **MANY_QUEUES))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all ranks hold the same proof and pairing pair" in r.stdout and "proof verified" in r.stdout
+
