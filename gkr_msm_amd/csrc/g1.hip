@@ -176,43 +176,73 @@ struct G1SrcJac {
     }
 };
 
-// intermediate cells of the tree: the 14 x 28 form as an addition leaves it (g1.hip.h, G1P14), 42 words = 168 bytes per cell --
-// neither the conversion to the wire form on the way out (3 x ~140 instructions) nor the one back on the way in (6 x ~100)
+// intermediate cells of the tree: the 14 x 28 form as an addition leaves it (G1P14: Jacobian, 42 words = 168 bytes) -- neither the
+// conversion to the wire form on the way out (3 x ~140 instructions) nor the one back on the way in (6 x ~100).
+// -DGM_G1_CELLS_XYZZ=1: XYZZ cells (g1.hip.h, G1X14: 56 words = 224 bytes; a cell + cell addition is 12 products + 2 squares instead
+// of the Jacobian 12 + 4 = 10 % fewer multiply-adds).  Measured in round 4, same box, alternating runs: 2^21-point MSM 11.41-11.47 ms
+// against 11.27-11.30 with Jacobian cells, outer buckets 22.1 against 21.8 ms -- the 33 % wider cells (247 VGPRs instead of 209, 28 KB
+// of LDS staging per workgroup instead of 21) take back what the two squares save.  Correct (the whole G1 / opening / proof suite
+// passes with it), not faster: off.
+#ifndef GM_G1_CELLS_XYZZ
+#define GM_G1_CELLS_XYZZ 0
+#endif
+#if GM_G1_CELLS_XYZZ
+typedef G1X14 G1Cell;
+static constexpr uint32_t G1_CELL_WORDS = 56;
+__device__ __forceinline__ G1Cell g1c_from_jac(const G1Jac& p) { return g1x_from_jac(p); }
+__device__ __forceinline__ G1Jac g1c_to_jac(const G1Cell& p) { return g1x_to_jac(p); }
+__device__ __forceinline__ G1Cell g1c_add(const G1Cell& p, const G1Cell& q) { return g1x_add(p, q); }
+__device__ __forceinline__ G1Cell g1c_add_aff(const G1Aff& p, const G1Aff& q) { return g1x_add_aff(p, q); }
+__device__ __forceinline__ const Fq14& g1c_coord(const G1Cell& p, int c) { return c == 0 ? p.x : c == 1 ? p.y : c == 2 ? p.zz : p.zzz; }
+__device__ __forceinline__ Fq14& g1c_coord(G1Cell& p, int c) { return c == 0 ? p.x : c == 1 ? p.y : c == 2 ? p.zz : p.zzz; }
+#else
+typedef G1P14 G1Cell;
 static constexpr uint32_t G1_CELL_WORDS = 42;
+__device__ __forceinline__ G1Cell g1c_from_jac(const G1Jac& p) { return g1p14_from(p); }
+__device__ __forceinline__ G1Jac g1c_to_jac(const G1Cell& p) { return g1p14_to(p); }
+__device__ __forceinline__ G1Cell g1c_add(const G1Cell& p, const G1Cell& q) { return g1_add14p(p, q); }
+__device__ __forceinline__ G1Cell g1c_add_aff(const G1Aff& p, const G1Aff& q) { return g1_add_aff14p(p, q); }
+__device__ __forceinline__ const Fq14& g1c_coord(const G1Cell& p, int c) { return c == 0 ? p.x : c == 1 ? p.y : p.z; }
+__device__ __forceinline__ Fq14& g1c_coord(G1Cell& p, int c) { return c == 0 ? p.x : c == 1 ? p.y : p.z; }
+#endif
+static constexpr int G1_CELL_COORDS = G1_CELL_WORDS / 14;
 struct __attribute__((packed, aligned(8))) G1Quad {
     uint32_t a, b, c, d;
 };
 struct G1SrcCells {
     const uint32_t* cells;
-    __device__ __forceinline__ G1P14 get(uint32_t cell) const {
+    __device__ __forceinline__ G1Cell get(uint32_t cell) const {
         const uint32_t* p = cells + (size_t)cell * G1_CELL_WORDS;
         uint32_t w[G1_CELL_WORDS];
 #pragma unroll
-        for (int k = 0; k < 10; k++) {
+        for (int k = 0; k < (int)G1_CELL_WORDS / 4; k++) {
             const G1Quad q = *reinterpret_cast<const G1Quad*>(p + 4 * k);
             w[4 * k] = q.a; w[4 * k + 1] = q.b; w[4 * k + 2] = q.c; w[4 * k + 3] = q.d;
         }
-        w[40] = p[40]; w[41] = p[41];
-        G1P14 r;
 #pragma unroll
-        for (int i = 0; i < 14; i++) { r.x.l[i] = w[i]; r.y.l[i] = w[14 + i]; r.z.l[i] = w[28 + i]; }
+        for (int k = 4 * ((int)G1_CELL_WORDS / 4); k < (int)G1_CELL_WORDS; k++) w[k] = p[k];
+        G1Cell r;
+#pragma unroll
+        for (int c = 0; c < G1_CELL_COORDS; c++)
+#pragma unroll
+            for (int i = 0; i < 14; i++) g1c_coord(r, c).l[i] = w[14 * c + i];
         return r;
     }
 };
 // one output cell of a level, in the cell form
-__device__ __forceinline__ G1P14 g1_pair14(const G1SrcAff& s, uint32_t c0, bool two) {
+__device__ __forceinline__ G1Cell g1_pair14(const G1SrcAff& s, uint32_t c0, bool two) {
     const G1Aff a = s.get(c0);
-    return two ? g1_add_aff14p(a, s.get(c0 + 1)) : g1p14_from(g1_from_aff(a));
+    return two ? g1c_add_aff(a, s.get(c0 + 1)) : g1c_from_jac(g1_from_aff(a));
 }
-__device__ __forceinline__ G1P14 g1_pair14(const G1SrcJac& s, uint32_t c0, bool two) {
-    const G1P14 a = g1p14_from(s.get(c0));
-    return two ? g1_add14p(a, g1p14_from(s.get(c0 + 1))) : a;
+__device__ __forceinline__ G1Cell g1_pair14(const G1SrcJac& s, uint32_t c0, bool two) {
+    const G1Cell a = g1c_from_jac(s.get(c0));
+    return two ? g1c_add(a, g1c_from_jac(s.get(c0 + 1))) : a;
 }
-__device__ __forceinline__ G1P14 g1_pair14(const G1SrcCells& s, uint32_t c0, bool two) {
-    const G1P14 a = s.get(c0);
-    return two ? g1_add14p(a, s.get(c0 + 1)) : a;
+__device__ __forceinline__ G1Cell g1_pair14(const G1SrcCells& s, uint32_t c0, bool two) {
+    const G1Cell a = s.get(c0);
+    return two ? g1c_add(a, s.get(c0 + 1)) : a;
 }
-__device__ __forceinline__ G1Jac g1_pair(const G1SrcCells& s, uint32_t c0, bool) { return g1p14_to(s.get(c0)); }
+__device__ __forceinline__ G1Jac g1_pair(const G1SrcCells& s, uint32_t c0, bool) { return g1c_to_jac(s.get(c0)); }
 __device__ __forceinline__ G1Jac g1_pair(const G1SrcAff& s, uint32_t c0, bool two) {
     const G1Aff a = s.get(c0);
     return two ? g1_add_aff(a, s.get(c0 + 1)) : g1_from_aff(a);
@@ -228,7 +258,7 @@ template <class Src>
 __global__ void __launch_bounds__(128) k_g1_level(Src src, const uint32_t* __restrict__ off_in,
                                                    const uint32_t* __restrict__ off_out, uint32_t nrows,
                                                    uint32_t* __restrict__ out, const uint32_t* __restrict__ br) {
-    // the 128 results of a workgroup are 21 KB of contiguous output: staged in LDS and written as whole lines (a lane storing
+    // the 128 results of a workgroup are 21 KB (28 KB with XYZZ cells) of contiguous output: staged in LDS and written as whole lines (a lane storing
     // its own cell leaves every 128-byte line partly written per store instruction: 1.7x the bytes in HBM writes measured)
     __shared__ uint2 stage[128 * (G1_CELL_WORDS / 2)];
     // the rows this workgroup's cells lie in (k_g1_block_rows) are few: their offsets go to LDS in one round trip and the row search
@@ -258,14 +288,12 @@ __global__ void __launch_bounds__(128) k_g1_level(Src src, const uint32_t* __res
         }
         const uint32_t p = j - o_r;
         const uint32_t in0 = off_in[r], len = off_in[r + 1] - in0;
-        const G1P14 v = g1_pair14(src, in0 + 2 * p, 2 * p + 1 < len);
+        const G1Cell v = g1_pair14(src, in0 + 2 * p, 2 * p + 1 < len);
         uint2* st = stage + threadIdx.x * (G1_CELL_WORDS / 2);
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
-            st[k] = make_uint2(v.x.l[2 * k], v.x.l[2 * k + 1]);
-            st[7 + k] = make_uint2(v.y.l[2 * k], v.y.l[2 * k + 1]);
-            st[14 + k] = make_uint2(v.z.l[2 * k], v.z.l[2 * k + 1]);
-        }
+        for (int c = 0; c < G1_CELL_COORDS; c++)
+#pragma unroll
+            for (int k = 0; k < 7; k++) st[7 * c + k] = make_uint2(g1c_coord(v, c).l[2 * k], g1c_coord(v, c).l[2 * k + 1]);
     }
     __syncthreads();
     const uint32_t b0 = blockIdx.x * blockDim.x;

@@ -209,6 +209,68 @@ __device__ __forceinline__ G1Jac g1_add_mixed14(const G1Jac& p, const G1Aff& q) 
 }
 __device__ __forceinline__ G1Jac g1_add_aff14(const G1Aff& p, const G1Aff& q) { return g1p14_to(g1_add_aff14p(p, q)); }
 #define GM_G1_DEVICE_FQ14 1
+
+// ---- XYZZ cells: (X, Y, ZZ, ZZZ) with x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2 -- what the sum-by-key tree keeps between its levels
+// (g1.hip).  A general addition is 12 products + 2 squares (EFD add-2008-s) against the Jacobian 12 + 4, affine + affine 4 + 2
+// (mmadd-2008-s) like the Jacobian one; the tree's results are group elements, so the representative does not matter, and the wire
+// form is only produced once, at the end: (X ZZ, Y ZZZ, ZZ) is a Jacobian representative of the same point (Z' = ZZ).
+// Invariant of a cell: limbs < 2^28; S <= 5.1 for X and Y, <= 1.1 for ZZ and ZZZ; infinity is ZZ = 0 limb for limb (Z = 0 converts
+// to it exactly, and ZZ3 of an addition with P != 0 is a product of non-zero residues).  tests/test_fq14_model_cpu.py asserts the
+// bounds below on the integer model.
+struct G1X14 {
+    Fq14 x, y, zz, zzz;
+};
+__device__ __forceinline__ G1X14 g1x_from_jac(const G1Jac& p) {
+    G1X14 r;
+    const Fq14 z = fq14_from(p.z);
+    r.x = fq14_from(p.x); r.y = fq14_from(p.y);
+    r.zz = fq14_sqr(z);
+    r.zzz = fq14_mul(z, r.zz);
+    return r;
+}
+__device__ __forceinline__ G1Jac g1x_to_jac(const G1X14& p) {
+    if (fq14_limbs_zero(p.zz)) return g1_inf();
+    Fq14 a, b;
+    fq14_mul2(p.x, p.zz, p.y, p.zzz, a, b);
+    G1Jac r;
+    r.x = fq14_to(a); r.y = fq14_to(b); r.z = fq14_to(p.zz);
+    return r;
+}
+// P = U2 - U1 + 4 q, R = S2 - S1 + 4 q (unnormalised: L < 2^29.6, S < 5.2).  AFF: ZZ3 = PP, ZZZ3 = PPP (both inputs affine)
+template <bool AFF>
+__device__ __forceinline__ G1X14 g1x_tail(const Fq14& U1, const Fq14& S1, const Fq14& P, const Fq14& R, const Fq14& zz12, const Fq14& zzz12) {
+    Fq14 PP, RR, PPP, Q, RW, SP;
+    fq14_sqr2(P, R, PP, RR);                                          // S 1.01
+    fq14_mul2(P, PP, U1, PP, PPP, Q);                                 // 2^57.6: S 1.002
+    const Fq14 T = fq14_norm(fq14_add(PPP, fq14_shl<1>(Q)));          // PPP + 2 Q: S 3.01
+    G1X14 r;
+    r.x = fq14_norm(fq14_sub4(RR, T));                                // S 5.01
+    const Fq14 W = fq14_sub16(Q, r.x);                                // L < 2^29.6, S 17.0
+    fq14_mul2(R, W, S1, PPP, RW, SP);                                 // 2^59.2: S 1.04
+    r.y = fq14_norm(fq14_sub4(RW, SP));                               // S 5.04
+    if (AFF) { r.zz = PP; r.zzz = PPP; }
+    else fq14_mul2(zz12, PP, zzz12, PPP, r.zz, r.zzz);                // S 1.001
+    return r;
+}
+__device__ __forceinline__ G1X14 g1x_add(const G1X14& p, const G1X14& q) {
+    if (fq14_limbs_zero(p.zz)) return q;
+    if (fq14_limbs_zero(q.zz)) return p;
+    Fq14 U1, U2, S1, S2, zz12, zzz12;
+    fq14_mul2(p.x, q.zz, q.x, p.zz, U1, U2);
+    const Fq14 P = fq14_sub4(U2, U1);
+    if (fq14_maybe_zero(P)) return g1x_from_jac(g1_add_c(g1x_to_jac(p), g1x_to_jac(q)));   // P = +-Q (or a rare false "maybe"): the exact path
+    fq14_mul2(p.y, q.zzz, q.y, p.zzz, S1, S2);
+    fq14_mul2(p.zz, q.zz, p.zzz, q.zzz, zz12, zzz12);
+    return g1x_tail<false>(U1, S1, P, fq14_sub4(S2, S1), zz12, zzz12);
+}
+__device__ __forceinline__ G1X14 g1x_add_aff(const G1Aff& p, const G1Aff& q) {
+    if (g1_aff_is_inf(p)) return g1x_from_jac(g1_from_aff(q));
+    if (g1_aff_is_inf(q)) return g1x_from_jac(g1_from_aff(p));
+    const Fq14 X1 = fq14_from(p.x), Y1 = fq14_from(p.y);
+    const Fq14 P = fq14_sub4(fq14_from(q.x), X1);
+    if (fq14_maybe_zero(P)) return g1x_from_jac(g1_add_aff_c(p, q));
+    return g1x_tail<true>(X1, Y1, P, fq14_sub4(fq14_from(q.y), Y1), X1, X1);
+}
 #endif
 
 GM_HD G1Jac g1_add(const G1Jac& p, const G1Jac& q) {

@@ -338,3 +338,78 @@ def test_cells_stay_within_bounds_through_the_levels_of_a_tree():
             cells = [add_cells(cells[k], cells[k + 1]) for k in range(0, len(cells), 2)]
             refs = [ref_add_jac(*refs[k], *refs[k + 1]) for k in range(0, len(refs), 2)]
         assert tuple(store(c) for c in cells[0]) == refs[0]
+
+
+# ---------------------------------------------------------------- XYZZ cells (g1.hip.h: G1X14, the form the sum-by-key tree keeps)
+def xyzz_tail(u1, s1, pp_, r_, zz12, zzz12):
+    """g1x_tail: P = U2 - U1 + 4 q, R = S2 - S1 + 4 q (unnormalised); add-2008-s / mmadd-2008-s.  Returns the cell (X3, Y3, ZZ3, ZZZ3)"""
+    PP, RR = sqr(pp_), sqr(r_)
+    PPP, Qv = mul(pp_, PP), mul(u1, PP)
+    t = norm(add(PPP, shl(Qv, 1)))
+    x3 = norm(sub(RR, t, BIAS4, 4))
+    w = sub(Qv, x3, BIAS16, 16)
+    rw, sp = mul(r_, w), mul(s1, PPP)
+    y3 = norm(sub(rw, sp, BIAS4, 4))
+    zz3, zzz3 = (PP, PPP) if zz12 is None else (mul(zz12, PP), mul(zzz12, PPP))
+    for c, bound in ((x3, 52), (y3, 52), (zz3, 11), (zzz3, 11)):
+        assert all(l <= M28 for l in c[:13]) and value(c) * 10 < bound * Q   # limbs < 2^28; S <= 5.2 (X, Y), 1.1 (ZZ, ZZZ)
+    return x3, y3, zz3, zzz3
+
+
+def xyzz_add_aff(x1, y1, x2, y2):
+    a, b, c, e = load(x1), load(y1), load(x2), load(y2)
+    return xyzz_tail(a, b, sub(c, a, BIAS4, 4), sub(e, b, BIAS4, 4), None, None)
+
+
+def xyzz_add(p, q):
+    (x1, y1, zz1, zzz1), (x2, y2, zz2, zzz2) = p, q
+    u1, u2 = mul(x1, zz2), mul(x2, zz1)
+    s1, s2 = mul(y1, zzz2), mul(y2, zzz1)
+    return xyzz_tail(u1, s1, sub(u2, u1, BIAS4, 4), sub(s2, s1, BIAS4, 4), mul(zz1, zz2), mul(zzz1, zzz2))
+
+
+def xyzz_from_jac(X, Y, Z):
+    z = load(Z)
+    zz = sqr(z)
+    return load(X), load(Y), zz, mul(z, zz)
+
+
+def xyzz_to_jac(c):
+    """(X ZZ, Y ZZZ, ZZ): a Jacobian representative with Z' = ZZ (x = X / ZZ = X' / Z'^2, y = Y / ZZZ = Y' / Z'^3 as ZZ^3 = ZZZ^2)"""
+    x, y, zz, zzz = c
+    return store(mul(x, zz)), store(mul(y, zzz)), store(zz)
+
+
+def jac_affine(X, Y, Z):
+    """Montgomery-domain Jacobian -> plain affine integers"""
+    x, y, z = (v * RI % Q for v in (X, Y, Z))
+    zi = pow(z, -1, Q)
+    return x * zi * zi % Q, y * zi * zi * zi % Q
+
+
+def test_xyzz_cells_give_the_same_point_and_stay_within_bounds():
+    """eight affine inputs, three levels in the XYZZ form against the Jacobian reference formulas: the same affine point; a Jacobian
+    source converted into a cell and added; the widest operands of every product asserted inside mul / sqr / sub"""
+    rng = random.Random(19)
+    for it in range(14):
+        pick = (lambda: rng.choice(adversarial())) if it < 4 else (lambda: rng.randrange(Q))
+        pts = [(pick(), pick()) for _ in range(8)]
+        cells, refs = [], []
+        for k in range(0, 8, 2):
+            (x1, y1), (x2, y2) = pts[k], pts[k + 1]
+            cells.append(xyzz_add_aff(x1, y1, x2, y2))
+            refs.append(ref_add_aff(x1, y1, x2, y2))
+        while len(cells) > 1:
+            cells = [xyzz_add(cells[k], cells[k + 1]) for k in range(0, len(cells), 2)]
+            refs = [ref_add_jac(*refs[k], *refs[k + 1]) for k in range(0, len(refs), 2)]
+        if any(v == 0 for v in refs[0][2:]) or it < 4:
+            continue      # adversarial field elements are not curve points: a zero denominator may occur; the bounds were still checked
+        assert jac_affine(*xyzz_to_jac(cells[0])) == jac_affine(*refs[0])
+        # a Jacobian source (wire form) as a cell, added to the tree's result
+        X, Y, Z = (rng.randrange(Q) for _ in range(3))
+        got = xyzz_add(cells[0], xyzz_from_jac(X, Y, Z))
+        assert jac_affine(*xyzz_to_jac(got)) == jac_affine(*ref_add_jac(*refs[0], X, Y, Z))
+    # infinity: Z = 0 gives ZZ = ZZZ = 0 limb for limb (the test the device uses)
+    c = xyzz_from_jac(5, 7, 0)
+    assert all(l == 0 for l in c[2]) and all(l == 0 for l in c[3])
+
