@@ -254,8 +254,10 @@ __device__ __forceinline__ G1Jac g1_pair(const G1SrcJac& s, uint32_t c0, bool tw
 
 // one tree level: out cell j of row r = in cell 2p (+ in cell 2p+1 when the row has it), p = j - off_out[r]
 static constexpr uint32_t G1_ROWS_LDS = 512;
+// (two waves per SIMD asked for: the Jacobian-source instance otherwise takes 277 VGPRs + 21 AGPRs = ONE wave per SIMD; at 256 with
+// 92 bytes of spills it runs the weighted sums of every MSM and the phase-2 pull commitments 14 % faster where they are large)
 template <class Src>
-__global__ void __launch_bounds__(128) k_g1_level(Src src, const uint32_t* __restrict__ off_in,
+__global__ void __launch_bounds__(128, 2) k_g1_level(Src src, const uint32_t* __restrict__ off_in,
                                                    const uint32_t* __restrict__ off_out, uint32_t nrows,
                                                    uint32_t* __restrict__ out, const uint32_t* __restrict__ br) {
     // the 128 results of a workgroup are 21 KB (28 KB with XYZZ cells) of contiguous output: staged in LDS and written as whole lines (a lane storing
