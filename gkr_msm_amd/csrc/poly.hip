@@ -14,40 +14,46 @@ namespace gm {
 
 __device__ __forceinline__ void seg_eval(const Seg& g, const Fr* a, Fr* o) { prim_exec(g.prim, a, o); }
 
+// PRIM: the one primitive every segment of the plan applies (an instance of its own: its registers, not the widest primitive's), or 0:
+// any plan through prim_exec's switch
+template <int PRIM>
 __global__ void __launch_bounds__(256) k_dense_map(SegPlan sp, ColPtrs in, ColPtrsMut out, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    constexpr int NI = PrimShape<PRIM>::n_in, NO = PrimShape<PRIM>::n_out;
     for (int s = 0; s < sp.nseg; s++) {
         const Seg g = sp.seg[s];
-        Fr a[6], o[4];
+        Fr a[NI], o[NO];
 #pragma unroll
-        for (int q = 0; q < 6; q++)
-            if (q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + i);
-        seg_eval(g, a, o);
+        for (int q = 0; q < NI; q++)
+            if (PRIM || q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + i);
+        if (PRIM) prim_exec(PRIM, a, o); else seg_eval(g, a, o);
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (q < g.n_out) fr_store(out.p[g.out0 + q] + i, o[q]);
+        for (int q = 0; q < NO; q++)
+            if (PRIM || q < g.n_out) fr_store(out.p[g.out0 + q] + i, o[q]);
     }
 }
 
 // element i goes to half (i >> lo_bit) & 1 at position ((i >> (lo_bit+1)) << lo_bit) | (i & (2^lo_bit - 1));
 // output o of half h lands in column 2*(o/bundle)*bundle + h*bundle + o%bundle   (dense.rs:126-138)
+template <int PRIM>
 __global__ void __launch_bounds__(256) k_dense_map_split(SegPlan sp, ColPtrs in, ColPtrsMut out, uint64_t n,
                                                           uint32_t lo_bit, uint32_t bundle) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t half = (uint32_t)(i >> lo_bit) & 1u;
     const uint64_t pos = ((i >> (lo_bit + 1)) << lo_bit) | (i & ((1ull << lo_bit) - 1));
+    constexpr int NI = PrimShape<PRIM>::n_in, NO = PrimShape<PRIM>::n_out;
     for (int s = 0; s < sp.nseg; s++) {
         const Seg g = sp.seg[s];
-        Fr a[6], o[4];
+        Fr a[NI], o[NO];
 #pragma unroll
-        for (int q = 0; q < 6; q++)
-            if (q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + i);
-        seg_eval(g, a, o);
+        for (int q = 0; q < NI; q++)
+            if (PRIM || q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + i);
+        if (PRIM) prim_exec(PRIM, a, o); else seg_eval(g, a, o);
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (q < g.n_out) {
+        for (int q = 0; q < NO; q++)
+            if (PRIM || q < g.n_out) {
                 const uint32_t oc = g.out0 + q;
                 const uint32_t col = 2 * (oc / bundle) * bundle + half * bundle + oc % bundle;
                 fr_store(out.p[col] + pos, o[q]);
@@ -102,7 +108,9 @@ int32_t launch_dense_map(const SegPlan& sp, const Fr* const* in, Fr* const* out,
     for (int i = 0; i < sp.n_ins; i++) ci.p[i] = in[i];
     for (int i = 0; i < sp.n_outs; i++) co.p[i] = out[i];
     if (n == 0) return GM_OK;
-    hipLaunchKernelGGL(k_dense_map, dim3(ceil_div(n, 256)), dim3(256), 0, s, sp, ci, co, n);
+#define GM_LAUNCH_DENSE_MAP(P) hipLaunchKernelGGL(k_dense_map<P>, dim3(ceil_div(n, 256)), dim3(256), 0, s, sp, ci, co, n)
+    GM_MAP_DISPATCH(uniform_prim_of(sp), GM_LAUNCH_DENSE_MAP)
+#undef GM_LAUNCH_DENSE_MAP
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -114,7 +122,9 @@ int32_t launch_dense_map_split(const SegPlan& sp, const Fr* const* in, Fr* const
     for (int i = 0; i < sp.n_ins; i++) ci.p[i] = in[i];
     for (int i = 0; i < 2 * sp.n_outs; i++) co.p[i] = out[i];
     if (n == 0) return GM_OK;
-    hipLaunchKernelGGL(k_dense_map_split, dim3(ceil_div(n, 256)), dim3(256), 0, s, sp, ci, co, n, lo_bit, bundle);
+#define GM_LAUNCH_DENSE_MAP_SPLIT(P) hipLaunchKernelGGL(k_dense_map_split<P>, dim3(ceil_div(n, 256)), dim3(256), 0, s, sp, ci, co, n, lo_bit, bundle)
+    GM_MAP_DISPATCH(uniform_prim_of(sp), GM_LAUNCH_DENSE_MAP_SPLIT)
+#undef GM_LAUNCH_DENSE_MAP_SPLIT
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

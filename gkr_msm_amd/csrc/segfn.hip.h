@@ -68,6 +68,47 @@ inline bool seg_plan_build(const GmFn& f, SegPlan* sp) {
     return true;
 }
 
+// The primitive of a plan whose segments ALL apply the same one (the witness builders' maps: a layer function repeated over column
+// bundles), 0 otherwise.  The map kernels (k_dense_map, k_dense_map_split, k_vv_map, k_vv_map_split) have an instance per primitive:
+// the generic instance runs prim_exec's switch, whose widest arm sets the register count for every arm (196 VGPRs = two waves per SIMD
+// for kernels that stream (k + m) x 32 B per element with 4-5 products); forcing three or four waves on it with launch bounds was
+// measured (round 4) and loses to its spills: gen-1 witness 92 -> 109 / 238 ms.
+inline int uniform_prim_of(const SegPlan& sp) {
+    if (sp.nseg < 1) return 0;
+    const int prim = sp.seg[0].prim;
+    for (int s = 1; s < sp.nseg; s++)
+        if (sp.seg[s].prim != prim) return 0;
+    switch (prim) {
+        case FN_AFF_L1: case FN_AFF_L2: case FN_AFF_L3: case FN_PROJ_L1: case FN_PROJ_L2: case FN_PROJ_L3: case FN_ID:
+        case FN_PT_BIT_CHOICE: case FN_ADD_INVERSES: case FN_LOGUP_LAYER: return prim;
+        default: return 0;
+    }
+}
+// inputs / outputs of a map kernel's instance: the primitive's own counts, or the widest (6 / 4) for the generic instance (PRIM = 0)
+template <int PRIM> struct PrimShape {
+    static constexpr int n_in = PRIM == FN_AFF_L1 ? 4 : (PRIM == FN_AFF_L2 || PRIM == FN_AFF_L3 || PRIM == FN_PT_BIT_CHOICE) ? 3
+                              : PRIM == FN_PROJ_L1 ? 6 : (PRIM == FN_PROJ_L2 || PRIM == FN_PROJ_L3 || PRIM == FN_LOGUP_LAYER) ? 4
+                              : PRIM == FN_ID ? 1 : PRIM == FN_ADD_INVERSES ? 2 : 6;
+    static constexpr int n_out = (PRIM == FN_AFF_L1 || PRIM == FN_AFF_L2 || PRIM == FN_AFF_L3 || PRIM == FN_PROJ_L3) ? 3
+                               : (PRIM == FN_PROJ_L1 || PRIM == FN_PROJ_L2) ? 4 : PRIM == FN_ID ? 1
+                               : (PRIM == FN_PT_BIT_CHOICE || PRIM == FN_ADD_INVERSES || PRIM == FN_LOGUP_LAYER) ? 2 : 4;
+};
+// launch KERNEL<prim> for the primitives uniform_prim_of returns, KERNEL<0> otherwise
+#define GM_MAP_DISPATCH(PRIM_, LAUNCH_)                                                                          \
+    switch (PRIM_) {                                                                                             \
+        case FN_AFF_L1: { LAUNCH_(FN_AFF_L1); } break;                                                           \
+        case FN_AFF_L2: { LAUNCH_(FN_AFF_L2); } break;                                                           \
+        case FN_AFF_L3: { LAUNCH_(FN_AFF_L3); } break;                                                           \
+        case FN_PROJ_L1: { LAUNCH_(FN_PROJ_L1); } break;                                                         \
+        case FN_PROJ_L2: { LAUNCH_(FN_PROJ_L2); } break;                                                         \
+        case FN_PROJ_L3: { LAUNCH_(FN_PROJ_L3); } break;                                                         \
+        case FN_ID: { LAUNCH_(FN_ID); } break;                                                                   \
+        case FN_PT_BIT_CHOICE: { LAUNCH_(FN_PT_BIT_CHOICE); } break;                                             \
+        case FN_ADD_INVERSES: { LAUNCH_(FN_ADD_INVERSES); } break;                                               \
+        case FN_LOGUP_LAYER: { LAUNCH_(FN_LOGUP_LAYER); } break;                                                 \
+        default: { LAUNCH_(0); } break;                                                                          \
+    }
+
 // host evaluation through the plan (pads, final combinator checks)
 inline void seg_plan_exec_host(const SegPlan& sp, const Fr* in, Fr* out) {
     for (int s = 0; s < sp.nseg; s++) {

@@ -35,19 +35,22 @@ __global__ void __launch_bounds__(256) k_image_gather(const Fr* __restrict__ pts
     fr_store(oz + j, z);
 }
 
+// PRIM: as k_dense_map (poly.hip): the plan's one primitive, or 0 for any plan
+template <int PRIM>
 __global__ void __launch_bounds__(256) k_vv_map(SegPlan sp, ColPtrs in, ColPtrsMut out, uint64_t total) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    constexpr int NI = PrimShape<PRIM>::n_in, NO = PrimShape<PRIM>::n_out;
     for (int s = 0; s < sp.nseg; s++) {
         const Seg g = sp.seg[s];
-        Fr a[6], o[4];
+        Fr a[NI], o[NO];
 #pragma unroll
-        for (int q = 0; q < 6; q++)
-            if (q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + i);
-        prim_exec(g.prim, a, o);
+        for (int q = 0; q < NI; q++)
+            if (PRIM || q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + i);
+        if (PRIM) prim_exec(PRIM, a, o); else prim_exec(g.prim, a, o);
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (q < g.n_out) fr_store(out.p[g.out0 + q] + i, o[q]);
+        for (int q = 0; q < NO; q++)
+            if (PRIM || q < g.n_out) fr_store(out.p[g.out0 + q] + i, o[q]);
     }
 }
 
@@ -58,6 +61,7 @@ struct PadVals {
 
 // split on the LSB of the in-row index: output cell p of row r holds f(in[2p]) in the "left" columns and
 // f(in[2p+1]) in the "right" columns; the cell past len/2 (when len/2 is odd) holds the output row pad.
+template <int PRIM>
 __global__ void __launch_bounds__(256) k_vv_map_split(SegPlan sp, ColPtrs in, ColPtrsMut out,
                                                        const uint32_t* __restrict__ off_in,
                                                        const uint32_t* __restrict__ off_out, uint32_t nrows,
@@ -68,19 +72,20 @@ __global__ void __launch_bounds__(256) k_vv_map_split(SegPlan sp, ColPtrs in, Co
     const uint32_t r = coarse_out ? find_row_coarse(off_out, nrows, coarse_out, j) : find_row(off_out, nrows, j);
     const uint32_t p = j - off_out[r];
     const uint32_t in0 = off_in[r], half_len = (off_in[r + 1] - in0) >> 1;
+    constexpr int NI = PrimShape<PRIM>::n_in, NO = PrimShape<PRIM>::n_out;
     if (p < half_len) {
         for (int s = 0; s < sp.nseg; s++) {
             const Seg g = sp.seg[s];
             for (uint32_t h = 0; h < 2; h++) {
-                Fr a[6], o[4];
+                Fr a[NI], o[NO];
                 const uint64_t src = (uint64_t)in0 + 2 * p + h;
 #pragma unroll
-                for (int q = 0; q < 6; q++)
-                    if (q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + src);
-                prim_exec(g.prim, a, o);
+                for (int q = 0; q < NI; q++)
+                    if (PRIM || q < g.n_in) a[q] = fr_load(in.p[g.in[q]] + src);
+                if (PRIM) prim_exec(PRIM, a, o); else prim_exec(g.prim, a, o);
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (q < g.n_out) {
+                for (int q = 0; q < NO; q++)
+                    if (PRIM || q < g.n_out) {
                         const uint32_t oc = g.out0 + q;
                         const uint32_t col = 2 * (oc / bundle) * bundle + h * bundle + oc % bundle;
                         fr_store(out.p[col] + j, o[q]);
@@ -238,7 +243,9 @@ int32_t vv_map(const SegPlan& sp, const gm_vv* in, gm_vv** out, hipStream_t s) {
     for (int i = 0; i < sp.n_ins; i++) ci.p[i] = in->cols[i]->fr();
     for (int i = 0; i < sp.n_outs; i++) co.p[i] = o->cols[i]->fr();
     if (in->total) {
-        hipLaunchKernelGGL(k_vv_map, dim3(ceil_div(in->total, 256)), dim3(256), 0, s, sp, ci, co, in->total);
+#define GM_LAUNCH_VV_MAP(P) hipLaunchKernelGGL(k_vv_map<P>, dim3(ceil_div(in->total, 256)), dim3(256), 0, s, sp, ci, co, in->total)
+        GM_MAP_DISPATCH(uniform_prim_of(sp), GM_LAUNCH_VV_MAP)
+#undef GM_LAUNCH_VV_MAP
         GM_LAUNCH_CHECK();
     }
     *out = o.release();
@@ -292,10 +299,13 @@ int32_t vv_map_split(const SegPlan& sp, const gm_vv* in, uint32_t bundle, gm_vv*
     for (int i = 0; i < sp.n_ins; i++) ci.p[i] = in->cols[i]->fr();
     for (int i = 0; i < 2 * sp.n_outs; i++) co.p[i] = o->cols[i]->fr();
     if (tot) {
-        hipLaunchKernelGGL(k_vv_map_split, dim3(ceil_div(tot, 256)), dim3(256), 0, s, sp, ci, co,
-                           reinterpret_cast<const uint32_t*>(in->off->p), reinterpret_cast<const uint32_t*>(o->off->p), in->nrows, bundle, pv,
-                           (o->coarse && o->coarse_off && o->off_level < o->coarse_off->size())
-                               ? reinterpret_cast<const uint32_t*>(o->coarse->p) + (*o->coarse_off)[o->off_level] : (const uint32_t*)nullptr);
+        const uint32_t* coarse_tab = (o->coarse && o->coarse_off && o->off_level < o->coarse_off->size())
+                                         ? reinterpret_cast<const uint32_t*>(o->coarse->p) + (*o->coarse_off)[o->off_level] : (const uint32_t*)nullptr;
+#define GM_LAUNCH_VV_MAP_SPLIT(P)                                                                                             \
+    hipLaunchKernelGGL(k_vv_map_split<P>, dim3(ceil_div(tot, 256)), dim3(256), 0, s, sp, ci, co,                                 \
+                       reinterpret_cast<const uint32_t*>(in->off->p), reinterpret_cast<const uint32_t*>(o->off->p), in->nrows, bundle, pv, coarse_tab)
+        GM_MAP_DISPATCH(uniform_prim_of(sp), GM_LAUNCH_VV_MAP_SPLIT)
+#undef GM_LAUNCH_VV_MAP_SPLIT
         GM_LAUNCH_CHECK();
     }
     *out = o.release();
