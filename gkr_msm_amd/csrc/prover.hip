@@ -1240,6 +1240,13 @@ __global__ void __launch_bounds__(256) k_pf_psel_at(const Fr* __restrict__ point
     const Fr pf = fr_add(fr_add(p0, fr_mul(g1, fr_sub(p1, fr_one()))), g2);
     fr_store(out + i, fr_mul(fr_load(eq_sel_y + iy), pf));
 }
+// development aid (GM_PF_DEBUG_SUMS=1): XOR of the 64-bit words of an array -- an order-independent checksum of a buffer
+__global__ void __launch_bounds__(256) k_pf_xor_words(const unsigned long long* __restrict__ p, uint64_t n_words, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) acc ^= p[i];
+    for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicXor(out, acc);
+}
 // out[i] = sum over the parts of parts[r * n + i]
 __global__ void __launch_bounds__(256) k_pf_sum_parts(const Fr* __restrict__ parts, uint32_t nparts, uint64_t n, Fr* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1394,6 +1401,18 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     }
     pf_timer.mark("adj + tables");
     const Fr supp_total = fr_zero();   // 2 (2^mlog - matrix_size) / tau_suppression_term with matrix_size = 2^mlog
+    static const bool dbg_xor = [] { const char* e = getenv("GM_PF_DEBUG_SUMS"); return e && e[0] == '1'; }();
+    DevBuf dbg_word;
+    if (dbg_xor) TRY(dbg_word.alloc(8));
+    auto xor_of = [&](const Fr* d, uint64_t n) -> unsigned long long {   // GM_PF_DEBUG_SUMS: checksum of n elements at d
+        unsigned long long h = 0;
+        if (hipMemsetAsync(dbg_word.p, 0, 8, s) != hipSuccess) return 0;
+        hipLaunchKernelGGL(k_pf_xor_words, dim3(1024), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d), n * 4,
+                           reinterpret_cast<unsigned long long*>(dbg_word.p));
+        (void)hipMemcpyAsync(&h, dbg_word.p, 8, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        return h;
+    };
 
     // ---- the logup tree.  A distributed array of global length L lives as slices of L / G; `split` re-spreads its halves.
     auto split_halves = [&](const DFrac& o, DFrac* lo, DFrac* hi) -> int32_t {
@@ -1434,6 +1453,10 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
                 }
             }
             const int32_t rc = comm_pull_dev(sh.comm, o.num, 2 * S * sizeof(Fr), (uint32_t)pc.size(), pc.data(), reinterpret_cast<void*>(s));
+            if (rc == 0 && dbg_xor)
+                fprintf(stderr, "[gm pf tree] rank %u split len %llu %s: src [num|den] %016llx -> lo %016llx %016llx hi %016llx %016llx\n", sh.rank,
+                        (unsigned long long)L, stay ? "stays distributed" : "turns replicated", xor_of(o.num, 2 * S), xor_of(lo->num, n_out),
+                        xor_of(lo->den, n_out), xor_of(hi->num, n_out), xor_of(hi->den, n_out));
             if (rc == 0) return GM_OK;
             if (rc != 100) return set_err(GM_ERR_STATE, "gm_comm pull_dev failed with %d", rc);
             host_staged = true;   // nothing was copied: this and the later levels through the host
@@ -1502,6 +1525,22 @@ int32_t pushforward_prove_sharded(const gm_msm_plan* plan, const uint64_t* d_poi
     Fr nd[2];
     TRY(read_fr(top.num, &nd[0], s));
     TRY(read_fr(top.den, &nd[1], s));
+    {   // GM_PF_DEBUG_SUMS=1 (development aid): field sums of what the tree was built from, per rank -- the access counts (whole on every
+        // rank: the sums must agree across the ranks), this rank's slice of the matrix fractions, and the root
+        static const bool dbg_sums = [] { const char* e = getenv("GM_PF_DEBUG_SUMS"); return e && e[0] == '1'; }();
+        if (dbg_sums || !fr_eq(nd[0], fr_mul(nd[1], supp_total))) {
+            auto host_sum = [&](const Fr* d, uint64_t n) -> Fr {
+                std::vector<Fr> h(n);
+                Fr acc = fr_zero();
+                if (hipMemcpyAsync(h.data(), d, n * sizeof(Fr), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return acc;
+                for (uint64_t i = 0; i < n; i++) acc = fr_add(acc, h[i]);
+                return acc;
+            };
+            const Fr s_c = host_sum(ac_c_p, X), s_d = host_sum(ac_d_p, D), s_n = host_sum(num->fr(), ML), s_dn = host_sum(num->fr() + ML, ML);
+            fprintf(stderr, "[gm pushforward sharded] rank %u: sum ac_c %08x%08x sum ac_d %08x%08x sum num slice %08x%08x sum den slice %08x%08x root %08x%08x / %08x%08x\n",
+                    sh.rank, s_c.l[1], s_c.l[0], s_d.l[1], s_d.l[0], s_n.l[1], s_n.l[0], s_dn.l[1], s_dn.l[0], nd[0].l[1], nd[0].l[0], nd[1].l[1], nd[1].l[0]);
+        }
+    }
     GM_REQUIRE(!fr_is_zero(nd[1]), "logup denominator is zero (logup_mainphase.rs:161)");
     GM_REQUIRE(fr_eq(nd[0], fr_mul(nd[1], supp_total)), "logup total does not match the suppression term (logup_mainphase.rs:162)");
     tr->write_scalars({nd[0], nd[1]});

@@ -66,6 +66,13 @@ def _proc(ranks, world, tag, shape, q, key_mode, env):
         ref = wg.prove(claims[0], claims[1], d_inv, k, tape)
         assert ref["pair"][0] == G.mul(ref["pair"][1], tau), "the unsharded proof does not verify"
         torch.cuda.synchronize()
+        # GM_TEST_EXTRA_STREAMS=k: k more streams with work on them before the sharded part (a process that also pipelines MSM steps holds
+        # that many hardware queues; with GPU_MAX_HW_QUEUES raised, four such processes oversubscribe the device's queues)
+        extra_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("GM_TEST_EXTRA_STREAMS", "0")))]
+        for st_ in extra_streams:
+            with torch.cuda.stream(st_):
+                torch.zeros(1024, device="cuda").add_(1)
+        torch.cuda.synchronize()
         results = {}
         prove_ms = {}
 
