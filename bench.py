@@ -810,6 +810,11 @@ def main():
         try:
             L.gm_release_cached_memory()     # the extra shapes (x_logsize 24) leave tens of GiB in the library's and torch's caches
             torch.cuda.empty_cache()
+            # GM_BENCH_OWN_STREAM=1: the sharded provers on a stream of their own instead of the default one (an experiment of round 4's
+            # end, DESIGN section 6 "An oversubscribed device": one more hardware queue per process made that condition worse)
+            torch.cuda.synchronize()
+            if os.environ.get("GM_BENCH_OWN_STREAM") == "1":
+                torch.cuda.set_stream(torch.cuda.Stream())
             if plan is None:     # the extra shapes released the x_logsize-20 plan and operands
                 d_pts, d_sc, sc, _ = make_inputs(x_main)
                 plan = harness.MsmPlan(x_log, d_log, y_size, y0, y1)
@@ -979,6 +984,8 @@ def main():
         except Exception as e:  # keep the MSM line even if the sharded prover leg fails on this node
             out.setdefault("sumcheck", {})["error"] = repr(e)[:300]
         watchdog.cancel()
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
 
     # ---- gen-1 prover (gkr_msm_simple.rs gkr_msm_prove, Fr part): BASELINE.json configs[2]
     if world == 1 and not args.no_sumcheck and args.gen1_log_points > 0:
