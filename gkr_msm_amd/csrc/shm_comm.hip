@@ -64,7 +64,10 @@ struct gm_shm {
     // A mapping is only as good as the peer's allocation: the peer publishes the epoch of its device pool with every handle (it moves
     // whenever the pool gave blocks back to the driver), and a new epoch drops everything opened from that peer -- also only between
     // calls (the epoch is compared at the head of a pull, before any address of that call has been resolved).
-    struct Opened { hipIpcMemHandle_t handle; void* ptr; uint32_t peer; uint64_t used_in; };
+    // The key of a mapping is the peer's ALLOCATION (its base address and size in the peer's address space, published with the handle),
+    // not the handle's bytes: the cache then does not depend on how the runtime encodes a handle (with the dmabuf form of HIP IPC,
+    // HSA_ENABLE_IPC_MODE_LEGACY=0 -- the only one this host driver supports -- the bytes are not documented to be unique per allocation).
+    struct Opened { uint64_t base_va, alloc_bytes; void* ptr; uint32_t peer; uint64_t used_in; };
     std::vector<Opened> opened;
     std::vector<uint64_t> peer_epoch;
     uint64_t pull_no = 0;          // pull_dev calls so far: the stamp of "touched by the current call"
@@ -78,9 +81,9 @@ struct gm_shm {
             else i++;
         peer_epoch[peer] = epoch;
     }
-    void* open_peer(uint32_t peer, const hipIpcMemHandle_t& h) {
+    void* open_peer(uint32_t peer, const hipIpcMemHandle_t& h, uint64_t base_va, uint64_t alloc_bytes) {
         for (size_t i = 0; i < opened.size(); i++)
-            if (opened[i].peer == peer && memcmp(&opened[i].handle, &h, sizeof(h)) == 0) {
+            if (opened[i].peer == peer && opened[i].base_va == base_va && opened[i].alloc_bytes == alloc_bytes) {
                 Opened o = opened[i];
                 o.used_in = pull_no;
                 opened.erase(opened.begin() + i);
@@ -90,7 +93,7 @@ struct gm_shm {
         void* p = nullptr;
         if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         ipc_opens++;
-        opened.push_back(Opened{h, p, peer, pull_no});
+        opened.push_back(Opened{base_va, alloc_bytes, p, peer, pull_no});
         return p;
     }
     void trim() {
@@ -154,6 +157,7 @@ static int32_t shm_all_gather(void* ctx, void* buf, uint64_t nbytes) {
 struct ShmIpcMsg {
     hipIpcMemHandle_t handle;
     uint64_t offset, bytes, epoch;
+    uint64_t base_va, alloc_bytes;   // the allocation the handle stands for, in the exporter's address space: the key of the peers' mapping caches
     uint32_t failed, pad;     // the rank's source could not be completed (stream error): every rank returns an error, nobody waits
     char bus[16];             // PCI bus id of the rank's device: a peer on the SAME device (ranks sharing a GPU: the one-box rehearsals) is
                               // copied from by a kernel -- hipMemcpyAsync from an IPC mapping takes the SDMA path, ~55 GB/s, where
@@ -186,6 +190,8 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         } else {
             mine.offset = (uint64_t)(static_cast<const char*>(d_src) - static_cast<const char*>(base));
             mine.bytes = src_bytes;
+            mine.base_va = (uint64_t)(uintptr_t)base;
+            mine.alloc_bytes = (uint64_t)size;
         }
     }
     mine.epoch = dev_pool().release_epoch.load();
@@ -200,7 +206,8 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
     mine.raw = exported ? (uint64_t)(uintptr_t)d_src : 0;
     // the source is complete before its handle goes out; a rank that cannot complete it says so IN the exchange (its peers would
     // otherwise sit in the all-gather until the time-out)
-    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); mine.failed = 1; mine.bytes = 0; }
+    static const bool dev_sync = [] { const char* e = getenv("GM_SHM_DEVICE_SYNC"); return e && e[0] == '1'; }();   // experiment: the whole device, not the stream
+    if ((dev_sync ? hipDeviceSynchronize() : hipStreamSynchronize(s)) != hipSuccess) { (void)hipGetLastError(); mine.failed = 1; mine.bytes = 0; }
     if (int32_t rc = shm_all_gather(c, msgs.data(), sizeof(ShmIpcMsg))) return rc;
     for (uint32_t r = 0; r < c->world; r++)
         if (msgs[r].failed) return r == c->rank ? 5 : 10;
@@ -220,7 +227,7 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
             if (!msgs[p.peer].raw) { usable = false; break; }
             src[k] = reinterpret_cast<const char*>((uintptr_t)msgs[p.peer].raw) + p.src_offset;
         } else {
-            void* peer_base = c->open_peer(p.peer, msgs[p.peer].handle);
+            void* peer_base = c->open_peer(p.peer, msgs[p.peer].handle, msgs[p.peer].base_va, msgs[p.peer].alloc_bytes);
             if (!peer_base) { usable = false; break; }
             src[k] = static_cast<const char*>(peer_base) + msgs[p.peer].offset + p.src_offset;
         }
@@ -246,7 +253,7 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
             if (hipGetLastError() != hipSuccess) err = 8;
         } else if (hipMemcpyAsync(p.d_dst, src[k], p.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) err = 8;
     }
-    if (hipStreamSynchronize(s) != hipSuccess && !err) err = 9;
+    if ((dev_sync ? hipDeviceSynchronize() : hipStreamSynchronize(s)) != hipSuccess && !err) err = 9;
     if (err) (void)hipGetLastError();
     // everybody is done reading (also after an error on this rank: the others must not hang in their barrier)
     std::vector<uint32_t> done(c->world, 0);
