@@ -20,6 +20,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <mutex>
 #include <cerrno>
 #include <cstring>
 #include <chrono>
@@ -49,6 +50,90 @@ size_t shm_bytes(uint32_t world) { return 64 + (size_t)world * 64 + (size_t)worl
 __global__ void __launch_bounds__(256) k_shm_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+// the same with SYSTEM-coherent loads (sc0 sc1: past this device's caches): GM_SHM_COPY_SC=1, an experiment for DESIGN section 6
+__global__ void __launch_bounds__(256) k_shm_copy16_sc(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src + i) : "memory");
+        dst[i] = v;
+    }
+}
+
+// HIP IPC mappings of peer processes' allocations, kept for the life of the PROCESS and shared by all its communicators.
+// The same few pool blocks / arenas come back pull after pull and proof after proof, and opening one costs ~a millisecond.  The key of
+// a mapping is the peer's ALLOCATION -- the exporting process, the allocation's base address and size in its address space, published
+// with the handle -- and the importing device; not the handle's bytes (their encoding is the runtime's business).
+// A mapping is never closed and opened again for an allocation that is still the same: round 4 found that a communicator which closed
+// its mappings on destruction, followed by a second communicator re-opening the SAME allocations, read other bytes through some of the
+// fresh mappings when the device was time-slicing the ranks' processes ("An oversubscribed device": one importer
+// wrong, another importer of the same allocation in the same call right).  What is closed: everything imported from a peer whose pool
+// gave memory back to the driver (it publishes an epoch with every handle; compared at the head of a pull, before any address of
+// that call has been resolved), and -- beyond GM_SHM_MAX_OPENED entries (default 128) -- the least recently used entries no pull of
+// any thread is working with.
+struct IpcCache {
+    struct Opened { uint64_t pid, base_va, alloc_bytes; int dev; void* ptr; uint64_t stamp; uint32_t in_use; };
+    std::mutex mu;
+    std::vector<Opened> opened;
+    std::vector<std::pair<uint64_t, uint64_t>> epoch_of;   // (pid, last epoch seen)
+    uint64_t clock = 0;
+    size_t max_opened = [] { const char* e = getenv("GM_SHM_MAX_OPENED"); long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 128); }();
+    static IpcCache& get() { static IpcCache c; return c; }
+    // a new epoch of `pid`: its allocations may have gone back to the driver -- drop what nobody is using (entries in use belong to a
+    // pull that resolved them under the epoch it was told; they go when it lets them go)
+    uint64_t sync_epoch(uint64_t pid, uint64_t epoch) {
+        std::lock_guard<std::mutex> g(mu);
+        uint64_t closed = 0;
+        for (auto& pe : epoch_of)
+            if (pe.first == pid) {
+                if (pe.second == epoch) return 0;
+                pe.second = epoch;
+                for (size_t i = 0; i < opened.size();)
+                    if (opened[i].pid == pid && opened[i].in_use == 0) { (void)hipIpcCloseMemHandle(opened[i].ptr); closed++; opened.erase(opened.begin() + i); }
+                    else i++;
+                return closed;
+            }
+        epoch_of.emplace_back(pid, epoch);
+        return 0;
+    }
+    // the mapping of (pid, base_va, alloc_bytes) on the current device, opened if need be; pinned (in_use) until release()
+    void* acquire(uint64_t pid, const hipIpcMemHandle_t& h, uint64_t base_va, uint64_t alloc_bytes, bool* was_new) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(mu);
+        for (Opened& o : opened)
+            if (o.pid == pid && o.base_va == base_va && o.alloc_bytes == alloc_bytes && o.dev == dev) {
+                o.stamp = ++clock;
+                o.in_use++;
+                *was_new = false;
+                return o.ptr;
+            }
+        void* p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        opened.push_back(Opened{pid, base_va, alloc_bytes, dev, p, ++clock, 1u});
+        *was_new = true;
+        return p;
+    }
+    void release(void* ptr) {
+        std::lock_guard<std::mutex> g(mu);
+        for (Opened& o : opened)
+            if (o.ptr == ptr && o.in_use) { o.in_use--; return; }
+    }
+    uint64_t trim() {   // least recently used first, never an entry a pull is working with
+        std::lock_guard<std::mutex> g(mu);
+        uint64_t closed = 0;
+        while (opened.size() > max_opened) {
+            size_t victim = opened.size();
+            for (size_t i = 0; i < opened.size(); i++)
+                if (opened[i].in_use == 0 && (victim == opened.size() || opened[i].stamp < opened[victim].stamp)) victim = i;
+            if (victim == opened.size()) break;
+            (void)hipIpcCloseMemHandle(opened[victim].ptr);
+            opened.erase(opened.begin() + victim);
+            closed++;
+        }
+        return closed;
+    }
+    size_t held() { std::lock_guard<std::mutex> g(mu); return opened.size(); }
+};
 
 struct gm_shm {
     std::string name;
@@ -57,56 +142,15 @@ struct gm_shm {
     size_t bytes = 0;
     uint64_t seq = 0;       // all_gather chunks done by this rank
     uint64_t calls = 0, payload = 0;
-    // peers' allocations opened through HIP IPC (pull_dev), kept open: the same few pool slabs / arenas come back call after call
-    // and opening one costs ~a millisecond.  Least recently used first out (a hit moves to the back); a mapping a pull has resolved
-    // an address into is never closed under it: open_peer only ADDS (the cache may exceed its bound while a call runs), trim() closes
-    // the surplus after the call's "done reading" barrier, oldest first, skipping what the call touched.
-    // A mapping is only as good as the peer's allocation: the peer publishes the epoch of its device pool with every handle (it moves
-    // whenever the pool gave blocks back to the driver), and a new epoch drops everything opened from that peer -- also only between
-    // calls (the epoch is compared at the head of a pull, before any address of that call has been resolved).
-    // The key of a mapping is the peer's ALLOCATION (its base address and size in the peer's address space, published with the handle),
-    // not the handle's bytes: the cache then does not depend on how the runtime encodes a handle (with the dmabuf form of HIP IPC,
-    // HSA_ENABLE_IPC_MODE_LEGACY=0 -- the only one this host driver supports -- the bytes are not documented to be unique per allocation).
-    struct Opened { uint64_t base_va, alloc_bytes; void* ptr; uint32_t peer; uint64_t used_in; };
-    std::vector<Opened> opened;
-    std::vector<uint64_t> peer_epoch;
-    uint64_t pull_no = 0;          // pull_dev calls so far: the stamp of "touched by the current call"
+    // peers' allocations opened through HIP IPC (pull_dev): a PROCESS-WIDE cache (IpcCache below), shared by every communicator of the process
+    uint64_t pull_no = 0;          // (diagnostics) pull_dev calls of this communicator so far
     uint64_t ipc_opens = 0, ipc_closes = 0;
-    size_t max_opened = [] { const char* e = getenv("GM_SHM_MAX_OPENED"); long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 128); }();
-    void sync_epoch(uint32_t peer, uint64_t epoch) {
-        if (peer_epoch.size() != world) peer_epoch.assign(world, ~0ull);
-        if (peer_epoch[peer] == epoch) return;
-        for (size_t i = 0; i < opened.size();)
-            if (opened[i].peer == peer) { (void)hipIpcCloseMemHandle(opened[i].ptr); ipc_closes++; opened.erase(opened.begin() + i); }
-            else i++;
-        peer_epoch[peer] = epoch;
-    }
-    void* open_peer(uint32_t peer, const hipIpcMemHandle_t& h, uint64_t base_va, uint64_t alloc_bytes) {
-        for (size_t i = 0; i < opened.size(); i++)
-            if (opened[i].peer == peer && opened[i].base_va == base_va && opened[i].alloc_bytes == alloc_bytes) {
-                Opened o = opened[i];
-                o.used_in = pull_no;
-                opened.erase(opened.begin() + i);
-                opened.push_back(o);
-                return o.ptr;
-            }
-        void* p = nullptr;
-        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        ipc_opens++;
-        opened.push_back(Opened{base_va, alloc_bytes, p, peer, pull_no});
-        return p;
-    }
-    void trim() {
-        for (size_t i = 0; i < opened.size() && opened.size() > max_opened;)
-            if (opened[i].used_in != pull_no) { (void)hipIpcCloseMemHandle(opened[i].ptr); ipc_closes++; opened.erase(opened.begin() + i); }
-            else i++;
-    }
+    bool last_open_was_new = false;   // (GM_SHM_DEBUG)
     ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
     std::atomic<uint64_t>* seq_of(uint32_t r) const { return reinterpret_cast<std::atomic<uint64_t>*>(base + 64 + (size_t)r * 64); }
     char* slot(uint32_t r, uint64_t n) const { return base + 64 + (size_t)world * 64 + ((size_t)r * 2 + (n & 1)) * SHM_SLOT; }
     ~gm_shm() {
-        for (const Opened& o : opened) (void)hipIpcCloseMemHandle(o.ptr);
-        if (base) munmap(base, bytes);
+        if (base) munmap(base, bytes);   // (the IPC mappings stay with the process: IpcCache)
     }
 };
 
@@ -213,9 +257,14 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
         if (msgs[r].failed) return r == c->rank ? 5 : 10;
     // mappings of a peer whose pool gave memory back are dropped now, before any address of this call is resolved
     for (uint32_t r = 0; r < c->world; r++)
-        if (r != c->rank && msgs[r].pid != mine.pid) c->sync_epoch(r, msgs[r].epoch);
+        if (r != c->rank && msgs[r].pid != mine.pid) c->ipc_closes += IpcCache::get().sync_epoch(msgs[r].pid, msgs[r].epoch);
     // open what this rank pulls from; then agree that everybody could
     std::vector<const char*> src(n, nullptr);
+    std::vector<void*> pinned;   // mappings this call resolved addresses into: released after the "done reading" barrier (or on the way out)
+    struct Unpin {
+        std::vector<void*>& v;
+        ~Unpin() { for (void* p_ : v) IpcCache::get().release(p_); }
+    } unpin{pinned};
     int32_t err = 0;
     bool usable = exported;
     for (uint32_t k = 0; k < n && usable; k++) {
@@ -227,8 +276,17 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
             if (!msgs[p.peer].raw) { usable = false; break; }
             src[k] = reinterpret_cast<const char*>((uintptr_t)msgs[p.peer].raw) + p.src_offset;
         } else {
-            void* peer_base = c->open_peer(p.peer, msgs[p.peer].handle, msgs[p.peer].base_va, msgs[p.peer].alloc_bytes);
+            void* peer_base = IpcCache::get().acquire(msgs[p.peer].pid, msgs[p.peer].handle, msgs[p.peer].base_va, msgs[p.peer].alloc_bytes,
+                                                      &c->last_open_was_new);
             if (!peer_base) { usable = false; break; }
+            pinned.push_back(peer_base);
+            if (c->last_open_was_new) c->ipc_opens++;
+            static const bool dbg = [] { const char* e = getenv("GM_SHM_DEBUG"); return e && e[0] == '1'; }();
+            if (dbg)
+                fprintf(stderr, "[gm shm pull %llu] rank %u piece %u <- rank %u: %s mapping %p of allocation %llx + %llu MiB, source offset %llu + %llu, %llu bytes\n",
+                        (unsigned long long)c->pull_no, c->rank, k, p.peer, c->last_open_was_new ? "NEW" : "cached", peer_base,
+                        (unsigned long long)msgs[p.peer].base_va, (unsigned long long)(msgs[p.peer].alloc_bytes >> 20),
+                        (unsigned long long)msgs[p.peer].offset, (unsigned long long)p.src_offset, (unsigned long long)p.bytes);
             src[k] = static_cast<const char*>(peer_base) + msgs[p.peer].offset + p.src_offset;
         }
     }
@@ -248,6 +306,11 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
             const uint64_t n16 = p.bytes / 16;
             uint64_t blocks = (n16 + 1023) / 1024;
             if (blocks > 4096) blocks = 4096;
+            static const bool copy_sc = [] { const char* e = getenv("GM_SHM_COPY_SC"); return e && e[0] == '1'; }();
+            if (copy_sc)
+                hipLaunchKernelGGL(k_shm_copy16_sc, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src[k]),
+                                   reinterpret_cast<uint4*>(p.d_dst), n16);
+            else
             hipLaunchKernelGGL(k_shm_copy16, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src[k]),
                                reinterpret_cast<uint4*>(p.d_dst), n16);
             if (hipGetLastError() != hipSuccess) err = 8;
@@ -259,7 +322,9 @@ static int32_t shm_pull_dev(void* ctx, const void* d_src, uint64_t src_bytes, ui
     std::vector<uint32_t> done(c->world, 0);
     done[c->rank] = err ? 2u : 1u;
     if (int32_t rc = shm_all_gather(c, done.data(), sizeof(uint32_t))) return rc;
-    c->trim();   // this rank's copies have completed: mappings the call did not touch may go
+    for (void* p_ : pinned) IpcCache::get().release(p_);   // this rank's copies have completed
+    pinned.clear();
+    c->ipc_closes += IpcCache::get().trim();
     if (err) return err;
     for (uint32_t r = 0; r < c->world; r++)
         if (done[r] != 1u) return 10;   // a peer failed
@@ -365,7 +430,7 @@ int32_t gm_comm_shm_ipc_stats(const gm_shm* c, uint64_t* opens, uint64_t* closes
     GM_REQUIRE(c, "null argument");
     if (opens) *opens = c->ipc_opens;
     if (closes) *closes = c->ipc_closes;
-    if (held) *held = c->opened.size();
+    if (held) *held = IpcCache::get().held();
     return GM_OK;
 }
 
