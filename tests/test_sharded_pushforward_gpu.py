@@ -57,8 +57,25 @@ def _claims_worker(rank, world, tag, x_log, d_log, nbits, dist_min, q, host_stag
         keys = ("msgs", "gamma", "tape_used", "rounds")
         ok = all(got[k] == ref[k] for k in keys) and all(
             (list(got[k][0]), list(got[k][1])) == (list(ref[k][0]), list(ref[k][1])) for k in ("matrix", "ac_c", "ac_d"))
-        q.put((rank, ok, "" if ok else "sharded argument differs (rounds %d vs %d, %d vs %d messages)" % (
-            got["rounds"], ref["rounds"], len(got["msgs"]), len(ref["msgs"])), comm.calls))
+        msg = "" if ok else "sharded argument differs (rounds %d vs %d, %d vs %d messages)" % (
+            got["rounds"], ref["rounds"], len(got["msgs"]), len(ref["msgs"]))
+        calls = comm.calls
+        if host_staged == "two-comms":
+            # a second communicator of the same job after the first one is gone: the peers' allocations are still open in this process
+            # (IpcCache, csrc/shm_comm.hip) -- nothing is imported a second time
+            opened_1 = comm.ipc_stats()
+            comm.close()
+            comm = gd.ShmComm("/gm-test-pf-%s-b" % tag, rank, world)
+            again = H.pushforward_prove(plan_s, d_pts, y_log, r, evs, tape, comm=comm)
+            opened_2 = comm.ipc_stats()
+            if again["msgs"] != ref["msgs"] or again["gamma"] != ref["gamma"]:
+                ok, msg = False, "the argument through the second communicator differs"
+            elif opened_1[0] == 0:
+                ok, msg = False, "the first communicator never opened a mapping: the device path was not exercised"
+            elif opened_2[1] != 0 or opened_2[2] != opened_1[2] + opened_2[0]:
+                # (the pool may hand the second proof other blocks as sources: NEW allocations are imported, none is closed or imported twice)
+                ok, msg = False, "mappings were closed or re-imported: first comm %r, second comm %r (opened, closed, held)" % (opened_1, opened_2)
+        q.put((rank, ok, msg, calls))
         comm.close()
     except Exception as e:
         import traceback
@@ -115,3 +132,13 @@ def test_sharded_pushforward_when_one_rank_cannot_export_its_buffers():
     """gm_comm::pull_dev answers "unavailable" on EVERY rank when one of them cannot export (or open) an IPC mapping -- devices hidden
     from each other, IPC switched off -- and the argument stages that redistribution through the host instead: same result, no hang"""
     _run(_claims_worker, 4, 7, 4, 32, 2, "rank1-cannot-export")
+
+
+def test_a_second_communicator_reuses_the_first_ones_ipc_mappings():
+    """two communicators in a row in the same processes (what bench.py --gpus N does): the second finds every peer allocation still
+    open -- HIP IPC mappings belong to the process -- and proves the same argument; closing and re-importing them was the cause of the
+    intermittent wrong reads of round 4"""
+    res = _run(_claims_worker, 4, 5, 2, 8, 2, host_staged="two-comms")
+    for rank, ok, msg, _ in sorted(res):
+        assert ok, "rank %d: %s" % (rank, msg)
+
