@@ -71,15 +71,15 @@ __global__ void __launch_bounds__(256) k_shm_copy16_sc(const uint4* __restrict__
 // that call has been resolved), and -- beyond GM_SHM_MAX_OPENED entries (default 128) -- the least recently used entries no pull of
 // any thread is working with.
 struct IpcCache {
-    struct Opened { uint64_t pid, base_va, alloc_bytes; int dev; void* ptr; uint64_t stamp; uint32_t in_use; };
+    struct Opened { uint64_t pid, base_va, alloc_bytes; int dev; void* ptr; uint64_t stamp; uint32_t in_use; bool dead; };
     std::mutex mu;
     std::vector<Opened> opened;
     std::vector<std::pair<uint64_t, uint64_t>> epoch_of;   // (pid, last epoch seen)
     uint64_t clock = 0;
     size_t max_opened = [] { const char* e = getenv("GM_SHM_MAX_OPENED"); long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 128); }();
     static IpcCache& get() { static IpcCache c; return c; }
-    // a new epoch of `pid`: its allocations may have gone back to the driver -- drop what nobody is using (entries in use belong to a
-    // pull that resolved them under the epoch it was told; they go when it lets them go)
+    // a new epoch of `pid`: its allocations may have gone back to the driver -- drop what nobody is using; an entry another thread's
+    // pull is working with (resolved under the epoch THAT pull was told) is marked dead: never handed out again, closed when let go
     uint64_t sync_epoch(uint64_t pid, uint64_t epoch) {
         std::lock_guard<std::mutex> g(mu);
         uint64_t closed = 0;
@@ -87,9 +87,11 @@ struct IpcCache {
             if (pe.first == pid) {
                 if (pe.second == epoch) return 0;
                 pe.second = epoch;
-                for (size_t i = 0; i < opened.size();)
-                    if (opened[i].pid == pid && opened[i].in_use == 0) { (void)hipIpcCloseMemHandle(opened[i].ptr); closed++; opened.erase(opened.begin() + i); }
-                    else i++;
+                for (size_t i = 0; i < opened.size();) {
+                    if (opened[i].pid == pid && opened[i].in_use == 0) { (void)hipIpcCloseMemHandle(opened[i].ptr); closed++; opened.erase(opened.begin() + i); continue; }
+                    if (opened[i].pid == pid) opened[i].dead = true;
+                    i++;
+                }
                 return closed;
             }
         epoch_of.emplace_back(pid, epoch);
@@ -101,7 +103,7 @@ struct IpcCache {
         (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> g(mu);
         for (Opened& o : opened)
-            if (o.pid == pid && o.base_va == base_va && o.alloc_bytes == alloc_bytes && o.dev == dev) {
+            if (!o.dead && o.pid == pid && o.base_va == base_va && o.alloc_bytes == alloc_bytes && o.dev == dev) {
                 o.stamp = ++clock;
                 o.in_use++;
                 *was_new = false;
@@ -109,14 +111,17 @@ struct IpcCache {
             }
         void* p = nullptr;
         if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        opened.push_back(Opened{pid, base_va, alloc_bytes, dev, p, ++clock, 1u});
+        opened.push_back(Opened{pid, base_va, alloc_bytes, dev, p, ++clock, 1u, false});
         *was_new = true;
         return p;
     }
     void release(void* ptr) {
         std::lock_guard<std::mutex> g(mu);
-        for (Opened& o : opened)
-            if (o.ptr == ptr && o.in_use) { o.in_use--; return; }
+        for (size_t i = 0; i < opened.size(); i++)
+            if (opened[i].ptr == ptr && opened[i].in_use) {
+                if (--opened[i].in_use == 0 && opened[i].dead) { (void)hipIpcCloseMemHandle(opened[i].ptr); opened.erase(opened.begin() + i); }
+                return;
+            }
     }
     uint64_t trim() {   // least recently used first, never an entry a pull is working with
         std::lock_guard<std::mutex> g(mu);
