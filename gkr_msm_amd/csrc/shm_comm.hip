@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_shm_copy16_sc(const uint4* __restrict__
 // fresh mappings when the device was time-slicing the ranks' processes ("An oversubscribed device": one importer
 // wrong, another importer of the same allocation in the same call right).  What is closed: everything imported from a peer whose pool
 // gave memory back to the driver (it publishes an epoch with every handle; compared at the head of a pull, before any address of
-// that call has been resolved), and -- beyond GM_SHM_MAX_OPENED entries (default 128) -- the least recently used entries no pull of
+// that call has been resolved), and -- beyond GM_SHM_MAX_OPENED entries (default 1024: evicting an entry invites exactly the close-and-import-again this cache exists to avoid) -- the least recently used entries no pull of
 // any thread is working with.
 struct IpcCache {
     struct Opened { uint64_t pid, base_va, alloc_bytes; int dev; void* ptr; uint64_t stamp; uint32_t in_use; bool dead; };
@@ -76,7 +76,7 @@ struct IpcCache {
     std::vector<Opened> opened;
     std::vector<std::pair<uint64_t, uint64_t>> epoch_of;   // (pid, last epoch seen)
     uint64_t clock = 0;
-    size_t max_opened = [] { const char* e = getenv("GM_SHM_MAX_OPENED"); long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 128); }();
+    size_t max_opened = [] { const char* e = getenv("GM_SHM_MAX_OPENED"); long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 1024); }();
     static IpcCache& get() { static IpcCache c; return c; }
     // a new epoch of `pid`: its allocations may have gone back to the driver -- drop what nobody is using; an entry another thread's
     // pull is working with (resolved under the epoch THAT pull was told) is marked dead: never handed out again, closed when let go

@@ -468,7 +468,7 @@ int32_t gm_comm_shm_create(const char* name, uint32_t rank, uint32_t world, gm_s
 int32_t gm_comm_shm_destroy(gm_shm* c);
 int32_t gm_comm_shm_as_comm(gm_shm* c, gm_comm* out);
 int32_t gm_comm_shm_stats(const gm_shm* c, uint64_t* all_gathers, uint64_t* bytes_per_rank_total);
-/* pull_dev's cache of opened peer allocations (HIP IPC): least recently used first out, bounded by GM_SHM_MAX_OPENED (default 128)
+/* pull_dev's cache of opened peer allocations (HIP IPC): least recently used first out, bounded by GM_SHM_MAX_OPENED (default 1024); the mappings belong to the process and outlive a communicator
  * BETWEEN calls -- a mapping the running call resolved an address into is never closed under it.  Counters for tests / diagnosis. */
 int32_t gm_comm_shm_ipc_stats(const gm_shm* c, uint64_t* opens, uint64_t* closes, uint64_t* held);
 
