@@ -306,10 +306,16 @@ def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
         a0, b0 = C.c_uint64(), C.c_uint64()
         ffi.lib().gm_sc_stage_counts(C.byref(a0), C.byref(b0))
         ws.prove_image_part(r_pt, evs, tape)            # warm-up (first-use allocations)
-        gd.shard_clock()
-        got = ws.prove_image_part(r_pt, evs, tape)
-        dt = got["call_s"]
-        clock = gd.shard_clock()
+        # two timed proofs, each started together (as bench.py's sync_all before its timed call), the faster one recorded
+        dt, clock, got = None, None, None
+        for _ in range(2):
+            comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))
+            gd.shard_clock()
+            g_ = ws.prove_image_part(r_pt, evs, tape)
+            c_ = gd.shard_clock()
+            if dt is None or g_["call_s"] < dt:
+                dt, clock = g_["call_s"], c_
+            got = g_
         a1, b1 = C.c_uint64(), C.c_uint64()
         ffi.lib().gm_sc_stage_counts(C.byref(a1), C.byref(b1))
         ok = (outs_s == outs and bs_s == bs and got["msgs"] == ref["msgs"] and got["point"] == ref["point"] and
@@ -354,7 +360,7 @@ def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
             w.close()
             plan.close()
         comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))   # everybody leaves together
-        q.put((rank, ok, dict(exchanges=calls, sharded_s=dt, unsharded_alone_s=one, stage_launches=(a1.value - a0.value) // 2,
+        q.put((rank, ok, dict(exchanges=calls, sharded_s=dt, unsharded_alone_s=one, stage_launches=(a1.value - a0.value) // 3,   # (three proofs: one warm-up, two timed)
                               stage_left=b1.value - b0.value, clock=clock, indep=indep), got["rounds"]))
         comm.close()
     except Exception as e:  # report instead of hanging the parent
@@ -400,7 +406,7 @@ def test_config_b_image_part_sharded_over_four_ranks():
     record("config_b_image_part_sharded_over_four_ranks", x_logsize=x_log, world=world, rounds=res[0][3], transport="shm",
            sharded_ms=round(1e3 * sharded, 1), unsharded_alone_ms=round(1e3 * alone, 1), ratio=round(sharded / alone, 2),
            stage_launches_per_rank=res[0][2]["stage_launches"], stage_left_early=sum(r[2]["stage_left"] for r in res),
-           exchanges_per_rank=res[0][2]["exchanges"],
+           exchanges_per_rank=res[0][2]["exchanges"], proofs_behind_the_exchange_count=3,
            time_inside_the_communicator_per_rank=[r[2]["clock"] for r in res], per_rank_ms=[round(1e3 * r[2]["sharded_s"], 1) for r in res],
            four_independent_share_sized_proofs_at_once=dict(what="every process proves an unsharded image part over y_size / world windows at the "
                                                             "same time, no exchange: what sharing ONE GPU between the processes costs by itself",
@@ -458,9 +464,16 @@ def _sharded_pf_worker(rank, world, port, x_log, d_log, nbits, q):
         plan_s = H.MsmPlan(x_log, d_log, y_size, y0, y1)
         plan_s.run(d_pts, d_sc)
         H.pushforward_prove(plan_s, d_pts, y_log, r_pt, evs, tape, comm=comm)      # warm-up: first-use allocations, IPC mappings
-        gd.shard_clock()
-        got = H.pushforward_prove(plan_s, d_pts, y_log, r_pt, evs, tape, comm=comm)
-        info.update(sharded_s=got["call_s"], rounds=got["rounds"], exchanges=comm.calls, clock=gd.shard_clock(), ipc=comm.ipc_stats(), digest=hashlib.sha256(repr(
+        best_s, best_clock, got = None, None, None
+        for _ in range(2):                                                          # two timed arguments, started together; the faster one
+            comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))
+            gd.shard_clock()
+            g_ = H.pushforward_prove(plan_s, d_pts, y_log, r_pt, evs, tape, comm=comm)
+            c_ = gd.shard_clock()
+            if best_s is None or g_["call_s"] < best_s:
+                best_s, best_clock = g_["call_s"], c_
+            got = g_
+        info.update(sharded_s=best_s, rounds=got["rounds"], exchanges=comm.calls, clock=best_clock, ipc=comm.ipc_stats(), digest=hashlib.sha256(repr(
             (got["msgs"], got["gamma"], got["matrix"], got["ac_c"], got["ac_d"])).encode()).hexdigest())
         q.put((rank, True, info))
         comm.sum_fr(np.zeros((1, 4), dtype=np.uint64))   # everybody leaves together
