@@ -265,6 +265,20 @@ def _release_unless_rank_thread():
         ffi.lib().gm_release_cached_memory()
 
 
+def _hold_hardware_queues():
+    """Four PROCESSES sharing one GPU are served by its scheduler per hardware queue: a process that holds one queue (one stream) gets its
+    latency-bound launches dispatched markedly later than one that holds four -- the sharded image part over 4 ranks measured 75 ms
+    with one stream per process and 55 ms with four (same library, same proof; bench.py's ranks hold four after their pipelined MSM
+    leg, which is why its figure was the lower one).  The workers of the shared-GPU rehearsals therefore hold GM_TEST_EXTRA_STREAMS
+    (default 3) more streams with a kernel run on each; with one process per GPU there is nobody to share the scheduler with."""
+    streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("GM_TEST_EXTRA_STREAMS", "3")))]
+    for st_ in streams:
+        with torch.cuda.stream(st_):
+            torch.zeros(1024, device="cuda").add_(1)
+    torch.cuda.synchronize()
+    return streams
+
+
 def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
     """one rank of the at-size sharded proof: operands from gm_gen_points / numpy (identical on every rank), the unsharded
     proof as the reference (pinned to the oracle by test_config_b_msm_and_image_part_at_full_size).  The ranks exchange through the
@@ -279,6 +293,7 @@ def _sharded_worker(rank, world, port, x_log, d_log, nbits, q):
         y_size = (nbits + d_log - 1) // d_log
         y_log = (y_size - 1).bit_length()
         d_pts, d_sc, sc = device_inputs(x_log, nbits, 0x474B524D534D)
+        extra_streams = _hold_hardware_queues()
         pr = np.random.default_rng(7)
         r_pt = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(y_log)]
         tape = [int.from_bytes(pr.bytes(16), "little") for _ in range(4000)]
@@ -407,6 +422,7 @@ def test_config_b_image_part_sharded_over_four_ranks():
            sharded_ms=round(1e3 * sharded, 1), unsharded_alone_ms=round(1e3 * alone, 1), ratio=round(sharded / alone, 2),
            stage_launches_per_rank=res[0][2]["stage_launches"], stage_left_early=sum(r[2]["stage_left"] for r in res),
            exchanges_per_rank=res[0][2]["exchanges"], proofs_behind_the_exchange_count=3,
+           streams_held_per_process=1 + int(os.environ.get("GM_TEST_EXTRA_STREAMS", "3")),
            time_inside_the_communicator_per_rank=[r[2]["clock"] for r in res], per_rank_ms=[round(1e3 * r[2]["sharded_s"], 1) for r in res],
            four_independent_share_sized_proofs_at_once=dict(what="every process proves an unsharded image part over y_size / world windows at the "
                                                             "same time, no exchange: what sharing ONE GPU between the processes costs by itself",
@@ -430,6 +446,7 @@ def _sharded_pf_worker(rank, world, port, x_log, d_log, nbits, q):
         y_log = (y_size - 1).bit_length()
         nv = y_log + d_log + x_log
         d_pts, d_sc, sc = device_inputs(x_log, nbits, 0x474B524D534D)
+        extra_streams = _hold_hardware_queues()
         pr = np.random.default_rng(7)
         tape = [int.from_bytes(pr.bytes(64), "little") % P for _ in range(4)] + [int.from_bytes(pr.bytes(16), "little") for _ in range(3000)]
         comm = gd.ShmComm("/gm-at-size-pf-%d" % port, rank, world)
